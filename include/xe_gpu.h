@@ -1,0 +1,165 @@
+/*
+ * xe_gpu.h -- C ABI of the MI355X flow path: export datagrams in, decoded
+ * structure-of-arrays flow fields + per-record monitoring-object match bitmask
+ * + per-object counters out.
+ *
+ * Plain C, plain pointers and sizes.  Every function returns 0 on success or
+ * a negative XE_E* code; xe_gpu_strerror() names it and xe_gpu_last_error()
+ * returns the detail text of the last failure on that handle.  A handle is
+ * single-producer: calls on one handle must not overlap.
+ *
+ * "reference" below is vmxdev/xenoeye; file:line are relative to its tree.
+ */
+#ifndef xe_gpu_h_included
+#define xe_gpu_h_included
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct xe_gpu xe_gpu;        /* configuration + device state */
+typedef struct xe_batch xe_batch;    /* one prepared batch, resident in HBM */
+
+enum
+{
+	XE_OK = 0,
+	XE_EINVAL = -1,       /* bad argument */
+	XE_ENOMEM = -2,       /* host allocation failed */
+	XE_EHIP = -3,         /* a HIP call failed (text in xe_gpu_last_error) */
+	XE_EPARSE = -4,       /* filter / list / config text did not parse */
+	XE_EUNSUPPORTED = -5, /* valid in the reference, not evaluable on the device */
+	XE_ESTATE = -6,       /* call out of order (e.g. batch before commit) */
+	XE_EIO = -7           /* file or directory could not be read */
+};
+
+#define XE_FLOW_INFO_SIZE 2312   /* sizeof(struct flow_info), flow-info.h:10-33 */
+#define XE_KIND_NETFLOW 0        /* Netflow v5 / v9 / IPFIX datagram */
+#define XE_KIND_SFLOW 1          /* sFlow v5 datagram */
+
+const char *xe_gpu_strerror(int code);
+const char *xe_gpu_last_error(const xe_gpu *h);
+
+/* ---- life cycle ---- */
+/* device: HIP device ordinal.  Fails with XE_EHIP when no GPU is usable:
+ * there is no CPU fallback. */
+int xe_gpu_create(xe_gpu **out, int device);
+void xe_gpu_destroy(xe_gpu *h);
+
+/* ---- configuration (load-time, host) ---- */
+/* replaces iplists_load() (iplist.c:299-322): every non-dot file of `dir`
+ * becomes a list named after the file.  Must precede the filters that name
+ * the lists, as in the reference (xenoeye.c:489 before monit_objects_init). */
+int xe_gpu_load_iplists(xe_gpu *h, const char *dir);
+/* the same loader (iplist.c:218-297) on a memory image of one list file */
+int xe_gpu_add_iplist(xe_gpu *h, const char *name, const char *text, size_t len);
+
+/* replaces the filter half of monit_object_info_parse() (monit-objects.c:47-105,
+ * parse_filter() filter-parser.c:225): adds one monitoring object.  parent = -1
+ * for a top-level object, else the index of an object added earlier; a child is
+ * evaluated only for records its parent matched (netflow.c:213-244).  Returns
+ * the object's index (= its bit in the match bitmask) or a negative code. */
+int xe_gpu_add_mo(xe_gpu *h, const char *name, int parent, const char *filter);
+/* replaces monit_objects_init() (monit-objects.c:470, directory walk :252-458):
+ * every directory below mo_dir holding an mo.conf is an object, nested
+ * directories are children.  Only the "filter" key is read. */
+int xe_gpu_load_mos(xe_gpu *h, const char *mo_dir);
+int xe_gpu_mo_count(const xe_gpu *h);
+const char *xe_gpu_mo_name(const xe_gpu *h, int mo);
+int xe_gpu_mo_parent(const xe_gpu *h, int mo);
+/* the compiled postfix program in the text form of filter_dump()
+ * (filter.c:1226-1256); returns the length written or a negative code */
+int xe_gpu_mo_dump(const xe_gpu *h, int mo, char *out, size_t outlen);
+
+/* parse_filter() + filter_dump() without touching a handle's objects; the
+ * handle supplies the IP-list names (may be NULL: no lists) */
+int xe_filter_check(const xe_gpu *h, const char *filter, char *dump, size_t dumplen,
+	char *err, size_t errlen);
+
+/* replaces one entry of devices.conf (devices.c:60-139).  use_ip / use_id say
+ * which of ip (network byte order) and id (host order, as written in the file)
+ * are set; marks are filter texts. */
+int xe_gpu_add_device(xe_gpu *h, int use_ip, uint32_t ip_net_order, int use_id, uint32_t id,
+	int sampling_rate, int skip_unmarked, const char *const *marks, int nmarks);
+/* replaces devices_load() (devices.c:142-196) */
+int xe_gpu_load_devices(xe_gpu *h, const char *path);
+
+/* flattens programs and tries and uploads them; required before the first
+ * batch and after any configuration change */
+int xe_gpu_commit(xe_gpu *h);
+
+/* ---- data path ---- */
+/* replaces the per-datagram entry points netflow_process() (netflow.h:157,
+ * netflow.c:788) and sflow_process() (sflow.h:17, sflow-impl.h:293) for a
+ * whole batch of datagrams in arrival order:
+ *   data      all datagrams back to back
+ *   offsets   n+1 byte offsets into data (datagram i = [offsets[i], offsets[i+1]))
+ *   src_ip4   per datagram: exporter IPv4 as flow_packet_info.src_addr_ipv4
+ *             (flow-info.h:38), i.e. the 4 address bytes in memory order
+ *   kinds     per datagram XE_KIND_*, or NULL for all-Netflow
+ * The host pre-pass walks set headers in order (templates arrive in-band),
+ * then everything the kernels need is copied to HBM.  The batch keeps no
+ * pointer into the caller's arrays. */
+int xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets,
+	const uint32_t *src_ip4, const uint8_t *kinds, size_t n, xe_batch **out);
+void xe_gpu_batch_free(xe_batch *b);
+
+/* decode + classify every record of the batch on the device.  stream is a
+ * hipStream_t (NULL = the null stream); the call only enqueues work.  May be
+ * repeated; each run overwrites the batch's outputs and re-zeroes its counters. */
+int xe_gpu_batch_run(xe_batch *b, void *stream);
+/* blocks until the batch's last run has finished */
+int xe_gpu_batch_sync(xe_batch *b);
+
+/* sizes */
+size_t xe_gpu_batch_records(const xe_batch *b);      /* records reaching classification */
+size_t xe_gpu_batch_mask_words(const xe_batch *b);   /* 64-bit words per record */
+size_t xe_gpu_batch_payload_bytes(const xe_batch *b);/* datagram bytes in the batch */
+/* bytes the kernels must move at minimum for this batch: datagram bytes +
+ * stored widths of every decoded field + 1 presence byte + mask words */
+size_t xe_gpu_batch_algorithmic_bytes(const xe_batch *b);
+
+/* results (device -> caller memory; each implies xe_gpu_batch_sync) */
+/* masks[record][words]: bit m of a record = object m received it, i.e. what
+ * monit_object_process_nf() (monit-objects.h:288) would have been called with */
+int xe_gpu_batch_masks(xe_batch *b, uint64_t *masks, size_t nwords_total);
+/* counters[object][3] = {records, sum in_bytes*sampling_rate, sum
+ * in_pkts*sampling_rate}, wrapping u64 (monit-objects.c:995-1007, scale 1) */
+int xe_gpu_batch_counters(xe_batch *b, uint64_t *counters, size_t n_u64);
+/* dropped[record] = 1 where device_rules_check() (devices.c:286-314) returned 0 */
+int xe_gpu_batch_dropped(xe_batch *b, uint8_t *dropped, size_t n);
+/* re-creates the reference's struct flow_info (flow-info.h:10-33) of
+ * records [first, first+count) from the structure-of-arrays output:
+ * out[count][XE_FLOW_INFO_SIZE]; payload_ptr is NULL */
+int xe_gpu_batch_flow_info(xe_batch *b, size_t first, size_t count, void *out);
+/* one decoded column as the device wrote it: width bytes per record (the
+ * field's maximum size; 6-byte MACs are stored in 8).  field = index in the
+ * field table (xe_field_*).  Returns XE_EINVAL when no template of the batch
+ * carries the field. */
+int xe_gpu_batch_column(xe_batch *b, int field, void *out, size_t outlen, size_t *width);
+/* device pointers of the resident outputs, for consumers that stay on the GPU */
+int xe_gpu_batch_device_ptrs(xe_batch *b, const void **masks, const void **counters,
+	const void **nparsed);
+
+/* ---- field table (netflow.def:2-64 + the virtual fields of flow-info.h:19-30) ---- */
+int xe_field_count(void);
+const char *xe_field_name(int field);
+int xe_field_id(int field);          /* element id, -1 for dev_ip6 / dev_id / dev_mark */
+int xe_field_size_min(int field);
+int xe_field_size_max(int field);
+size_t xe_field_offset(int field);   /* offsetof(struct flow_info, <field>) */
+
+/* ---- flattened IP-list probe (tests): deepest-node match of iplist_match4/6
+ * (iplist.c:160-216) evaluated on the DEVICE for n addresses */
+int xe_gpu_iplist_match(xe_gpu *h, const char *list, int family, const uint8_t *addrs,
+	size_t n, uint8_t *out);
+
+/* library build info: "gfx950" when the code object was built for MI355X */
+const char *xe_gpu_build_arch(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

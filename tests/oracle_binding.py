@@ -1,0 +1,202 @@
+"""ctypes binding of the CPU oracle (oracle/libxe_oracle.so) and of the
+reference units prebuilt under oracle/_ref.  Test infrastructure only."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "libxe_oracle.so")
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+
+FLOW_INFO_SIZE = 2312
+
+
+class Oracle:
+    def __init__(self, path=ORACLE_SO):
+        if not os.path.exists(path):
+            raise RuntimeError("oracle not built: run `make -C oracle` (or __graft_entry__.build())")
+        L = self.L = C.CDLL(path)
+        L.xo_field_name.restype = C.c_char_p
+        for f in ("xo_field_off", "xo_field_off_size", "xo_field_off_has", "xo_off_sampling_rate",
+                  "xo_off_payload_ptr", "xo_log_nrecords", "xo_log_mask_words"):
+            getattr(L, f).restype = C.c_size_t
+        L.xo_iplist_add_text.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        L.xo_iplist_load_dir.argtypes = [C.c_char_p]
+        L.xo_iplist_match4.argtypes = [C.c_char_p, C.c_uint32]
+        L.xo_iplist_match6.argtypes = [C.c_char_p, C.c_char_p]
+        L.xo_iplist_nodes.argtypes = [C.c_char_p, C.c_int]
+        L.xo_iplist_nodes.restype = C.c_size_t
+        L.xo_filter_parse.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        L.xo_filter_dump.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+        L.xo_filter_match.argtypes = [C.c_int, C.c_void_p]
+        L.xo_mo_add.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_size_t]
+        L.xo_device_add.argtypes = [C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int,
+                                    C.POINTER(C.c_char_p), C.c_int, C.c_char_p, C.c_size_t]
+        L.xo_netflow_process.argtypes = [C.c_char_p, C.c_int, C.c_uint32]
+        L.xo_sflow_process.argtypes = [C.c_char_p, C.c_int, C.c_uint32]
+        L.xo_log_config.argtypes = [C.c_int, C.c_size_t]
+        L.xo_log_mask.argtypes = [C.c_size_t]
+        L.xo_log_mask.restype = C.POINTER(C.c_uint64)
+        L.xo_log_dropped.argtypes = [C.c_size_t]
+        L.xo_log_flow.argtypes = [C.c_size_t]
+        L.xo_log_flow.restype = C.c_void_p
+        L.xo_counters.restype = C.POINTER(C.c_uint64)
+        L.xo_mac_addr_read.argtypes = [C.c_char_p, C.c_char_p]
+        self.reset()
+
+    def reset(self):
+        self.L.xo_reset()
+
+    # field table
+    def fields(self):
+        out = []
+        for i in range(self.L.xo_nfields()):
+            out.append(dict(idx=i, name=self.L.xo_field_name(i).decode(), id=self.L.xo_field_id(i),
+                            type=self.L.xo_field_type(i), min=self.L.xo_field_min(i),
+                            max=self.L.xo_field_max(i), off=self.L.xo_field_off(i),
+                            off_size=self.L.xo_field_off_size(i), off_has=self.L.xo_field_off_has(i)))
+        return out
+
+    def iplist_add(self, name, text):
+        if isinstance(text, str):
+            text = text.encode()
+        return self.L.xo_iplist_add_text(name.encode(), text, len(text))
+
+    def iplist_load_dir(self, d):
+        return self.L.xo_iplist_load_dir(d.encode())
+
+    def match4(self, name, addr_bytes):
+        return self.L.xo_iplist_match4(name.encode(), int.from_bytes(addr_bytes, "little"))
+
+    def match6(self, name, addr_bytes):
+        return self.L.xo_iplist_match6(name.encode(), bytes(addr_bytes))
+
+    def filter_parse(self, text):
+        err = C.create_string_buffer(1100)
+        h = self.L.xo_filter_parse(text.encode(), err, len(err))
+        if h < 0:
+            raise ValueError(err.value.decode(errors="replace"))
+        return h
+
+    def filter_dump(self, h):
+        buf = C.create_string_buffer(1 << 16)
+        n = self.L.xo_filter_dump(h, buf, len(buf))
+        assert n >= 0
+        return buf.value.decode()
+
+    def filter_match(self, h, flow_bytes):
+        b = C.create_string_buffer(bytes(flow_bytes), FLOW_INFO_SIZE)
+        return self.L.xo_filter_match(h, C.cast(b, C.c_void_p))
+
+    def mo_add(self, filt, parent=-1):
+        err = C.create_string_buffer(1100)
+        i = self.L.xo_mo_add(parent, filt.encode(), err, len(err))
+        if i < 0:
+            raise ValueError(err.value.decode(errors="replace"))
+        return i
+
+    def device_add(self, ip=None, dev_id=None, sampling_rate=0, skip_unmarked=False, marks=()):
+        import socket
+        err = C.create_string_buffer(1100)
+        arr = (C.c_char_p * max(1, len(marks)))(*[m.encode() for m in marks])
+        ipn = int.from_bytes(socket.inet_aton(ip), "little") if ip is not None else 0
+        ok = self.L.xo_device_add(ip is not None, ipn, dev_id is not None, dev_id or 0,
+                                  sampling_rate, int(skip_unmarked), arr, len(marks), err, len(err))
+        if not ok:
+            raise ValueError(err.value.decode(errors="replace"))
+
+    def log_config(self, keep_flows=True, max_records=0):
+        self.L.xo_log_config(int(keep_flows), max_records)
+
+    def netflow(self, pkt, src_ip4_bytes):
+        return self.L.xo_netflow_process(bytes(pkt), len(pkt), int.from_bytes(src_ip4_bytes, "little"))
+
+    def sflow(self, pkt, src_ip4_bytes=b"\0\0\0\0"):
+        return self.L.xo_sflow_process(bytes(pkt), len(pkt), int.from_bytes(src_ip4_bytes, "little"))
+
+    def nrecords(self):
+        return self.L.xo_log_nrecords()
+
+    def masks(self):
+        n, w = self.nrecords(), self.L.xo_log_mask_words()
+        if n == 0:
+            return np.zeros((0, w), dtype=np.uint64)
+        p = self.L.xo_log_mask(0)
+        return np.ctypeslib.as_array(p, shape=(n, w)).copy()
+
+    def dropped(self):
+        return np.array([self.L.xo_log_dropped(i) for i in range(self.nrecords())], dtype=np.uint8)
+
+    def flows(self):
+        n = self.nrecords()
+        if n == 0:
+            return np.zeros((0, FLOW_INFO_SIZE), dtype=np.uint8)
+        p = self.L.xo_log_flow(0)
+        assert p, "log_config(keep_flows=True) first"
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n, FLOW_INFO_SIZE)).copy()
+
+    def counters(self):
+        n = self.L.xo_nmo()
+        p = self.L.xo_counters()
+        return np.ctypeslib.as_array(p, shape=(max(n, 1), 3)).copy()[:n]
+
+    def log_clear(self):
+        self.L.xo_log_clear()
+
+
+def have_ref(name):
+    return os.path.exists(os.path.join(REF_DIR, name))
+
+
+class RefIplist:
+    """The reference's own iplist.c (oracle/_ref/libref_iplist.so).  Its list
+    registry is process-global and load-once, so every call loads a fresh
+    directory of uniquely named lists."""
+
+    def __init__(self):
+        L = self.L = C.CDLL(os.path.join(REF_DIR, "libref_iplist.so"))
+        L.iplists_load.argtypes = [C.c_char_p]
+        L.iplist_get_by_name.argtypes = [C.c_char_p]
+        L.iplist_get_by_name.restype = C.c_void_p
+        L.iplist_match4.argtypes = [C.c_void_p, C.c_uint32]
+        L.iplist_match6.argtypes = [C.c_void_p, C.c_char_p]
+
+    def load_dir(self, d):
+        return self.L.iplists_load(d.encode())
+
+    def get(self, name):
+        return self.L.iplist_get_by_name(name.encode())
+
+    def match4(self, h, addr_bytes):
+        return self.L.iplist_match4(h, int.from_bytes(addr_bytes, "little"))
+
+    def match6(self, h, addr_bytes):
+        return self.L.iplist_match6(h, bytes(addr_bytes))
+
+
+class RefSflow:
+    def __init__(self):
+        L = self.L = C.CDLL(os.path.join(REF_DIR, "libref_sflow.so"))
+        L.ref_sflow_process.argtypes = [C.c_char_p, C.c_int]
+        L.ref_sflow_nrec.restype = C.c_size_t
+        L.ref_sflow_rec.argtypes = [C.c_size_t]
+        L.ref_sflow_rec.restype = C.c_void_p
+        L.ref_flow_info_size.restype = C.c_size_t
+        assert L.ref_flow_info_size() == FLOW_INFO_SIZE
+
+    def process(self, pkt):
+        rc = self.L.ref_sflow_process(bytes(pkt), len(pkt))
+        n = self.L.ref_sflow_nrec()
+        recs = np.zeros((n, FLOW_INFO_SIZE), dtype=np.uint8)
+        for i in range(n):
+            recs[i] = np.frombuffer(C.string_at(self.L.ref_sflow_rec(i), FLOW_INFO_SIZE), dtype=np.uint8)
+        return rc, recs
+
+
+class RefUtils:
+    def __init__(self):
+        L = self.L = C.CDLL(os.path.join(REF_DIR, "libref_utils.so"))
+        L.mac_addr_read.argtypes = [C.c_char_p, C.c_char_p]
+        L.tcp_flags_to_str.argtypes = [C.c_uint8]
+        L.tcp_flags_to_str.restype = C.c_char_p

@@ -1,0 +1,256 @@
+"""xenoeye_amd: MI355X flow path (Netflow v5/v9/IPFIX/sFlow decode + monitoring
+object classification) behind the C ABI of include/xe_gpu.h.
+
+This module is only a ctypes view of libxenoeye_gpu.so for tests, the
+benchmark and Python callers; all work happens in the library.  There is no
+Python or CPU implementation of the path here: without the built library (or
+without a GPU) every entry point raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxenoeye_gpu.so")
+FLOW_INFO_SIZE = 2312
+
+_lib = None
+
+
+class XeError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        super().__init__("xe_gpu error %d: %s" % (code, detail))
+
+
+def load_library(path=LIB_PATH):
+    """Load the HIP library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RuntimeError("%s is missing: run `python __graft_entry__.py` (build()) first; "
+                           "there is no fallback implementation" % path)
+    L = C.CDLL(path)
+    vp, cp, sz, i32, u32 = C.c_void_p, C.c_char_p, C.c_size_t, C.c_int, C.c_uint32
+    sig = {
+        "xe_gpu_strerror": (cp, [i32]),
+        "xe_gpu_last_error": (cp, [vp]),
+        "xe_gpu_build_arch": (cp, []),
+        "xe_gpu_create": (i32, [C.POINTER(vp), i32]),
+        "xe_gpu_destroy": (None, [vp]),
+        "xe_gpu_load_iplists": (i32, [vp, cp]),
+        "xe_gpu_add_iplist": (i32, [vp, cp, cp, sz]),
+        "xe_gpu_add_mo": (i32, [vp, cp, i32, cp]),
+        "xe_gpu_load_mos": (i32, [vp, cp]),
+        "xe_gpu_mo_count": (i32, [vp]),
+        "xe_gpu_mo_name": (cp, [vp, i32]),
+        "xe_gpu_mo_parent": (i32, [vp, i32]),
+        "xe_gpu_mo_dump": (i32, [vp, i32, cp, sz]),
+        "xe_filter_check": (i32, [vp, cp, cp, sz, cp, sz]),
+        "xe_gpu_add_device": (i32, [vp, i32, u32, i32, u32, i32, i32, C.POINTER(cp), i32]),
+        "xe_gpu_load_devices": (i32, [vp, cp]),
+        "xe_gpu_commit": (i32, [vp]),
+        "xe_gpu_batch_prepare": (i32, [vp, vp, vp, vp, vp, sz, C.POINTER(vp)]),
+        "xe_gpu_batch_free": (None, [vp]),
+        "xe_gpu_batch_run": (i32, [vp, vp]),
+        "xe_gpu_batch_sync": (i32, [vp]),
+        "xe_gpu_batch_records": (sz, [vp]),
+        "xe_gpu_batch_mask_words": (sz, [vp]),
+        "xe_gpu_batch_payload_bytes": (sz, [vp]),
+        "xe_gpu_batch_algorithmic_bytes": (sz, [vp]),
+        "xe_gpu_batch_masks": (i32, [vp, vp, sz]),
+        "xe_gpu_batch_counters": (i32, [vp, vp, sz]),
+        "xe_gpu_batch_dropped": (i32, [vp, vp, sz]),
+        "xe_gpu_batch_flow_info": (i32, [vp, sz, sz, vp]),
+        "xe_gpu_batch_column": (i32, [vp, i32, vp, sz, C.POINTER(sz)]),
+        "xe_gpu_batch_device_ptrs": (i32, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+        "xe_field_count": (i32, []),
+        "xe_field_name": (cp, [i32]),
+        "xe_field_id": (i32, [i32]),
+        "xe_field_size_min": (i32, [i32]),
+        "xe_field_size_max": (i32, [i32]),
+        "xe_field_offset": (sz, [i32]),
+        "xe_gpu_iplist_match": (i32, [vp, cp, i32, vp, sz, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)   # AttributeError = the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = None  # filled lazily by tests from include/xe_gpu.h
+
+
+def fields():
+    L = load_library()
+    return [dict(idx=i, name=L.xe_field_name(i).decode(), id=L.xe_field_id(i), min=L.xe_field_size_min(i),
+                 max=L.xe_field_size_max(i), off=L.xe_field_offset(i)) for i in range(L.xe_field_count())]
+
+
+def filter_check(text, engine=None):
+    """(ok_on_device, dump_text, error_text) for a filter string."""
+    L = load_library()
+    dump = C.create_string_buffer(1 << 16)
+    err = C.create_string_buffer(1024)
+    rc = L.xe_filter_check(engine._h if engine else None, text.encode(), dump, len(dump), err, len(err))
+    return rc, dump.value.decode(), err.value.decode(errors="replace")
+
+
+class Engine:
+    """One xe_gpu handle: configuration + device state on one GPU."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.xe_gpu_create(C.byref(h), device)
+        if rc != 0:
+            raise XeError(rc, "xe_gpu_create(device=%d): %s (no GPU, no fallback)" %
+                          (device, self.L.xe_gpu_strerror(rc).decode()))
+        self._h = h
+
+    def close(self):
+        if self._h:
+            self.L.xe_gpu_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise XeError(rc, "%s: %s" % (self.L.xe_gpu_strerror(rc).decode(),
+                                          self.L.xe_gpu_last_error(self._h).decode(errors="replace")))
+        return rc
+
+    def load_iplists(self, d):
+        self._chk(self.L.xe_gpu_load_iplists(self._h, d.encode()))
+
+    def add_iplist(self, name, text):
+        if isinstance(text, str):
+            text = text.encode()
+        self._chk(self.L.xe_gpu_add_iplist(self._h, name.encode(), text, len(text)))
+
+    def add_mo(self, name, filt, parent=-1):
+        return self._chk(self.L.xe_gpu_add_mo(self._h, name.encode(), parent, filt.encode()))
+
+    def load_mos(self, d):
+        self._chk(self.L.xe_gpu_load_mos(self._h, d.encode()))
+
+    def load_devices(self, path):
+        self._chk(self.L.xe_gpu_load_devices(self._h, path.encode()))
+
+    def mo_count(self):
+        return self.L.xe_gpu_mo_count(self._h)
+
+    def mo_name(self, i):
+        return self.L.xe_gpu_mo_name(self._h, i).decode()
+
+    def mo_parent(self, i):
+        return self.L.xe_gpu_mo_parent(self._h, i)
+
+    def mo_dump(self, i):
+        buf = C.create_string_buffer(1 << 16)
+        self._chk(self.L.xe_gpu_mo_dump(self._h, i, buf, len(buf)))
+        return buf.value.decode()
+
+    def add_device(self, ip=None, dev_id=None, sampling_rate=0, skip_unmarked=False, marks=()):
+        import socket
+        arr = (C.c_char_p * max(1, len(marks)))(*[m.encode() for m in marks])
+        ipn = int.from_bytes(socket.inet_aton(ip), "little") if ip is not None else 0
+        self._chk(self.L.xe_gpu_add_device(self._h, int(ip is not None), ipn, int(dev_id is not None),
+                                           dev_id or 0, sampling_rate, int(skip_unmarked), arr, len(marks)))
+
+    def commit(self):
+        self._chk(self.L.xe_gpu_commit(self._h))
+
+    def iplist_match(self, name, family, addrs):
+        a = np.ascontiguousarray(addrs, dtype=np.uint8)
+        n = a.size // (4 if family == 4 else 16)
+        out = np.zeros(n, dtype=np.uint8)
+        self._chk(self.L.xe_gpu_iplist_match(self._h, name.encode(), family, a.ctypes.data, n, out.ctypes.data))
+        return out
+
+    def prepare(self, batch):
+        """batch: synth.Batch or (data, offsets, src, kinds) arrays."""
+        if hasattr(batch, "packed"):
+            data, offs, src, kinds = batch.packed()
+        else:
+            data, offs, src, kinds = batch
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        src = np.ascontiguousarray(src, dtype=np.uint32)
+        kinds = None if kinds is None else np.ascontiguousarray(kinds, dtype=np.uint8)
+        n = len(offs) - 1
+        b = C.c_void_p()
+        self._chk(self.L.xe_gpu_batch_prepare(self._h, data.ctypes.data, offs.ctypes.data, src.ctypes.data,
+                                              kinds.ctypes.data if kinds is not None else None, n, C.byref(b)))
+        return PreparedBatch(self, b)
+
+
+class PreparedBatch:
+    def __init__(self, eng, handle):
+        self.eng = eng
+        self.L = eng.L
+        self._b = handle
+        self.records = self.L.xe_gpu_batch_records(handle)
+        self.mask_words = self.L.xe_gpu_batch_mask_words(handle)
+        self.payload_bytes = self.L.xe_gpu_batch_payload_bytes(handle)
+        self.algorithmic_bytes = self.L.xe_gpu_batch_algorithmic_bytes(handle)
+
+    def free(self):
+        if self._b:
+            self.L.xe_gpu_batch_free(self._b)
+            self._b = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def run(self, stream=None):
+        self.eng._chk(self.L.xe_gpu_batch_run(self._b, stream))
+
+    def sync(self):
+        self.eng._chk(self.L.xe_gpu_batch_sync(self._b))
+
+    def masks(self):
+        out = np.zeros((self.records, self.mask_words), dtype=np.uint64)
+        self.eng._chk(self.L.xe_gpu_batch_masks(self._b, out.ctypes.data, out.size))
+        return out
+
+    def counters(self):
+        n = self.eng.mo_count()
+        out = np.zeros((max(n, 1), 3), dtype=np.uint64)
+        self.eng._chk(self.L.xe_gpu_batch_counters(self._b, out.ctypes.data, out.size))
+        return out[:n]
+
+    def dropped(self):
+        out = np.zeros(max(self.records, 1), dtype=np.uint8)
+        self.eng._chk(self.L.xe_gpu_batch_dropped(self._b, out.ctypes.data, out.size))
+        return out[:self.records]
+
+    def flow_info(self, first=0, count=None):
+        count = self.records - first if count is None else count
+        out = np.zeros((count, FLOW_INFO_SIZE), dtype=np.uint8)
+        if count:
+            self.eng._chk(self.L.xe_gpu_batch_flow_info(self._b, first, count, out.ctypes.data))
+        return out
+
+    def column(self, field):
+        w = C.c_size_t()
+        probe = np.zeros(1, dtype=np.uint8)
+        # first call only learns the width
+        self.L.xe_gpu_batch_column(self._b, field, probe.ctypes.data, 0, C.byref(w))
+        if w.value == 0:
+            raise XeError(-1, "field %d has no column in this batch" % field)
+        out = np.zeros((self.records, w.value), dtype=np.uint8)
+        self.eng._chk(self.L.xe_gpu_batch_column(self._b, field, out.ctypes.data, out.size, C.byref(w)))
+        return out

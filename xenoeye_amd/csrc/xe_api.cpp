@@ -1,0 +1,880 @@
+/*
+ * xe_api.cpp -- the C ABI of include/xe_gpu.h: handle life cycle, flattening
+ * of the configuration into device arrays, batch upload / launch / download
+ * and the re-creation of struct flow_info from the column output.
+ *
+ * There is no CPU evaluation path in this file or behind it: without a HIP
+ * device xe_gpu_create() fails and nothing else can be called.
+ */
+#include <hip/hip_runtime_api.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <arpa/inet.h>
+#include "xe_kernels.h"
+
+extern "C" int xe_launch_init_tables(void);
+
+struct xe_gpu
+{
+	int device;
+	struct xe_host hs;
+	int committed;
+	void *d_progs, *d_ops, *d_terms, *d_opnds, *d_trie, *d_lists, *d_devrules;
+	uint32_t nmo, mask_words, nprogs_total;
+	struct xe_list_dev *h_lists;
+	void *d_tmpls, *d_tents;
+	size_t up_tmpls, up_tents;
+	char err[512];
+};
+
+struct xe_batch
+{
+	struct xe_gpu *h;
+	struct xe_plan plan;
+	size_t ntot, payload_bytes;
+	void *d_pkt, *d_sets, *d_exps, *d_sfrecs, *d_out;
+	size_t out_bytes, masks_off, nparsed_off, marks_off, counters_off, sfhas_off;
+	struct xe_kparams kp;
+	hipStream_t last_stream;
+	int ran;
+};
+
+#define ALIGN_UP(x, a) (((x) + (a) - 1) / (a) * (a))
+
+static int
+hip_fail(struct xe_gpu *h, hipError_t e, const char *what)
+{
+	if (h) snprintf(h->err, sizeof(h->err), "%s: %s", what, hipGetErrorString(e));
+	return XE_EHIP;
+}
+
+#define HIPCHK(H, CALL) do { hipError_t e_ = (CALL); if (e_ != hipSuccess) return hip_fail((H), e_, #CALL); } while (0)
+
+extern "C" const char *
+xe_gpu_strerror(int code)
+{
+	switch (code) {
+		case XE_OK: return "ok";
+		case XE_EINVAL: return "invalid argument";
+		case XE_ENOMEM: return "out of host memory";
+		case XE_EHIP: return "HIP runtime error";
+		case XE_EPARSE: return "parse error";
+		case XE_EUNSUPPORTED: return "not evaluable on the device";
+		case XE_ESTATE: return "call out of order";
+		case XE_EIO: return "cannot read file or directory";
+		default: return "unknown error";
+	}
+}
+
+extern "C" const char *
+xe_gpu_last_error(const xe_gpu *h)
+{
+	return h ? h->err : "";
+}
+
+extern "C" const char *
+xe_gpu_build_arch(void)
+{
+	return XE_BUILD_ARCH;
+}
+
+extern "C" int
+xe_gpu_create(xe_gpu **out, int device)
+{
+	int ndev = 0;
+	xe_gpu *h;
+
+	if (!out) return XE_EINVAL;
+	*out = NULL;
+	if ((hipGetDeviceCount(&ndev) != hipSuccess) || (device < 0) || (device >= ndev)) return XE_EHIP;
+	if (hipSetDevice(device) != hipSuccess) return XE_EHIP;
+	h = (xe_gpu *)calloc(1, sizeof(*h));
+	if (!h) return XE_ENOMEM;
+	h->device = device;
+	xe_host_init(&h->hs);
+	if (xe_launch_init_tables() != XE_OK) {
+		free(h);
+		return XE_EHIP;
+	}
+	*out = h;
+	return XE_OK;
+}
+
+static void
+free_config_dev(xe_gpu *h)
+{
+	void **p[] = { &h->d_progs, &h->d_ops, &h->d_terms, &h->d_opnds, &h->d_trie, &h->d_lists, &h->d_devrules };
+	for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); i++) {
+		if (*p[i]) (void)hipFree(*p[i]);
+		*p[i] = NULL;
+	}
+	free(h->h_lists);
+	h->h_lists = NULL;
+}
+
+extern "C" void
+xe_gpu_destroy(xe_gpu *h)
+{
+	if (!h) return;
+	(void)hipSetDevice(h->device);
+	free_config_dev(h);
+	if (h->d_tmpls) (void)hipFree(h->d_tmpls);
+	if (h->d_tents) (void)hipFree(h->d_tents);
+	xe_host_free(&h->hs);
+	free(h);
+}
+
+/* ------------------------------------------------------------------ configuration */
+extern "C" int
+xe_gpu_load_iplists(xe_gpu *h, const char *dir)
+{
+	int rc;
+	if (!h || !dir) return XE_EINVAL;
+	rc = xe_iplist_load_dir(&h->hs.lists, dir);
+	if (rc != XE_OK) snprintf(h->err, sizeof(h->err), "cannot load IP lists from '%s'", dir);
+	h->committed = 0;
+	return rc;
+}
+
+extern "C" int
+xe_gpu_add_iplist(xe_gpu *h, const char *name, const char *text, size_t len)
+{
+	if (!h || !name || (!text && len)) return XE_EINVAL;
+	h->committed = 0;
+	return xe_iplist_load_text(&h->hs.lists, name, text, len);
+}
+
+/* deepest stack the bit-stack evaluator would need */
+static size_t
+prog_depth(const struct xe_filter *f)
+{
+	size_t sp = 0, mx = 0;
+	for (size_t i = 0; i < f->nops; i++) {
+		uint32_t op = f->ops[i] & 3;
+		if (op == XE_OP_BASIC) { sp++; if (sp > mx) mx = sp; }
+		else if ((op == XE_OP_AND) || (op == XE_OP_OR)) { if (sp >= 2) sp--; }
+	}
+	return mx;
+}
+
+static int
+compile_checked(xe_gpu *h, const char *text, struct xe_filter *f)
+{
+	char perr[600];
+	int rc = xe_filter_compile(&h->hs.lists, text ? text : "", f, perr, sizeof(perr));
+
+	if (rc != XE_OK) {
+		snprintf(h->err, sizeof(h->err), "filter '%.200s': %.250s", text ? text : "", perr);
+		return rc;
+	}
+	if (!f->device_ok) {
+		snprintf(h->err, sizeof(h->err), "filter '%.200s': %s", text, f->why);
+		xe_filter_free(f);
+		return XE_EUNSUPPORTED;
+	}
+	if (prog_depth(f) > 64) {
+		snprintf(h->err, sizeof(h->err), "filter '%.200s': expression nests deeper than 64", text);
+		xe_filter_free(f);
+		return XE_EUNSUPPORTED;
+	}
+	return XE_OK;
+}
+
+extern "C" int
+xe_gpu_add_mo(xe_gpu *h, const char *name, int parent, const char *filter)
+{
+	struct xe_mo *nm;
+	struct xe_filter f;
+	int rc;
+
+	if (!h || (parent < -1) || (parent >= (int)h->hs.nmos)) return XE_EINVAL;
+	rc = compile_checked(h, filter, &f);
+	if (rc != XE_OK) return rc;
+	nm = (struct xe_mo *)realloc(h->hs.mos, (h->hs.nmos + 1) * sizeof(*nm));
+	if (!nm) { xe_filter_free(&f); return XE_ENOMEM; }
+	h->hs.mos = nm;
+	nm = &h->hs.mos[h->hs.nmos];
+	memset(nm, 0, sizeof(*nm));
+	snprintf(nm->name, sizeof(nm->name), "%s", name ? name : "");
+	nm->parent = parent;
+	nm->filter = f;
+	h->committed = 0;
+	return (int)h->hs.nmos++;
+}
+
+extern "C" int xe_gpu_mo_count(const xe_gpu *h) { return h ? (int)h->hs.nmos : XE_EINVAL; }
+
+extern "C" const char *
+xe_gpu_mo_name(const xe_gpu *h, int mo)
+{
+	return (h && (mo >= 0) && ((size_t)mo < h->hs.nmos)) ? h->hs.mos[mo].name : NULL;
+}
+
+extern "C" int
+xe_gpu_mo_parent(const xe_gpu *h, int mo)
+{
+	return (h && (mo >= 0) && ((size_t)mo < h->hs.nmos)) ? h->hs.mos[mo].parent : XE_EINVAL;
+}
+
+extern "C" int
+xe_gpu_mo_dump(const xe_gpu *h, int mo, char *out, size_t outlen)
+{
+	if (!h || (mo < 0) || ((size_t)mo >= h->hs.nmos) || !out) return XE_EINVAL;
+	return xe_filter_dump_text(&h->hs.lists, &h->hs.mos[mo].filter, out, outlen);
+}
+
+extern "C" int
+xe_filter_check(const xe_gpu *h, const char *filter, char *dump, size_t dumplen, char *err, size_t errlen)
+{
+	struct xe_filter f;
+	int rc = xe_filter_compile(h ? &h->hs.lists : NULL, filter ? filter : "", &f, err, errlen);
+	if (rc != XE_OK) return rc;
+	if (dump && dumplen) xe_filter_dump_text(h ? &h->hs.lists : NULL, &f, dump, dumplen);
+	rc = f.device_ok ? XE_OK : XE_EUNSUPPORTED;
+	if ((rc != XE_OK) && err && errlen) snprintf(err, errlen, "%s", f.why);
+	xe_filter_free(&f);
+	return rc;
+}
+
+extern "C" int
+xe_gpu_add_device(xe_gpu *h, int use_ip, uint32_t ip, int use_id, uint32_t id, int sampling_rate,
+	int skip_unmarked, const char *const *marks, int nmarks)
+{
+	struct xe_device d, *nd;
+
+	if (!h || (nmarks < 0) || (nmarks && !marks)) return XE_EINVAL;
+	memset(&d, 0, sizeof(d));
+	d.use_ip = use_ip;
+	d.ip = ip;
+	d.use_id = use_id;
+	d.id = htonl(id);   /* devices.c:100 */
+	d.sampling_rate = sampling_rate;
+	d.skip_unmarked = skip_unmarked;
+	if (nmarks) {
+		d.marks = (struct xe_filter *)calloc((size_t)nmarks, sizeof(struct xe_filter));
+		if (!d.marks) return XE_ENOMEM;
+		for (int i = 0; i < nmarks; i++) {
+			int rc = compile_checked(h, marks[i], &d.marks[i]);
+			if (rc != XE_OK) {
+				for (int j = 0; j < i; j++) xe_filter_free(&d.marks[j]);
+				free(d.marks);
+				return rc;
+			}
+			d.nmarks++;
+		}
+	}
+	nd = (struct xe_device *)realloc(h->hs.devs, (h->hs.ndevs + 1) * sizeof(*nd));
+	if (!nd) return XE_ENOMEM;
+	h->hs.devs = nd;
+	h->hs.devs[h->hs.ndevs++] = d;
+	h->committed = 0;
+	return XE_OK;
+}
+
+static int
+add_mo_cb(void *user, const char *name, int parent, const char *filter)
+{
+	return xe_gpu_add_mo((xe_gpu *)user, name, parent, filter);
+}
+
+static int
+add_dev_cb(void *user, int use_ip, uint32_t ip, int use_id, uint32_t id, int rate, int skip,
+	const char *const *marks, int nmarks)
+{
+	return xe_gpu_add_device((xe_gpu *)user, use_ip, ip, use_id, id, rate, skip, marks, nmarks);
+}
+
+extern "C" int
+xe_gpu_load_mos(xe_gpu *h, const char *mo_dir)
+{
+	if (!h || !mo_dir) return XE_EINVAL;
+	return xe_conf_load_mos(&h->hs, mo_dir, add_mo_cb, h);
+}
+
+extern "C" int
+xe_gpu_load_devices(xe_gpu *h, const char *path)
+{
+	if (!h || !path) return XE_EINVAL;
+	return xe_conf_load_devices(&h->hs, path, add_dev_cb, h);
+}
+
+static uint64_t
+be_bytes(const uint8_t *b, int n)
+{
+	uint64_t v = 0;
+	for (int i = 0; i < n; i++) v = (v << 8) | b[i];
+	return v;
+}
+
+static int
+upload(xe_gpu *h, void **dst, const void *src, size_t bytes)
+{
+	*dst = NULL;
+	if (!bytes) bytes = 16;
+	HIPCHK(h, hipMalloc(dst, ALIGN_UP(bytes, 256)));
+	if (src) HIPCHK(h, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+	return XE_OK;
+}
+
+/* append one compiled filter to the flat arrays */
+static int
+append_prog(struct xe_blob *progs, struct xe_blob *ops, struct xe_blob *terms, struct xe_blob *opnds,
+	const struct xe_filter *f, int parent)
+{
+	struct xe_prog pr;
+	int cval = 0;
+	uint32_t term_base = (uint32_t)terms->n, opnd_base = (uint32_t)opnds->n;
+
+	memset(&pr, 0, sizeof(pr));
+	pr.parent = parent;
+	pr.op_base = (uint32_t)ops->n;
+	if (xe_filter_constant(f, &cval)) {
+		pr.flags = XE_PROG_CONST;
+		pr.cval = (uint16_t)cval;
+		return xe_blob_push(progs, &pr, sizeof(pr)) ? XE_OK : XE_ENOMEM;
+	}
+	pr.nops = (uint32_t)f->nops;
+	for (size_t i = 0; i < f->nops; i++) {
+		uint32_t w = f->ops[i];
+		if ((w & 3) == XE_OP_BASIC) w = XE_OP_BASIC | (((w >> 2) + term_base) << 2);
+		if (!xe_blob_push(ops, &w, 4)) return XE_ENOMEM;
+	}
+	for (size_t i = 0; i < f->nterms; i++) {
+		struct xe_term t = f->terms[i];
+		t.opnd_base += opnd_base;
+		if (!xe_blob_push(terms, &t, sizeof(t))) return XE_ENOMEM;
+		for (uint32_t j = 0; j < f->terms[i].nopnd; j++) {
+			const struct xe_opnd *o = &f->opnds[f->terms[i].opnd_base + j];
+			const uint8_t *b = (const uint8_t *)&o->w[0];
+			struct xe_dopnd d;
+
+			memset(&d, 0, sizeof(d));
+			d.is_list = o->is_list;
+			switch (t.type) {
+				case XE_BT_ADDR4:
+					if (o->is_list) d.list = o->w[0];
+					else { d.net_lo = be_bytes(b, 4); d.mask_lo = be_bytes(b + 4, 4); }
+					break;
+				case XE_BT_ADDR6:
+					if (o->is_list) d.list = o->w[0];
+					else {
+						d.net_hi = be_bytes(b, 8); d.net_lo = be_bytes(b + 8, 8);
+						d.mask_hi = be_bytes(b + 16, 8); d.mask_lo = be_bytes(b + 24, 8);
+					}
+					break;
+				case XE_BT_RANGE:
+					d.low = (int32_t)o->w[0];
+					d.high = (int32_t)o->w[1];
+					break;
+				case XE_BT_MAC:
+					d.net_lo = be_bytes(b, 6);
+					break;
+				default:
+					break;
+			}
+			if (!xe_blob_push(opnds, &d, sizeof(d))) return XE_ENOMEM;
+		}
+	}
+	return xe_blob_push(progs, &pr, sizeof(pr)) ? XE_OK : XE_ENOMEM;
+}
+
+extern "C" int
+xe_gpu_commit(xe_gpu *h)
+{
+	struct xe_blob progs = {0}, ops = {0}, terms = {0}, opnds = {0}, trie = {0}, rules = {0};
+	int rc = XE_OK;
+
+	if (!h) return XE_EINVAL;
+	HIPCHK(h, hipSetDevice(h->device));
+	free_config_dev(h);
+
+	for (size_t m = 0; (m < h->hs.nmos) && (rc == XE_OK); m++) {
+		rc = append_prog(&progs, &ops, &terms, &opnds, &h->hs.mos[m].filter, h->hs.mos[m].parent);
+	}
+	for (size_t d = 0; (d < h->hs.ndevs) && (rc == XE_OK); d++) {
+		struct xe_devrule r;
+		memset(&r, 0, sizeof(r));
+		r.first_prog = (uint32_t)progs.n;
+		r.nprogs = (uint32_t)h->hs.devs[d].nmarks;
+		r.skip_unmarked = (uint32_t)h->hs.devs[d].skip_unmarked;
+		for (size_t k = 0; (k < h->hs.devs[d].nmarks) && (rc == XE_OK); k++) {
+			rc = append_prog(&progs, &ops, &terms, &opnds, &h->hs.devs[d].marks[k], -1);
+		}
+		if ((rc == XE_OK) && !xe_blob_push(&rules, &r, sizeof(r))) rc = XE_ENOMEM;
+	}
+	if (rc == XE_OK) {
+		h->h_lists = (struct xe_list_dev *)calloc(h->hs.lists.n ? h->hs.lists.n : 1, sizeof(struct xe_list_dev));
+		if (!h->h_lists) rc = XE_ENOMEM;
+		else rc = xe_iplists_flatten(&h->hs.lists, &trie, h->h_lists);
+	}
+	if (rc == XE_OK) rc = upload(h, &h->d_progs, progs.p, progs.n * sizeof(struct xe_prog));
+	if (rc == XE_OK) rc = upload(h, &h->d_ops, ops.p, ops.n * 4);
+	if (rc == XE_OK) rc = upload(h, &h->d_terms, terms.p, terms.n * sizeof(struct xe_term));
+	if (rc == XE_OK) rc = upload(h, &h->d_opnds, opnds.p, opnds.n * sizeof(struct xe_dopnd));
+	if (rc == XE_OK) rc = upload(h, &h->d_trie, trie.p, trie.n * 4);
+	if (rc == XE_OK) rc = upload(h, &h->d_lists, h->h_lists, h->hs.lists.n * sizeof(struct xe_list_dev));
+	if (rc == XE_OK) rc = upload(h, &h->d_devrules, rules.p, rules.n * sizeof(struct xe_devrule));
+	if (rc == XE_OK) {
+		h->nmo = (uint32_t)h->hs.nmos;
+		h->mask_words = h->nmo ? (h->nmo + 63) / 64 : 1;
+		h->nprogs_total = (uint32_t)progs.n;
+		h->committed = 1;
+	} else {
+		free_config_dev(h);
+	}
+	free(progs.p); free(ops.p); free(terms.p); free(opnds.p); free(trie.p); free(rules.p);
+	return rc;
+}
+
+/* ------------------------------------------------------------------ batches */
+static int
+sync_templates(xe_gpu *h)
+{
+	size_t nt = h->hs.dev_tmpls.n, ne = h->hs.dev_tents.n;
+	int rc;
+
+	if (h->d_tmpls && (nt == h->up_tmpls) && (ne == h->up_tents)) return XE_OK;
+	if (h->d_tmpls) (void)hipFree(h->d_tmpls);
+	if (h->d_tents) (void)hipFree(h->d_tents);
+	h->d_tmpls = h->d_tents = NULL;
+	rc = upload(h, &h->d_tmpls, h->hs.dev_tmpls.p, nt * sizeof(struct xe_tmpl));
+	if (rc == XE_OK) rc = upload(h, &h->d_tents, h->hs.dev_tents.p, ne * sizeof(struct xe_tent));
+	h->up_tmpls = nt;
+	h->up_tents = ne;
+	return rc;
+}
+
+extern "C" void
+xe_gpu_batch_free(xe_batch *b)
+{
+	if (!b) return;
+	(void)hipSetDevice(b->h->device);
+	if (b->ran) (void)hipStreamSynchronize(b->last_stream);
+	if (b->d_pkt) (void)hipFree(b->d_pkt);
+	if (b->d_sets) (void)hipFree(b->d_sets);
+	if (b->d_exps) (void)hipFree(b->d_exps);
+	if (b->d_sfrecs) (void)hipFree(b->d_sfrecs);
+	if (b->d_out) (void)hipFree(b->d_out);
+	xe_plan_free(&b->plan);
+	free(b);
+}
+
+extern "C" int
+xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint32_t *src_ip4,
+	const uint8_t *kinds, size_t n, xe_batch **out)
+{
+	xe_batch *b;
+	int rc;
+	size_t total, off, f;
+
+	if (!h || !out || (n && (!data || !offsets || !src_ip4))) return XE_EINVAL;
+	*out = NULL;
+	if (!h->committed) {
+		snprintf(h->err, sizeof(h->err), "xe_gpu_commit() must follow configuration changes");
+		return XE_ESTATE;
+	}
+	HIPCHK(h, hipSetDevice(h->device));
+	b = (xe_batch *)calloc(1, sizeof(*b));
+	if (!b) return XE_ENOMEM;
+	b->h = h;
+	rc = xe_prepass(&h->hs, data, offsets, src_ip4, kinds, n, &b->plan);
+	if (rc != XE_OK) {
+		snprintf(h->err, sizeof(h->err), "pre-pass failed: %s", xe_gpu_strerror(rc));
+		free(b);
+		return rc;
+	}
+	rc = sync_templates(h);
+	if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
+
+	total = n ? (size_t)offsets[n] : 0;
+	b->payload_bytes = total;
+	b->ntot = b->plan.nrec + b->plan.nsf;
+
+	/* input: packet bytes followed by 64 zero bytes so that an unchecked
+	 * wide load near the end stays inside the allocation */
+	rc = upload(h, &b->d_pkt, NULL, total + 64);
+	if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
+	if (total) {
+		hipError_t e = hipMemcpy(b->d_pkt, data, total, hipMemcpyHostToDevice);
+		if (e != hipSuccess) { xe_gpu_batch_free(b); return hip_fail(h, e, "hipMemcpy(packets)"); }
+	}
+	{
+		hipError_t e = hipMemset((uint8_t *)b->d_pkt + total, 0, 64);
+		if (e != hipSuccess) { xe_gpu_batch_free(b); return hip_fail(h, e, "hipMemset(pad)"); }
+	}
+	rc = upload(h, &b->d_sets, b->plan.sets.p, b->plan.sets.n * sizeof(struct xe_set));
+	if (rc == XE_OK) rc = upload(h, &b->d_exps, b->plan.exporters.p, b->plan.exporters.n * sizeof(struct xe_exporter));
+	if (rc == XE_OK) rc = upload(h, &b->d_sfrecs, b->plan.sfrecs.p, b->plan.sfrecs.n * sizeof(struct xe_sfrec));
+	if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
+
+	/* output layout */
+	memset(&b->kp, 0, sizeof(b->kp));
+	off = 0;
+	b->masks_off = off;    off = ALIGN_UP(off + b->ntot * h->mask_words * 8, 256);
+	b->nparsed_off = off;  off = ALIGN_UP(off + b->ntot, 256);
+	b->marks_off = off;    if (h->hs.ndevs) off = ALIGN_UP(off + b->ntot * 4, 256);
+	b->counters_off = off; off = ALIGN_UP(off + (size_t)(h->nmo ? h->nmo : 1) * 24, 256);
+	b->sfhas_off = off;    off = ALIGN_UP(off + b->plan.nsf * 4, 256);
+	for (f = 0; f < XE_NFIELDS; f++) {
+		b->kp.col_off[f] = ~0ull;
+		b->kp.vsize_off[f] = ~0ull;
+	}
+	if (b->plan.nsf) {
+		/* fields the sFlow decoder can set (sflow.c:35-77, sflow-impl.h:97-260) */
+		static const int sf_fields[] = { XF_in_bytes, XF_in_pkts, XF_protocol, XF_src_tos, XF_dst_tos,
+			XF_tcp_flags, XF_l4_src_port, XF_ip4_src_addr, XF_input_snmp, XF_l4_dst_port,
+			XF_ip4_dst_addr, XF_output_snmp, XF_ip6_src_addr, XF_ip6_dst_addr, XF_icmp_type,
+			XF_min_ttl, XF_max_ttl, XF_src_mac, XF_dst_mac, XF_src_vlan, XF_dst_vlan,
+			XF_src_dot1q_cvlan, XF_dst_dot1q_cvlan };
+		for (size_t i = 0; i < sizeof(sf_fields) / sizeof(sf_fields[0]); i++) {
+			b->plan.field_mask[sf_fields[i] >> 6] |= 1ull << (sf_fields[i] & 63);
+		}
+	}
+	for (f = 0; f < XE_NTABLE_FIELDS; f++) {
+		if (!((b->plan.field_mask[f >> 6] >> (f & 63)) & 1)) continue;
+		b->kp.col_off[f] = off;
+		off = ALIGN_UP(off + b->ntot * xe_fields[f].col_width, 256);
+	}
+	/* per-record sizes: strings, and anything some template declares variable-length */
+	{
+		const struct xe_tmpl *tm = (const struct xe_tmpl *)h->hs.dev_tmpls.p;
+		const struct xe_tent *te = (const struct xe_tent *)h->hs.dev_tents.p;
+		uint64_t need[2] = {0, 0};
+		for (size_t t = 0; t < h->hs.dev_tmpls.n; t++) {
+			for (uint32_t j = 0; j < tm[t].nfields; j++) {
+				const struct xe_tent *e = &te[tm[t].ent_base + j];
+				if ((e->field != XE_F_NONE) && ((e->len == 0xFFFF) || (e->flags & XE_TE_STR))) {
+					need[e->field >> 6] |= 1ull << (e->field & 63);
+				}
+			}
+		}
+		for (f = 0; f < XE_NTABLE_FIELDS; f++) {
+			if (b->kp.col_off[f] == ~0ull) continue;
+			if (!((need[f >> 6] >> (f & 63)) & 1)) continue;
+			b->kp.vsize_off[f] = off;
+			off = ALIGN_UP(off + b->ntot * 2, 256);
+		}
+	}
+	b->out_bytes = off ? off : 256;
+	{
+		hipError_t e = hipMalloc(&b->d_out, b->out_bytes);
+		if (e != hipSuccess) { xe_gpu_batch_free(b); return hip_fail(h, e, "hipMalloc(outputs)"); }
+	}
+
+	b->kp.progs = (const struct xe_prog *)h->d_progs;
+	b->kp.ops = (const uint32_t *)h->d_ops;
+	b->kp.terms = (const struct xe_term *)h->d_terms;
+	b->kp.opnds = (const struct xe_dopnd *)h->d_opnds;
+	b->kp.trie = (const uint32_t *)h->d_trie;
+	b->kp.lists = (const struct xe_list_dev *)h->d_lists;
+	b->kp.devrules = (const struct xe_devrule *)h->d_devrules;
+	b->kp.nmo = h->nmo;
+	b->kp.mask_words = h->mask_words;
+	b->kp.ndevrules = (uint32_t)h->hs.ndevs;
+	b->kp.tmpls = (const struct xe_tmpl *)h->d_tmpls;
+	b->kp.tents = (const struct xe_tent *)h->d_tents;
+	b->kp.pkt = (const uint8_t *)b->d_pkt;
+	b->kp.sets = (const struct xe_set *)b->d_sets;
+	b->kp.exps = (const struct xe_exporter *)b->d_exps;
+	b->kp.sfrecs = (const struct xe_sfrec *)b->d_sfrecs;
+	b->kp.nsets = (uint32_t)b->plan.sets.n;
+	b->kp.nrec = (uint32_t)b->plan.nrec;
+	b->kp.nsf = (uint32_t)b->plan.nsf;
+	b->kp.out_base = (uint8_t *)b->d_out;
+	b->kp.masks = (uint64_t *)((uint8_t *)b->d_out + b->masks_off);
+	b->kp.nparsed = (uint8_t *)b->d_out + b->nparsed_off;
+	b->kp.marks = h->hs.ndevs ? (uint32_t *)((uint8_t *)b->d_out + b->marks_off) : NULL;
+	b->kp.counters = (unsigned long long *)((uint8_t *)b->d_out + b->counters_off);
+	b->kp.sf_has = (uint32_t *)((uint8_t *)b->d_out + b->sfhas_off);
+	*out = b;
+	return XE_OK;
+}
+
+extern "C" int
+xe_gpu_batch_run(xe_batch *b, void *stream)
+{
+	int rc;
+	if (!b) return XE_EINVAL;
+	/* templates learnt by later batches may have moved the device tables */
+	b->kp.tmpls = (const struct xe_tmpl *)b->h->d_tmpls;
+	b->kp.tents = (const struct xe_tent *)b->h->d_tents;
+	rc = xe_launch_batch(&b->kp, stream);
+	if (rc != XE_OK) {
+		snprintf(b->h->err, sizeof(b->h->err), "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+		return rc;
+	}
+	b->last_stream = (hipStream_t)stream;
+	b->ran = 1;
+	return XE_OK;
+}
+
+extern "C" int
+xe_gpu_batch_sync(xe_batch *b)
+{
+	if (!b) return XE_EINVAL;
+	if (!b->ran) return XE_ESTATE;
+	HIPCHK(b->h, hipStreamSynchronize(b->last_stream));
+	return XE_OK;
+}
+
+extern "C" size_t xe_gpu_batch_records(const xe_batch *b) { return b ? b->ntot : 0; }
+extern "C" size_t xe_gpu_batch_mask_words(const xe_batch *b) { return b ? b->h->mask_words : 0; }
+extern "C" size_t xe_gpu_batch_payload_bytes(const xe_batch *b) { return b ? b->payload_bytes : 0; }
+
+extern "C" size_t
+xe_gpu_batch_algorithmic_bytes(const xe_batch *b)
+{
+	if (!b) return 0;
+	return b->payload_bytes + b->plan.soa_bytes_per_rec_sum + b->ntot * (1 + 8 * (size_t)b->h->mask_words);
+}
+
+static int
+fetch(xe_batch *b, void *dst, size_t off, size_t bytes)
+{
+	int rc = xe_gpu_batch_sync(b);
+	if (rc != XE_OK) return rc;
+	if (!bytes) return XE_OK;
+	HIPCHK(b->h, hipMemcpy(dst, (uint8_t *)b->d_out + off, bytes, hipMemcpyDeviceToHost));
+	return XE_OK;
+}
+
+extern "C" int
+xe_gpu_batch_masks(xe_batch *b, uint64_t *masks, size_t nwords_total)
+{
+	if (!b || (nwords_total < b->ntot * b->h->mask_words)) return XE_EINVAL;
+	return fetch(b, masks, b->masks_off, b->ntot * b->h->mask_words * 8);
+}
+
+extern "C" int
+xe_gpu_batch_counters(xe_batch *b, uint64_t *counters, size_t n_u64)
+{
+	if (!b || (n_u64 < (size_t)b->h->nmo * 3)) return XE_EINVAL;
+	return fetch(b, counters, b->counters_off, (size_t)b->h->nmo * 24);
+}
+
+extern "C" int
+xe_gpu_batch_dropped(xe_batch *b, uint8_t *dropped, size_t n)
+{
+	uint32_t *mk;
+	int rc;
+
+	if (!b || (n < b->ntot)) return XE_EINVAL;
+	memset(dropped, 0, b->ntot);
+	if (!b->kp.marks) return xe_gpu_batch_sync(b);
+	mk = (uint32_t *)malloc(b->ntot * 4 + 4);
+	if (!mk) return XE_ENOMEM;
+	rc = fetch(b, mk, b->marks_off, b->ntot * 4);
+	if (rc == XE_OK) {
+		for (size_t i = 0; i < b->ntot; i++) dropped[i] = (mk[i] & XE_MARK_DROPPED) ? 1 : 0;
+	}
+	free(mk);
+	return rc;
+}
+
+extern "C" int
+xe_gpu_batch_column(xe_batch *b, int field, void *out, size_t outlen, size_t *width)
+{
+	size_t w;
+	if (!b || (field < 0) || (field >= XE_NTABLE_FIELDS) || (b->kp.col_off[field] == ~0ull)) return XE_EINVAL;
+	w = xe_fields[field].col_width;
+	if (width) *width = w;
+	if (outlen < b->ntot * w) return XE_EINVAL;
+	return fetch(b, out, b->kp.col_off[field], b->ntot * w);
+}
+
+extern "C" int
+xe_gpu_batch_device_ptrs(xe_batch *b, const void **masks, const void **counters, const void **nparsed)
+{
+	if (!b) return XE_EINVAL;
+	if (masks) *masks = b->kp.masks;
+	if (counters) *counters = b->kp.counters;
+	if (nparsed) *nparsed = b->kp.nparsed;
+	return XE_OK;
+}
+
+/* ------------------------------------------------------------------ flow_info */
+struct slice
+{
+	uint8_t *nparsed;
+	uint32_t *marks;
+	uint32_t *sfhas;
+	uint8_t *col[XE_NFIELDS];
+	uint16_t *vsize[XE_NFIELDS];
+};
+
+static void
+slice_free(struct slice *s)
+{
+	free(s->nparsed);
+	free(s->marks);
+	free(s->sfhas);
+	for (int f = 0; f < XE_NFIELDS; f++) { free(s->col[f]); free(s->vsize[f]); }
+}
+
+static void
+put_field(uint8_t *fi, int f, const uint8_t *bytes, int size)
+{
+	int one = 1;
+	memcpy(fi + xe_fields[f].off, bytes, xe_fields[f].size_max);
+	memcpy(fi + xe_fields[f].off_size, &size, 4);
+	memcpy(fi + xe_fields[f].off_has, &one, 4);
+}
+
+/* sizes the sFlow decoder reports for its fields (sflow.c:35-77, sflow-impl.h) */
+static int
+sf_field_size(int f)
+{
+	switch (f) {
+		case XF_in_bytes: case XF_in_pkts: return 8;
+		case XF_input_snmp: case XF_output_snmp: case XF_ip4_src_addr: case XF_ip4_dst_addr: return 4;
+		case XF_ip6_src_addr: case XF_ip6_dst_addr: return 16;
+		case XF_src_mac: case XF_dst_mac: return 6;
+		case XF_l4_src_port: case XF_l4_dst_port: case XF_src_vlan: case XF_dst_vlan:
+		case XF_src_dot1q_cvlan: case XF_dst_dot1q_cvlan: return 2;
+		default: return 1;
+	}
+}
+
+extern "C" int
+xe_gpu_batch_flow_info(xe_batch *b, size_t first, size_t count, void *out)
+{
+	struct slice s;
+	xe_gpu *h;
+	const struct xe_set *sets;
+	const struct xe_tmpl *tm;
+	const struct xe_tent *te;
+	const struct xe_exporter *ex;
+	const struct xe_sfrec *sf;
+	int rc = XE_OK;
+	size_t si = 0;
+
+	if (!b || !out || (first + count > b->ntot)) return XE_EINVAL;
+	if (!count) return XE_OK;
+	h = b->h;
+	memset(&s, 0, sizeof(s));
+	memset(out, 0, count * XE_FLOW_INFO_SIZE);
+
+#define GRAB(DST, TYPE, OFF, ELT) do { \
+	(DST) = (TYPE *)malloc(count * (ELT) + 8); \
+	if (!(DST)) { rc = XE_ENOMEM; goto done; } \
+	rc = fetch(b, (DST), (OFF) + first * (ELT), count * (ELT)); \
+	if (rc != XE_OK) goto done; } while (0)
+
+	GRAB(s.nparsed, uint8_t, b->nparsed_off, 1);
+	if (b->kp.marks) GRAB(s.marks, uint32_t, b->marks_off, 4);
+	for (int f = 0; f < XE_NTABLE_FIELDS; f++) {
+		if (b->kp.col_off[f] != ~0ull) GRAB(s.col[f], uint8_t, b->kp.col_off[f], xe_fields[f].col_width);
+		if (b->kp.vsize_off[f] != ~0ull) GRAB(s.vsize[f], uint16_t, b->kp.vsize_off[f], 2);
+	}
+	if (b->plan.nsf && (first + count > b->plan.nrec)) {
+		size_t sf_first = (first > b->plan.nrec) ? first - b->plan.nrec : 0;
+		size_t sf_count = first + count - b->plan.nrec - sf_first;
+		s.sfhas = (uint32_t *)calloc(count + 2, 4);
+		if (!s.sfhas) { rc = XE_ENOMEM; goto done; }
+		rc = fetch(b, s.sfhas + (b->plan.nrec + sf_first - first), b->sfhas_off + sf_first * 4, sf_count * 4);
+		if (rc != XE_OK) goto done;
+	}
+
+	sets = (const struct xe_set *)b->plan.sets.p;
+	tm = (const struct xe_tmpl *)h->hs.dev_tmpls.p;
+	te = (const struct xe_tent *)h->hs.dev_tents.p;
+	ex = (const struct xe_exporter *)b->plan.exporters.p;
+	sf = (const struct xe_sfrec *)b->plan.sfrecs.p;
+
+	if (first < b->plan.nrec) {
+		size_t lo = 0, hi = b->plan.sets.n - 1;
+		while (lo < hi) {
+			size_t mid = (lo + hi + 1) / 2;
+			if (sets[mid].first_rec <= first) lo = mid; else hi = mid - 1;
+		}
+		si = lo;
+	}
+	for (size_t k = 0; k < count; k++) {
+		size_t r = first + k;
+		uint8_t *fi = (uint8_t *)out + k * XE_FLOW_INFO_SIZE;
+		const struct xe_exporter *e;
+		uint32_t rate;
+
+		if (r < b->plan.nrec) {
+			const struct xe_tmpl *t;
+			const struct xe_tent *en;
+			uint32_t np = s.nparsed[k];
+
+			while (r >= (size_t)sets[si].first_rec + sets[si].nrec) si++;
+			t = &tm[sets[si].tmpl];
+			en = &te[t->ent_base];
+			e = &ex[sets[si].exporter];
+			for (uint32_t j = 0; j < np; j++) {
+				int f = en[j].field;
+				if (f == XE_F_NONE) continue;
+				if (s.vsize[f]) {
+					uint16_t vs = s.vsize[f][k];
+					if (vs == 0xFFFF) continue;
+					put_field(fi, f, s.col[f] + k * xe_fields[f].col_width, vs);
+				} else {
+					if (!(en[j].flags & XE_TE_VALID)) continue;
+					put_field(fi, f, s.col[f] + k * xe_fields[f].col_width, en[j].len);
+				}
+			}
+			/* virtual_fields_init(), netflow.c:112-124 */
+			put_field(fi, XF_dev_ip, e->dev_ip, 4);
+			put_field(fi, XF_dev_id, e->dev_id, 4);
+			rate = e->sampling_rate;
+		} else {
+			const struct xe_sfrec *q = &sf[r - b->plan.nrec];
+			uint32_t hb = s.sfhas[k];
+			static const int order[] = { XF_in_bytes, XF_in_pkts, XF_protocol, XF_src_tos, XF_dst_tos,
+				XF_tcp_flags, XF_l4_src_port, XF_ip4_src_addr, XF_input_snmp, XF_l4_dst_port,
+				XF_ip4_dst_addr, XF_output_snmp, XF_ip6_src_addr, XF_ip6_dst_addr, XF_icmp_type,
+				XF_min_ttl, XF_max_ttl, XF_src_mac, XF_dst_mac, XF_src_vlan, XF_dst_vlan,
+				XF_src_dot1q_cvlan, XF_dst_dot1q_cvlan };
+			for (size_t i = 0; i < sizeof(order) / sizeof(order[0]); i++) {
+				int f = order[i];
+				if (!((hb >> i) & 1)) continue;
+				put_field(fi, f, s.col[f] + k * xe_fields[f].col_width, sf_field_size(f));
+			}
+			/* sflow_reset(), sflow-impl.h:274-291 */
+			put_field(fi, XF_dev_id, q->dev_id, 4);
+			if (q->agent_ver == 4) put_field(fi, XF_dev_ip, q->agent, 4);
+			else put_field(fi, XF_dev_ip6, q->agent, 16);
+			rate = q->sampling_rate;
+		}
+		if (s.marks && (s.marks[k] & XE_MARK_HAS)) {
+			uint32_t mk = htonl(s.marks[k] & 0x3FFFFFFFu);
+			put_field(fi, XF_dev_mark, (const uint8_t *)&mk, 4);
+		}
+		memcpy(fi + XE_OFF_SAMPLING_RATE, &rate, 4);
+	}
+done:
+	slice_free(&s);
+	return rc;
+#undef GRAB
+}
+
+/* ------------------------------------------------------------------ list probe */
+extern "C" int
+xe_gpu_iplist_match(xe_gpu *h, const char *list, int family, const uint8_t *addrs, size_t n, uint8_t *out)
+{
+	int li, rc;
+	void *d_a = NULL, *d_o = NULL;
+	size_t ab = (family == 4) ? 4 : 16;
+
+	if (!h || !list || ((family != 4) && (family != 6)) || (n && (!addrs || !out)) || (n > 0xFFFFFFF0u)) return XE_EINVAL;
+	if (!h->committed) return XE_ESTATE;
+	li = xe_iplist_find(&h->hs.lists, list);
+	if (li < 0) return XE_EINVAL;
+	if (!n) return XE_OK;
+	HIPCHK(h, hipSetDevice(h->device));
+	rc = upload(h, &d_a, addrs, n * ab);
+	if (rc == XE_OK) rc = upload(h, &d_o, NULL, n);
+	if (rc == XE_OK) rc = xe_launch_trie_probe((const uint32_t *)h->d_trie, h->h_lists[li], family,
+		(const uint8_t *)d_a, (uint32_t)n, (uint8_t *)d_o, NULL);
+	if (rc == XE_OK) {
+		hipError_t e = hipMemcpy(out, d_o, n, hipMemcpyDeviceToHost);
+		if (e != hipSuccess) rc = hip_fail(h, e, "hipMemcpy(probe)");
+	}
+	if (d_a) (void)hipFree(d_a);
+	if (d_o) (void)hipFree(d_o);
+	return rc;
+}

@@ -1,0 +1,294 @@
+/*
+ * xe_internal.h -- structures shared by the host modules and the HIP kernels.
+ * Everything in the "device formats" section is laid out by hand (fixed-width
+ * members, no pointers) because the same bytes are read by the GPU.
+ */
+#ifndef xe_internal_h_included
+#define xe_internal_h_included
+
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/xe_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ fields */
+enum { XE_T_ADDR = 0, XE_T_INT = 1, XE_T_MAC = 2, XE_T_STR = 3 };
+
+#define XE_NFIELDS 66          /* 63 table fields + dev_ip6, dev_id, dev_mark */
+#define XE_NTABLE_FIELDS 63
+#define XE_F_NONE 0xFF
+
+struct xe_field
+{
+	const char *name;
+	int32_t id;          /* element id on the wire, -1 for virtual fields */
+	uint8_t type;
+	uint16_t size_min, size_max;
+	uint16_t off, off_size, off_has;   /* offsets in struct flow_info */
+	uint16_t col_width;  /* bytes per record in the structure-of-arrays output */
+};
+
+extern const struct xe_field xe_fields[XE_NFIELDS];
+int xe_field_by_id(int id);                /* -1 when unknown */
+int xe_field_by_name(const char *name);    /* -1 when unknown */
+#define XE_OFF_PAYLOAD_PTR 2248
+#define XE_OFF_SAMPLING_RATE 2304
+
+/* indices the code refers to by name (kept in step with xe_fields[] by a
+ * start-up self check) */
+enum
+{
+	XF_in_bytes = 0, XF_in_pkts = 1, XF_protocol = 2, XF_src_tos = 3, XF_dst_tos = 4,
+	XF_tcp_flags = 5, XF_l4_src_port = 6, XF_ip4_src_addr = 7, XF_src_mask = 8,
+	XF_input_snmp = 9, XF_l4_dst_port = 10, XF_ip4_dst_addr = 11, XF_dst_mask = 12,
+	XF_output_snmp = 13, XF_ip4_next_hop = 14, XF_src_as = 15, XF_dst_as = 16,
+	XF_bgp_next_hop = 17, XF_last_switched = 18, XF_first_switched = 19,
+	XF_ip6_src_addr = 20, XF_ip6_dst_addr = 21, XF_icmp_type = 22, XF_sampler_id = 23,
+	XF_min_ttl = 24, XF_max_ttl = 25, XF_frag_id = 26, XF_src_mac = 27, XF_dst_mac = 28,
+	XF_src_vlan = 29, XF_dst_vlan = 30, XF_ip_protocol_version = 31, XF_direction = 32,
+	XF_if_name = 33, XF_fwd_status = 34, XF_flow_start_ms = 35, XF_flow_end_ms = 36,
+	XF_flow_end_reason = 37, XF_ip_ttl = 38, XF_ioctets = 39, XF_roctets = 40,
+	XF_ipackets = 41, XF_rpackets = 42, XF_ingrs_vrf = 43, XF_egrs_vrf = 44,
+	XF_src_dot1q_vlan = 45, XF_src_dot1q_cvlan = 46, XF_dst_dot1q_vlan = 47,
+	XF_dst_dot1q_cvlan = 48, XF_obs_time_ms = 49, XF_vas_session_id = 50,
+	XF_vas_http_host = 51, XF_dev_ip = 52, XF_dns_name = 53, XF_dns_ips = 54, XF_sni = 55,
+	XF_class0 = 56, XF_class1 = 57, XF_class2 = 58, XF_class3 = 59, XF_class4 = 60,
+	XF_pad1 = 61, XF_pad2 = 62, XF_dev_ip6 = 63, XF_dev_id = 64, XF_dev_mark = 65
+};
+
+/* ------------------------------------------------------------------ device formats */
+
+/* one field of an exporter template */
+struct xe_tent
+{
+	uint16_t len;        /* encoded length; 0xFFFF = IPFIX variable length */
+	uint8_t field;       /* destination field, XE_F_NONE = unknown element (skipped) */
+	uint8_t flags;       /* XE_TE_* */
+	uint16_t off;        /* offset inside a fixed-length record */
+	uint8_t next_same;   /* next entry with the same destination, 0xFF = none */
+	uint8_t pad;
+};
+#define XE_TE_VALID 1    /* length inside [size_min, size_max] */
+#define XE_TE_STR 2      /* string: left-aligned copy */
+#define XE_TE_REPEAT 4   /* an earlier entry of this template has the same destination */
+
+#define XE_TMPL_MAXF 254
+#define XE_MODE_V9 0     /* field admitted while pos + len <= avail (netflow.c:284) */
+#define XE_MODE_IPFIX 1  /* field parsed, then stop when pos >= avail (netflow.c:596) */
+
+struct xe_tmpl
+{
+	uint32_t ent_base;   /* first entry in the entries array */
+	uint16_t nfields;
+	uint16_t stride;     /* record length when fixed */
+	uint8_t mode;
+	uint8_t varlen;      /* has a variable-length element */
+	uint8_t repeats;     /* some destination occurs more than once */
+	uint8_t pad;
+	uint32_t has_lo_hi[3]; /* unused on device; presence mask of a fully parsed record */
+	uint8_t fmap[72];    /* field -> first entry index, 0xFF = not in template */
+};
+
+/* a run of records that share template, exporter and spacing */
+struct xe_set
+{
+	uint64_t data_off;   /* first record, byte offset in the batch buffer */
+	uint32_t first_rec;  /* index of its first record in the batch */
+	uint32_t nrec;
+	int32_t avail;       /* byte budget measured from data_off (the reference's
+	                        `length` minus what was consumed before) */
+	uint32_t stride;     /* bytes between consecutive records */
+	uint32_t tmpl;
+	int32_t dgram_left;  /* bytes from data_off to the datagram's end: reads
+	                        past it return zero */
+	uint32_t exporter;
+	uint32_t flags;      /* XE_SET_* */
+};
+#define XE_SET_CHECKED 1 /* a read may pass the datagram end: bounds-check bytes */
+
+struct xe_exporter
+{
+	uint8_t dev_ip[4];    /* flow_packet_info.src_addr_ipv4 bytes */
+	uint8_t dev_id[4];    /* raw source id / observation domain bytes */
+	uint32_t sampling_rate;
+	int32_t device;       /* index of the devices.conf entry, -1 none */
+};
+
+/* one sFlow flow sample element that yields a record */
+struct xe_sfrec
+{
+	uint64_t hdr_off;     /* sampled header (tag 1) or IPv4 struct (tag 3) in the batch */
+	uint32_t header_len;  /* tag 1: declared header length */
+	int32_t dgram_left;   /* bytes from hdr_off to the datagram end */
+	uint32_t frame_len_be;/* 4 bytes as on the wire: in_bytes[4..8] */
+	uint32_t sampling_rate;
+	uint32_t in_if_be, out_if_be; /* input_snmp / output_snmp bytes as stored */
+	uint8_t kind;         /* 1 raw header, 3 IPv4 struct */
+	uint8_t rp_type;      /* 0 ethernet, 1 IPv4, 2 IPv6 */
+	uint8_t agent_ver;    /* 4 or 6 */
+	uint8_t chained;      /* 1 = the previous record's fields carry over (same sample) */
+	uint8_t dev_id[4];
+	uint8_t agent[16];
+	uint32_t exporter;
+	uint32_t pad;
+};
+
+/* flat filter programs */
+enum { XE_OP_BASIC = 0, XE_OP_NOT = 1, XE_OP_AND = 2, XE_OP_OR = 3 };
+enum { XE_BT_ADDR4 = 0, XE_BT_ADDR6 = 1, XE_BT_RANGE = 2, XE_BT_MAC = 3, XE_BT_STRING = 4 };
+enum { XE_FN_NONE = 0, XE_FN_DIV = 1, XE_FN_DIV_R = 2, XE_FN_DIV_L = 3, XE_FN_MIN = 4 };
+enum { XE_DIR_NONE = 0, XE_DIR_SRC = 1, XE_DIR_DST = 2, XE_DIR_BOTH = 3 };
+
+struct xe_term
+{
+	uint8_t type, dir, fsrc, fdst;   /* fsrc/fdst: field indices */
+	uint8_t func, fa, fb, pad;       /* functions: operand fields */
+	int32_t k;
+	uint32_t nopnd;
+	uint32_t opnd_base;              /* index into the operand array */
+};
+
+#define XE_OPND_WORDS 10
+struct xe_opnd
+{
+	uint32_t is_list;
+	uint32_t w[XE_OPND_WORDS - 1];
+	/* range: w[0]=low w[1]=high (int32)   addr4: w[0]=addr w[1]=mask (bytes as stored)
+	 * list:  w[0]=list index              addr6: w[0..3]=addr w[4..7]=mask
+	 * mac:   w[0..1] = 6 bytes */
+};
+
+#define XE_PROG_CONST 1      /* result is `cval` whatever the record */
+struct xe_prog
+{
+	uint32_t op_base, nops;
+	int32_t parent;
+	uint16_t flags;
+	uint16_t cval;
+};
+
+/* flattened IP list: per family a 65536-entry root over the first 16 address
+ * bits, then 8-bit-stride bitmap nodes.  Root / child entry: bit31 set =
+ * terminal, bit0 = result; else node index. */
+#define XE_TRIE_TERM 0x80000000u
+#define XE_NODE_WORDS 20     /* child[8] result[8] base cum[2] pad */
+struct xe_list_dev
+{
+	uint32_t root4, root6;   /* word offsets into the trie array, 0 = family empty */
+	uint32_t nodes4, nodes6; /* word offsets of node 0 */
+};
+
+/* ------------------------------------------------------------------ host side */
+struct xe_blob { void *p; size_t n, cap; };  /* growable array helper */
+int xe_blob_push(struct xe_blob *b, const void *item, size_t item_size);
+
+/* ip lists */
+struct xe_bnode { uint32_t next[2]; int32_t is_leaf; };
+struct xe_iplist
+{
+	char name[256];
+	struct xe_bnode *n4, *n6;
+	size_t c4, c6, cap4, cap6;
+};
+struct xe_iplists { struct xe_iplist *l; size_t n; };
+
+int xe_iplist_load_text(struct xe_iplists *reg, const char *name, const char *text, size_t len);
+int xe_iplist_load_dir(struct xe_iplists *reg, const char *dir);
+int xe_iplist_find(const struct xe_iplists *reg, const char *name);  /* first match, -1 none */
+void xe_iplists_free(struct xe_iplists *reg);
+/* appends the flattened form of every list to `words` (uint32 array) and
+ * fills dev[] (reg->n entries) */
+int xe_iplists_flatten(const struct xe_iplists *reg, struct xe_blob *words, struct xe_list_dev *dev);
+
+/* filters */
+struct xe_filter     /* one compiled expression, host form */
+{
+	uint32_t *ops;  size_t nops;      /* op | term_index << 2 */
+	struct xe_term *terms; size_t nterms;
+	struct xe_opnd *opnds; size_t nopnds;
+	/* host-only operand annotations for the dump: mask length / list index */
+	int32_t *opnd_note;
+	int device_ok;                    /* 0: uses something the device cannot evaluate */
+	char why[128];
+};
+int xe_filter_compile(const struct xe_iplists *reg, const char *text, struct xe_filter *out,
+	char *err, size_t errlen);
+void xe_filter_free(struct xe_filter *f);
+int xe_filter_dump_text(const struct xe_iplists *reg, const struct xe_filter *f, char *out, size_t outlen);
+/* static analysis of the stack discipline (filter.c:960-1012): returns 1 and
+ * sets *cval when the result does not depend on the record */
+int xe_filter_constant(const struct xe_filter *f, int *cval);
+
+/* devices.conf entries */
+struct xe_device
+{
+	int use_ip, use_id;
+	uint32_t ip, id;   /* ip: bytes as stored; id: htonl(value) */
+	int sampling_rate, skip_unmarked;
+	struct xe_filter *marks; size_t nmarks;
+};
+
+struct xe_mo
+{
+	char name[256];
+	int parent;
+	struct xe_filter filter;
+};
+
+/* exporter templates kept across batches */
+struct xe_tkey { uint8_t ver; uint16_t tid; uint32_t src_ip, source_id; };
+struct xe_tslot
+{
+	struct xe_tkey key;
+	uint8_t *raw; size_t raw_len;     /* bytes as stored by the reference */
+	uint32_t dev_slot;                /* index into the device template table */
+};
+
+struct xe_host
+{
+	struct xe_iplists lists;
+	struct xe_mo *mos; size_t nmos;
+	struct xe_device *devs; size_t ndevs;
+	/* template store */
+	struct xe_tslot *tslots; size_t ntslots, tslots_cap;
+	uint32_t *thash; size_t thash_cap;        /* open addressing, slot index + 1 */
+	struct xe_blob dev_tmpls;   /* struct xe_tmpl */
+	struct xe_blob dev_tents;   /* struct xe_tent */
+	uint32_t v5_slot_plus1;     /* device template of the fixed v5 record, 0 = not built */
+	char err[512];
+};
+
+void xe_host_init(struct xe_host *hs);
+void xe_host_free(struct xe_host *hs);
+
+/* result of the host pre-pass over one batch */
+struct xe_plan
+{
+	struct xe_blob sets;       /* struct xe_set */
+	struct xe_blob exporters;  /* struct xe_exporter */
+	struct xe_blob sfrecs;     /* struct xe_sfrec */
+	size_t nrec;               /* netflow records (sets) */
+	size_t nsf;                /* sflow records */
+	uint64_t field_mask[2];    /* fields some template of the batch can set */
+	size_t soa_bytes_per_rec_sum; /* sum over records of stored widths (algorithmic bytes) */
+	size_t skipped_datagrams;  /* unknown version / aborted */
+};
+
+int xe_prepass(struct xe_host *hs, const uint8_t *data, const uint64_t *offs, const uint32_t *src,
+	const uint8_t *kinds, size_t n, struct xe_plan *plan);
+void xe_plan_free(struct xe_plan *p);
+
+/* small JSON-with-comments reader used by the config loaders */
+int xe_conf_load_mos(struct xe_host *hs, const char *mo_dir,
+	int (*add)(void *user, const char *name, int parent, const char *filter), void *user);
+int xe_conf_load_devices(struct xe_host *hs, const char *path,
+	int (*add)(void *user, int use_ip, uint32_t ip, int use_id, uint32_t id, int rate,
+		int skip_unmarked, const char *const *marks, int nmarks), void *user);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

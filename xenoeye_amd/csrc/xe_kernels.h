@@ -1,0 +1,76 @@
+/*
+ * xe_kernels.h -- launch interface between the C ABI glue and the HIP kernels.
+ */
+#ifndef xe_kernels_h_included
+#define xe_kernels_h_included
+
+#include "xe_internal.h"
+
+/* per devices.conf entry: its mark programs live after the object programs */
+struct xe_devrule
+{
+	uint32_t first_prog, nprogs;
+	uint32_t skip_unmarked;
+	uint32_t pad;
+};
+
+/* device operand, numeric form: addresses and MACs as big-endian integers so
+ * that "bit i from the most significant" is plain shifting */
+struct xe_dopnd
+{
+	uint32_t is_list;
+	uint32_t list;
+	int32_t low, high;
+	uint64_t net_hi, net_lo;     /* addr4 / mac use net_lo only */
+	uint64_t mask_hi, mask_lo;
+};
+
+#define XE_MARK_DROPPED 0x80000000u
+#define XE_MARK_HAS 0x40000000u
+
+/* sFlow per-record status written by the kernel */
+#define XE_SF_SKIPPED 0x80   /* parser state below NO_IP: record not delivered (sflow.c:164-168) */
+
+struct xe_kparams
+{
+	/* configuration */
+	const struct xe_prog *progs;
+	const uint32_t *ops;
+	const struct xe_term *terms;
+	const struct xe_dopnd *opnds;
+	const uint32_t *trie;
+	const struct xe_list_dev *lists;
+	const struct xe_devrule *devrules;
+	uint32_t nmo, mask_words, ndevrules, pad0;
+	/* templates */
+	const struct xe_tmpl *tmpls;
+	const struct xe_tent *tents;
+	/* batch input */
+	const uint8_t *pkt;
+	const struct xe_set *sets;
+	const struct xe_exporter *exps;
+	const struct xe_sfrec *sfrecs;
+	uint32_t nsets, nrec, nsf, pad1;
+	/* batch output; record index space = [0,nrec) netflow then [nrec,nrec+nsf) sflow */
+	uint64_t *masks;
+	uint8_t *nparsed;            /* netflow: fields parsed; sflow: parser state | XE_SF_SKIPPED */
+	uint32_t *marks;             /* NULL when no devices.conf entry exists */
+	unsigned long long *counters;
+	uint8_t *out_base;           /* columns: out_base + col_off[f] + rec * width */
+	uint64_t col_off[XE_NFIELDS];   /* ~0 = column absent */
+	uint64_t vsize_off[XE_NFIELDS]; /* u16 per record, ~0 = absent */
+	uint32_t *sf_has;            /* sflow: presence bits of the fields its parser can set */
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* enqueue decode+classify of the whole batch on `stream` (hipStream_t) */
+int xe_launch_batch(const struct xe_kparams *kp, void *stream);
+/* n addresses (4 or 16 bytes each) against one flattened list */
+int xe_launch_trie_probe(const uint32_t *trie, struct xe_list_dev list, int family,
+	const uint8_t *addrs, uint32_t n, uint8_t *out, void *stream);
+#ifdef __cplusplus
+}
+#endif
+#endif

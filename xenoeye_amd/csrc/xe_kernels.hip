@@ -1,0 +1,632 @@
+/*
+ * xe_kernels.hip -- gfx950 kernels of the flow path.
+ *
+ * xe_nf_kernel: one thread per Netflow v5/v9/IPFIX record.  The thread finds
+ * the run ("set") its record belongs to, decodes the template's fields from
+ * the export packet into the structure-of-arrays columns, evaluates every
+ * monitoring-object program against the record and stores the match bitmask;
+ * per-object counters are reduced per wave and added with one atomic per wave.
+ *
+ * Field values are handled as big-endian integers: the reference keeps a
+ * field as SIZEMAX bytes with the wire bytes right-aligned (netflow.c:91), so
+ * "the SIZEMAX bytes read as one big-endian number" equals "the wire bytes
+ * read as one big-endian number"; filters compare exactly that number
+ * (filter.c:275, :484-488) and the IP-list walk consumes its bits from the
+ * most significant end (iplist.c:171-184).
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "xe_kernels.h"
+
+#define XE_BLOCK 256
+
+struct val128 { uint64_t hi, lo; };
+
+/* ------------------------------------------------------------------ packet bytes */
+struct pkt_src
+{
+	const uint8_t *p;   /* record start */
+	int32_t left;       /* bytes to the datagram end, may be <= 0 */
+	bool checked;
+};
+
+__device__ __forceinline__ uint32_t
+pkt_byte(const pkt_src &s, int32_t off)
+{
+	if (s.checked && (off >= s.left)) return 0;
+	return s.p[off];
+}
+
+/* len wire bytes at off as a big-endian number (len <= 16) */
+__device__ __forceinline__ val128
+pkt_be(const pkt_src &s, int32_t off, uint32_t len)
+{
+	val128 v = {0, 0};
+	for (uint32_t i = 0; i < len; i++) {
+		v.hi = (v.hi << 8) | (v.lo >> 56);
+		v.lo = (v.lo << 8) | pkt_byte(s, off + (int32_t)i);
+	}
+	return v;
+}
+
+/* ------------------------------------------------------------------ flattened IP list */
+__device__ __forceinline__ uint32_t
+node_step(const uint32_t *N, uint32_t chunk, bool *stop, uint32_t *result)
+{
+	uint32_t w = chunk >> 5, b = chunk & 31;
+	uint32_t cw = N[w];
+	if ((cw >> b) & 1) {
+		const uint8_t *cum = (const uint8_t *)(N + 17);
+		*stop = false;
+		return N[16] + cum[w] + __popc(cw & ((1u << b) - 1u));
+	}
+	*stop = true;
+	*result = (N[8 + w] >> b) & 1;
+	return 0;
+}
+
+__device__ uint32_t
+trie_match4(const uint32_t *T, const xe_list_dev &L, uint32_t a)
+{
+	if (!L.root4) return 0;
+	uint32_t e = T[L.root4 + (a >> 16)];
+	for (int lvl = 0; lvl < 2; lvl++) {
+		if (e & XE_TRIE_TERM) return e & 1;
+		bool stop;
+		uint32_t res = 0;
+		e = node_step(T + L.nodes4 + (size_t)e * XE_NODE_WORDS, (a >> (8 - 8 * lvl)) & 255, &stop, &res);
+		if (stop) return res;
+	}
+	return (e & XE_TRIE_TERM) ? (e & 1) : 0;
+}
+
+__device__ uint32_t
+trie_match6(const uint32_t *T, const xe_list_dev &L, uint64_t hi, uint64_t lo)
+{
+	if (!L.root6) return 0;
+	uint32_t e = T[L.root6 + (uint32_t)(hi >> 48)];
+	for (int k = 2; k < 16; k++) {
+		if (e & XE_TRIE_TERM) return e & 1;
+		uint32_t chunk = (k < 8) ? (uint32_t)(hi >> (56 - 8 * k)) & 255 : (uint32_t)(lo >> (56 - 8 * (k - 8))) & 255;
+		bool stop;
+		uint32_t res = 0;
+		e = node_step(T + L.nodes6 + (size_t)e * XE_NODE_WORDS, chunk, &stop, &res);
+		if (stop) return res;
+	}
+	return (e & XE_TRIE_TERM) ? (e & 1) : 0;
+}
+
+/* ------------------------------------------------------------------ field sources */
+/* what a filter term asks of a record: presence + value of a field */
+struct fval { bool has; val128 v; };
+
+__device__ __forceinline__ uint64_t
+low_mask(uint32_t bytes)
+{
+	return (bytes >= 8) ? ~0ull : ((1ull << (8 * bytes)) - 1ull);
+}
+
+/* a Netflow/IPFIX record in the export packet */
+struct nf_rec
+{
+	pkt_src src;
+	const xe_tmpl *t;
+	const xe_tent *e;
+	const xe_exporter *ex;
+	uint32_t nparsed;
+	uint32_t mark;        /* XE_MARK_* | count */
+
+	/* offset and length of entry j; variable-length templates are re-walked */
+	__device__ void locate(uint32_t j, int32_t *off, uint32_t *len) const
+	{
+		if (!t->varlen) {
+			*off = e[j].off;
+			*len = e[j].len;
+			return;
+		}
+		int32_t pos = 0;
+		for (uint32_t i = 0;; i++) {
+			uint32_t l = e[i].len;
+			int32_t adj = 0;
+			if ((t->mode == XE_MODE_IPFIX) && (l == 0xFFFF)) {
+				uint32_t b0 = pkt_byte(src, pos);
+				if (b0 != 255) { l = b0; adj = 1; }
+				else { l = (pkt_byte(src, pos + 1) << 8) | pkt_byte(src, pos + 2); adj = 3; }
+			}
+			if (i == j) { *off = pos + adj; *len = l; return; }
+			pos += (int32_t)l + adj;
+		}
+	}
+
+	/* is entry j's length acceptable for its field (netflow.c:83) */
+	__device__ bool valid(uint32_t j, uint32_t len, const uint16_t *fmin, const uint16_t *fmax) const
+	{
+		if (e[j].len != 0xFFFF) return (e[j].flags & XE_TE_VALID) != 0;
+		return (len >= fmin[e[j].field]) && (len <= fmax[e[j].field]);
+	}
+};
+
+/* field size limits, filled once per launch from the host table */
+__constant__ uint16_t c_fmin[XE_NFIELDS];
+__constant__ uint16_t c_fmax[XE_NFIELDS];
+__constant__ uint16_t c_colw[XE_NFIELDS];
+__constant__ uint8_t c_fstr[XE_NFIELDS];
+
+/* value of a non-string field after all parsed occurrences were applied in
+ * template order (a later, shorter occurrence overlays only its own bytes:
+ * netflow.c:91 copies into the tail of the slot without clearing it) */
+__device__ fval
+nf_get(const nf_rec &r, uint32_t f, uint32_t *size_out)
+{
+	fval out;
+	out.has = false;
+	out.v.hi = out.v.lo = 0;
+	if (size_out) *size_out = 0;
+	if (f == XF_dev_ip) {
+		/* virtual_fields_init() runs after the template fields (netflow.c:293) */
+		const uint8_t *b = r.ex->dev_ip;
+		out.has = true;
+		out.v.lo = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3];
+		if (size_out) *size_out = 4;
+		return out;
+	}
+	if (f == XF_dev_id) {
+		const uint8_t *b = r.ex->dev_id;
+		out.has = true;
+		out.v.lo = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3];
+		if (size_out) *size_out = 4;
+		return out;
+	}
+	if (f == XF_dev_mark) {
+		out.has = (r.mark & XE_MARK_HAS) != 0;
+		out.v.lo = r.mark & 0x3FFFFFFFu;
+		if (size_out) *size_out = 4;
+		return out;
+	}
+	if (f >= XE_NTABLE_FIELDS) return out;
+	uint32_t j = r.t->fmap[f];
+	while (j != 0xFF) {
+		if (j < r.nparsed) {
+			int32_t off;
+			uint32_t len;
+			r.locate(j, &off, &len);
+			if (r.valid(j, len, c_fmin, c_fmax)) {
+				val128 nv = pkt_be(r.src, off, len > 16 ? 16 : len);
+				if (len >= 16) {
+					out.v = nv;
+				} else if (len > 8) {
+					uint64_t m = low_mask(len - 8);
+					out.v.hi = (out.v.hi & ~m) | (nv.hi & m);
+					out.v.lo = nv.lo;
+				} else {
+					uint64_t m = low_mask(len);
+					out.v.lo = (out.v.lo & ~m) | (nv.lo & m);
+				}
+				out.has = true;
+				if (size_out) *size_out = len;
+			}
+		}
+		j = r.e[j].next_same;
+	}
+	return out;
+}
+
+/* ------------------------------------------------------------------ filter VM */
+__device__ __forceinline__ bool
+in_ranges(const xe_dopnd *o, uint32_t n, int64_t v)
+{
+	for (uint32_t i = 0; i < n; i++) {
+		if ((v >= o[i].low) && (v <= o[i].high)) return true;
+	}
+	return false;
+}
+
+/* get_nf_val(): sizes 1, 2, 4, 8 read big-endian, anything else is 0 (filter.h:370-394) */
+__device__ __forceinline__ uint64_t
+nf_val(const fval &f, uint32_t sizemax)
+{
+	return ((sizemax == 1) || (sizemax == 2) || (sizemax == 4) || (sizemax == 8)) ? f.v.lo : 0;
+}
+
+template <typename REC, fval (*GET)(const REC &, uint32_t, uint32_t *)>
+__device__ bool
+term_match(const xe_kparams &kp, const REC &rec, const xe_term &t)
+{
+	const xe_dopnd *o = kp.opnds + t.opnd_base;
+
+	if (t.func != XE_FN_NONE) {
+		uint64_t a = nf_val(GET(rec, t.fa, nullptr), c_fmax[t.fa]);
+		uint64_t b = nf_val(GET(rec, t.fb, nullptr), c_fmax[t.fb]);
+		if (t.func == XE_FN_MIN) {
+			/* filter.c:685-709 */
+			return in_ranges(o, t.nopnd, (int64_t)((a < b) ? a : b));
+		}
+		/* xdiv(), filter.h:396-418: the quotient is truncated to int first */
+		int32_t q = 0;
+		if (b != 0) {
+			q = (int32_t)(a / b);
+			if ((t.func == XE_FN_DIV_R) && (t.k > 1)) q = (q / t.k) * t.k;
+		}
+		return in_ranges(o, t.nopnd, q);
+	}
+
+	switch (t.type) {
+		case XE_BT_ADDR4:
+		case XE_BT_ADDR6: {
+			/* filter.c:255-466: SRC/DST need the field present; BOTH tries
+			 * whichever side is present */
+			fval c[2];
+			int nc = 0;
+			if (t.dir == XE_DIR_SRC) { c[0] = GET(rec, t.fsrc, nullptr); if (!c[0].has) return false; nc = 1; }
+			else if (t.dir == XE_DIR_DST) { c[0] = GET(rec, t.fdst, nullptr); if (!c[0].has) return false; nc = 1; }
+			else if (t.dir == XE_DIR_BOTH) {
+				fval s = GET(rec, t.fsrc, nullptr), d = GET(rec, t.fdst, nullptr);
+				if (s.has) c[nc++] = s;
+				if (d.has) c[nc++] = d;
+			}
+			if (!nc) return false;
+			/* an IPv4-typed term over a 16-byte field looks at its first 4 bytes */
+			bool wide4 = (t.type == XE_BT_ADDR4) && (c_fmax[t.fsrc] == 16);
+			for (uint32_t i = 0; i < t.nopnd; i++) {
+				for (int k = 0; k < nc; k++) {
+					if (t.type == XE_BT_ADDR4) {
+						uint32_t a = wide4 ? (uint32_t)(c[k].v.hi >> 32) : (uint32_t)c[k].v.lo;
+						if (o[i].is_list) {
+							if (trie_match4(kp.trie, kp.lists[o[i].list], a)) return true;
+						} else if ((a & (uint32_t)o[i].mask_lo) == (uint32_t)o[i].net_lo) {
+							return true;
+						}
+					} else {
+						if (o[i].is_list) {
+							if (trie_match6(kp.trie, kp.lists[o[i].list], c[k].v.hi, c[k].v.lo)) return true;
+						} else if (((c[k].v.hi & o[i].mask_hi) == o[i].net_hi)
+							&& ((c[k].v.lo & o[i].mask_lo) == o[i].net_lo)) {
+							return true;
+						}
+					}
+				}
+			}
+			return false;
+		}
+		case XE_BT_RANGE: {
+			/* filter.c:468-550: no presence test; 1/2/4-byte fields only */
+			if (t.dir == XE_DIR_NONE) return false;
+			if (t.dir & XE_DIR_SRC) {
+				uint32_t sm = c_fmax[t.fsrc];
+				int32_t r1 = (sm <= 4) ? (int32_t)(uint32_t)GET(rec, t.fsrc, nullptr).v.lo : 0;
+				if (in_ranges(o, t.nopnd, r1)) return true;
+			}
+			if (t.dir & XE_DIR_DST) {
+				uint32_t sm = c_fmax[t.fdst];
+				int32_t r2 = (sm <= 4) ? (int32_t)(uint32_t)GET(rec, t.fdst, nullptr).v.lo : 0;
+				if (in_ranges(o, t.nopnd, r2)) return true;
+			}
+			return false;
+		}
+		case XE_BT_MAC: {
+			/* filter.c:552-606: 6-byte compare, no presence test */
+			if (t.dir == XE_DIR_NONE) return false;
+			uint64_t m1 = (t.dir & XE_DIR_SRC) ? GET(rec, t.fsrc, nullptr).v.lo : 0;
+			uint64_t m2 = (t.dir & XE_DIR_DST) ? GET(rec, t.fdst, nullptr).v.lo : 0;
+			for (uint32_t i = 0; i < t.nopnd; i++) {
+				if ((t.dir & XE_DIR_SRC) && (o[i].net_lo == m1)) return true;
+				if ((t.dir & XE_DIR_DST) && (o[i].net_lo == m2)) return true;
+			}
+			return false;
+		}
+		default:
+			return false;
+	}
+}
+
+/* postfix program over a bit stack: bit 0 = top (filter.c:960-1012; depth
+ * errors are resolved at compile time into constant programs) */
+template <typename REC, fval (*GET)(const REC &, uint32_t, uint32_t *)>
+__device__ bool
+prog_match(const xe_kparams &kp, const REC &rec, const xe_prog &pr)
+{
+	if (pr.flags & XE_PROG_CONST) return pr.cval != 0;
+	uint64_t st = 0;
+	for (uint32_t i = 0; i < pr.nops; i++) {
+		uint32_t w = kp.ops[pr.op_base + i];
+		switch (w & 3) {
+			case XE_OP_BASIC:
+				st = (st << 1) | (uint64_t)term_match<REC, GET>(kp, rec, kp.terms[w >> 2]);
+				break;
+			case XE_OP_NOT:
+				st ^= 1;
+				break;
+			case XE_OP_AND: {
+				uint64_t top = st & 1;
+				st >>= 1;
+				st &= (top | ~1ull);
+				break;
+			}
+			default: {
+				uint64_t top = st & 1;
+				st >>= 1;
+				st |= top;
+				break;
+			}
+		}
+	}
+	return (st & 1) != 0;
+}
+
+__device__ __forceinline__ unsigned long long
+wave_sum(unsigned long long v)
+{
+	for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+	return v;
+}
+
+/* device rules (devices.c:237-314), then the object walk (netflow.c:213-244):
+ * object m receives the record iff its program matches and its parent
+ * received it; parents always have a smaller index.  Returns false when the
+ * record is dropped by skip-unmarked. */
+template <typename REC, fval (*GET)(const REC &, uint32_t, uint32_t *)>
+__device__ void
+classify(const xe_kparams &kp, REC &rec, int32_t device, uint32_t ridx, bool active,
+	unsigned long long bytes_x_rate, unsigned long long pkts_x_rate)
+{
+	bool dropped = false;
+
+	if (active && kp.marks) {
+		uint32_t mk = 0;
+		if (device >= 0) {
+			const xe_devrule dr = kp.devrules[device];
+			uint32_t cnt = 0;
+			for (uint32_t i = 0; i < dr.nprogs; i++) {
+				cnt += prog_match<REC, GET>(kp, rec, kp.progs[dr.first_prog + i]) ? 1u : 0u;
+			}
+			if (dr.skip_unmarked && (cnt == 0)) {
+				dropped = true;
+				mk = XE_MARK_DROPPED;
+			} else {
+				mk = XE_MARK_HAS | (cnt & 0x3FFFFFFFu);
+			}
+		}
+		rec.mark = mk;
+		kp.marks[ridx] = mk;
+	}
+
+	for (uint32_t w = 0; w < kp.mask_words; w++) {
+		uint64_t bits = 0;
+		uint32_t m0 = w * 64, m1 = (m0 + 64 < kp.nmo) ? m0 + 64 : kp.nmo;
+		for (uint32_t m = m0; m < m1; m++) {
+			bool hit = false;
+			if (active && !dropped) {
+				const xe_prog pr = kp.progs[m];
+				bool parent_ok = true;
+				if (pr.parent >= 0) {
+					/* a parent in an earlier word was stored already */
+					parent_ok = ((uint32_t)pr.parent >= m0)
+						? ((bits >> ((uint32_t)pr.parent - m0)) & 1) != 0
+						: ((kp.masks[(size_t)ridx * kp.mask_words + ((uint32_t)pr.parent >> 6)]
+							>> ((uint32_t)pr.parent & 63)) & 1) != 0;
+				}
+				hit = parent_ok && prog_match<REC, GET>(kp, rec, pr);
+			}
+			if (hit) bits |= 1ull << (m - m0);
+			/* counters: wave-wide sums, one atomic per wave and counter */
+			unsigned long long ball = __ballot(hit);
+			if (ball) {
+				unsigned long long sb = wave_sum(hit ? bytes_x_rate : 0ull);
+				unsigned long long sp = wave_sum(hit ? pkts_x_rate : 0ull);
+				if ((threadIdx.x & 63) == 0) {
+					atomicAdd(&kp.counters[3 * m + 0], (unsigned long long)__popcll(ball));
+					atomicAdd(&kp.counters[3 * m + 1], sb);
+					atomicAdd(&kp.counters[3 * m + 2], sp);
+				}
+			}
+		}
+		if (active) kp.masks[(size_t)ridx * kp.mask_words + w] = bits;
+	}
+}
+
+/* store a non-string field value into its column in flow_info byte order */
+__device__ __forceinline__ void
+store_col(const xe_kparams &kp, uint32_t f, uint32_t ridx, const val128 &v)
+{
+	uint32_t w = c_colw[f], sm = c_fmax[f];
+	uint8_t *dst = kp.out_base + kp.col_off[f] + (size_t)ridx * w;
+	switch (w) {
+		case 1: *dst = (uint8_t)v.lo; break;
+		case 2: *(uint16_t *)dst = __builtin_bswap16((uint16_t)v.lo); break;
+		case 4: *(uint32_t *)dst = __builtin_bswap32((uint32_t)v.lo); break;
+		case 8: *(uint64_t *)dst = __builtin_bswap64(v.lo << (8 * (8 - sm))); break;
+		default:
+			((uint64_t *)dst)[0] = __builtin_bswap64(v.hi);
+			((uint64_t *)dst)[1] = __builtin_bswap64(v.lo);
+			break;
+	}
+}
+
+__global__ void __launch_bounds__(XE_BLOCK)
+xe_nf_kernel(const xe_kparams kp)
+{
+	uint32_t ridx = blockIdx.x * XE_BLOCK + threadIdx.x;
+	bool active = ridx < kp.nrec;
+	nf_rec rec;
+	unsigned long long bxr = 0, pxr = 0;
+	int32_t device = -1;
+
+	rec.mark = 0;
+	rec.nparsed = 0;
+	if (active) {
+		/* the set whose [first_rec, first_rec + nrec) holds this record */
+		uint32_t lo = 0, hi = kp.nsets - 1;
+		while (lo < hi) {
+			uint32_t mid = (lo + hi + 1) >> 1;
+			if (kp.sets[mid].first_rec <= ridx) lo = mid; else hi = mid - 1;
+		}
+		const xe_set s = kp.sets[lo];
+		uint32_t i = ridx - s.first_rec;
+		int64_t roff = (int64_t)i * s.stride;
+		int32_t avail = s.avail - (int32_t)roff;
+
+		rec.src.p = kp.pkt + s.data_off + roff;
+		rec.src.left = s.dgram_left - (int32_t)roff;
+		rec.src.checked = (s.flags & XE_SET_CHECKED) != 0;
+		rec.t = kp.tmpls + s.tmpl;
+		rec.e = kp.tents + rec.t->ent_base;
+		rec.ex = kp.exps + s.exporter;
+		device = rec.ex->device;
+
+		/* how many template fields the reference parses for this record */
+		uint32_t nf = rec.t->nfields, np = 0;
+		int32_t pos = 0;
+		if (rec.t->mode == XE_MODE_V9) {
+			for (; np < nf; np++) {
+				if ((pos + (int32_t)rec.e[np].len) > avail) break;
+				pos += rec.e[np].len;
+			}
+		} else {
+			for (; np < nf;) {
+				int32_t off;
+				uint32_t len;
+				if (rec.t->varlen) {
+					rec.locate(np, &off, &len);
+					pos = off + (int32_t)len;
+				} else {
+					pos += rec.e[np].len;
+				}
+				np++;
+				if (pos >= avail) break;
+			}
+		}
+		rec.nparsed = np;
+		kp.nparsed[ridx] = (uint8_t)np;
+
+		/* decode into the columns */
+		for (uint32_t j = 0; j < np; j++) {
+			uint32_t f = rec.e[j].field;
+			if (f == XE_F_NONE) continue;
+			bool special = rec.t->varlen || (rec.e[j].flags & XE_TE_REPEAT)
+				|| (rec.e[j].next_same != 0xFF) || c_fstr[f];
+			if (!special) {
+				bool ok = (rec.e[j].flags & XE_TE_VALID) != 0;
+				if (ok) store_col(kp, f, ridx, pkt_be(rec.src, rec.e[j].off, rec.e[j].len));
+				if (kp.vsize_off[f] != ~0ull) {
+					((uint16_t *)(kp.out_base + kp.vsize_off[f]))[ridx] = ok ? rec.e[j].len : (uint16_t)0xFFFF;
+				}
+				continue;
+			}
+			int32_t off;
+			uint32_t len;
+			rec.locate(j, &off, &len);
+			bool ok = rec.valid(j, len, c_fmin, c_fmax);
+			if (c_fstr[f]) {
+				/* left-aligned copy; the first occurrence also clears the
+				 * rest of the slot (the record starts zeroed, netflow.c:275) */
+				uint32_t w = c_colw[f];
+				uint8_t *dst = kp.out_base + kp.col_off[f] + (size_t)ridx * w;
+				bool first = !(rec.e[j].flags & XE_TE_REPEAT);
+				if (first) {
+					for (uint32_t b = 0; b < w; b++) dst[b] = (ok && (b < len)) ? (uint8_t)pkt_byte(rec.src, off + (int32_t)b) : 0;
+				} else if (ok) {
+					for (uint32_t b = 0; b < len; b++) dst[b] = (uint8_t)pkt_byte(rec.src, off + (int32_t)b);
+				}
+				if (kp.vsize_off[f] != ~0ull) {
+					uint16_t *vs = (uint16_t *)(kp.out_base + kp.vsize_off[f]) + ridx;
+					if (ok) *vs = (uint16_t)len;
+					else if (first) *vs = 0xFFFF;
+				}
+			} else {
+				uint32_t sz = 0;
+				fval fv = nf_get(rec, f, &sz);
+				if (fv.has) store_col(kp, f, ridx, fv.v);
+				if (kp.vsize_off[f] != ~0ull) {
+					((uint16_t *)(kp.out_base + kp.vsize_off[f]))[ridx] = fv.has ? (uint16_t)sz : 0xFFFF;
+				}
+			}
+		}
+
+		/* what the counters add: get_nf_val(8 bytes) * sampling_rate, wrapping */
+		uint64_t rate = rec.ex->sampling_rate;
+		bxr = nf_get(rec, XF_in_bytes, nullptr).v.lo * rate;
+		pxr = nf_get(rec, XF_in_pkts, nullptr).v.lo * rate;
+	}
+	classify<nf_rec, nf_get>(kp, rec, device, ridx, active, bxr, pxr);
+}
+
+/* ------------------------------------------------------------------ list probe */
+__global__ void
+xe_trie_probe_kernel(const uint32_t *trie, xe_list_dev L, int family, const uint8_t *addrs, uint32_t n, uint8_t *out)
+{
+	uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	if (family == 4) {
+		const uint8_t *a = addrs + 4 * (size_t)i;
+		uint32_t v = ((uint32_t)a[0] << 24) | ((uint32_t)a[1] << 16) | ((uint32_t)a[2] << 8) | a[3];
+		out[i] = (uint8_t)trie_match4(trie, L, v);
+	} else {
+		const uint8_t *a = addrs + 16 * (size_t)i;
+		uint64_t hi = 0, lo = 0;
+		for (int k = 0; k < 8; k++) { hi = (hi << 8) | a[k]; lo = (lo << 8) | a[8 + k]; }
+		out[i] = (uint8_t)trie_match6(trie, L, hi, lo);
+	}
+}
+
+/* ------------------------------------------------------------------ launch */
+static int g_tables_ready = 0;
+
+static hipError_t
+upload_tables(void)
+{
+	uint16_t mn[XE_NFIELDS], mx[XE_NFIELDS], cw[XE_NFIELDS];
+	uint8_t st[XE_NFIELDS];
+	hipError_t e;
+
+	for (int i = 0; i < XE_NFIELDS; i++) {
+		mn[i] = xe_fields[i].size_min;
+		mx[i] = xe_fields[i].size_max;
+		cw[i] = xe_fields[i].col_width;
+		st[i] = xe_fields[i].type == XE_T_STR;
+	}
+	if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_fmin), mn, sizeof(mn))) != hipSuccess) return e;
+	if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_fmax), mx, sizeof(mx))) != hipSuccess) return e;
+	if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_colw), cw, sizeof(cw))) != hipSuccess) return e;
+	if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_fstr), st, sizeof(st))) != hipSuccess) return e;
+	return hipSuccess;
+}
+
+extern "C" int
+xe_launch_init_tables(void)
+{
+	/* constant tables live per device; the caller invokes this once per
+	 * handle with its device current */
+	hipError_t e = upload_tables();
+	if (e != hipSuccess) return XE_EHIP;
+	g_tables_ready = 1;
+	return XE_OK;
+}
+
+extern "C" int
+xe_launch_batch(const struct xe_kparams *kp, void *stream)
+{
+	hipStream_t st = (hipStream_t)stream;
+
+	if (!g_tables_ready) return XE_ESTATE;
+	if (kp->nmo) {
+		if (hipMemsetAsync(kp->counters, 0, (size_t)kp->nmo * 3 * sizeof(unsigned long long), st) != hipSuccess) {
+			return XE_EHIP;
+		}
+	}
+	if (kp->nrec) {
+		uint32_t blocks = (kp->nrec + XE_BLOCK - 1) / XE_BLOCK;
+		hipLaunchKernelGGL(xe_nf_kernel, dim3(blocks), dim3(XE_BLOCK), 0, st, *kp);
+		if (hipGetLastError() != hipSuccess) return XE_EHIP;
+	}
+	return XE_OK;
+}
+
+extern "C" int
+xe_launch_trie_probe(const uint32_t *trie, struct xe_list_dev list, int family,
+	const uint8_t *addrs, uint32_t n, uint8_t *out, void *stream)
+{
+	if (!n) return XE_OK;
+	hipLaunchKernelGGL(xe_trie_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+		trie, list, family, addrs, n, out);
+	return (hipGetLastError() == hipSuccess) ? XE_OK : XE_EHIP;
+}

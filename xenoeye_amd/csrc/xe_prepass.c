@@ -1,0 +1,825 @@
+/*
+ * xe_prepass.c -- host walk over a batch of export datagrams.
+ *
+ * Templates arrive in-band and the reference's set loops carry a cursor from
+ * one set to the next, so the order-dependent part of the path is done here,
+ * sequentially per datagram, reading only headers: Netflow v9 / IPFIX / v5
+ * datagram headers, set headers and template sets (netflow.c:319-365,
+ * :628-678, :727-746), sFlow datagram / sample / element headers
+ * (sflow-impl.h:68-405).  The output is a list of runs ("sets") of records
+ * that share template, exporter and spacing; record bytes themselves are only
+ * touched on the GPU (the one exception: IPFIX records with variable-length
+ * elements, whose length prefixes must be read to find the next record).
+ *
+ * The set arithmetic reproduces the reference exactly, including:
+ *   - the set length passed down includes the 4-byte set header although the
+ *     cursor already passed it (netflow.c:342-358, :651-666);
+ *   - a v9 data set is iterated header.count times, whatever it holds
+ *     (netflow.c:272), with the field cursor carried from record to record;
+ *   - after a v9 data set the cursor advances by the full length, i.e. 4
+ *     bytes too far (netflow.c:315); after a v9 template set only by the size
+ *     of the first template (netflow.c:173);
+ *   - bytes past the end of a datagram read as zero (the reference re-uses a
+ *     64 KiB buffer; zero is what a fresh buffer holds).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <arpa/inet.h>
+#include "xe_internal.h"
+
+/* ------------------------------------------------------------------ helpers */
+struct dgram
+{
+	const uint8_t *p;     /* first byte */
+	long len;
+	uint64_t base;        /* offset of p in the batch buffer */
+	uint32_t src_ip;      /* bytes as stored */
+	uint32_t source_id;   /* raw */
+	uint32_t exporter;    /* index in plan->exporters */
+};
+
+static inline uint8_t
+g8(const struct dgram *d, long off)
+{
+	return ((off >= 0) && (off < d->len)) ? d->p[off] : 0;
+}
+
+static inline uint32_t
+g16(const struct dgram *d, long off)
+{
+	return ((uint32_t)g8(d, off) << 8) | g8(d, off + 1);
+}
+
+static inline uint32_t
+g32raw(const struct dgram *d, long off)   /* 4 bytes in memory order */
+{
+	uint8_t b[4];
+	uint32_t v;
+	b[0] = g8(d, off); b[1] = g8(d, off + 1); b[2] = g8(d, off + 2); b[3] = g8(d, off + 3);
+	memcpy(&v, b, 4);
+	return v;
+}
+
+static void
+gcopy(const struct dgram *d, long off, uint8_t *dst, long n)
+{
+	long i;
+	for (i = 0; i < n; i++) dst[i] = g8(d, off + i);
+}
+
+void
+xe_host_init(struct xe_host *hs)
+{
+	memset(hs, 0, sizeof(*hs));
+}
+
+void
+xe_host_free(struct xe_host *hs)
+{
+	size_t i, j;
+	for (i = 0; i < hs->nmos; i++) xe_filter_free(&hs->mos[i].filter);
+	free(hs->mos);
+	for (i = 0; i < hs->ndevs; i++) {
+		for (j = 0; j < hs->devs[i].nmarks; j++) xe_filter_free(&hs->devs[i].marks[j]);
+		free(hs->devs[i].marks);
+	}
+	free(hs->devs);
+	xe_iplists_free(&hs->lists);
+	for (i = 0; i < hs->ntslots; i++) free(hs->tslots[i].raw);
+	free(hs->tslots);
+	free(hs->thash);
+	free(hs->dev_tmpls.p);
+	free(hs->dev_tents.p);
+	memset(hs, 0, sizeof(*hs));
+}
+
+void
+xe_plan_free(struct xe_plan *p)
+{
+	free(p->sets.p);
+	free(p->exporters.p);
+	free(p->sfrecs.p);
+	memset(p, 0, sizeof(*p));
+}
+
+/* ------------------------------------------------------------------ devices.conf lookup */
+/* devices.c:205-232 / :246-270; the second test is `if`, not `else if` */
+static int
+device_find(const struct xe_host *hs, uint32_t ip, uint32_t id)
+{
+	size_t i;
+	for (i = 0; i < hs->ndevs; i++) {
+		const struct xe_device *d = &hs->devs[i];
+		if (d->use_ip && d->use_id) {
+			if ((ip == d->ip) && (id == d->id)) return (int)i;
+		} else if (d->use_ip) {
+			if (ip == d->ip) return (int)i;
+		}
+		if (d->use_id) {
+			if (id == d->id) return (int)i;
+		}
+	}
+	return -1;
+}
+
+/* exporter = (source address, source id) pair seen in this batch; carries the
+ * per-packet values of netflow.c:112-144 */
+static int
+exporter_get(struct xe_host *hs, struct xe_plan *plan, uint32_t ip, uint32_t id, uint32_t *out)
+{
+	struct xe_exporter *ex = plan->exporters.p;
+	struct xe_exporter ne;
+	size_t i;
+	int dev;
+
+	/* most recent first: consecutive datagrams usually share the exporter */
+	for (i = plan->exporters.n; i-- > 0;) {
+		if (!memcmp(ex[i].dev_ip, &ip, 4) && !memcmp(ex[i].dev_id, &id, 4)) {
+			*out = (uint32_t)i;
+			return 1;
+		}
+		if (plan->exporters.n - i > 4096) break;   /* bound the scan; duplicates are harmless */
+	}
+	memset(&ne, 0, sizeof(ne));
+	memcpy(ne.dev_ip, &ip, 4);
+	memcpy(ne.dev_id, &id, 4);
+	dev = device_find(hs, ip, id);
+	ne.device = dev;
+	ne.sampling_rate = (dev >= 0) ? (uint32_t)hs->devs[dev].sampling_rate : 1;
+	*out = (uint32_t)plan->exporters.n;
+	return xe_blob_push(&plan->exporters, &ne, sizeof(ne));
+}
+
+/* ------------------------------------------------------------------ template store */
+static uint64_t
+tkey_hash(const struct xe_tkey *k)
+{
+	uint64_t h = 0xcbf29ce484222325ull;
+	h = (h ^ k->ver) * 0x100000001b3ull;
+	h = (h ^ k->tid) * 0x100000001b3ull;
+	h = (h ^ k->src_ip) * 0x100000001b3ull;
+	h = (h ^ k->source_id) * 0x100000001b3ull;
+	return h ^ (h >> 29);
+}
+
+static int
+tkey_eq(const struct xe_tkey *a, const struct xe_tkey *b)
+{
+	return (a->ver == b->ver) && (a->tid == b->tid) && (a->src_ip == b->src_ip)
+		&& (a->source_id == b->source_id);
+}
+
+/* netflow_template_find() (netflow-templates.c:140-181) reduced to "latest
+ * template for (version, template id as on the wire, exporter, source id)" */
+static struct xe_tslot *
+tmpl_find(struct xe_host *hs, const struct xe_tkey *k)
+{
+	size_t m, i;
+	if (!hs->thash_cap) return NULL;
+	m = hs->thash_cap - 1;
+	for (i = tkey_hash(k) & m;; i = (i + 1) & m) {
+		uint32_t v = hs->thash[i];
+		if (!v) return NULL;
+		if (tkey_eq(&hs->tslots[v - 1].key, k)) return &hs->tslots[v - 1];
+	}
+}
+
+static int
+thash_insert(struct xe_host *hs, uint32_t slot)
+{
+	size_t m, i;
+	if ((hs->ntslots + 1) * 2 > hs->thash_cap) {
+		size_t ncap = hs->thash_cap ? hs->thash_cap * 2 : 1024, j;
+		uint32_t *nh = calloc(ncap, sizeof(uint32_t));
+		if (!nh) return 0;
+		for (j = 0; j < hs->ntslots; j++) {
+			if (j == slot) continue;
+			for (i = tkey_hash(&hs->tslots[j].key) & (ncap - 1); nh[i]; i = (i + 1) & (ncap - 1)) {}
+			nh[i] = (uint32_t)j + 1;
+		}
+		free(hs->thash);
+		hs->thash = nh;
+		hs->thash_cap = ncap;
+	}
+	m = hs->thash_cap - 1;
+	for (i = tkey_hash(&hs->tslots[slot].key) & m; hs->thash[i]; i = (i + 1) & m) {}
+	hs->thash[i] = slot + 1;
+	return 1;
+}
+
+/* build (or re-use) the device form of a template.  pairs: n x {type, len}. */
+static int
+dev_template(struct xe_host *hs, int mode, const uint16_t *types, const uint16_t *lens, size_t n,
+	uint32_t *slot_out)
+{
+	struct xe_tmpl t;
+	struct xe_tent *ents;
+	struct xe_tmpl *existing = hs->dev_tmpls.p;
+	size_t i, j, keep = n;
+	uint64_t pos = 0;
+	int varlen = 0;
+
+	/* entries that start past 65535 can never be reached: every set length
+	 * is a 16-bit number and both record loops stop at it */
+	for (i = 0; i < n; i++) {
+		if (pos > 0xFFFF) { keep = i; break; }
+		if ((mode == XE_MODE_IPFIX) && (lens[i] == 0xFFFF)) varlen = 1;
+		else pos += lens[i];
+	}
+	if (keep > XE_TMPL_MAXF) return XE_EUNSUPPORTED;
+
+	ents = calloc(keep ? keep : 1, sizeof(*ents));
+	if (!ents) return XE_ENOMEM;
+	memset(&t, 0, sizeof(t));
+	memset(t.fmap, 0xFF, sizeof(t.fmap));
+	t.mode = (uint8_t)mode;
+	t.nfields = (uint16_t)keep;
+	t.varlen = (uint8_t)varlen;
+	pos = 0;
+	for (i = 0; i < keep; i++) {
+		int f = xe_field_by_id(types[i]);
+		struct xe_tent *e = &ents[i];
+
+		e->len = lens[i];
+		e->off = (uint16_t)((pos > 0xFFFF) ? 0xFFFF : pos);
+		e->field = (f < 0) ? XE_F_NONE : (uint8_t)f;
+		e->next_same = 0xFF;
+		if (f >= 0) {
+			int l = lens[i];
+			/* a variable-length element is validated per record */
+			if ((mode == XE_MODE_IPFIX) && (lens[i] == 0xFFFF)) e->flags |= XE_TE_VALID;
+			else if ((l >= xe_fields[f].size_min) && (l <= xe_fields[f].size_max)) e->flags |= XE_TE_VALID;
+			if (xe_fields[f].type == XE_T_STR) e->flags |= XE_TE_STR;
+			if (t.fmap[f] == 0xFF) {
+				t.fmap[f] = (uint8_t)i;
+			} else {
+				for (j = t.fmap[f]; ents[j].next_same != 0xFF; j = ents[j].next_same) {}
+				ents[j].next_same = (uint8_t)i;
+				e->flags |= XE_TE_REPEAT;
+				t.repeats = 1;
+			}
+		}
+		if (!((mode == XE_MODE_IPFIX) && (lens[i] == 0xFFFF))) pos += lens[i];
+	}
+	t.stride = (uint16_t)((pos > 0xFFFF) ? 0xFFFF : pos);
+	if (pos > 0xFFFF) t.varlen = 2;   /* records longer than any set: walked one by one */
+
+	/* identical templates (typically the same router model behind many
+	 * exporters) share one device slot */
+	for (i = 0; i < hs->dev_tmpls.n; i++) {
+		const struct xe_tmpl *o = &existing[i];
+		if ((o->mode == t.mode) && (o->nfields == t.nfields) && (o->stride == t.stride)
+			&& (o->varlen == t.varlen)
+			&& !memcmp((struct xe_tent *)hs->dev_tents.p + o->ent_base, ents, keep * sizeof(*ents))) {
+			free(ents);
+			*slot_out = (uint32_t)i;
+			return XE_OK;
+		}
+	}
+	t.ent_base = (uint32_t)hs->dev_tents.n;
+	for (i = 0; i < keep; i++) {
+		if (!xe_blob_push(&hs->dev_tents, &ents[i], sizeof(*ents))) { free(ents); return XE_ENOMEM; }
+	}
+	free(ents);
+	*slot_out = (uint32_t)hs->dev_tmpls.n;
+	if (!xe_blob_push(&hs->dev_tmpls, &t, sizeof(t))) return XE_ENOMEM;
+	return XE_OK;
+}
+
+/* netflow_template_add() (netflow-templates.c:183-251) without persistence:
+ * raw = the bytes the reference stores */
+static int
+tmpl_put(struct xe_host *hs, const struct xe_tkey *k, const uint8_t *raw, size_t raw_len)
+{
+	struct xe_tslot *s = tmpl_find(hs, k);
+	uint16_t *types, *lens;
+	size_t n, i, step, first;
+	int rc, mode;
+	uint32_t slot;
+
+	if (s && (s->raw_len == raw_len) && !memcmp(s->raw, raw, raw_len)) return XE_OK;
+
+	n = ((size_t)raw[2] << 8) | raw[3];
+	if (k->ver == 9) { mode = XE_MODE_V9; step = 4; first = 4; }
+	else { mode = XE_MODE_IPFIX; step = 8; first = 4; }
+	types = malloc((n ? n : 1) * 2 * sizeof(uint16_t));
+	if (!types) return XE_ENOMEM;
+	lens = types + (n ? n : 1);
+	for (i = 0; i < n; i++) {
+		const uint8_t *e = raw + first + step * i;
+		types[i] = (uint16_t)((e[0] << 8) | e[1]);
+		lens[i] = (uint16_t)((e[2] << 8) | e[3]);
+	}
+	rc = dev_template(hs, mode, types, lens, n, &slot);
+	free(types);
+	if (rc != XE_OK) return rc;
+
+	if (!s) {
+		if (hs->ntslots == hs->tslots_cap) {
+			size_t nc = hs->tslots_cap ? hs->tslots_cap * 2 : 256;
+			struct xe_tslot *nt = realloc(hs->tslots, nc * sizeof(*nt));
+			if (!nt) return XE_ENOMEM;
+			hs->tslots = nt;
+			hs->tslots_cap = nc;
+		}
+		s = &hs->tslots[hs->ntslots];
+		memset(s, 0, sizeof(*s));
+		s->key = *k;
+		if (!thash_insert(hs, (uint32_t)hs->ntslots)) return XE_ENOMEM;
+		hs->ntslots++;
+	}
+	free(s->raw);
+	s->raw = malloc(raw_len ? raw_len : 1);
+	if (!s->raw) return XE_ENOMEM;
+	memcpy(s->raw, raw, raw_len);
+	s->raw_len = raw_len;
+	s->dev_slot = slot;
+	return XE_OK;
+}
+
+/* ------------------------------------------------------------------ set emission */
+static int
+emit_set(struct xe_plan *plan, const struct xe_host *hs, const struct dgram *d, long rel_off,
+	uint32_t nrec, long avail, uint32_t stride, uint32_t tmpl, long extent)
+{
+	struct xe_set s;
+	const struct xe_tmpl *t = (const struct xe_tmpl *)hs->dev_tmpls.p + tmpl;
+	const struct xe_tent *e = (const struct xe_tent *)hs->dev_tents.p + t->ent_base;
+	size_t i, w = 0;
+
+	if (!nrec) return 1;
+	if (plan->nrec + nrec > 0xFFFFFFF0u) return 0;
+	memset(&s, 0, sizeof(s));
+	s.data_off = d->base + (uint64_t)rel_off;
+	s.first_rec = (uint32_t)plan->nrec;
+	s.nrec = nrec;
+	s.avail = (int32_t)avail;
+	s.stride = stride;
+	s.tmpl = tmpl;
+	s.dgram_left = (int32_t)(d->len - rel_off);
+	s.exporter = d->exporter;
+	/* extent = the furthest byte (relative to rel_off) any record of the run
+	 * may look at; past the datagram end the kernels must substitute zeros */
+	if ((extent < 0) || ((rel_off + extent) > d->len) || (rel_off < 0) || t->varlen) s.flags |= XE_SET_CHECKED;
+	plan->nrec += nrec;
+	for (i = 0; i < t->nfields; i++) {
+		if ((e[i].field != XE_F_NONE) && (e[i].flags & XE_TE_VALID)) {
+			int f = e[i].field;
+			plan->field_mask[f >> 6] |= 1ull << (f & 63);
+			if (!(e[i].flags & XE_TE_REPEAT)) w += xe_fields[f].col_width;
+		}
+	}
+	plan->soa_bytes_per_rec_sum += w * nrec;
+	return xe_blob_push(&plan->sets, &s, sizeof(s));
+}
+
+/* ------------------------------------------------------------------ netflow v9 */
+/* parse_netflow_v9_flowset(), netflow.c:246-317 */
+static int
+v9_data_set(struct xe_host *hs, struct xe_plan *plan, struct dgram *d, long *ptr, uint16_t fsid_raw,
+	long length, long count)
+{
+	struct xe_tkey k = { 9, fsid_raw, d->src_ip, d->source_id };
+	struct xe_tslot *ts = tmpl_find(hs, &k);
+	const struct xe_tmpl *t;
+	const struct xe_tent *e;
+	long S, nfull, done, start;
+
+	if (!ts) return 0;
+	t = (const struct xe_tmpl *)hs->dev_tmpls.p + ts->dev_slot;
+	e = (const struct xe_tent *)hs->dev_tents.p + t->ent_base;
+	S = (t->varlen == 2) ? 0x10000 : t->stride;
+
+	/* records that fit completely: (k+1)*S <= length */
+	nfull = (S > 0) ? (length / S) : count;
+	if (nfull > count) nfull = count;
+	if (S == 0) {
+		/* every field is empty: `count` records, all at the set start */
+		if (!emit_set(plan, hs, d, *ptr, (uint32_t)count, length, 0, ts->dev_slot, 0)) return -1;
+		*ptr += length;
+		return 1;
+	}
+	if (!emit_set(plan, hs, d, *ptr, (uint32_t)nfull, length, (uint32_t)S, ts->dev_slot, nfull * S)) return -1;
+	done = nfull;
+	start = nfull * S;
+	/* the remaining iterations each start where the previous one stopped
+	 * (the field cursor is not reset, netflow.c:271-291) */
+	while (done < count) {
+		long pos = start;
+		size_t i;
+		for (i = 0; i < t->nfields; i++) {
+			if ((pos + e[i].len) > length) break;
+			pos += e[i].len;
+		}
+		if (pos == start) {
+			/* nothing consumed: all later iterations are identical */
+			if (!emit_set(plan, hs, d, *ptr + start, (uint32_t)(count - done), length - start, 0,
+				ts->dev_slot, 0)) return -1;
+			break;
+		}
+		if (!emit_set(plan, hs, d, *ptr + start, 1, length - start, 0, ts->dev_slot, pos - start)) return -1;
+		start = pos;
+		done++;
+	}
+	*ptr += length;
+	return 1;
+}
+
+/* parse_netflow_v9(), netflow.c:319-365 */
+static int
+walk_v9(struct xe_host *hs, struct xe_plan *plan, struct dgram *d)
+{
+	long ptr = 20;
+	long count = g16(d, 2);
+
+	d->source_id = g32raw(d, 16);
+	if (!exporter_get(hs, plan, d->src_ip, d->source_id, &d->exporter)) return XE_ENOMEM;
+
+	while (ptr < d->len) {
+		uint8_t idb[2] = { g8(d, ptr), g8(d, ptr + 1) };
+		uint16_t fsid_raw;
+		long fsid = (idb[0] << 8) | idb[1];
+		long length = g16(d, ptr + 2);
+
+		memcpy(&fsid_raw, idb, 2);
+		ptr += 4;
+		if (fsid == 0) {
+			/* parse_netflow_v9_template(), netflow.c:147-186: one
+			 * template, cursor += its size */
+			long fc = g16(d, ptr + 2);
+			long tsize = 4 + fc * 4;
+			uint8_t *raw;
+			struct xe_tkey k = { 9, 0, d->src_ip, d->source_id };
+			int rc;
+
+			if (tsize > length) { plan->skipped_datagrams++; return XE_OK; }
+			raw = malloc((size_t)tsize);
+			if (!raw) return XE_ENOMEM;
+			gcopy(d, ptr, raw, tsize);
+			memcpy(&k.tid, raw, 2);
+			rc = tmpl_put(hs, &k, raw, (size_t)tsize);
+			free(raw);
+			if (rc != XE_OK) return rc;
+			ptr += tsize;
+		} else if (fsid == 1) {
+			break;
+		} else {
+			int rc = v9_data_set(hs, plan, d, &ptr, fsid_raw, length, count);
+			if (rc < 0) return XE_ENOMEM;
+			if (rc == 0) break;
+		}
+	}
+	return XE_OK;
+}
+
+/* ------------------------------------------------------------------ IPFIX */
+/* parse_ipfix_template() + ipfix_template_convert(), netflow.c:389-485 */
+static int
+ipfix_template(struct xe_host *hs, struct dgram *d, long ptr, long length, int *ok)
+{
+	long fc, avail = length - 4, p, i;
+	uint8_t *raw;
+	struct xe_tkey k = { 10, 0, d->src_ip, d->source_id };
+	int rc;
+
+	*ok = 0;
+	if (4 > length) return XE_OK;
+	fc = g16(d, ptr + 2);
+	if (fc < 1) return XE_OK;
+	raw = calloc(1, 4 + 8 * (size_t)fc);
+	if (!raw) return XE_ENOMEM;
+	gcopy(d, ptr, raw, 4);
+	p = ptr + 4;
+	for (i = 0; i < fc; i++) {
+		uint8_t e[8];
+		gcopy(d, p, e, 8);
+		if (e[0] & 0x80) {
+			if ((p - ptr + 8) > avail) { free(raw); return XE_OK; }
+			e[0] &= 0x7f;
+			memcpy(raw + 4 + 8 * i, e, 8);
+			p += 8;
+		} else {
+			if ((p - ptr + 4) > avail) { free(raw); return XE_OK; }
+			memcpy(raw + 4 + 8 * i, e, 4);
+			p += 4;
+		}
+	}
+	memcpy(&k.tid, raw, 2);
+	rc = tmpl_put(hs, &k, raw, 4 + 8 * (size_t)fc);
+	free(raw);
+	if (rc == XE_OK) *ok = 1;
+	return rc;
+}
+
+/* parse_ipfix_flowset(), netflow.c:547-625 */
+static int
+ipfix_data_set(struct xe_host *hs, struct xe_plan *plan, struct dgram *d, long ptr, uint16_t fsid_raw,
+	long length)
+{
+	struct xe_tkey k = { 10, fsid_raw, d->src_ip, d->source_id };
+	struct xe_tslot *ts = tmpl_find(hs, &k);
+	const struct xe_tmpl *t;
+	const struct xe_tent *e;
+	long fc, S;
+
+	if (!ts) return 0;
+	t = (const struct xe_tmpl *)hs->dev_tmpls.p + ts->dev_slot;
+	e = (const struct xe_tent *)hs->dev_tents.p + t->ent_base;
+	fc = ((long)ts->raw[2] << 8) | ts->raw[3];   /* the loop test uses the full field count */
+	S = t->stride;
+
+	if (!t->varlen) {
+		long nrec;
+		if (S == 0) {
+			/* all fields empty: the reference never leaves its loop */
+			plan->skipped_datagrams++;
+			return 1;
+		}
+		/* record k exists iff length - k*S >= field_count; a record that
+		 * reaches `length` ends the loop but is itself delivered */
+		if (length < fc) return 1;
+		nrec = (length - fc) / S + 1;
+		if (!emit_set(plan, hs, d, ptr, (uint32_t)nrec, length, (uint32_t)S, ts->dev_slot, nrec * S)) return -1;
+		return 1;
+	}
+	/* variable-length elements (netflow.c:367-383): find each record's start */
+	{
+		long pos = 0;
+		int stop = 0;
+		while (!stop) {
+			long start = pos;
+			size_t i;
+			if ((length - pos) < fc) break;
+			for (i = 0; i < t->nfields; i++) {
+				long fl = e[i].len, adj = 0;
+				if (fl == 0xFFFF) {
+					uint8_t b0 = g8(d, ptr + pos);
+					if (b0 != 255) { fl = b0; adj = 1; }
+					else { fl = g16(d, ptr + pos + 1); adj = 3; }
+				}
+				pos += fl + adj;
+				if (pos >= length) { stop = 1; break; }
+			}
+			if (!emit_set(plan, hs, d, ptr + start, 1, length - start, 0, ts->dev_slot, -1)) return -1;
+			/* a template cut at 65535 bytes never gets here without stop */
+			if (!stop && (pos == start)) { plan->skipped_datagrams++; break; }
+		}
+	}
+	return 1;
+}
+
+/* parse_ipfix(), netflow.c:628-678 */
+static int
+walk_ipfix(struct xe_host *hs, struct xe_plan *plan, struct dgram *d)
+{
+	long ptr = 16;
+
+	d->source_id = g32raw(d, 12);
+	if (!exporter_get(hs, plan, d->src_ip, d->source_id, &d->exporter)) return XE_ENOMEM;
+
+	while (ptr < d->len) {
+		uint8_t idb[2] = { g8(d, ptr), g8(d, ptr + 1) };
+		uint16_t fsid_raw;
+		long fsid = (idb[0] << 8) | idb[1];
+		long length = g16(d, ptr + 2);
+
+		memcpy(&fsid_raw, idb, 2);
+		ptr += 4;
+		if (fsid == 2) {
+			int ok, rc = ipfix_template(hs, d, ptr, length, &ok);
+			if (rc != XE_OK) return rc;
+			if (!ok) break;
+		} else if (fsid == 3) {
+			/* options template: skipped */
+		} else if (fsid > 255) {
+			int rc = ipfix_data_set(hs, plan, d, ptr, fsid_raw, length);
+			if (rc < 0) return XE_ENOMEM;
+			if (rc == 0) break;
+		}
+		/* length 0 would park the reference on this set header forever */
+		if (length == 0) { plan->skipped_datagrams++; break; }
+		ptr += length - 4;
+	}
+	return XE_OK;
+}
+
+/* ------------------------------------------------------------------ netflow v5 */
+/* netflow.h:42-62: the fixed 48-byte record as a template; the two pads are
+ * unknown elements */
+static int
+v5_template(struct xe_host *hs, uint32_t *slot)
+{
+	static const uint16_t types[] = { 8, 12, 15, 10, 14, 2, 1, 22, 21, 7, 11, 0xFFFE, 6, 4, 5, 16, 17, 9, 13, 0xFFFD };
+	static const uint16_t lens[] = { 4, 4, 4, 2, 2, 4, 4, 4, 4, 2, 2, 1, 1, 1, 1, 2, 2, 1, 1, 2 };
+	return dev_template(hs, XE_MODE_V9, types, lens, sizeof(lens) / sizeof(lens[0]), slot);
+}
+
+/* parse_netflow_v5(), netflow.c:727-786 */
+static int
+walk_v5(struct xe_host *hs, struct xe_plan *plan, struct dgram *d)
+{
+	long n = g16(d, 2);
+	uint32_t slot;
+	int rc = XE_OK;
+
+	if ((24 + 48 * n) != d->len) { plan->skipped_datagrams++; return XE_OK; }
+	d->source_id = g8(d, 21);   /* engine_id widened to a host-order word */
+	if (!exporter_get(hs, plan, d->src_ip, d->source_id, &d->exporter)) return XE_ENOMEM;
+	if (hs->v5_slot_plus1) {
+		slot = hs->v5_slot_plus1 - 1;
+	} else {
+		rc = v5_template(hs, &slot);
+		if (rc != XE_OK) return rc;
+		hs->v5_slot_plus1 = slot + 1;
+	}
+	if (!emit_set(plan, hs, d, 24, (uint32_t)n, 48 * n, 48, slot, 48 * n)) return XE_ENOMEM;
+	return XE_OK;
+}
+
+/* ------------------------------------------------------------------ sFlow v5 */
+struct sfcur { const struct dgram *d; long p; int bad; };
+
+/* READ_SF_BYTES / READ32_H, sflow-impl.h:51-65 */
+static uint32_t
+sf_u32(struct sfcur *c)
+{
+	uint32_t v;
+	if (c->bad || ((c->p + 4) > c->d->len)) { c->bad = 1; return 0; }
+	v = ((uint32_t)g8(c->d, c->p) << 24) | ((uint32_t)g8(c->d, c->p + 1) << 16)
+		| ((uint32_t)g8(c->d, c->p + 2) << 8) | g8(c->d, c->p + 3);
+	c->p += 4;
+	return v;
+}
+
+static uint32_t
+sf_raw32(struct sfcur *c)
+{
+	uint32_t v;
+	if (c->bad || ((c->p + 4) > c->d->len)) { c->bad = 1; return 0; }
+	v = g32raw(c->d, c->p);
+	c->p += 4;
+	return v;
+}
+
+/* sf5_flow(), sflow-impl.h:68-272 */
+static int
+sf_flow_sample(struct xe_plan *plan, struct sfcur *c, int expanded, const struct xe_sfrec *proto)
+{
+	struct xe_sfrec r = *proto;
+	uint32_t nel, j, v;
+	int chained = 0;
+
+	sf_u32(c);                       /* length */
+	sf_u32(c);                       /* sequence */
+	sf_u32(c);                       /* source id (or class) */
+	if (expanded) sf_u32(c);         /* source index */
+	r.sampling_rate = sf_u32(c);
+	sf_u32(c);                       /* pool */
+	sf_u32(c);                       /* drops */
+	if (expanded) sf_u32(c);         /* input format */
+	v = sf_u32(c);
+	if (!expanded) v &= 0x3fffffff;
+	v = htonl(v);
+	r.in_if_be = v;
+	if (expanded) sf_u32(c);         /* output format */
+	v = sf_u32(c);
+	if (!expanded) v &= 0x3fffffff;
+	v = htonl(v);
+	r.out_if_be = v;
+	nel = sf_u32(c);
+	if (c->bad) return XE_OK;
+
+	for (j = 0; j < nel; j++) {
+		uint32_t tag = sf_u32(c), ell = sf_u32(c);
+		if (c->bad) return XE_OK;
+		if (tag == 1) {
+			uint32_t hp = sf_u32(c), hl;
+			r.frame_len_be = sf_raw32(c);
+			sf_u32(c);               /* stripped */
+			hl = sf_u32(c);
+			if (c->bad) return XE_OK;
+			if (hp == 1) r.rp_type = 0;
+			else if (hp == 11) r.rp_type = 1;
+			else if (hp == 12) r.rp_type = 2;
+			else { c->bad = 1; return XE_OK; }
+			r.kind = 1;
+			r.header_len = hl;
+			r.hdr_off = c->d->base + (uint64_t)c->p;
+			r.dgram_left = (int32_t)(c->d->len - c->p);
+			r.chained = (uint8_t)chained;
+			if (!xe_blob_push(&plan->sfrecs, &r, sizeof(r))) return XE_ENOMEM;
+			plan->nsf++;
+			chained = 1;
+			c->p += (hl % 4) ? (long)hl + (4 - (hl % 4)) : (long)hl;
+		} else if (tag == 1001) {
+			sf_u32(c); sf_u32(c); sf_u32(c); sf_u32(c);
+		} else if (tag == 3) {
+			r.frame_len_be = sf_raw32(c);
+			if (c->bad) return XE_OK;
+			/* the 7 words after the length are read one by one and a
+			 * short datagram aborts before the record is delivered */
+			if ((c->p + 28) > c->d->len) { c->bad = 1; return XE_OK; }
+			r.kind = 3;
+			r.header_len = 28;
+			r.hdr_off = c->d->base + (uint64_t)c->p;
+			r.dgram_left = (int32_t)(c->d->len - c->p);
+			r.chained = (uint8_t)chained;
+			if (!xe_blob_push(&plan->sfrecs, &r, sizeof(r))) return XE_ENOMEM;
+			plan->nsf++;
+			chained = 1;
+			c->p += 28;
+		} else {
+			c->p += ell;
+		}
+	}
+	return XE_OK;
+}
+
+/* sflow_process(), sflow-impl.h:293-405 */
+static int
+walk_sflow(struct xe_host *hs, struct xe_plan *plan, struct dgram *d)
+{
+	struct sfcur c = { d, 0, 0 };
+	struct xe_sfrec proto;
+	uint32_t v, n, i;
+
+	memset(&proto, 0, sizeof(proto));
+	if (sf_u32(&c) != 5) return XE_OK;
+	v = sf_u32(&c);
+	if (c.bad) return XE_OK;
+	if (v == 1) {
+		proto.agent_ver = 4;
+		if ((c.p + 4) > d->len) return XE_OK;
+		gcopy(d, c.p, proto.agent, 4);
+		c.p += 4;
+	} else if (v == 2) {
+		proto.agent_ver = 6;
+		if ((c.p + 16) > d->len) return XE_OK;
+		gcopy(d, c.p, proto.agent, 16);
+		c.p += 16;
+	} else {
+		return XE_OK;
+	}
+	v = sf_raw32(&c);
+	memcpy(proto.dev_id, &v, 4);
+	sf_u32(&c);
+	sf_u32(&c);
+	n = sf_u32(&c);
+	if (c.bad) return XE_OK;
+	/* device rules use the UDP source and the packet's source_id field,
+	 * which sflow_process() never sets: 0 here */
+	if (!exporter_get(hs, plan, d->src_ip, 0, &d->exporter)) return XE_ENOMEM;
+	proto.exporter = d->exporter;
+
+	for (i = 0; i < n; i++) {
+		v = sf_u32(&c);
+		if (c.bad) break;
+		if ((v == 1) || (v == 3)) {
+			int rc = sf_flow_sample(plan, &c, v == 3, &proto);
+			if (rc != XE_OK) return rc;
+			if (c.bad) break;
+		} else {
+			uint32_t l = sf_u32(&c);
+			if (c.bad) break;
+			c.p += l;
+		}
+	}
+	return XE_OK;
+}
+
+/* ------------------------------------------------------------------ entry */
+int
+xe_prepass(struct xe_host *hs, const uint8_t *data, const uint64_t *offs, const uint32_t *src,
+	const uint8_t *kinds, size_t n, struct xe_plan *plan)
+{
+	size_t i;
+
+	memset(plan, 0, sizeof(*plan));
+	for (i = 0; i < n; i++) {
+		struct dgram d;
+		int rc = XE_OK;
+
+		memset(&d, 0, sizeof(d));
+		d.p = data + offs[i];
+		d.len = (long)(offs[i + 1] - offs[i]);
+		if (d.len > 65536) d.len = 65536;
+		d.base = offs[i];
+		d.src_ip = src[i];
+		if (kinds && (kinds[i] == XE_KIND_SFLOW)) {
+			rc = walk_sflow(hs, plan, &d);
+		} else {
+			/* netflow_process(), netflow.c:804-819 */
+			switch (g16(&d, 0)) {
+				case 5: rc = walk_v5(hs, plan, &d); break;
+				case 9: rc = walk_v9(hs, plan, &d); break;
+				case 10: rc = walk_ipfix(hs, plan, &d); break;
+				default: plan->skipped_datagrams++; break;
+			}
+		}
+		if (rc != XE_OK) {
+			xe_plan_free(plan);
+			return rc;
+		}
+	}
+	return XE_OK;
+}
