@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Flow-path benchmark: device-resident decode + classify throughput.
+
+One step = one pass of the HIP path (counter reset + decode/classify kernels)
+over one batch of synthetic export packets that already sits in HBM.  The
+workload is BASELINE.json configs[1]: IPFIX from 64 exporters, 70 % IPv4
+records (46 B) / 30 % IPv6 records (62 B), 16 monitoring objects over 8 IP
+lists of 10 000 IPv4 + 10 000 IPv6 prefixes each.  With --gpus N every rank
+gets its own exporters (weak scaling, no data-path collective); rank 0 prints
+one JSON line.
+
+Besides the throughput the line carries
+  roofline      algorithmic bytes per launch / mean kernel time (HIP events on
+                the launch stream) against the 8 TB/s HBM peak;
+  cpu_baseline  the CPU oracle (a scalar restatement of the reference's
+                algorithm) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--records", type=int, default=1 << 22, help="records per GPU per step")
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2"])
+    ap.add_argument("--cpu-sample", type=int, default=2000000, help="records timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--traffic", type=float, default=None,
+                    help="HBM bytes per launch from a rocprofv3 --pmc pass (reported as roofline.traffic)")
+    return ap.parse_args()
+
+
+def build_workload(name, nrec, rank):
+    from xenoeye_amd import synth
+    if name == "c1":
+        return synth.workload_c1(nrec, seed=synth.SEED_C1 ^ (rank << 32)), \
+            "C1 netflow-v9 1 exporter 21B records 1 object (src net mynet)"
+    w = synth.workload_c2(nrec, seed=synth.SEED_C2 ^ (rank << 32))
+    return w, "C2 ipfix 64 exporters 70% v4(46B)/30% v6(62B) 16 objects x 10k+10k-prefix lists"
+
+
+def cpu_baseline(w, sample):
+    """Time the oracle on the first datagrams that hold about `sample` records."""
+    from oracle_binding import Oracle
+    orc = Oracle()
+    for name, text in w["iplists"].items():
+        orc.iplist_add(name, text)
+    for filt, parent in w["mos"]:
+        orc.mo_add(filt, parent)
+    orc.log_config(keep_flows=False)
+    pkts, srcs = w["batch"].pkts, w["batch"].src
+    per_dgram = max(1.0, w["nrec"] / max(1, len(pkts)))
+    nd = min(len(pkts), int(sample / per_dgram) + 1)
+    L = orc.L
+    t0 = time.perf_counter()
+    for p, s in zip(pkts[:nd], srcs[:nd]):
+        L.xo_netflow_process(p, len(p), int.from_bytes(s, "little"))
+    dt = time.perf_counter() - t0
+    nrec = orc.nrecords()
+    orc.reset()
+    return nrec / dt, nrec, nd, dt
+
+
+def main():
+    args = parse_args()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the flow path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import xenoeye_amd
+    w, wl_name = build_workload(args.workload, args.records, rank)
+    eng = xenoeye_amd.Engine(device=local_rank)
+    for name, text in w["iplists"].items():
+        eng.add_iplist(name, text)
+    for filt, parent in w["mos"]:
+        eng.add_mo("mo", filt, parent)
+    eng.commit()
+
+    packed = w["batch"].packed()
+    t_prep0 = time.perf_counter()
+    batch = eng.prepare(packed)
+    t_prep = time.perf_counter() - t_prep0
+    nrec = batch.records
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.run(stream)
+    barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record()
+        batch.run(stream)
+        b.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+    # end-to-end including host pre-pass + H2D + D2H of masks and counters (one pass, reported only)
+    t1 = time.perf_counter()
+    b2 = eng.prepare(packed)
+    b2.run(stream)
+    m = b2.masks()
+    c = b2.counters()
+    t_e2e = time.perf_counter() - t1
+    b2.free()
+    del m
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(nrec)], dtype=torch.float64, device="cuda")
+    pay = torch.tensor([float(batch.payload_bytes)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dist.all_reduce(pay, op=dist.ReduceOp.SUM)
+        # per-object counters are merged across shards by plain u64 addition
+        ctr = torch.from_numpy(c.astype(np.int64)).cuda()
+        dist.all_reduce(ctr, op=dist.ReduceOp.SUM)
+    dt_all = float(tmax.item())
+    value = float(tot.item()) * args.steps / dt_all
+
+    if rank == 0:
+        alg = batch.algorithmic_bytes
+        achieved = alg / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "device-resident flow records/sec decoded+classified",
+            "value": value,
+            "unit": "records/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_all / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": wl_name, "records_per_gpu_per_step": nrec,
+                       "datagrams_per_gpu": len(w["batch"]), "objects": len(w["mos"]),
+                       "sharding": "exporters per rank, no data-path collective"},
+            "payload_GBps": float(pay.item()) * args.steps / dt_all / 1e9,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": args.traffic,
+                         "kernel": "xe_nf_kernel", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_launch": alg,
+                         "algorithmic_bytes_per_record": alg / max(nrec, 1)},
+            "host_inclusive": {"prepare_s": t_prep, "prepare_run_fetch_s": t_e2e,
+                               "records_per_s": nrec / t_e2e},
+        }
+        if args.cpu_sample > 0:
+            rps, n_cpu, nd, secs = cpu_baseline(w, args.cpu_sample)
+            out["cpu_baseline"] = {"value": rps, "unit": "records/s", "cores": 1, "kind": "port",
+                                   "sample": "first %d datagrams (%d records) of the same batch, %.1f s, "
+                                             "oracle/xe_oracle.c single thread" % (nd, n_cpu, secs)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

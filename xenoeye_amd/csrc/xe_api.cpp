@@ -25,6 +25,11 @@ struct xe_gpu
 	struct xe_list_dev *h_lists;
 	void *d_tmpls, *d_tents;
 	size_t up_tmpls, up_tents;
+	/* operand slots and distinct terms (see xe_kernels.h) */
+	uint8_t fslot[XE_NFIELDS];
+	uint8_t slot_hi[XE_MAX_SLOTS];
+	uint32_t nslots, nslots_hi, nterms;
+	int fast_ok;
 	char err[512];
 };
 
@@ -34,6 +39,7 @@ struct xe_batch
 	struct xe_plan plan;
 	size_t ntot, payload_bytes;
 	void *d_pkt, *d_sets, *d_exps, *d_sfrecs, *d_out;
+	void *d_fsets, *d_fwstart, *d_tile_first, *d_tile_tmpl, *d_ssets, *d_swstart;
 	size_t out_bytes, masks_off, nparsed_off, marks_off, counters_off, sfhas_off;
 	struct xe_kparams kp;
 	hipStream_t last_stream;
@@ -317,6 +323,79 @@ upload(xe_gpu *h, void **dst, const void *src, size_t bytes)
 	return XE_OK;
 }
 
+/* device form of one operand */
+static struct xe_dopnd
+make_dopnd(const struct xe_term *t, const struct xe_opnd *o)
+{
+	const uint8_t *b = (const uint8_t *)&o->w[0];
+	struct xe_dopnd d;
+
+	memset(&d, 0, sizeof(d));
+	d.is_list = o->is_list;
+	switch (t->type) {
+		case XE_BT_ADDR4:
+			if (o->is_list) d.list = o->w[0];
+			else { d.net_lo = be_bytes(b, 4); d.mask_lo = be_bytes(b + 4, 4); }
+			break;
+		case XE_BT_ADDR6:
+			if (o->is_list) d.list = o->w[0];
+			else {
+				d.net_hi = be_bytes(b, 8); d.net_lo = be_bytes(b + 8, 8);
+				d.mask_hi = be_bytes(b + 16, 8); d.mask_lo = be_bytes(b + 24, 8);
+			}
+			break;
+		case XE_BT_RANGE:
+			d.low = (int32_t)o->w[0];
+			d.high = (int32_t)o->w[1];
+			break;
+		case XE_BT_MAC:
+			d.net_lo = be_bytes(b, 6);
+			break;
+		default:
+			break;
+	}
+	return d;
+}
+
+/* index of an identical term already in the table, or a new one: objects
+ * that share a condition (the same list on the same field, the same port
+ * range ...) have it evaluated once per record */
+static int
+intern_term(struct xe_blob *terms, struct xe_blob *opnds, const struct xe_filter *f, size_t ti, uint32_t *id)
+{
+	struct xe_term t = f->terms[ti];
+	struct xe_dopnd tmp[64], *ops = tmp;
+	const struct xe_term *have = (const struct xe_term *)terms->p;
+	const struct xe_dopnd *hop = (const struct xe_dopnd *)opnds->p;
+	int rc = XE_OK;
+
+	t.pad = 0;
+	if (t.nopnd > 64) {
+		ops = (struct xe_dopnd *)malloc(t.nopnd * sizeof(*ops));
+		if (!ops) return XE_ENOMEM;
+	}
+	for (uint32_t j = 0; j < t.nopnd; j++) ops[j] = make_dopnd(&t, &f->opnds[f->terms[ti].opnd_base + j]);
+	for (size_t k = 0; k < terms->n; k++) {
+		const struct xe_term *o = &have[k];
+		if ((o->type == t.type) && (o->dir == t.dir) && (o->fsrc == t.fsrc) && (o->fdst == t.fdst)
+			&& (o->func == t.func) && (o->fa == t.fa) && (o->fb == t.fb) && (o->k == t.k)
+			&& (o->nopnd == t.nopnd)
+			&& !memcmp(hop + o->opnd_base, ops, t.nopnd * sizeof(*ops))) {
+			*id = (uint32_t)k;
+			goto out;
+		}
+	}
+	t.opnd_base = (uint32_t)opnds->n;
+	for (uint32_t j = 0; j < t.nopnd; j++) {
+		if (!xe_blob_push(opnds, &ops[j], sizeof(*ops))) { rc = XE_ENOMEM; goto out; }
+	}
+	*id = (uint32_t)terms->n;
+	if (!xe_blob_push(terms, &t, sizeof(t))) rc = XE_ENOMEM;
+out:
+	if (ops != tmp) free(ops);
+	return rc;
+}
+
 /* append one compiled filter to the flat arrays */
 static int
 append_prog(struct xe_blob *progs, struct xe_blob *ops, struct xe_blob *terms, struct xe_blob *opnds,
@@ -324,7 +403,6 @@ append_prog(struct xe_blob *progs, struct xe_blob *ops, struct xe_blob *terms, s
 {
 	struct xe_prog pr;
 	int cval = 0;
-	uint32_t term_base = (uint32_t)terms->n, opnd_base = (uint32_t)opnds->n;
 
 	memset(&pr, 0, sizeof(pr));
 	pr.parent = parent;
@@ -337,46 +415,43 @@ append_prog(struct xe_blob *progs, struct xe_blob *ops, struct xe_blob *terms, s
 	pr.nops = (uint32_t)f->nops;
 	for (size_t i = 0; i < f->nops; i++) {
 		uint32_t w = f->ops[i];
-		if ((w & 3) == XE_OP_BASIC) w = XE_OP_BASIC | (((w >> 2) + term_base) << 2);
+		if ((w & 3) == XE_OP_BASIC) {
+			uint32_t id;
+			int rc = intern_term(terms, opnds, f, w >> 2, &id);
+			if (rc != XE_OK) return rc;
+			w = XE_OP_BASIC | (id << 2);
+		}
 		if (!xe_blob_push(ops, &w, 4)) return XE_ENOMEM;
 	}
-	for (size_t i = 0; i < f->nterms; i++) {
-		struct xe_term t = f->terms[i];
-		t.opnd_base += opnd_base;
-		if (!xe_blob_push(terms, &t, sizeof(t))) return XE_ENOMEM;
-		for (uint32_t j = 0; j < f->terms[i].nopnd; j++) {
-			const struct xe_opnd *o = &f->opnds[f->terms[i].opnd_base + j];
-			const uint8_t *b = (const uint8_t *)&o->w[0];
-			struct xe_dopnd d;
+	return xe_blob_push(progs, &pr, sizeof(pr)) ? XE_OK : XE_ENOMEM;
+}
 
-			memset(&d, 0, sizeof(d));
-			d.is_list = o->is_list;
-			switch (t.type) {
-				case XE_BT_ADDR4:
-					if (o->is_list) d.list = o->w[0];
-					else { d.net_lo = be_bytes(b, 4); d.mask_lo = be_bytes(b + 4, 4); }
-					break;
-				case XE_BT_ADDR6:
-					if (o->is_list) d.list = o->w[0];
-					else {
-						d.net_hi = be_bytes(b, 8); d.net_lo = be_bytes(b + 8, 8);
-						d.mask_hi = be_bytes(b + 16, 8); d.mask_lo = be_bytes(b + 24, 8);
-					}
-					break;
-				case XE_BT_RANGE:
-					d.low = (int32_t)o->w[0];
-					d.high = (int32_t)o->w[1];
-					break;
-				case XE_BT_MAC:
-					d.net_lo = be_bytes(b, 6);
-					break;
-				default:
-					break;
-			}
-			if (!xe_blob_push(opnds, &d, sizeof(d))) return XE_ENOMEM;
+/* give every field some object program reads a slot in the per-lane operand file */
+static void
+assign_slots(xe_gpu *h, const struct xe_term *terms, size_t nobj_terms)
+{
+	memset(h->fslot, 0xFF, sizeof(h->fslot));
+	memset(h->slot_hi, 0xFF, sizeof(h->slot_hi));
+	h->nslots = h->nslots_hi = 0;
+	h->fast_ok = 1;
+	for (size_t i = 0; i < nobj_terms; i++) {
+		const struct xe_term *t = &terms[i];
+		uint8_t fl[2];
+		int n = 0;
+		if (t->func != XE_FN_NONE) { fl[n++] = t->fa; fl[n++] = t->fb; }
+		else {
+			if (t->dir & XE_DIR_SRC) fl[n++] = t->fsrc;
+			if (t->dir & XE_DIR_DST) fl[n++] = t->fdst;
+		}
+		for (int k = 0; k < n; k++) {
+			uint8_t f = fl[k];
+			if (h->fslot[f] != 0xFF) continue;
+			if (h->nslots >= XE_MAX_SLOTS) { h->fast_ok = 0; return; }
+			h->fslot[f] = (uint8_t)h->nslots;
+			if (xe_fields[f].size_max > 8) h->slot_hi[h->nslots] = (uint8_t)h->nslots_hi++;
+			h->nslots++;
 		}
 	}
-	return xe_blob_push(progs, &pr, sizeof(pr)) ? XE_OK : XE_ENOMEM;
 }
 
 extern "C" int
@@ -391,6 +466,14 @@ xe_gpu_commit(xe_gpu *h)
 
 	for (size_t m = 0; (m < h->hs.nmos) && (rc == XE_OK); m++) {
 		rc = append_prog(&progs, &ops, &terms, &opnds, &h->hs.mos[m].filter, h->hs.mos[m].parent);
+	}
+	if (rc == XE_OK) {
+		/* the fast kernel evaluates the object programs' terms [0, nterms);
+		 * terms used only by device mark filters follow them */
+		h->nterms = (uint32_t)terms.n;
+		assign_slots(h, (const struct xe_term *)terms.p, terms.n);
+		if (h->nterms > XE_MAX_FAST_TERMS) h->fast_ok = 0;
+		if ((size_t)(h->nslots + h->nslots_hi) * 256 * 8 + (size_t)h->hs.nmos * 24 > 60 * 1024) h->fast_ok = 0;
 	}
 	for (size_t d = 0; (d < h->hs.ndevs) && (rc == XE_OK); d++) {
 		struct xe_devrule r;
@@ -456,8 +539,120 @@ xe_gpu_batch_free(xe_batch *b)
 	if (b->d_exps) (void)hipFree(b->d_exps);
 	if (b->d_sfrecs) (void)hipFree(b->d_sfrecs);
 	if (b->d_out) (void)hipFree(b->d_out);
+	{
+		void *extra[] = { b->d_fsets, b->d_fwstart, b->d_tile_first, b->d_tile_tmpl, b->d_ssets, b->d_swstart };
+		for (size_t i = 0; i < sizeof(extra) / sizeof(extra[0]); i++) if (extra[i]) (void)hipFree(extra[i]);
+	}
 	xe_plan_free(&b->plan);
 	free(b);
+}
+
+/* Split the runs between the two kernels and lay out the fast kernel's tiles.
+ * A run is "regular" when its template is fixed-length without repeated or
+ * string elements, none of its reads can pass the datagram end and its
+ * exporter has no devices.conf entry.  Regular runs are grouped by template
+ * (stable, so arrival order is kept inside a group) and each group is padded
+ * to whole 64-record tiles: a wave then works on one template only. */
+static int
+build_work_lists(xe_gpu *h, xe_batch *b)
+{
+	const struct xe_set *sets = (const struct xe_set *)b->plan.sets.p;
+	const struct xe_tmpl *tm = (const struct xe_tmpl *)h->hs.dev_tmpls.p;
+	const struct xe_tent *te = (const struct xe_tent *)h->hs.dev_tents.p;
+	const struct xe_exporter *ex = (const struct xe_exporter *)b->plan.exporters.p;
+	size_t ns = b->plan.sets.n, nt = h->hs.dev_tmpls.n, i;
+	uint8_t *tfast = NULL, *is_fast = NULL;
+	uint64_t *gcount = NULL, *gpos = NULL;
+	struct xe_set *fs = NULL, *ss = NULL;
+	uint32_t *fw = NULL, *sw = NULL, *tfirst = NULL, *ttmpl = NULL;
+	size_t nfast = 0, nslow = 0, ntiles = 0, work = 0, slowrec = 0;
+	int rc = XE_ENOMEM;
+
+	tfast = (uint8_t *)calloc(nt + 1, 1);
+	is_fast = (uint8_t *)calloc(ns + 1, 1);
+	gcount = (uint64_t *)calloc(nt + 1, sizeof(uint64_t));
+	gpos = (uint64_t *)calloc(nt + 1, sizeof(uint64_t));
+	if (!tfast || !is_fast || !gcount || !gpos) goto out;
+	for (i = 0; i < nt; i++) {
+		int ok = h->fast_ok && !tm[i].varlen && !tm[i].repeats;
+		for (uint32_t j = 0; ok && (j < tm[i].nfields); j++) {
+			if ((te[tm[i].ent_base + j].field != XE_F_NONE) && (te[tm[i].ent_base + j].flags & XE_TE_STR)) ok = 0;
+			if (te[tm[i].ent_base + j].len > 16 && (te[tm[i].ent_base + j].flags & XE_TE_VALID)
+				&& (te[tm[i].ent_base + j].field != XE_F_NONE)) ok = 0;
+		}
+		tfast[i] = (uint8_t)ok;
+	}
+	for (i = 0; i < ns; i++) {
+		int ok = tfast[sets[i].tmpl] && !(sets[i].flags & XE_SET_CHECKED) && (ex[sets[i].exporter].device < 0);
+		is_fast[i] = (uint8_t)ok;
+		if (ok) { nfast++; gcount[sets[i].tmpl]++; } else { nslow++; slowrec += sets[i].nrec; }
+	}
+	fs = (struct xe_set *)malloc((nfast + 1) * sizeof(*fs));
+	fw = (uint32_t *)malloc((nfast + 1) * sizeof(uint32_t));
+	ss = (struct xe_set *)malloc((nslow + 1) * sizeof(*ss));
+	sw = (uint32_t *)malloc((nslow + 1) * sizeof(uint32_t));
+	if (!fs || !fw || !ss || !sw) goto out;
+	/* group positions */
+	{
+		uint64_t acc = 0;
+		for (i = 0; i < nt; i++) { gpos[i] = acc; acc += gcount[i]; }
+	}
+	{
+		size_t k = 0;
+		uint64_t w = 0;
+		for (i = 0; i < ns; i++) {
+			if (is_fast[i]) fs[gpos[sets[i].tmpl]++] = sets[i];
+			else { ss[k] = sets[i]; sw[k] = (uint32_t)w; w += sets[i].nrec; k++; }
+		}
+	}
+	/* work indices with per-group padding, then the tile tables */
+	for (i = 0; i < nfast; i++) {
+		if (i && (fs[i].tmpl != fs[i - 1].tmpl)) work = (work + 63) / 64 * 64;
+		fw[i] = (uint32_t)work;
+		work += fs[i].nrec;
+	}
+	if (work > 0xFFFFFF00u) { rc = XE_EUNSUPPORTED; goto out; }
+	ntiles = (work + 63) / 64;
+	tfirst = (uint32_t *)malloc((ntiles + 1) * sizeof(uint32_t));
+	ttmpl = (uint32_t *)malloc((ntiles + 1) * sizeof(uint32_t));
+	if (!tfirst || !ttmpl) goto out;
+	{
+		size_t sidx = 0;
+		for (size_t t = 0; t < ntiles; t++) {
+			uint64_t g0 = (uint64_t)t * 64;
+			while ((sidx + 1 < nfast) && (fw[sidx + 1] <= g0)) sidx++;
+			tfirst[t] = (uint32_t)sidx;
+			ttmpl[t] = fs[sidx].tmpl;
+		}
+	}
+	rc = upload(h, &b->d_fsets, fs, nfast * sizeof(*fs));
+	if (rc == XE_OK) rc = upload(h, &b->d_fwstart, fw, nfast * 4);
+	if (rc == XE_OK) rc = upload(h, &b->d_tile_first, tfirst, ntiles * 4);
+	if (rc == XE_OK) rc = upload(h, &b->d_tile_tmpl, ttmpl, ntiles * 4);
+	if (rc == XE_OK) rc = upload(h, &b->d_ssets, ss, nslow * sizeof(*ss));
+	if (rc == XE_OK) rc = upload(h, &b->d_swstart, sw, nslow * 4);
+	if (rc == XE_OK) {
+		b->kp.fsets = (const struct xe_set *)b->d_fsets;
+		b->kp.fwstart = (const uint32_t *)b->d_fwstart;
+		b->kp.tile_first = (const uint32_t *)b->d_tile_first;
+		b->kp.tile_tmpl = (const uint32_t *)b->d_tile_tmpl;
+		b->kp.nfsets = (uint32_t)nfast;
+		b->kp.ntiles = (uint32_t)ntiles;
+		b->kp.ssets = (const struct xe_set *)b->d_ssets;
+		b->kp.swstart = (const uint32_t *)b->d_swstart;
+		b->kp.nssets = (uint32_t)nslow;
+		b->kp.nslowrec = (uint32_t)slowrec;
+		memcpy(b->kp.fslot, h->fslot, sizeof(h->fslot));
+		memcpy(b->kp.slot_hi, h->slot_hi, sizeof(h->slot_hi));
+		b->kp.nslots = h->nslots;
+		b->kp.nslots_hi = h->nslots_hi;
+		b->kp.nterms = h->nterms;
+		b->kp.lds_counters = (h->hs.nmos <= XE_MAX_LDS_COUNTER_MOS) ? 1u : 0u;
+	}
+out:
+	free(tfast); free(is_fast); free(gcount); free(gpos);
+	free(fs); free(fw); free(ss); free(sw); free(tfirst); free(ttmpl);
+	return rc;
 }
 
 extern "C" int
@@ -508,8 +703,11 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 	if (rc == XE_OK) rc = upload(h, &b->d_sfrecs, b->plan.sfrecs.p, b->plan.sfrecs.n * sizeof(struct xe_sfrec));
 	if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
 
-	/* output layout */
 	memset(&b->kp, 0, sizeof(b->kp));
+	rc = build_work_lists(h, b);
+	if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
+
+	/* output layout */
 	off = 0;
 	b->masks_off = off;    off = ALIGN_UP(off + b->ntot * h->mask_words * 8, 256);
 	b->nparsed_off = off;  off = ALIGN_UP(off + b->ntot, 256);

@@ -25,6 +25,7 @@ struct xe_dopnd
 	uint64_t mask_hi, mask_lo;
 };
 
+#define XE_MAX_SLOTS 32
 #define XE_MARK_DROPPED 0x80000000u
 #define XE_MARK_HAS 0x40000000u
 
@@ -60,7 +61,30 @@ struct xe_kparams
 	uint64_t col_off[XE_NFIELDS];   /* ~0 = column absent */
 	uint64_t vsize_off[XE_NFIELDS]; /* u16 per record, ~0 = absent */
 	uint32_t *sf_has;            /* sflow: presence bits of the fields its parser can set */
+
+	/* fast path: regular runs (fixed-length template without repeated or
+	 * string elements, every read inside the datagram, exporter without a
+	 * devices.conf entry), grouped by template so that a wave decodes one
+	 * template; 64 records per tile */
+	const struct xe_set *fsets;
+	const uint32_t *fwstart;     /* work index of each grouped set's first record */
+	const uint32_t *tile_first;  /* per tile: first grouped set that may hold its records */
+	const uint32_t *tile_tmpl;   /* per tile: template slot */
+	uint32_t nfsets, ntiles;
+	/* everything else goes through the general kernel */
+	const struct xe_set *ssets;
+	const uint32_t *swstart;
+	uint32_t nssets, nslowrec;
+	/* filter operand slots: the fields some program reads, kept per lane in LDS */
+	uint8_t fslot[XE_NFIELDS];   /* field -> slot, 0xFF = not read by any program */
+	uint8_t slot_hi[XE_MAX_SLOTS]; /* slot -> index of its upper 8 bytes, 0xFF = field <= 8 bytes */
+	uint32_t nslots, nslots_hi;
+	uint32_t nterms;             /* distinct terms */
+	uint32_t lds_counters;       /* per-block counter staging fits in LDS */
 };
+
+#define XE_MAX_FAST_TERMS 256
+#define XE_MAX_LDS_COUNTER_MOS 1024
 
 #ifdef __cplusplus
 extern "C" {

@@ -1,11 +1,13 @@
 /*
  * xe_kernels.hip -- gfx950 kernels of the flow path.
  *
- * xe_nf_kernel: one thread per Netflow v5/v9/IPFIX record.  The thread finds
- * the run ("set") its record belongs to, decodes the template's fields from
- * the export packet into the structure-of-arrays columns, evaluates every
- * monitoring-object program against the record and stores the match bitmask;
- * per-object counters are reduced per wave and added with one atomic per wave.
+ * Two kernels decode Netflow v5/v9/IPFIX records (one thread per record) from
+ * the export packets into the structure-of-arrays columns, evaluate every
+ * monitoring-object program against the record and store the match bitmask
+ * and per-object counters:
+ *   xe_nf_fast_kernel     regular runs, one template per wave, wave-uniform
+ *                         interpretation (see its header comment);
+ *   xe_nf_general_kernel  everything else, interpreted per lane.
  *
  * Field values are handled as big-endian integers: the reference keeps a
  * field as SIZEMAX bytes with the wire bytes right-aligned (netflow.c:91), so
@@ -442,11 +444,16 @@ store_col(const xe_kparams &kp, uint32_t f, uint32_t ridx, const val128 &v)
 	}
 }
 
+/* General kernel: any run the fast kernel does not take (reads that may pass
+ * the datagram end, variable-length / repeated / string elements, exporters
+ * with a devices.conf entry).  One thread per record, everything interpreted
+ * per lane. */
 __global__ void __launch_bounds__(XE_BLOCK)
-xe_nf_kernel(const xe_kparams kp)
+xe_nf_general_kernel(const xe_kparams kp)
 {
-	uint32_t ridx = blockIdx.x * XE_BLOCK + threadIdx.x;
-	bool active = ridx < kp.nrec;
+	uint32_t g = blockIdx.x * XE_BLOCK + threadIdx.x;
+	bool active = g < kp.nslowrec;
+	uint32_t ridx = 0;
 	nf_rec rec;
 	unsigned long long bxr = 0, pxr = 0;
 	int32_t device = -1;
@@ -454,14 +461,15 @@ xe_nf_kernel(const xe_kparams kp)
 	rec.mark = 0;
 	rec.nparsed = 0;
 	if (active) {
-		/* the set whose [first_rec, first_rec + nrec) holds this record */
-		uint32_t lo = 0, hi = kp.nsets - 1;
+		/* the run whose work range holds this thread */
+		uint32_t lo = 0, hi = kp.nssets - 1;
 		while (lo < hi) {
 			uint32_t mid = (lo + hi + 1) >> 1;
-			if (kp.sets[mid].first_rec <= ridx) lo = mid; else hi = mid - 1;
+			if (kp.swstart[mid] <= g) lo = mid; else hi = mid - 1;
 		}
-		const xe_set s = kp.sets[lo];
-		uint32_t i = ridx - s.first_rec;
+		const xe_set s = kp.ssets[lo];
+		uint32_t i = g - kp.swstart[lo];
+		ridx = s.first_rec + i;
 		int64_t roff = (int64_t)i * s.stride;
 		int32_t avail = s.avail - (int32_t)roff;
 
@@ -550,6 +558,356 @@ xe_nf_kernel(const xe_kparams kp)
 	classify<nf_rec, nf_get>(kp, rec, device, ridx, active, bxr, pxr);
 }
 
+/* ------------------------------------------------------------------ fast kernel */
+/*
+ * One wave = one tile of 64 records that share a template, so the walk over
+ * the template's fields, over the distinct filter terms and over the object
+ * programs is wave-uniform (scalar loads, scalar branches); only packet
+ * bytes, field values, IP-list lookups and match bits are per lane.
+ *
+ * Per lane state kept in LDS: the value of every field some program reads
+ * ("operand slots", laid out [slot][lane] so that lanes hit distinct banks).
+ * A block walks tiles grid-stride and stages its per-object counters in LDS;
+ * they reach HBM with one atomic per block and counter.
+ */
+struct fast_lane
+{
+	uint64_t present;     /* bit per operand slot: the field is set in this record */
+	uint64_t *lo, *hi;    /* LDS: lo[slot * XE_BLOCK + tid], hi[hi_index * XE_BLOCK + tid] */
+	uint32_t tid;
+};
+
+__device__ __forceinline__ void
+slot_get(const xe_kparams &kp, const fast_lane &L, uint32_t field, bool &has, uint64_t &hi, uint64_t &lo)
+{
+	uint32_t s = kp.fslot[field];
+	has = false;
+	hi = lo = 0;
+	if (s == 0xFF) return;
+	has = ((L.present >> s) & 1) != 0;
+	if (has) lo = L.lo[s * XE_BLOCK + L.tid];
+	uint32_t h = kp.slot_hi[s];
+	if ((h != 0xFF) && has) hi = L.hi[h * XE_BLOCK + L.tid];
+}
+
+__device__ __forceinline__ void
+slot_put(const xe_kparams &kp, fast_lane &L, uint32_t field, bool act, uint64_t hi, uint64_t lo)
+{
+	uint32_t s = kp.fslot[field];
+	if (s == 0xFF) return;
+	if (act) {
+		L.lo[s * XE_BLOCK + L.tid] = lo;
+		uint32_t h = kp.slot_hi[s];
+		if (h != 0xFF) L.hi[h * XE_BLOCK + L.tid] = hi;
+		L.present |= 1ull << s;
+	}
+}
+
+/* len (wave-uniform, 1..16) wire bytes at p as a big-endian number.  Odd
+ * lengths read up to 7 bytes past the field and shift them out; the batch
+ * buffer is padded so that such a read stays inside the allocation. */
+__device__ __forceinline__ void
+load_be(const uint8_t *p, uint32_t len, uint64_t &hi, uint64_t &lo)
+{
+	hi = 0;
+	if (len <= 2) {
+		if (len == 1) {
+			lo = *p;
+		} else {
+			uint16_t v;
+			__builtin_memcpy(&v, p, 2);
+			lo = __builtin_bswap16(v);
+		}
+	} else if (len <= 4) {
+		uint32_t v;
+		__builtin_memcpy(&v, p, 4);
+		lo = __builtin_bswap32(v) >> (8 * (4 - len));
+	} else if (len <= 8) {
+		uint64_t v;
+		__builtin_memcpy(&v, p, 8);
+		lo = __builtin_bswap64(v) >> (8 * (8 - len));
+	} else {
+		uint64_t a, b;
+		__builtin_memcpy(&a, p, 8);
+		__builtin_memcpy(&b, p + 8, 8);
+		a = __builtin_bswap64(a);
+		b = __builtin_bswap64(b);
+		uint32_t sh = 8 * (16 - len);
+		if (sh == 0) {
+			hi = a;
+			lo = b;
+		} else {
+			lo = (b >> sh) | (a << (64 - sh));
+			hi = a >> sh;
+		}
+	}
+}
+
+__device__ __forceinline__ uint32_t
+node_walk(const uint32_t *N, uint32_t chunk)
+{
+	uint32_t w = chunk >> 5, b = chunk & 31;
+	uint32_t cw = N[w];
+	if ((cw >> b) & 1) {
+		const uint8_t *cum = (const uint8_t *)(N + 17);
+		return N[16] + cum[w] + __popc(cw & ((1u << b) - 1u));
+	}
+	return XE_TRIE_TERM | ((N[8 + w] >> b) & 1);
+}
+
+/* iplist_match4() for the lanes with act set; the list is wave-uniform */
+__device__ __forceinline__ bool
+fast_trie4(const uint32_t *T, const xe_list_dev &L, uint32_t a, bool act)
+{
+	if (!L.root4) return false;
+	uint32_t e = XE_TRIE_TERM;
+	if (act) e = T[L.root4 + (a >> 16)];
+#pragma unroll
+	for (int lvl = 0; lvl < 2; lvl++) {
+		bool walk = !(e & XE_TRIE_TERM);
+		if (!__ballot(walk)) break;
+		if (walk) e = node_walk(T + L.nodes4 + (size_t)e * XE_NODE_WORDS, (a >> (8 - 8 * lvl)) & 255);
+	}
+	return (e & XE_TRIE_TERM) ? ((e & 1) != 0) : false;
+}
+
+__device__ __forceinline__ bool
+fast_trie6(const uint32_t *T, const xe_list_dev &L, uint64_t hi, uint64_t lo, bool act)
+{
+	if (!L.root6) return false;
+	uint32_t e = XE_TRIE_TERM;
+	if (act) e = T[L.root6 + (uint32_t)(hi >> 48)];
+	for (int k = 2; k < 16; k++) {
+		bool walk = !(e & XE_TRIE_TERM);
+		if (!__ballot(walk)) break;
+		uint32_t chunk = (k < 8) ? (uint32_t)(hi >> (56 - 8 * k)) & 255 : (uint32_t)(lo >> (56 - 8 * (k - 8))) & 255;
+		if (walk) e = node_walk(T + L.nodes6 + (size_t)e * XE_NODE_WORDS, chunk);
+	}
+	return (e & XE_TRIE_TERM) ? ((e & 1) != 0) : false;
+}
+
+__device__ __forceinline__ bool
+in_ranges_u(const xe_dopnd *o, uint32_t n, int64_t v)
+{
+	bool r = false;
+	for (uint32_t i = 0; i < n; i++) r |= (v >= o[i].low) && (v <= o[i].high);
+	return r;
+}
+
+/* one distinct term for all lanes; same semantics as term_match() */
+__device__ bool
+fast_term(const xe_kparams &kp, const fast_lane &L, const xe_term &t)
+{
+	const xe_dopnd *o = kp.opnds + t.opnd_base;
+	bool has;
+	uint64_t hi, lo;
+
+	if (t.func != XE_FN_NONE) {
+		uint32_t sa = c_fmax[t.fa], sb = c_fmax[t.fb];
+		slot_get(kp, L, t.fa, has, hi, lo);
+		uint64_t a = ((sa == 1) || (sa == 2) || (sa == 4) || (sa == 8)) ? lo : 0;
+		slot_get(kp, L, t.fb, has, hi, lo);
+		uint64_t b = ((sb == 1) || (sb == 2) || (sb == 4) || (sb == 8)) ? lo : 0;
+		if (t.func == XE_FN_MIN) return in_ranges_u(o, t.nopnd, (int64_t)((a < b) ? a : b));
+		int32_t q = 0;
+		if (b != 0) {
+			q = (int32_t)(a / b);
+			if ((t.func == XE_FN_DIV_R) && (t.k > 1)) q = (q / t.k) * t.k;
+		}
+		return in_ranges_u(o, t.nopnd, q);
+	}
+	if (t.dir == XE_DIR_NONE) return false;
+
+	bool res = false;
+	for (uint32_t side = XE_DIR_SRC; side <= XE_DIR_DST; side <<= 1) {
+		if (!(t.dir & side)) continue;
+		uint32_t f = (side == XE_DIR_SRC) ? t.fsrc : t.fdst;
+		slot_get(kp, L, f, has, hi, lo);
+		switch (t.type) {
+			case XE_BT_ADDR4: {
+				uint32_t a = (c_fmax[f] == 16) ? (uint32_t)(hi >> 32) : (uint32_t)lo;
+				for (uint32_t i = 0; i < t.nopnd; i++) {
+					bool m;
+					if (o[i].is_list) m = fast_trie4(kp.trie, kp.lists[o[i].list], a, has && !res);
+					else m = (a & (uint32_t)o[i].mask_lo) == (uint32_t)o[i].net_lo;
+					res |= has && m;
+				}
+				break;
+			}
+			case XE_BT_ADDR6:
+				for (uint32_t i = 0; i < t.nopnd; i++) {
+					bool m;
+					if (o[i].is_list) m = fast_trie6(kp.trie, kp.lists[o[i].list], hi, lo, has && !res);
+					else m = ((hi & o[i].mask_hi) == o[i].net_hi) && ((lo & o[i].mask_lo) == o[i].net_lo);
+					res |= has && m;
+				}
+				break;
+			case XE_BT_RANGE: {
+				/* absent fields compare as 0; only 1/2/4-byte fields carry a value */
+				int32_t r = (c_fmax[f] <= 4) ? (int32_t)(uint32_t)lo : 0;
+				res |= in_ranges_u(o, t.nopnd, r);
+				break;
+			}
+			case XE_BT_MAC:
+				for (uint32_t i = 0; i < t.nopnd; i++) res |= (o[i].net_lo == lo);
+				break;
+			default:
+				break;
+		}
+	}
+	return res;
+}
+
+__global__ void __launch_bounds__(XE_BLOCK)
+xe_nf_fast_kernel(const xe_kparams kp)
+{
+	extern __shared__ uint64_t lds[];
+	fast_lane L;
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	unsigned long long *lcnt = (unsigned long long *)(lds + (size_t)(kp.nslots + kp.nslots_hi) * XE_BLOCK);
+
+	L.tid = threadIdx.x;
+	L.lo = lds;
+	L.hi = lds + (size_t)kp.nslots * XE_BLOCK;
+	if (kp.lds_counters) {
+		for (uint32_t i = threadIdx.x; i < kp.nmo * 3; i += XE_BLOCK) lcnt[i] = 0;
+		__syncthreads();
+	}
+
+	for (uint32_t tile = blockIdx.x * (XE_BLOCK / 64) + wave; tile < kp.ntiles; tile += gridDim.x * (XE_BLOCK / 64)) {
+		const uint32_t tmpl = __builtin_amdgcn_readfirstlane(kp.tile_tmpl[tile]);
+		const xe_tmpl *T = kp.tmpls + tmpl;
+		const xe_tent *E = kp.tents + T->ent_base;
+		const uint32_t nf = T->nfields;
+		const bool ipfix = T->mode == XE_MODE_IPFIX;
+
+		/* which run, which record */
+		uint32_t g = tile * 64 + lane;
+		uint32_t s = __builtin_amdgcn_readfirstlane(kp.tile_first[tile]);
+		while ((s + 1 < kp.nfsets) && (kp.fwstart[s + 1] <= g)) s++;
+		const xe_set S = kp.fsets[s];
+		uint32_t i = g - kp.fwstart[s];
+		const bool live = (S.tmpl == tmpl) && (i < S.nrec);
+		const uint32_t ridx = S.first_rec + i;
+		const uint8_t *p = kp.pkt + S.data_off + (uint64_t)i * S.stride;
+		const int32_t avail = live ? (S.avail - (int32_t)(i * S.stride)) : -0x7fffffff;
+
+		L.present = 0;
+		uint64_t bytes = 0, pkts = 0;
+		uint32_t np = 0;
+
+		/* decode */
+		for (uint32_t j = 0; j < nf; j++) {
+			const xe_tent e = E[j];
+			bool act = ipfix ? (live && ((j == 0) || ((int32_t)e.off < avail)))
+				: (((int32_t)e.off + (int32_t)e.len) <= avail);
+			if (!__ballot(act)) break;
+			np += act ? 1u : 0u;
+			if ((e.field == XE_F_NONE) || !(e.flags & XE_TE_VALID)) continue;
+			uint64_t hi = 0, lo = 0;
+			if (act) {
+				load_be(p + e.off, e.len, hi, lo);
+				val128 v = { hi, lo };
+				store_col(kp, e.field, ridx, v);
+			}
+			slot_put(kp, L, e.field, act, hi, lo);
+			if (e.field == XF_in_bytes) bytes = act ? lo : bytes;
+			if (e.field == XF_in_pkts) pkts = act ? lo : pkts;
+		}
+		if (live) {
+			kp.nparsed[ridx] = (uint8_t)np;
+			if (kp.marks) kp.marks[ridx] = 0;
+		}
+
+		/* virtual fields (netflow.c:112-124) and what the counters add */
+		uint64_t rate = 0;
+		if (live) {
+			const xe_exporter *ex = kp.exps + S.exporter;
+			uint32_t ipw, idw;
+			__builtin_memcpy(&ipw, ex->dev_ip, 4);
+			__builtin_memcpy(&idw, ex->dev_id, 4);
+			rate = ex->sampling_rate;
+			slot_put(kp, L, XF_dev_ip, true, 0, __builtin_bswap32(ipw));
+			slot_put(kp, L, XF_dev_id, true, 0, __builtin_bswap32(idw));
+		}
+		const unsigned long long bxr = bytes * rate, pxr = pkts * rate;
+
+		/* every distinct term once */
+		uint64_t tb0 = 0, tb1 = 0, tb2 = 0, tb3 = 0;
+		for (uint32_t t = 0; t < kp.nterms; t++) {
+			const xe_term tm = kp.terms[t];
+			uint64_t bit = (uint64_t)(live && fast_term(kp, L, tm)) << (t & 63);
+			switch (t >> 6) {
+				case 0: tb0 |= bit; break;
+				case 1: tb1 |= bit; break;
+				case 2: tb2 |= bit; break;
+				default: tb3 |= bit; break;
+			}
+		}
+
+		/* object programs over the term bits */
+		for (uint32_t w = 0; w < kp.mask_words; w++) {
+			uint64_t bits = 0;
+			uint32_t m0 = w * 64, m1 = (m0 + 64 < kp.nmo) ? m0 + 64 : kp.nmo;
+			for (uint32_t m = m0; m < m1; m++) {
+				const xe_prog pr = kp.progs[m];
+				bool hit;
+				if (pr.flags & XE_PROG_CONST) {
+					hit = pr.cval != 0;
+				} else {
+					uint64_t st = 0;
+					for (uint32_t k = 0; k < pr.nops; k++) {
+						uint32_t op = kp.ops[pr.op_base + k];
+						uint32_t code = op & 3;
+						if (code == XE_OP_BASIC) {
+							uint32_t id = op >> 2, wsel = id >> 6;
+							uint64_t word = (wsel == 0) ? tb0 : (wsel == 1) ? tb1 : (wsel == 2) ? tb2 : tb3;
+							st = (st << 1) | ((word >> (id & 63)) & 1);
+						} else if (code == XE_OP_NOT) {
+							st ^= 1;
+						} else {
+							uint64_t top = st & 1;
+							st >>= 1;
+							if (code == XE_OP_AND) st &= (top | ~1ull);
+							else st |= top;
+						}
+					}
+					hit = (st & 1) != 0;
+				}
+				hit = hit && live;
+				if (pr.parent >= 0) {
+					uint32_t par = (uint32_t)pr.parent;
+					bool pok;
+					if (par >= m0) pok = ((bits >> (par - m0)) & 1) != 0;
+					else pok = live && (((kp.masks[(size_t)ridx * kp.mask_words + (par >> 6)] >> (par & 63)) & 1) != 0);
+					hit = hit && pok;
+				}
+				if (hit) bits |= 1ull << (m - m0);
+				unsigned long long ball = __ballot(hit);
+				if (ball) {
+					unsigned long long sb = wave_sum(hit ? bxr : 0ull);
+					unsigned long long sp = wave_sum(hit ? pxr : 0ull);
+					if (lane == 0) {
+						unsigned long long *dst = kp.lds_counters ? (lcnt + 3 * m) : (kp.counters + 3 * m);
+						atomicAdd(dst + 0, (unsigned long long)__popcll(ball));
+						atomicAdd(dst + 1, sb);
+						atomicAdd(dst + 2, sp);
+					}
+				}
+			}
+			if (live) kp.masks[(size_t)ridx * kp.mask_words + w] = bits;
+		}
+	}
+
+	if (kp.lds_counters) {
+		__syncthreads();
+		for (uint32_t i = threadIdx.x; i < kp.nmo * 3; i += XE_BLOCK) {
+			unsigned long long v = lcnt[i];
+			if (v) atomicAdd(kp.counters + i, v);
+		}
+	}
+}
+
 /* ------------------------------------------------------------------ list probe */
 __global__ void
 xe_trie_probe_kernel(const uint32_t *trie, xe_list_dev L, int family, const uint8_t *addrs, uint32_t n, uint8_t *out)
@@ -613,9 +971,20 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream)
 			return XE_EHIP;
 		}
 	}
-	if (kp->nrec) {
-		uint32_t blocks = (kp->nrec + XE_BLOCK - 1) / XE_BLOCK;
-		hipLaunchKernelGGL(xe_nf_kernel, dim3(blocks), dim3(XE_BLOCK), 0, st, *kp);
+	if (kp->ntiles) {
+		/* grid-stride over tiles: enough blocks to fill 256 CUs several times
+		 * over, few enough that the per-block counter flush stays cheap */
+		uint32_t per_block = XE_BLOCK / 64;
+		uint32_t blocks = (kp->ntiles + per_block - 1) / per_block;
+		size_t shmem = (size_t)(kp->nslots + kp->nslots_hi) * XE_BLOCK * 8
+			+ (kp->lds_counters ? (size_t)kp->nmo * 24 : 0);
+		if (blocks > 4096) blocks = 4096;
+		hipLaunchKernelGGL(xe_nf_fast_kernel, dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
+		if (hipGetLastError() != hipSuccess) return XE_EHIP;
+	}
+	if (kp->nslowrec) {
+		uint32_t blocks = (kp->nslowrec + XE_BLOCK - 1) / XE_BLOCK;
+		hipLaunchKernelGGL(xe_nf_general_kernel, dim3(blocks), dim3(XE_BLOCK), 0, st, *kp);
 		if (hipGetLastError() != hipSuccess) return XE_EHIP;
 	}
 	return XE_OK;
