@@ -686,19 +686,71 @@ fast_trie6(const uint32_t *T, const xe_list_dev &L, uint64_t hi, uint64_t lo, bo
 	return (e & XE_TRIE_TERM) ? ((e & 1) != 0) : false;
 }
 
+/*
+ * Configuration data (templates, terms, operands, programs, list
+ * descriptors, tile tables) is read with wave-uniform indices.  Reading it
+ * through constant-address-space pointers makes those loads scalar (s_load,
+ * served by the scalar cache) instead of 64-lane vector loads that all fetch
+ * the same address; the arrays are never written while a kernel runs.
+ */
+#define XE_CONST __attribute__((address_space(4)))
+typedef const XE_CONST uint32_t *cu32;
+typedef const XE_CONST uint64_t *cu64;
+
+struct tent_s { uint32_t len, field, flags, off; };
+__device__ __forceinline__ tent_s
+ld_tent(const xe_tent *E, uint32_t j)
+{
+	uint64_t w = ((cu64)E)[j];
+	tent_s e;
+	e.len = (uint32_t)w & 0xFFFF;
+	e.field = (uint32_t)(w >> 16) & 0xFF;
+	e.flags = (uint32_t)(w >> 24) & 0xFF;
+	e.off = (uint32_t)(w >> 32) & 0xFFFF;
+	return e;
+}
+
+struct term_s { uint32_t type, dir, fsrc, fdst, func, fa, fb, nopnd; int32_t k; const xe_dopnd *o; };
+__device__ __forceinline__ term_s
+ld_term(const xe_kparams &kp, uint32_t t)
+{
+	cu32 q = (cu32)(kp.terms + t);
+	uint32_t w0 = q[0], w1 = q[1];
+	term_s r;
+	r.type = w0 & 0xFF; r.dir = (w0 >> 8) & 0xFF; r.fsrc = (w0 >> 16) & 0xFF; r.fdst = w0 >> 24;
+	r.func = w1 & 0xFF; r.fa = (w1 >> 8) & 0xFF; r.fb = (w1 >> 16) & 0xFF;
+	r.k = (int32_t)q[2];
+	r.nopnd = q[3];
+	r.o = kp.opnds + q[4];
+	return r;
+}
+
 __device__ __forceinline__ bool
 in_ranges_u(const xe_dopnd *o, uint32_t n, int64_t v)
 {
 	bool r = false;
-	for (uint32_t i = 0; i < n; i++) r |= (v >= o[i].low) && (v <= o[i].high);
+	for (uint32_t i = 0; i < n; i++) {
+		cu32 q = (cu32)(o + i);
+		int32_t lo = (int32_t)q[2], hi = (int32_t)q[3];
+		r |= (v >= lo) && (v <= hi);
+	}
 	return r;
+}
+
+__device__ __forceinline__ xe_list_dev
+ld_list(const xe_kparams &kp, uint32_t idx)
+{
+	cu32 q = (cu32)(kp.lists + idx);
+	xe_list_dev L;
+	L.root4 = q[0]; L.root6 = q[1]; L.nodes4 = q[2]; L.nodes6 = q[3];
+	return L;
 }
 
 /* one distinct term for all lanes; same semantics as term_match() */
 __device__ bool
-fast_term(const xe_kparams &kp, const fast_lane &L, const xe_term &t)
+fast_term(const xe_kparams &kp, const fast_lane &L, const term_s &t)
 {
-	const xe_dopnd *o = kp.opnds + t.opnd_base;
+	const xe_dopnd *o = t.o;
 	bool has;
 	uint64_t hi, lo;
 
@@ -723,22 +775,27 @@ fast_term(const xe_kparams &kp, const fast_lane &L, const xe_term &t)
 		if (!(t.dir & side)) continue;
 		uint32_t f = (side == XE_DIR_SRC) ? t.fsrc : t.fdst;
 		slot_get(kp, L, f, has, hi, lo);
+		if (((t.type == XE_BT_ADDR4) || (t.type == XE_BT_ADDR6)) && !__ballot(has)) continue;
 		switch (t.type) {
 			case XE_BT_ADDR4: {
 				uint32_t a = (c_fmax[f] == 16) ? (uint32_t)(hi >> 32) : (uint32_t)lo;
 				for (uint32_t i = 0; i < t.nopnd; i++) {
+					cu32 q = (cu32)(o + i);
+					cu64 r = (cu64)(o + i);
 					bool m;
-					if (o[i].is_list) m = fast_trie4(kp.trie, kp.lists[o[i].list], a, has && !res);
-					else m = (a & (uint32_t)o[i].mask_lo) == (uint32_t)o[i].net_lo;
+					if (q[0]) m = fast_trie4(kp.trie, ld_list(kp, q[1]), a, has && !res);
+					else m = (a & (uint32_t)r[5]) == (uint32_t)r[3];
 					res |= has && m;
 				}
 				break;
 			}
 			case XE_BT_ADDR6:
 				for (uint32_t i = 0; i < t.nopnd; i++) {
+					cu32 q = (cu32)(o + i);
+					cu64 r = (cu64)(o + i);
 					bool m;
-					if (o[i].is_list) m = fast_trie6(kp.trie, kp.lists[o[i].list], hi, lo, has && !res);
-					else m = ((hi & o[i].mask_hi) == o[i].net_hi) && ((lo & o[i].mask_lo) == o[i].net_lo);
+					if (q[0]) m = fast_trie6(kp.trie, ld_list(kp, q[1]), hi, lo, has && !res);
+					else m = ((hi & r[4]) == r[2]) && ((lo & r[5]) == r[3]);
 					res |= has && m;
 				}
 				break;
@@ -749,7 +806,7 @@ fast_term(const xe_kparams &kp, const fast_lane &L, const xe_term &t)
 				break;
 			}
 			case XE_BT_MAC:
-				for (uint32_t i = 0; i < t.nopnd; i++) res |= (o[i].net_lo == lo);
+				for (uint32_t i = 0; i < t.nopnd; i++) res |= (((cu64)(o + i))[3] == lo);
 				break;
 			default:
 				break;
@@ -774,16 +831,17 @@ xe_nf_fast_kernel(const xe_kparams kp)
 		__syncthreads();
 	}
 
-	for (uint32_t tile = blockIdx.x * (XE_BLOCK / 64) + wave; tile < kp.ntiles; tile += gridDim.x * (XE_BLOCK / 64)) {
-		const uint32_t tmpl = __builtin_amdgcn_readfirstlane(kp.tile_tmpl[tile]);
-		const xe_tmpl *T = kp.tmpls + tmpl;
-		const xe_tent *E = kp.tents + T->ent_base;
-		const uint32_t nf = T->nfields;
-		const bool ipfix = T->mode == XE_MODE_IPFIX;
+	const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (XE_BLOCK / 64) + wave);
+	for (uint32_t tile = wave0; tile < kp.ntiles; tile += gridDim.x * (XE_BLOCK / 64)) {
+		const uint32_t tmpl = ((cu32)kp.tile_tmpl)[tile];
+		cu32 TQ = (cu32)(kp.tmpls + tmpl);
+		const xe_tent *E = kp.tents + TQ[0];
+		const uint32_t nf = TQ[1] & 0xFFFF;
+		const bool ipfix = (TQ[2] & 0xFF) == XE_MODE_IPFIX;
 
 		/* which run, which record */
 		uint32_t g = tile * 64 + lane;
-		uint32_t s = __builtin_amdgcn_readfirstlane(kp.tile_first[tile]);
+		uint32_t s = ((cu32)kp.tile_first)[tile];
 		while ((s + 1 < kp.nfsets) && (kp.fwstart[s + 1] <= g)) s++;
 		const xe_set S = kp.fsets[s];
 		uint32_t i = g - kp.fwstart[s];
@@ -798,7 +856,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 
 		/* decode */
 		for (uint32_t j = 0; j < nf; j++) {
-			const xe_tent e = E[j];
+			const tent_s e = ld_tent(E, j);
 			bool act = ipfix ? (live && ((j == 0) || ((int32_t)e.off < avail)))
 				: (((int32_t)e.off + (int32_t)e.len) <= avail);
 			if (!__ballot(act)) break;
@@ -835,7 +893,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 		/* every distinct term once */
 		uint64_t tb0 = 0, tb1 = 0, tb2 = 0, tb3 = 0;
 		for (uint32_t t = 0; t < kp.nterms; t++) {
-			const xe_term tm = kp.terms[t];
+			const term_s tm = ld_term(kp, t);
 			uint64_t bit = (uint64_t)(live && fast_term(kp, L, tm)) << (t & 63);
 			switch (t >> 6) {
 				case 0: tb0 |= bit; break;
@@ -850,14 +908,16 @@ xe_nf_fast_kernel(const xe_kparams kp)
 			uint64_t bits = 0;
 			uint32_t m0 = w * 64, m1 = (m0 + 64 < kp.nmo) ? m0 + 64 : kp.nmo;
 			for (uint32_t m = m0; m < m1; m++) {
-				const xe_prog pr = kp.progs[m];
+				cu32 PQ = (cu32)(kp.progs + m);
+				const uint32_t op_base = PQ[0], nops = PQ[1], pflags = PQ[3];
+				const int32_t parent = (int32_t)PQ[2];
 				bool hit;
-				if (pr.flags & XE_PROG_CONST) {
-					hit = pr.cval != 0;
+				if (pflags & XE_PROG_CONST) {
+					hit = (pflags >> 16) != 0;
 				} else {
 					uint64_t st = 0;
-					for (uint32_t k = 0; k < pr.nops; k++) {
-						uint32_t op = kp.ops[pr.op_base + k];
+					for (uint32_t k = 0; k < nops; k++) {
+						uint32_t op = ((cu32)kp.ops)[op_base + k];
 						uint32_t code = op & 3;
 						if (code == XE_OP_BASIC) {
 							uint32_t id = op >> 2, wsel = id >> 6;
@@ -875,8 +935,8 @@ xe_nf_fast_kernel(const xe_kparams kp)
 					hit = (st & 1) != 0;
 				}
 				hit = hit && live;
-				if (pr.parent >= 0) {
-					uint32_t par = (uint32_t)pr.parent;
+				if (parent >= 0) {
+					uint32_t par = (uint32_t)parent;
 					bool pok;
 					if (par >= m0) pok = ((bits >> (par - m0)) & 1) != 0;
 					else pok = live && (((kp.masks[(size_t)ridx * kp.mask_words + (par >> 6)] >> (par & 63)) & 1) != 0);
