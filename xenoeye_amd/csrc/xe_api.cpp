@@ -20,8 +20,8 @@ struct xe_gpu
 	int device;
 	struct xe_host hs;
 	int committed;
-	void *d_progs, *d_ops, *d_terms, *d_opnds, *d_trie, *d_lists, *d_devrules;
-	uint32_t nmo, mask_words, nprogs_total;
+	void *d_progs, *d_ops, *d_terms, *d_opnds, *d_trie, *d_lists, *d_devrules, *d_lookups;
+	uint32_t nmo, mask_words, nprogs_total, nlookups;
 	struct xe_list_dev *h_lists;
 	void *d_tmpls, *d_tents;
 	size_t up_tmpls, up_tents;
@@ -110,7 +110,8 @@ xe_gpu_create(xe_gpu **out, int device)
 static void
 free_config_dev(xe_gpu *h)
 {
-	void **p[] = { &h->d_progs, &h->d_ops, &h->d_terms, &h->d_opnds, &h->d_trie, &h->d_lists, &h->d_devrules };
+	void **p[] = { &h->d_progs, &h->d_ops, &h->d_terms, &h->d_opnds, &h->d_trie, &h->d_lists, &h->d_devrules,
+		&h->d_lookups };
 	for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); i++) {
 		if (*p[i]) (void)hipFree(*p[i]);
 		*p[i] = NULL;
@@ -360,8 +361,34 @@ make_dopnd(const struct xe_term *t, const struct xe_opnd *o)
 /* index of an identical term already in the table, or a new one: objects
  * that share a condition (the same list on the same field, the same port
  * range ...) have it evaluated once per record */
+/* lookup bit of the (list, family, field) membership test; the probe for
+ * (group of the list, family, field) is added on first use */
+static int32_t
+intern_lookup(struct xe_blob *probes, uint32_t list, int family, uint8_t field)
+{
+	struct xe_probe *have = (struct xe_probe *)probes->p;
+	struct xe_probe pr;
+	uint32_t group = list / XE_LIST_GROUP, l = list % XE_LIST_GROUP;
+
+	for (size_t i = 0; i < probes->n; i++) {
+		if ((have[i].group == group) && (have[i].family == family) && (have[i].field == field)) {
+			have[i].used |= (uint8_t)(1u << l);
+			return (int32_t)(i * XE_LIST_GROUP + l);
+		}
+	}
+	memset(&pr, 0, sizeof(pr));
+	pr.group = group;
+	pr.family = (uint8_t)family;
+	pr.field = field;
+	pr.wide4 = (family == 4) && (xe_fields[field].size_max == 16);
+	pr.used = (uint8_t)(1u << l);
+	if (!xe_blob_push(probes, &pr, sizeof(pr))) return -1;
+	return (int32_t)((probes->n - 1) * XE_LIST_GROUP + l);
+}
+
 static int
-intern_term(struct xe_blob *terms, struct xe_blob *opnds, const struct xe_filter *f, size_t ti, uint32_t *id)
+intern_term(struct xe_blob *terms, struct xe_blob *opnds, struct xe_blob *lookups, const struct xe_filter *f,
+	size_t ti, uint32_t *id)
 {
 	struct xe_term t = f->terms[ti];
 	struct xe_dopnd tmp[64], *ops = tmp;
@@ -374,7 +401,14 @@ intern_term(struct xe_blob *terms, struct xe_blob *opnds, const struct xe_filter
 		ops = (struct xe_dopnd *)malloc(t.nopnd * sizeof(*ops));
 		if (!ops) return XE_ENOMEM;
 	}
-	for (uint32_t j = 0; j < t.nopnd; j++) ops[j] = make_dopnd(&t, &f->opnds[f->terms[ti].opnd_base + j]);
+	for (uint32_t j = 0; j < t.nopnd; j++) {
+		ops[j] = make_dopnd(&t, &f->opnds[f->terms[ti].opnd_base + j]);
+		if (ops[j].is_list && (t.func == XE_FN_NONE) && ((t.type == XE_BT_ADDR4) || (t.type == XE_BT_ADDR6))) {
+			int fam = (t.type == XE_BT_ADDR4) ? 4 : 6;
+			ops[j].low = (t.dir & XE_DIR_SRC) ? intern_lookup(lookups, ops[j].list, fam, t.fsrc) : -1;
+			ops[j].high = (t.dir & XE_DIR_DST) ? intern_lookup(lookups, ops[j].list, fam, t.fdst) : -1;
+		}
+	}
 	for (size_t k = 0; k < terms->n; k++) {
 		const struct xe_term *o = &have[k];
 		if ((o->type == t.type) && (o->dir == t.dir) && (o->fsrc == t.fsrc) && (o->fdst == t.fdst)
@@ -399,7 +433,7 @@ out:
 /* append one compiled filter to the flat arrays */
 static int
 append_prog(struct xe_blob *progs, struct xe_blob *ops, struct xe_blob *terms, struct xe_blob *opnds,
-	const struct xe_filter *f, int parent)
+	struct xe_blob *lookups, const struct xe_filter *f, int parent)
 {
 	struct xe_prog pr;
 	int cval = 0;
@@ -417,7 +451,7 @@ append_prog(struct xe_blob *progs, struct xe_blob *ops, struct xe_blob *terms, s
 		uint32_t w = f->ops[i];
 		if ((w & 3) == XE_OP_BASIC) {
 			uint32_t id;
-			int rc = intern_term(terms, opnds, f, w >> 2, &id);
+			int rc = intern_term(terms, opnds, lookups, f, w >> 2, &id);
 			if (rc != XE_OK) return rc;
 			w = XE_OP_BASIC | (id << 2);
 		}
@@ -457,7 +491,7 @@ assign_slots(xe_gpu *h, const struct xe_term *terms, size_t nobj_terms)
 extern "C" int
 xe_gpu_commit(xe_gpu *h)
 {
-	struct xe_blob progs = {0}, ops = {0}, terms = {0}, opnds = {0}, trie = {0}, rules = {0};
+	struct xe_blob progs = {0}, ops = {0}, terms = {0}, opnds = {0}, trie = {0}, rules = {0}, lookups = {0};
 	int rc = XE_OK;
 
 	if (!h) return XE_EINVAL;
@@ -465,7 +499,7 @@ xe_gpu_commit(xe_gpu *h)
 	free_config_dev(h);
 
 	for (size_t m = 0; (m < h->hs.nmos) && (rc == XE_OK); m++) {
-		rc = append_prog(&progs, &ops, &terms, &opnds, &h->hs.mos[m].filter, h->hs.mos[m].parent);
+		rc = append_prog(&progs, &ops, &terms, &opnds, &lookups, &h->hs.mos[m].filter, h->hs.mos[m].parent);
 	}
 	if (rc == XE_OK) {
 		/* the fast kernel evaluates the object programs' terms [0, nterms);
@@ -473,6 +507,8 @@ xe_gpu_commit(xe_gpu *h)
 		h->nterms = (uint32_t)terms.n;
 		assign_slots(h, (const struct xe_term *)terms.p, terms.n);
 		if (h->nterms > XE_MAX_FAST_TERMS) h->fast_ok = 0;
+		h->nlookups = (uint32_t)lookups.n;
+		if (h->nlookups > XE_MAX_PROBES) h->fast_ok = 0;
 		if ((size_t)(h->nslots + h->nslots_hi) * 256 * 8 + (size_t)h->hs.nmos * 24 > 60 * 1024) h->fast_ok = 0;
 	}
 	for (size_t d = 0; (d < h->hs.ndevs) && (rc == XE_OK); d++) {
@@ -482,7 +518,7 @@ xe_gpu_commit(xe_gpu *h)
 		r.nprogs = (uint32_t)h->hs.devs[d].nmarks;
 		r.skip_unmarked = (uint32_t)h->hs.devs[d].skip_unmarked;
 		for (size_t k = 0; (k < h->hs.devs[d].nmarks) && (rc == XE_OK); k++) {
-			rc = append_prog(&progs, &ops, &terms, &opnds, &h->hs.devs[d].marks[k], -1);
+			rc = append_prog(&progs, &ops, &terms, &opnds, &lookups, &h->hs.devs[d].marks[k], -1);
 		}
 		if ((rc == XE_OK) && !xe_blob_push(&rules, &r, sizeof(r))) rc = XE_ENOMEM;
 	}
@@ -491,6 +527,39 @@ xe_gpu_commit(xe_gpu *h)
 		if (!h->h_lists) rc = XE_ENOMEM;
 		else rc = xe_iplists_flatten(&h->hs.lists, &trie, h->h_lists);
 	}
+	/* interleaved root tables of the probes' groups, appended to the trie array */
+	if (rc == XE_OK) {
+		struct xe_probe *pp = (struct xe_probe *)lookups.p;
+		for (size_t i = 0; (i < lookups.n) && (rc == XE_OK); i++) {
+			uint32_t done = 0;
+			for (size_t j = 0; j < i; j++) {
+				if ((pp[j].group == pp[i].group) && (pp[j].family == pp[i].family)) { pp[i].root_off = pp[j].root_off; done = 1; break; }
+			}
+			if (done) continue;
+			while (trie.n % 8) { uint32_t z = 0; if (!xe_blob_push(&trie, &z, 4)) { rc = XE_ENOMEM; break; } }
+			if (rc != XE_OK) break;
+			pp[i].root_off = (uint32_t)trie.n;
+			{
+				size_t need = (trie.n + 65536 * XE_LIST_GROUP) * 4;
+				if (need > trie.cap) {
+					void *np = realloc(trie.p, need * 2);
+					if (!np) { rc = XE_ENOMEM; break; }
+					trie.p = np;
+					trie.cap = need * 2;
+				}
+				uint32_t *dst = (uint32_t *)trie.p + trie.n;
+				for (uint32_t idx = 0; idx < 65536; idx++) {
+					for (uint32_t l = 0; l < XE_LIST_GROUP; l++) {
+						size_t li = (size_t)pp[i].group * XE_LIST_GROUP + l;
+						uint32_t ro = (li < h->hs.lists.n) ? ((pp[i].family == 4) ? h->h_lists[li].root4 : h->h_lists[li].root6) : 0;
+						dst[idx * XE_LIST_GROUP + l] = ro ? ((const uint32_t *)trie.p)[ro + idx] : XE_TRIE_TERM;
+					}
+				}
+				trie.n += 65536 * XE_LIST_GROUP;
+			}
+		}
+		if ((rc == XE_OK) && (trie.n > 0xFFFFFFF0u)) rc = XE_EUNSUPPORTED;
+	}
 	if (rc == XE_OK) rc = upload(h, &h->d_progs, progs.p, progs.n * sizeof(struct xe_prog));
 	if (rc == XE_OK) rc = upload(h, &h->d_ops, ops.p, ops.n * 4);
 	if (rc == XE_OK) rc = upload(h, &h->d_terms, terms.p, terms.n * sizeof(struct xe_term));
@@ -498,6 +567,7 @@ xe_gpu_commit(xe_gpu *h)
 	if (rc == XE_OK) rc = upload(h, &h->d_trie, trie.p, trie.n * 4);
 	if (rc == XE_OK) rc = upload(h, &h->d_lists, h->h_lists, h->hs.lists.n * sizeof(struct xe_list_dev));
 	if (rc == XE_OK) rc = upload(h, &h->d_devrules, rules.p, rules.n * sizeof(struct xe_devrule));
+	if (rc == XE_OK) rc = upload(h, &h->d_lookups, lookups.p, lookups.n * sizeof(struct xe_probe));
 	if (rc == XE_OK) {
 		h->nmo = (uint32_t)h->hs.nmos;
 		h->mask_words = h->nmo ? (h->nmo + 63) / 64 : 1;
@@ -506,7 +576,7 @@ xe_gpu_commit(xe_gpu *h)
 	} else {
 		free_config_dev(h);
 	}
-	free(progs.p); free(ops.p); free(terms.p); free(opnds.p); free(trie.p); free(rules.p);
+	free(progs.p); free(ops.p); free(terms.p); free(opnds.p); free(trie.p); free(rules.p); free(lookups.p);
 	return rc;
 }
 
@@ -647,6 +717,8 @@ build_work_lists(xe_gpu *h, xe_batch *b)
 		b->kp.nslots = h->nslots;
 		b->kp.nslots_hi = h->nslots_hi;
 		b->kp.nterms = h->nterms;
+		b->kp.probes = (const struct xe_probe *)h->d_lookups;
+		b->kp.nprobes = h->nlookups;
 		b->kp.lds_counters = (h->hs.nmos <= XE_MAX_LDS_COUNTER_MOS) ? 1u : 0u;
 	}
 out:

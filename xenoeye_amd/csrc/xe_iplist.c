@@ -9,10 +9,9 @@
  *
  * The device form replaces the one-bit-per-step pointer chase with a
  * 65536-entry root table over the first 16 address bits followed by
- * 8-bit-stride nodes that carry two 256-bit maps (child present / result
- * where the walk stops) and a popcount-indexed child base, so a lookup is one
- * root load plus at most (bits-16)/8 node visits, each inside one 80-byte
- * record.
+ * 8-bit-stride nodes of one 128-byte line each (child map / result map /
+ * popcount-indexed child base per 32 chunk values), so a lookup is one root
+ * load plus at most (bits-16)/8 node visits of one 16-byte load each.
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -271,10 +270,10 @@ node_cb(void *vctx, uint32_t first, uint32_t count, int kind, uint32_t value)
 
 	if (kind == 0) {
 		if (value) {
-			for (i = first; i < first + count; i++) c->node[8 + (i >> 5)] |= 1u << (i & 31);
+			for (i = first; i < first + count; i++) c->node[4 * (i >> 5) + 1] |= 1u << (i & 31);
 		}
 	} else {
-		c->node[first >> 5] |= 1u << (first & 31);
+		c->node[4 * (first >> 5)] |= 1u << (first & 31);
 		c->child_bnodes[c->nchild] = value;
 		c->child_chunk[c->nchild] = first;
 		c->nchild++;
@@ -316,22 +315,22 @@ flatten_family(const struct xe_bnode *bt, struct xe_blob *words, uint32_t *root_
 	/* breadth-first so that the children of a node get consecutive ids;
 	 * node k of the family lives at nodes_pos + k * XE_NODE_WORDS, and ids
 	 * are handed out in queue order, so the queue index IS the node id */
+	while (words->n % XE_NODE_WORDS) {
+		if (!xe_blob_push(words, &zero, 4)) { free(queue.p); return 0; }
+	}
 	nodes_pos = words->n;
 	for (qi = 0; qi < queue.n; qi++) {
 		struct pending p = ((struct pending *)queue.p)[qi];
 		uint32_t nw[XE_NODE_WORDS];
 		uint32_t k, cum = 0;
-		uint8_t *cumb;
 
 		memset(nw, 0, sizeof(nw));
 		c.node = nw;
 		c.nchild = 0;
 		expand(bt, p.bnode, 8, 0, node_cb, &c);
-		nw[16] = next_dnode;   /* first child id */
-		cumb = (uint8_t *)&nw[17];
 		for (k = 0; k < 8; k++) {
-			cumb[k] = (uint8_t)cum;
-			cum += (uint32_t)__builtin_popcount(nw[k]);
+			nw[4 * k + 2] = next_dnode + cum;   /* first child of this group */
+			cum += (uint32_t)__builtin_popcount(nw[4 * k]);
 		}
 		/* children in increasing chunk order = rank order of the bitmap */
 		for (k = 0; k < c.nchild; k++) {

@@ -20,7 +20,7 @@ struct xe_dopnd
 {
 	uint32_t is_list;
 	uint32_t list;
-	int32_t low, high;
+	int32_t low, high;           /* list operands: lookup ids of the src / dst side, -1 none */
 	uint64_t net_hi, net_lo;     /* addr4 / mac use net_lo only */
 	uint64_t mask_hi, mask_lo;
 };
@@ -80,10 +80,13 @@ struct xe_kparams
 	uint8_t slot_hi[XE_MAX_SLOTS]; /* slot -> index of its upper 8 bytes, 0xFF = field <= 8 bytes */
 	uint32_t nslots, nslots_hi;
 	uint32_t nterms;             /* distinct terms */
+	const struct xe_probe *probes;
+	uint32_t nprobes, pad2;
 	uint32_t lds_counters;       /* per-block counter staging fits in LDS */
 };
 
 #define XE_MAX_FAST_TERMS 256
+#define XE_MAX_PROBES 8
 #define XE_MAX_LDS_COUNTER_MOS 1024
 
 #ifdef __cplusplus

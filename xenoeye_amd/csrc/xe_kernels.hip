@@ -18,6 +18,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "xe_kernels.h"
 
 #define XE_BLOCK 256
@@ -55,15 +56,14 @@ pkt_be(const pkt_src &s, int32_t off, uint32_t len)
 __device__ __forceinline__ uint32_t
 node_step(const uint32_t *N, uint32_t chunk, bool *stop, uint32_t *result)
 {
-	uint32_t w = chunk >> 5, b = chunk & 31;
-	uint32_t cw = N[w];
-	if ((cw >> b) & 1) {
-		const uint8_t *cum = (const uint8_t *)(N + 17);
+	const uint4 gq = *(const uint4 *)(N + 4 * (chunk >> 5));
+	uint32_t b = chunk & 31;
+	if ((gq.x >> b) & 1) {
 		*stop = false;
-		return N[16] + cum[w] + __popc(cw & ((1u << b) - 1u));
+		return gq.z + __popc(gq.x & ((1u << b) - 1u));
 	}
 	*stop = true;
-	*result = (N[8 + w] >> b) & 1;
+	*result = (gq.y >> b) & 1;
 	return 0;
 }
 
@@ -643,49 +643,6 @@ load_be(const uint8_t *p, uint32_t len, uint64_t &hi, uint64_t &lo)
 	}
 }
 
-__device__ __forceinline__ uint32_t
-node_walk(const uint32_t *N, uint32_t chunk)
-{
-	uint32_t w = chunk >> 5, b = chunk & 31;
-	uint32_t cw = N[w];
-	if ((cw >> b) & 1) {
-		const uint8_t *cum = (const uint8_t *)(N + 17);
-		return N[16] + cum[w] + __popc(cw & ((1u << b) - 1u));
-	}
-	return XE_TRIE_TERM | ((N[8 + w] >> b) & 1);
-}
-
-/* iplist_match4() for the lanes with act set; the list is wave-uniform */
-__device__ __forceinline__ bool
-fast_trie4(const uint32_t *T, const xe_list_dev &L, uint32_t a, bool act)
-{
-	if (!L.root4) return false;
-	uint32_t e = XE_TRIE_TERM;
-	if (act) e = T[L.root4 + (a >> 16)];
-#pragma unroll
-	for (int lvl = 0; lvl < 2; lvl++) {
-		bool walk = !(e & XE_TRIE_TERM);
-		if (!__ballot(walk)) break;
-		if (walk) e = node_walk(T + L.nodes4 + (size_t)e * XE_NODE_WORDS, (a >> (8 - 8 * lvl)) & 255);
-	}
-	return (e & XE_TRIE_TERM) ? ((e & 1) != 0) : false;
-}
-
-__device__ __forceinline__ bool
-fast_trie6(const uint32_t *T, const xe_list_dev &L, uint64_t hi, uint64_t lo, bool act)
-{
-	if (!L.root6) return false;
-	uint32_t e = XE_TRIE_TERM;
-	if (act) e = T[L.root6 + (uint32_t)(hi >> 48)];
-	for (int k = 2; k < 16; k++) {
-		bool walk = !(e & XE_TRIE_TERM);
-		if (!__ballot(walk)) break;
-		uint32_t chunk = (k < 8) ? (uint32_t)(hi >> (56 - 8 * k)) & 255 : (uint32_t)(lo >> (56 - 8 * (k - 8))) & 255;
-		if (walk) e = node_walk(T + L.nodes6 + (size_t)e * XE_NODE_WORDS, chunk);
-	}
-	return (e & XE_TRIE_TERM) ? ((e & 1) != 0) : false;
-}
-
 /*
  * Configuration data (templates, terms, operands, programs, list
  * descriptors, tile tables) is read with wave-uniform indices.  Reading it
@@ -696,6 +653,20 @@ fast_trie6(const uint32_t *T, const xe_list_dev &L, uint64_t hi, uint64_t lo, bo
 #define XE_CONST __attribute__((address_space(4)))
 typedef const XE_CONST uint32_t *cu32;
 typedef const XE_CONST uint64_t *cu64;
+typedef const XE_CONST uint8_t *cu8;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+/* one node visit: the 16-byte group of the chunk (read-only data, so the
+ * load may be scheduled freely among the stores to the output columns) */
+__device__ __forceinline__ uint32_t
+node_walk(const uint32_t *nodes, uint32_t node, uint32_t chunk)
+{
+	const XE_CONST u32x4 *gp = (const XE_CONST u32x4 *)(nodes + (size_t)node * XE_NODE_WORDS) + (chunk >> 5);
+	const u32x4 gq = *gp;
+	uint32_t b = chunk & 31;
+	if ((gq.x >> b) & 1) return gq.z + __popc(gq.x & ((1u << b) - 1u));
+	return XE_TRIE_TERM | ((gq.y >> b) & 1);
+}
 
 struct tent_s { uint32_t len, field, flags, off; };
 __device__ __forceinline__ tent_s
@@ -746,9 +717,76 @@ ld_list(const xe_kparams &kp, uint32_t idx)
 	return L;
 }
 
-/* one distinct term for all lanes; same semantics as term_match() */
+/*
+ * All IP-list membership tests of a tile.  Per probe (one field against one
+ * group of up to 8 lists) a single 32-byte gather fetches the root entries of
+ * all lists of the group; then, level by level, the lists that still have
+ * lanes walking visit one node each, all visits of a level in flight
+ * together.  Bit (8 * probe + l) of the result = list l of the probe's group
+ * matched (0 where the lane's field is absent).
+ */
+__device__ uint64_t
+fast_lookups(const xe_kparams &kp, const fast_lane &L)
+{
+	uint64_t bits = 0;
+
+	for (uint32_t pr = 0; pr < kp.nprobes; pr++) {
+		cu32 q = (cu32)(kp.probes + pr);
+		const uint32_t root_off = q[0], w1 = q[1], group = q[2];
+		const uint32_t family = w1 & 0xFF, field = (w1 >> 8) & 0xFF, wide4 = (w1 >> 16) & 1, used = w1 >> 24;
+		bool has;
+		uint64_t hi, lo;
+		uint32_t e[XE_LIST_GROUP];
+
+		slot_get(kp, L, field, has, hi, lo);
+		if (!__ballot(has)) continue;
+		const uint32_t a4 = wide4 ? (uint32_t)(hi >> 32) : (uint32_t)lo;
+		u32x4 r0 = { XE_TRIE_TERM, XE_TRIE_TERM, XE_TRIE_TERM, XE_TRIE_TERM }, r1 = r0;
+		if (has) {
+			uint32_t top = (family == 6) ? (uint32_t)(hi >> 48) : (a4 >> 16);
+			const XE_CONST u32x4 *rp = (const XE_CONST u32x4 *)(kp.trie + root_off) + (size_t)top * 2;
+			r0 = rp[0];
+			r1 = rp[1];
+		}
+		e[0] = r0.x; e[1] = r0.y; e[2] = r0.z; e[3] = r0.w;
+		e[4] = r1.x; e[5] = r1.y; e[6] = r1.z; e[7] = r1.w;
+#pragma unroll
+		for (int l = 0; l < XE_LIST_GROUP; l++) {
+			if (!((used >> l) & 1)) e[l] = XE_TRIE_TERM;
+		}
+		for (uint32_t lvl = 0; lvl < 14; lvl++) {
+			bool any = false;
+			uint32_t chunk;
+			if (family == 4) {
+				chunk = (a4 >> (8 - 8 * (lvl & 1))) & 255;
+			} else {
+				uint32_t byte = lvl + 2;
+				chunk = (byte < 8) ? (uint32_t)(hi >> (56 - 8 * byte)) & 255
+					: (uint32_t)(lo >> (56 - 8 * (byte - 8))) & 255;
+			}
+#pragma unroll
+			for (int l = 0; l < XE_LIST_GROUP; l++) {
+				const bool walk = !(e[l] & XE_TRIE_TERM);
+				if (__ballot(walk)) {
+					cu32 lq = (cu32)(kp.lists + group * XE_LIST_GROUP + l);
+					any = true;
+					if (walk) e[l] = node_walk(kp.trie + ((family == 4) ? lq[2] : lq[3]), e[l], chunk);
+				}
+			}
+			if (!any) break;
+		}
+#pragma unroll
+		for (int l = 0; l < XE_LIST_GROUP; l++) {
+			bits |= (uint64_t)(((e[l] & XE_TRIE_TERM) ? e[l] : 0u) & 1u) << (pr * XE_LIST_GROUP + l);
+		}
+	}
+	return bits;
+}
+
+/* one distinct term for all lanes; same semantics as term_match(), with the
+ * list memberships taken from fast_lookups() */
 __device__ bool
-fast_term(const xe_kparams &kp, const fast_lane &L, const term_s &t)
+fast_term(const xe_kparams &kp, const fast_lane &L, const term_s &t, uint64_t lkbits)
 {
 	const xe_dopnd *o = t.o;
 	bool has;
@@ -783,7 +821,7 @@ fast_term(const xe_kparams &kp, const fast_lane &L, const term_s &t)
 					cu32 q = (cu32)(o + i);
 					cu64 r = (cu64)(o + i);
 					bool m;
-					if (q[0]) m = fast_trie4(kp.trie, ld_list(kp, q[1]), a, has && !res);
+					if (q[0]) m = ((lkbits >> q[(side == XE_DIR_SRC) ? 2 : 3]) & 1) != 0;
 					else m = (a & (uint32_t)r[5]) == (uint32_t)r[3];
 					res |= has && m;
 				}
@@ -794,7 +832,7 @@ fast_term(const xe_kparams &kp, const fast_lane &L, const term_s &t)
 					cu32 q = (cu32)(o + i);
 					cu64 r = (cu64)(o + i);
 					bool m;
-					if (q[0]) m = fast_trie6(kp.trie, ld_list(kp, q[1]), hi, lo, has && !res);
+					if (q[0]) m = ((lkbits >> q[(side == XE_DIR_SRC) ? 2 : 3]) & 1) != 0;
 					else m = ((hi & r[4]) == r[2]) && ((lo & r[5]) == r[3]);
 					res |= has && m;
 				}
@@ -890,11 +928,12 @@ xe_nf_fast_kernel(const xe_kparams kp)
 		}
 		const unsigned long long bxr = bytes * rate, pxr = pkts * rate;
 
-		/* every distinct term once */
+		/* every IP-list membership, then every distinct term, once */
+		const uint64_t lkbits = (kp.pad2 & 1) ? 0 : fast_lookups(kp, L);
 		uint64_t tb0 = 0, tb1 = 0, tb2 = 0, tb3 = 0;
-		for (uint32_t t = 0; t < kp.nterms; t++) {
+		for (uint32_t t = 0; (t < kp.nterms) && !(kp.pad2 & 2); t++) {
 			const term_s tm = ld_term(kp, t);
-			uint64_t bit = (uint64_t)(live && fast_term(kp, L, tm)) << (t & 63);
+			uint64_t bit = (uint64_t)(live && fast_term(kp, L, tm, lkbits)) << (t & 63);
 			switch (t >> 6) {
 				case 0: tb0 |= bit; break;
 				case 1: tb1 |= bit; break;
@@ -904,7 +943,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 		}
 
 		/* object programs over the term bits */
-		for (uint32_t w = 0; w < kp.mask_words; w++) {
+		for (uint32_t w = 0; (w < kp.mask_words) && !(kp.pad2 & 8); w++) {
 			uint64_t bits = 0;
 			uint32_t m0 = w * 64, m1 = (m0 + 64 < kp.nmo) ? m0 + 64 : kp.nmo;
 			for (uint32_t m = m0; m < m1; m++) {
@@ -943,7 +982,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 					hit = hit && pok;
 				}
 				if (hit) bits |= 1ull << (m - m0);
-				unsigned long long ball = __ballot(hit);
+				unsigned long long ball = (kp.pad2 & 4) ? 0 : __ballot(hit);
 				if (ball) {
 					unsigned long long sb = wave_sum(hit ? bxr : 0ull);
 					unsigned long long sp = wave_sum(hit ? pxr : 0ull);
@@ -1024,8 +1063,16 @@ extern "C" int
 xe_launch_batch(const struct xe_kparams *kp, void *stream)
 {
 	hipStream_t st = (hipStream_t)stream;
+	struct xe_kparams kcopy;
 
 	if (!g_tables_ready) return XE_ESTATE;
+	/* XE_ABLATE (diagnostic): bit 0 skip list lookups, 1 terms, 2 counters,
+	 * 3 programs, 4 decode stores.  Results are wrong with any bit set. */
+	if (getenv("XE_ABLATE")) {
+		kcopy = *kp;
+		kcopy.pad2 = (uint32_t)atoi(getenv("XE_ABLATE"));
+		kp = &kcopy;
+	}
 	if (kp->nmo) {
 		if (hipMemsetAsync(kp->counters, 0, (size_t)kp->nmo * 3 * sizeof(unsigned long long), st) != hipSuccess) {
 			return XE_EHIP;
