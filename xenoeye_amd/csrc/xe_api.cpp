@@ -20,7 +20,7 @@ struct xe_gpu
 	int device;
 	struct xe_host hs;
 	int committed;
-	void *d_progs, *d_ops, *d_terms, *d_opnds, *d_trie, *d_lists, *d_devrules, *d_lookups;
+	void *d_progs, *d_ops, *d_terms, *d_opnds, *d_trie, *d_lists, *d_devrules, *d_lookups, *d_fterms;
 	uint32_t nmo, mask_words, nprogs_total, nlookups;
 	struct xe_list_dev *h_lists;
 	void *d_tmpls, *d_tents;
@@ -39,7 +39,7 @@ struct xe_batch
 	struct xe_plan plan;
 	size_t ntot, payload_bytes;
 	void *d_pkt, *d_sets, *d_exps, *d_sfrecs, *d_out;
-	void *d_fsets, *d_fwstart, *d_tile_first, *d_tile_tmpl, *d_ssets, *d_swstart;
+	void *d_fsets, *d_fwstart, *d_tile_first, *d_tile_tmpl, *d_ssets, *d_swstart, *d_tentx;
 	size_t out_bytes, masks_off, nparsed_off, marks_off, counters_off, sfhas_off;
 	struct xe_kparams kp;
 	hipStream_t last_stream;
@@ -111,7 +111,7 @@ static void
 free_config_dev(xe_gpu *h)
 {
 	void **p[] = { &h->d_progs, &h->d_ops, &h->d_terms, &h->d_opnds, &h->d_trie, &h->d_lists, &h->d_devrules,
-		&h->d_lookups };
+		&h->d_lookups, &h->d_fterms };
 	for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); i++) {
 		if (*p[i]) (void)hipFree(*p[i]);
 		*p[i] = NULL;
@@ -560,6 +560,38 @@ xe_gpu_commit(xe_gpu *h)
 		}
 		if ((rc == XE_OK) && (trie.n > 0xFFFFFFF0u)) rc = XE_EUNSUPPORTED;
 	}
+	if (rc == XE_OK) {
+		struct xe_probe *pp = (struct xe_probe *)lookups.p;
+		for (size_t i = 0; i < lookups.n; i++) {
+			for (uint32_t l = 0; l < XE_LIST_GROUP; l++) {
+				size_t li = (size_t)pp[i].group * XE_LIST_GROUP + l;
+				pp[i].nodes_off[l] = (li < h->hs.lists.n)
+					? ((pp[i].family == 4) ? h->h_lists[li].nodes4 : h->h_lists[li].nodes6) : 0;
+			}
+		}
+	}
+	if (rc == XE_OK) {
+		/* fast-kernel view of the object programs' terms */
+		const struct xe_term *tt = (const struct xe_term *)terms.p;
+		const struct xe_dopnd *oo = (const struct xe_dopnd *)opnds.p;
+		struct xe_fterm *ft = (struct xe_fterm *)calloc(h->nterms ? h->nterms : 1, sizeof(*ft));
+		if (!ft) rc = XE_ENOMEM;
+		for (uint32_t t = 0; (rc == XE_OK) && (t < h->nterms); t++) {
+			int all_lists = (tt[t].func == XE_FN_NONE) && (tt[t].nopnd > 0)
+				&& ((tt[t].type == XE_BT_ADDR4) || (tt[t].type == XE_BT_ADDR6));
+			uint64_t m = 0;
+			for (uint32_t j = 0; all_lists && (j < tt[t].nopnd); j++) {
+				const struct xe_dopnd *o = &oo[tt[t].opnd_base + j];
+				if (!o->is_list) { all_lists = 0; break; }
+				if ((o->low >= 0) && (o->low < 64)) m |= 1ull << o->low;
+				if ((o->high >= 0) && (o->high < 64)) m |= 1ull << o->high;
+			}
+			ft[t].kind = all_lists ? 1 : 0;
+			ft[t].mask = all_lists ? m : 0;
+		}
+		if (rc == XE_OK) rc = upload(h, &h->d_fterms, ft, (size_t)h->nterms * sizeof(*ft));
+		free(ft);
+	}
 	if (rc == XE_OK) rc = upload(h, &h->d_progs, progs.p, progs.n * sizeof(struct xe_prog));
 	if (rc == XE_OK) rc = upload(h, &h->d_ops, ops.p, ops.n * 4);
 	if (rc == XE_OK) rc = upload(h, &h->d_terms, terms.p, terms.n * sizeof(struct xe_term));
@@ -610,7 +642,8 @@ xe_gpu_batch_free(xe_batch *b)
 	if (b->d_sfrecs) (void)hipFree(b->d_sfrecs);
 	if (b->d_out) (void)hipFree(b->d_out);
 	{
-		void *extra[] = { b->d_fsets, b->d_fwstart, b->d_tile_first, b->d_tile_tmpl, b->d_ssets, b->d_swstart };
+		void *extra[] = { b->d_fsets, b->d_fwstart, b->d_tile_first, b->d_tile_tmpl, b->d_ssets, b->d_swstart,
+			b->d_tentx };
 		for (size_t i = 0; i < sizeof(extra) / sizeof(extra[0]); i++) if (extra[i]) (void)hipFree(extra[i]);
 	}
 	xe_plan_free(&b->plan);
@@ -717,6 +750,7 @@ build_work_lists(xe_gpu *h, xe_batch *b)
 		b->kp.nslots = h->nslots;
 		b->kp.nslots_hi = h->nslots_hi;
 		b->kp.nterms = h->nterms;
+		b->kp.fterms = (const struct xe_fterm *)h->d_fterms;
 		b->kp.probes = (const struct xe_probe *)h->d_lookups;
 		b->kp.nprobes = h->nlookups;
 		b->kp.lds_counters = (h->hs.nmos <= XE_MAX_LDS_COUNTER_MOS) ? 1u : 0u;
@@ -830,6 +864,34 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 	{
 		hipError_t e = hipMalloc(&b->d_out, b->out_bytes);
 		if (e != hipSuccess) { xe_gpu_batch_free(b); return hip_fail(h, e, "hipMalloc(outputs)"); }
+	}
+
+	/* per-batch resolved template fields for the fast kernel */
+	{
+		const struct xe_tent *te = (const struct xe_tent *)h->hs.dev_tents.p;
+		size_t ne = h->hs.dev_tents.n;
+		struct xe_tentx *tx = (struct xe_tentx *)calloc(ne ? ne : 1, sizeof(*tx));
+		if (!tx) { xe_gpu_batch_free(b); return XE_ENOMEM; }
+		for (size_t i = 0; i < ne; i++) {
+			int f = te[i].field;
+			tx[i].off = te[i].off;
+			tx[i].len = (uint8_t)((te[i].len > 255) ? 255 : te[i].len);
+			tx[i].field = te[i].field;
+			tx[i].slot = 0xFF;
+			if ((f != XE_F_NONE) && (te[i].flags & XE_TE_VALID) && (te[i].len <= 16)
+				&& (b->kp.col_off[f] != ~0ull)) {
+				tx[i].flags = XE_TE_VALID;
+				tx[i].slot = h->fslot[f];
+				tx[i].colw = (uint8_t)xe_fields[f].col_width;
+				tx[i].special = (uint8_t)(((f == XF_in_bytes) ? 1 : 0) | ((f == XF_in_pkts) ? 2 : 0)
+					| ((xe_fields[f].size_max == 6) ? 4 : 0));
+				tx[i].col = (uint64_t)(uintptr_t)((uint8_t *)b->d_out + b->kp.col_off[f]);
+			}
+		}
+		rc = upload(h, &b->d_tentx, tx, ne * sizeof(*tx));
+		free(tx);
+		if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
+		b->kp.tentx = (const struct xe_tentx *)b->d_tentx;
 	}
 
 	b->kp.progs = (const struct xe_prog *)h->d_progs;

@@ -208,6 +208,27 @@ struct xe_probe
 	uint8_t used;        /* bit l: list (8 * group + l) is tested on this field */
 	uint32_t group;
 	uint32_t pad;
+	uint32_t nodes_off[XE_LIST_GROUP];   /* word offset of node 0 of each list (this family) */
+};
+
+/* per-batch resolved form of a template field for the fast kernel */
+struct xe_tentx
+{
+	uint16_t off;
+	uint8_t len;
+	uint8_t field;
+	uint8_t flags;       /* XE_TE_VALID only when the field is known and its length valid */
+	uint8_t slot;        /* operand slot, 0xFF none */
+	uint8_t colw;        /* column width in bytes */
+	uint8_t special;     /* 1 in_bytes, 2 in_pkts, 4 six-byte value in an 8-byte column */
+	uint64_t col;        /* device address of the field's column */
+};
+
+/* fast-kernel view of a distinct term */
+struct xe_fterm
+{
+	uint64_t kind;       /* bit 0: every operand is an IP list -> result = lookup bits & mask */
+	uint64_t mask;
 };
 
 struct xe_list_dev

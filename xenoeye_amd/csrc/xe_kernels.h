@@ -80,6 +80,8 @@ struct xe_kparams
 	uint8_t slot_hi[XE_MAX_SLOTS]; /* slot -> index of its upper 8 bytes, 0xFF = field <= 8 bytes */
 	uint32_t nslots, nslots_hi;
 	uint32_t nterms;             /* distinct terms */
+	const struct xe_tentx *tentx;   /* parallel to tents */
+	const struct xe_fterm *fterms;  /* parallel to terms[0, nterms) */
 	const struct xe_probe *probes;
 	uint32_t nprobes, pad2;
 	uint32_t lds_counters;       /* per-block counter staging fits in LDS */

@@ -732,7 +732,10 @@ fast_lookups(const xe_kparams &kp, const fast_lane &L)
 
 	for (uint32_t pr = 0; pr < kp.nprobes; pr++) {
 		cu32 q = (cu32)(kp.probes + pr);
-		const uint32_t root_off = q[0], w1 = q[1], group = q[2];
+		const uint32_t root_off = q[0], w1 = q[1];
+		uint32_t nodes[XE_LIST_GROUP];
+#pragma unroll
+		for (int l = 0; l < XE_LIST_GROUP; l++) nodes[l] = q[4 + l];
 		const uint32_t family = w1 & 0xFF, field = (w1 >> 8) & 0xFF, wide4 = (w1 >> 16) & 1, used = w1 >> 24;
 		bool has;
 		uint64_t hi, lo;
@@ -768,9 +771,8 @@ fast_lookups(const xe_kparams &kp, const fast_lane &L)
 			for (int l = 0; l < XE_LIST_GROUP; l++) {
 				const bool walk = !(e[l] & XE_TRIE_TERM);
 				if (__ballot(walk)) {
-					cu32 lq = (cu32)(kp.lists + group * XE_LIST_GROUP + l);
 					any = true;
-					if (walk) e[l] = node_walk(kp.trie + ((family == 4) ? lq[2] : lq[3]), e[l], chunk);
+					if (walk) e[l] = node_walk(kp.trie + nodes[l], e[l], chunk);
 				}
 			}
 			if (!any) break;
@@ -873,7 +875,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 	for (uint32_t tile = wave0; tile < kp.ntiles; tile += gridDim.x * (XE_BLOCK / 64)) {
 		const uint32_t tmpl = ((cu32)kp.tile_tmpl)[tile];
 		cu32 TQ = (cu32)(kp.tmpls + tmpl);
-		const xe_tent *E = kp.tents + TQ[0];
+		const uint32_t ent_base = TQ[0];
 		const uint32_t nf = TQ[1] & 0xFFFF;
 		const bool ipfix = (TQ[2] & 0xFF) == XE_MODE_IPFIX;
 
@@ -886,29 +888,71 @@ xe_nf_fast_kernel(const xe_kparams kp)
 		const bool live = (S.tmpl == tmpl) && (i < S.nrec);
 		const uint32_t ridx = S.first_rec + i;
 		const uint8_t *p = kp.pkt + S.data_off + (uint64_t)i * S.stride;
+		/* (packet bytes are read-only: constant-address-space loads below may
+		 * be scheduled across the column stores) */
 		const int32_t avail = live ? (S.avail - (int32_t)(i * S.stride)) : -0x7fffffff;
 
 		L.present = 0;
 		uint64_t bytes = 0, pkts = 0;
 		uint32_t np = 0;
 
-		/* decode */
+		/* decode: one pre-resolved micro-op per template field (offset, length,
+		 * column address and width, operand slot), 16 bytes, one scalar load */
 		for (uint32_t j = 0; j < nf; j++) {
-			const tent_s e = ld_tent(E, j);
-			bool act = ipfix ? (live && ((j == 0) || ((int32_t)e.off < avail)))
-				: (((int32_t)e.off + (int32_t)e.len) <= avail);
+			cu64 xq = (cu64)(kp.tentx + ent_base + j);
+			const uint64_t w0 = xq[0];
+			const uint32_t off = (uint32_t)w0 & 0xFFFF, len = (uint32_t)(w0 >> 16) & 0xFF;
+			const uint32_t flags = (uint32_t)(w0 >> 32) & 0xFF, slot = (uint32_t)(w0 >> 40) & 0xFF;
+			const uint32_t colw = (uint32_t)(w0 >> 48) & 0xFF, special = (uint32_t)(w0 >> 56);
+			bool act = ipfix ? (live && ((j == 0) || ((int32_t)off < avail)))
+				: (((int32_t)off + (int32_t)len) <= avail);
 			if (!__ballot(act)) break;
 			np += act ? 1u : 0u;
-			if ((e.field == XE_F_NONE) || !(e.flags & XE_TE_VALID)) continue;
+			if (!(flags & XE_TE_VALID)) continue;
+			uint8_t *col = (uint8_t *)xq[1] + (size_t)ridx * colw;
+			const XE_CONST uint8_t *src = (const XE_CONST uint8_t *)(p + off);
 			uint64_t hi = 0, lo = 0;
 			if (act) {
-				load_be(p + e.off, e.len, hi, lo);
-				val128 v = { hi, lo };
-				store_col(kp, e.field, ridx, v);
+				if (len <= 4) {
+					uint32_t raw;
+					__builtin_memcpy(&raw, src, 4);
+					lo = __builtin_bswap32(raw) >> (8 * (4 - len));
+				} else if (len <= 8) {
+					uint64_t raw;
+					__builtin_memcpy(&raw, src, 8);
+					lo = __builtin_bswap64(raw) >> (8 * (8 - len));
+				} else {
+					uint64_t a, b;
+					__builtin_memcpy(&a, src, 8);
+					__builtin_memcpy(&b, src + 8, 8);
+					a = __builtin_bswap64(a);
+					b = __builtin_bswap64(b);
+					const uint32_t sh = 8 * (16 - len);
+					lo = sh ? ((b >> sh) | (a << (64 - sh))) : b;
+					hi = a >> sh;
+				}
+				/* column bytes = the field as the reference stores it: value
+				 * right-aligned in its maximum size, big-endian */
+				if (colw <= 2) {
+					if (colw == 1) *col = (uint8_t)lo;
+					else *(uint16_t *)col = __builtin_bswap16((uint16_t)lo);
+				} else if (colw == 4) {
+					*(uint32_t *)col = __builtin_bswap32((uint32_t)lo);
+				} else if (colw == 8) {
+					*(uint64_t *)col = __builtin_bswap64(lo << ((special & 4) ? 16 : 0));
+				} else {
+					((uint64_t *)col)[0] = __builtin_bswap64(hi);
+					((uint64_t *)col)[1] = __builtin_bswap64(lo);
+				}
+				if (slot != 0xFF) {
+					L.lo[slot * XE_BLOCK + L.tid] = lo;
+					const uint32_t h = kp.slot_hi[slot];
+					if (h != 0xFF) L.hi[h * XE_BLOCK + L.tid] = hi;
+					L.present |= 1ull << slot;
+				}
 			}
-			slot_put(kp, L, e.field, act, hi, lo);
-			if (e.field == XF_in_bytes) bytes = act ? lo : bytes;
-			if (e.field == XF_in_pkts) pkts = act ? lo : pkts;
+			if (special & 1) bytes = act ? lo : bytes;
+			if (special & 2) pkts = act ? lo : pkts;
 		}
 		if (live) {
 			kp.nparsed[ridx] = (uint8_t)np;
@@ -932,8 +976,18 @@ xe_nf_fast_kernel(const xe_kparams kp)
 		const uint64_t lkbits = (kp.pad2 & 1) ? 0 : fast_lookups(kp, L);
 		uint64_t tb0 = 0, tb1 = 0, tb2 = 0, tb3 = 0;
 		for (uint32_t t = 0; (t < kp.nterms) && !(kp.pad2 & 2); t++) {
-			const term_s tm = ld_term(kp, t);
-			uint64_t bit = (uint64_t)(live && fast_term(kp, L, tm, lkbits)) << (t & 63);
+			/* a term whose operands are all IP lists is a mask over the
+			 * lookup bits (absent fields already read 0 there) */
+			cu64 fq = (cu64)(kp.fterms + t);
+			const uint64_t fmask = fq[1];
+			bool r;
+			if (fq[0] & 1) {
+				r = (lkbits & fmask) != 0;
+			} else {
+				const term_s tm = ld_term(kp, t);
+				r = fast_term(kp, L, tm, lkbits);
+			}
+			uint64_t bit = (uint64_t)(live && r) << (t & 63);
 			switch (t >> 6) {
 				case 0: tb0 |= bit; break;
 				case 1: tb1 |= bit; break;
