@@ -128,7 +128,9 @@ int xe_gpu_batch_masks(xe_batch *b, uint64_t *masks, size_t nwords_total);
 /* counters[object][3] = {records, sum in_bytes*sampling_rate, sum
  * in_pkts*sampling_rate}, wrapping u64 (monit-objects.c:995-1007, scale 1) */
 int xe_gpu_batch_counters(xe_batch *b, uint64_t *counters, size_t n_u64);
-/* dropped[record] = 1 where device_rules_check() (devices.c:286-314) returned 0 */
+/* status[record]: 0 = classified; 1 = device_rules_check() (devices.c:286-314)
+ * returned 0; 2 = sFlow sample whose sampled header did not reach the IP layer
+ * and is therefore not classified at all (sflow.c:164-168) */
 int xe_gpu_batch_dropped(xe_batch *b, uint8_t *dropped, size_t n);
 /* re-creates the reference's struct flow_info (flow-info.h:10-33) of
  * records [first, first+count) from the structure-of-arrays output:

@@ -32,16 +32,22 @@ def run_oracle(orc, batch, keep_flows=True):
 def compare(batch_out, orc, flows=True, sflow_states=None):
     """batch_out: PreparedBatch after run(); orc: oracle after run_oracle()."""
     n = orc.nrecords()
-    assert batch_out.records == n, "record count: device %d, oracle %d" % (batch_out.records, n)
+    dd, od = batch_out.dropped(), orc.dropped()
+    # sFlow samples that never reach classification have a slot on the device
+    # (status 2) but no entry in the oracle's log
+    sel = dd != 2
+    assert int(sel.sum()) == n, "record count: device %d, oracle %d" % (int(sel.sum()), n)
+    dd = dd[sel]
     dm, om = batch_out.masks(), orc.masks()
+    assert not dm[~sel].any(), "an unclassified sample has match bits"
+    dm = dm[sel]
     assert dm.shape == om.shape
     bad = np.nonzero((dm != om).any(axis=1))[0]
     assert bad.size == 0, "match bitmask differs at records %s" % bad[:10]
-    dd, od = batch_out.dropped(), orc.dropped()
     assert np.array_equal(dd, od), "dropped flags differ"
     assert np.array_equal(batch_out.counters(), orc.counters()), "counters differ"
     if flows and n:
-        df, of = batch_out.flow_info(), orc.flows()
+        df, of = batch_out.flow_info()[sel], orc.flows()
         # a dropped record never reaches consumers; the reference leaves its
         # dev_mark unset, compare only delivered records byte for byte
         keep = od == 0

@@ -988,19 +988,33 @@ xe_gpu_batch_counters(xe_batch *b, uint64_t *counters, size_t n_u64)
 extern "C" int
 xe_gpu_batch_dropped(xe_batch *b, uint8_t *dropped, size_t n)
 {
-	uint32_t *mk;
 	int rc;
 
 	if (!b || (n < b->ntot)) return XE_EINVAL;
 	memset(dropped, 0, b->ntot);
-	if (!b->kp.marks) return xe_gpu_batch_sync(b);
-	mk = (uint32_t *)malloc(b->ntot * 4 + 4);
-	if (!mk) return XE_ENOMEM;
-	rc = fetch(b, mk, b->marks_off, b->ntot * 4);
-	if (rc == XE_OK) {
-		for (size_t i = 0; i < b->ntot; i++) dropped[i] = (mk[i] & XE_MARK_DROPPED) ? 1 : 0;
+	rc = xe_gpu_batch_sync(b);
+	if (rc != XE_OK) return rc;
+	if (b->kp.marks) {
+		uint32_t *mk = (uint32_t *)malloc(b->ntot * 4 + 4);
+		if (!mk) return XE_ENOMEM;
+		rc = fetch(b, mk, b->marks_off, b->ntot * 4);
+		if (rc == XE_OK) {
+			for (size_t i = 0; i < b->ntot; i++) dropped[i] = (mk[i] & XE_MARK_DROPPED) ? 1 : 0;
+		}
+		free(mk);
+		if (rc != XE_OK) return rc;
 	}
-	free(mk);
+	if (b->plan.nsf) {
+		/* sFlow samples whose header parse ended before the IP layer never
+		 * reach classification (sflow.c:164-168) */
+		uint8_t *st = (uint8_t *)malloc(b->plan.nsf + 1);
+		if (!st) return XE_ENOMEM;
+		rc = fetch(b, st, b->nparsed_off + b->plan.nrec, b->plan.nsf);
+		if (rc == XE_OK) {
+			for (size_t i = 0; i < b->plan.nsf; i++) if (st[i] & XE_SF_SKIPPED) dropped[b->plan.nrec + i] = 2;
+		}
+		free(st);
+	}
 	return rc;
 }
 

@@ -898,6 +898,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 
 		/* decode: one pre-resolved micro-op per template field (offset, length,
 		 * column address and width, operand slot), 16 bytes, one scalar load */
+#pragma unroll 4
 		for (uint32_t j = 0; j < nf; j++) {
 			cu64 xq = (cu64)(kp.tentx + ent_base + j);
 			const uint64_t w0 = xq[0];
@@ -906,7 +907,6 @@ xe_nf_fast_kernel(const xe_kparams kp)
 			const uint32_t colw = (uint32_t)(w0 >> 48) & 0xFF, special = (uint32_t)(w0 >> 56);
 			bool act = ipfix ? (live && ((j == 0) || ((int32_t)off < avail)))
 				: (((int32_t)off + (int32_t)len) <= avail);
-			if (!__ballot(act)) break;
 			np += act ? 1u : 0u;
 			if (!(flags & XE_TE_VALID)) continue;
 			uint8_t *col = (uint8_t *)xq[1] + (size_t)ridx * colw;
@@ -1061,6 +1061,288 @@ xe_nf_fast_kernel(const xe_kparams kp)
 	}
 }
 
+/* ------------------------------------------------------------------ sFlow v5 */
+/*
+ * One thread per flow-sample element that yields a record (the host pre-pass
+ * located them).  The thread walks the sampled header the way rawparse.h does
+ * (Ethernet, up to two VLAN tags, IPv4 / IPv6 with the IPIP and 6in6 cases,
+ * TCP / UDP / ICMP) and fills the flow fields with the hooks of sflow.c:35-77,
+ * quirks included: every copy is left-aligned in its field, the IPv6
+ * destination is copied from the source address, VLAN fields keep the whole
+ * TCI, and only parser states below NO_IP are skipped.
+ */
+#define SF_NFIELDS 23
+/* bit / slot order of the fields the sFlow decoder can set (same order as the
+ * host uses when it re-creates struct flow_info) */
+__constant__ uint8_t c_sf_field[SF_NFIELDS] = {
+	XF_in_bytes, XF_in_pkts, XF_protocol, XF_src_tos, XF_dst_tos, XF_tcp_flags, XF_l4_src_port,
+	XF_ip4_src_addr, XF_input_snmp, XF_l4_dst_port, XF_ip4_dst_addr, XF_output_snmp, XF_ip6_src_addr,
+	XF_ip6_dst_addr, XF_icmp_type, XF_min_ttl, XF_max_ttl, XF_src_mac, XF_dst_mac, XF_src_vlan,
+	XF_dst_vlan, XF_src_dot1q_cvlan, XF_dst_dot1q_cvlan };
+/* byte offset of each of those fields in the per-thread flow image */
+__constant__ uint8_t c_sf_off[SF_NFIELDS + 1] = {
+	0, 8, 16, 17, 18, 19, 21, 23, 27, 31, 33, 37, 41, 57, 73, 75, 76, 77, 83, 89, 91, 93, 95, 97 };
+enum { SFI_in_bytes, SFI_in_pkts, SFI_protocol, SFI_src_tos, SFI_dst_tos, SFI_tcp_flags, SFI_l4_src_port,
+	SFI_ip4_src, SFI_input_snmp, SFI_l4_dst_port, SFI_ip4_dst, SFI_output_snmp, SFI_ip6_src, SFI_ip6_dst,
+	SFI_icmp_type, SFI_min_ttl, SFI_max_ttl, SFI_src_mac, SFI_dst_mac, SFI_src_vlan, SFI_dst_vlan,
+	SFI_src_cvlan, SFI_dst_cvlan };
+
+struct sf_rec
+{
+	uint8_t b[100];       /* field bytes as struct flow_info holds them */
+	uint32_t has;
+	uint32_t mark;
+	const xe_sfrec *q;
+	pkt_src src;          /* the sampled header / IPv4 structure */
+};
+
+__device__ void
+sf_copy(sf_rec &r, int fi, int32_t off, int n)
+{
+	for (int i = 0; i < n; i++) r.b[c_sf_off[fi] + i] = (uint8_t)pkt_byte(r.src, off + i);
+	r.has |= 1u << fi;
+}
+
+__device__ void
+sf_on_ip(sf_rec &r, int32_t iph)   /* sflow.c:47-54 */
+{
+	sf_copy(r, SFI_ip4_src, iph + 12, 4);
+	sf_copy(r, SFI_ip4_dst, iph + 16, 4);
+	sf_copy(r, SFI_src_tos, iph + 1, 1);
+	sf_copy(r, SFI_dst_tos, iph + 1, 1);
+	sf_copy(r, SFI_min_ttl, iph + 8, 1);
+	sf_copy(r, SFI_max_ttl, iph + 8, 1);
+	sf_copy(r, SFI_protocol, iph + 9, 1);
+}
+
+__device__ void
+sf_on_ip6(sf_rec &r, int32_t ip6h, uint32_t nexthdr)   /* sflow.c:57-62 */
+{
+	sf_copy(r, SFI_ip6_src, ip6h + 8, 16);
+	sf_copy(r, SFI_ip6_dst, ip6h + 8, 16);
+	sf_copy(r, SFI_min_ttl, ip6h + 7, 1);
+	sf_copy(r, SFI_max_ttl, ip6h + 7, 1);
+	r.b[c_sf_off[SFI_protocol]] = (uint8_t)nexthdr;
+	r.has |= 1u << SFI_protocol;
+}
+
+__device__ __forceinline__ uint32_t
+sf_be16(const sf_rec &r, int32_t off)
+{
+	return (pkt_byte(r.src, off) << 8) | pkt_byte(r.src, off + 1);
+}
+
+/* rawpacket_parse(), rawparse.h:89-281; returns the parser state 0..4 */
+__device__ int
+sf_rawparse(sf_rec &r, int32_t end, int type)
+{
+	int32_t ptr = 0;
+	uint32_t h_proto;
+
+	if ((ptr + 14) >= end) return 0;
+	if (type == 0) {
+		sf_copy(r, SFI_dst_mac, 0, 6);
+		sf_copy(r, SFI_src_mac, 6, 6);
+		h_proto = sf_be16(r, 12);
+		ptr = 14;
+		if ((h_proto == 0x8100) || (h_proto == 0x88a8)) {
+			if ((ptr + 4) >= end) return 1;
+			sf_copy(r, SFI_src_vlan, ptr, 2);
+			sf_copy(r, SFI_dst_vlan, ptr, 2);
+			h_proto = sf_be16(r, ptr + 2);
+			ptr += 4;
+		}
+		if ((h_proto == 0x8100) || (h_proto == 0x88a8)) {
+			if ((ptr + 4) >= end) return 1;
+			sf_copy(r, SFI_src_cvlan, ptr, 2);
+			sf_copy(r, SFI_dst_cvlan, ptr, 2);
+			h_proto = sf_be16(r, ptr + 2);
+			ptr += 4;
+		}
+	} else {
+		h_proto = (type == 1) ? 0x0800 : 0x86dd;
+	}
+
+	uint32_t l4;
+	if (h_proto == 0x0800) {
+		if ((ptr + 20) >= end) return 2;
+		int32_t iph = ptr;
+		if ((sf_be16(r, iph + 6) & 0x3fff) != 0) {
+			sf_on_ip(r, iph);
+			return 3;
+		}
+		ptr += (int32_t)(pkt_byte(r.src, iph) & 0x0f) * 4;
+		if (pkt_byte(r.src, iph + 9) == 4) {
+			if ((ptr + 20) >= end) return 2;
+			iph = ptr;
+			ptr += (int32_t)(pkt_byte(r.src, iph) & 0x0f) * 4;
+		}
+		sf_on_ip(r, iph);
+		l4 = pkt_byte(r.src, iph + 9);
+		if ((l4 != 6) && (l4 != 17) && (l4 != 1)) return 3;
+	} else if (h_proto == 0x86dd) {
+		if ((ptr + 40) >= end) return 2;
+		int32_t ip6h = ptr;
+		ptr += 40;
+		l4 = pkt_byte(r.src, ip6h + 6);
+		if (l4 == 4) {
+			if ((ptr + 20) >= end) return 2;
+			int32_t iph = ptr;
+			l4 = pkt_byte(r.src, iph + 9);
+			ptr += (int32_t)(pkt_byte(r.src, iph) & 0x0f) * 4;
+			sf_on_ip(r, iph);
+		} else if (l4 == 41) {
+			if ((ptr + 40) >= end) return 2;
+			ip6h = ptr;
+			ptr += 40;
+			l4 = pkt_byte(r.src, ip6h + 6);
+			sf_on_ip6(r, ip6h, l4);
+		} else {
+			sf_on_ip6(r, ip6h, l4);
+		}
+		if (l4 == 58) l4 = 1;
+		if ((l4 != 6) && (l4 != 17) && (l4 != 1)) return 3;
+	} else {
+		return 2;
+	}
+
+	if (l4 == 6) {
+		if ((ptr + 20) >= end) return 3;
+		sf_copy(r, SFI_l4_src_port, ptr, 2);
+		sf_copy(r, SFI_l4_dst_port, ptr + 2, 2);
+		sf_copy(r, SFI_tcp_flags, ptr + 13, 1);
+	} else if (l4 == 17) {
+		if ((ptr + 8) >= end) return 3;
+		sf_copy(r, SFI_l4_src_port, ptr, 2);
+		sf_copy(r, SFI_l4_dst_port, ptr + 2, 2);
+	} else {
+		if ((ptr + 8) >= end) return 3;
+		sf_copy(r, SFI_icmp_type, ptr, 1);
+	}
+	return 4;
+}
+
+/* apply one element to the flow image; returns the parser state (4 for the
+ * IPv4 structure element, which is always delivered) */
+__device__ int
+sf_apply(const xe_kparams &kp, sf_rec &r, const xe_sfrec *q)
+{
+	r.src.p = kp.pkt + q->hdr_off;
+	r.src.left = q->dgram_left;
+	r.src.checked = true;
+	/* sflow-impl.h:164-171 / :224-234 */
+	for (int i = 0; i < 4; i++) r.b[c_sf_off[SFI_in_bytes] + 4 + i] = ((const uint8_t *)&q->frame_len_be)[i];
+	r.b[c_sf_off[SFI_in_pkts] + 7] = 1;
+	r.has |= (1u << SFI_in_bytes) | (1u << SFI_in_pkts);
+	if (q->kind == 1) return sf_rawparse(r, (int32_t)q->header_len, q->rp_type);
+
+	/* IPv4 structure, sflow-impl.h:236-260: seven 4-byte words */
+	r.b[c_sf_off[SFI_protocol]] = (uint8_t)pkt_byte(r.src, 3);
+	r.has |= 1u << SFI_protocol;
+	sf_copy(r, SFI_ip4_src, 4, 4);
+	sf_copy(r, SFI_ip4_dst, 8, 4);
+	sf_copy(r, SFI_l4_src_port, 14, 2);
+	sf_copy(r, SFI_l4_dst_port, 18, 2);
+	sf_copy(r, SFI_tcp_flags, 23, 1);
+	sf_copy(r, SFI_src_tos, 27, 1);
+	if (r.b[c_sf_off[SFI_protocol]] == 1) {
+		r.b[c_sf_off[SFI_icmp_type]] = (uint8_t)pkt_byte(r.src, 17);
+		r.has |= 1u << SFI_icmp_type;
+	}
+	return 4;
+}
+
+__device__ fval
+sf_get(const sf_rec &r, uint32_t f, uint32_t *size_out)
+{
+	fval out;
+	out.has = false;
+	out.v.hi = out.v.lo = 0;
+	(void)size_out;
+	if (f == XF_dev_id) {
+		const uint8_t *b = r.q->dev_id;
+		out.has = true;
+		out.v.lo = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3];
+		return out;
+	}
+	if ((f == XF_dev_ip) || (f == XF_dev_ip6)) {
+		bool v4 = r.q->agent_ver == 4;
+		if ((f == XF_dev_ip) != v4) return out;
+		out.has = true;
+		for (int i = 0; i < (v4 ? 4 : 16); i++) {
+			out.v.hi = (out.v.hi << 8) | (out.v.lo >> 56);
+			out.v.lo = (out.v.lo << 8) | r.q->agent[i];
+		}
+		return out;
+	}
+	if (f == XF_dev_mark) {
+		out.has = (r.mark & XE_MARK_HAS) != 0;
+		out.v.lo = r.mark & 0x3FFFFFFFu;
+		return out;
+	}
+	for (int i = 0; i < SF_NFIELDS; i++) {
+		if (c_sf_field[i] != f) continue;
+		out.has = ((r.has >> i) & 1) != 0;
+		/* the field's maximum-size bytes read as one big-endian number */
+		for (int k = c_sf_off[i]; k < c_sf_off[i + 1]; k++) {
+			out.v.hi = (out.v.hi << 8) | (out.v.lo >> 56);
+			out.v.lo = (out.v.lo << 8) | r.b[k];
+		}
+		return out;
+	}
+	return out;
+}
+
+__global__ void __launch_bounds__(XE_BLOCK)
+xe_sf_kernel(const xe_kparams kp)
+{
+	uint32_t g = blockIdx.x * XE_BLOCK + threadIdx.x;
+	bool active = g < kp.nsf;
+	uint32_t ridx = kp.nrec + g;
+	sf_rec rec;
+	unsigned long long bxr = 0, pxr = 0;
+	int32_t device = -1;
+	bool deliver = false;
+
+	rec.has = 0;
+	rec.mark = 0;
+	rec.q = kp.sfrecs;
+	if (active) {
+		/* elements of one sample share the flow: replay the earlier ones */
+		uint32_t first = g;
+		while ((first > 0) && kp.sfrecs[first].chained) first--;
+		for (int i = 0; i < 100; i++) rec.b[i] = 0;
+		rec.q = kp.sfrecs + g;
+		/* sf5_flow(), sflow-impl.h:106-143: interface indices */
+		for (int i = 0; i < 4; i++) {
+			rec.b[c_sf_off[SFI_input_snmp] + i] = ((const uint8_t *)&rec.q->in_if_be)[i];
+			rec.b[c_sf_off[SFI_output_snmp] + i] = ((const uint8_t *)&rec.q->out_if_be)[i];
+		}
+		rec.has |= (1u << SFI_input_snmp) | (1u << SFI_output_snmp);
+		int state = 4;
+		for (uint32_t k = first; k <= g; k++) state = sf_apply(kp, rec, kp.sfrecs + k);
+		deliver = state >= 2;   /* sflow.c:164-168 */
+		kp.nparsed[ridx] = (uint8_t)(state | (deliver ? 0 : XE_SF_SKIPPED));
+		kp.sf_has[g] = rec.has;
+		for (int i = 0; i < SF_NFIELDS; i++) {
+			if (!((rec.has >> i) & 1)) continue;
+			uint32_t f = c_sf_field[i], w = c_colw[f];
+			uint8_t *dst = kp.out_base + kp.col_off[f] + (size_t)ridx * w;
+			uint32_t n = c_sf_off[i + 1] - c_sf_off[i];
+			for (uint32_t k = 0; k < w; k++) dst[k] = (k < n) ? rec.b[c_sf_off[i] + k] : 0;
+		}
+		device = kp.exps[rec.q->exporter].device;
+		uint64_t rate = rec.q->sampling_rate;
+		bxr = sf_get(rec, XF_in_bytes, nullptr).v.lo * rate;
+		pxr = sf_get(rec, XF_in_pkts, nullptr).v.lo * rate;
+		if (!deliver && kp.marks) kp.marks[ridx] = 0;
+	}
+	classify<sf_rec, sf_get>(kp, rec, device, ridx, active && deliver, bxr, pxr);
+	if (active && !deliver) {
+		for (uint32_t w = 0; w < kp.mask_words; w++) kp.masks[(size_t)ridx * kp.mask_words + w] = 0;
+	}
+}
+
 /* ------------------------------------------------------------------ list probe */
 __global__ void
 xe_trie_probe_kernel(const uint32_t *trie, xe_list_dev L, int family, const uint8_t *addrs, uint32_t n, uint8_t *out)
@@ -1146,6 +1428,11 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream)
 	if (kp->nslowrec) {
 		uint32_t blocks = (kp->nslowrec + XE_BLOCK - 1) / XE_BLOCK;
 		hipLaunchKernelGGL(xe_nf_general_kernel, dim3(blocks), dim3(XE_BLOCK), 0, st, *kp);
+		if (hipGetLastError() != hipSuccess) return XE_EHIP;
+	}
+	if (kp->nsf) {
+		uint32_t blocks = (kp->nsf + XE_BLOCK - 1) / XE_BLOCK;
+		hipLaunchKernelGGL(xe_sf_kernel, dim3(blocks), dim3(XE_BLOCK), 0, st, *kp);
 		if (hipGetLastError() != hipSuccess) return XE_EHIP;
 	}
 	return XE_OK;
