@@ -246,8 +246,12 @@ static struct iplist *iplists = NULL;
 static size_t n_iplists = 0;
 
 /* iplist.c:52-158 (same walk for both families; addr = bytes as stored) */
+/* A mask longer than the address makes the reference walk past the address
+ * bytes (iplist.c:75) and put the leaf flag on a node deeper than any lookup
+ * goes (lookups stop after 32 / 128 bits, iplist.c:171,200): what lookups can
+ * see is the full-length path WITHOUT a leaf.  maxbits restates that. */
 static int
-trie_add(struct trie_node **nodes, size_t *n, const uint8_t *addr, int mask)
+trie_add(struct trie_node **nodes, size_t *n, const uint8_t *addr, int mask, int maxbits)
 {
 	int i;
 	uint32_t node = 0;
@@ -259,7 +263,7 @@ trie_add(struct trie_node **nodes, size_t *n, const uint8_t *addr, int mask)
 		}
 		*n = 1;
 	}
-	for (i = 0; i < mask; i++) {
+	for (i = 0; (i < mask) && (i < maxbits); i++) {
 		int bit = !!(addr[i / 8] & (1 << (7 - (i % 8))));
 		uint32_t next = (*nodes)[node].next[bit];
 		struct trie_node *tmp;
@@ -281,7 +285,9 @@ trie_add(struct trie_node **nodes, size_t *n, const uint8_t *addr, int mask)
 		node = (uint32_t)*n;
 		(*n)++;
 	}
-	(*nodes)[node].is_leaf = 1;
+	if (mask <= maxbits) {
+		(*nodes)[node].is_leaf = 1;
+	}
 	return 1;
 }
 
@@ -368,17 +374,9 @@ iplist_load_stream(FILE *f, const char *listname)
 			}
 		}
 		if (inet_pton(AF_INET, str_addr, a4)) {
-			/* the reference does not range-check the mask and would
-			 * read past the address; the oracle skips such lines */
-			if (mask > 32) {
-				continue;
-			}
-			trie_add(&l->nodes4, &l->n4, a4, mask);
+			trie_add(&l->nodes4, &l->n4, a4, mask, 32);
 		} else if (inet_pton(AF_INET6, str_addr, a6)) {
-			if (mask > 128) {
-				continue;
-			}
-			trie_add(&l->nodes6, &l->n6, a6, mask);
+			trie_add(&l->nodes6, &l->n6, a6, mask, 128);
 		}
 	}
 	n_iplists++;
@@ -1186,6 +1184,12 @@ factor(struct finput *f, struct fexpr *e)  /* filter-parser.c:158-189 */
 	if (rule(f, e)) {
 		/* ok */
 	} else if (accept_(f, TK_LPAREN)) {
+		if (f->end) {
+			/* '(' was the last token: it stays current, and the reference
+			 * recurses here until its stack runs out.  Reported instead. */
+			mkerror(f, "Unexpected end of input after '('");
+			return 0;
+		}
 		if (!expression(f, e)) return 0;
 		if (!accept_(f, TK_RPAREN)) {
 			mkerror(f, "Expected ')' after expression");

@@ -1,0 +1,136 @@
+"""ctypes view of the library's GPU-free host entry points (xe_hosttest.c):
+filter compiler, IP-list flattener, datagram pre-pass.  No flow results are
+computed on the CPU by the product; these only expose its host-side planning."""
+import ctypes as C
+
+import numpy as np
+
+import xenoeye_amd
+
+
+class ListDev(C.Structure):
+    _fields_ = [("root4", C.c_uint32), ("root6", C.c_uint32), ("nodes4", C.c_uint32), ("nodes6", C.c_uint32)]
+
+
+class Set(C.Structure):
+    _fields_ = [("data_off", C.c_uint64), ("first_rec", C.c_uint32), ("nrec", C.c_uint32), ("avail", C.c_int32),
+                ("stride", C.c_uint32), ("tmpl", C.c_uint32), ("dgram_left", C.c_int32),
+                ("exporter", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class Exporter(C.Structure):
+    _fields_ = [("dev_ip", C.c_uint8 * 4), ("dev_id", C.c_uint8 * 4), ("sampling_rate", C.c_uint32),
+                ("device", C.c_int32)]
+
+
+TERM = 0x80000000
+NODE_WORDS = 32
+
+
+class Host:
+    def __init__(self):
+        L = self.L = xenoeye_amd.load_library()
+        L.xe_ht_create.restype = C.c_void_p
+        L.xe_ht_free.argtypes = [C.c_void_p]
+        L.xe_ht_add_iplist.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]
+        L.xe_ht_load_iplists.argtypes = [C.c_void_p, C.c_char_p]
+        L.xe_ht_filter_dump.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
+        L.xe_ht_flatten.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_size_t),
+                                    C.POINTER(ListDev), C.c_size_t]
+        L.xe_ht_release.argtypes = [C.c_void_p]
+        L.xe_ht_nlists.argtypes = [C.c_void_p]
+        L.xe_ht_nlists.restype = C.c_size_t
+        L.xe_ht_add_device.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int]
+        L.xe_ht_prepass.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                    C.POINTER(C.c_int)]
+        L.xe_ht_prepass.restype = C.c_void_p
+        L.xe_ht_plan_free.argtypes = [C.c_void_p]
+        for f in ("nrec", "nsf", "nsets", "nexporters", "skipped"):
+            fn = getattr(L, "xe_ht_plan_" + f)
+            fn.argtypes = [C.c_void_p]
+            fn.restype = C.c_size_t
+        L.xe_ht_plan_sets.argtypes = [C.c_void_p]
+        L.xe_ht_plan_sets.restype = C.POINTER(Set)
+        L.xe_ht_plan_exporters.argtypes = [C.c_void_p]
+        L.xe_ht_plan_exporters.restype = C.POINTER(Exporter)
+        L.xe_ht_list_mos.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        L.xe_ht_list_devices.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        self.h = L.xe_ht_create()
+
+    def close(self):
+        if self.h:
+            self.L.xe_ht_free(self.h)
+            self.h = None
+
+    def add_iplist(self, name, text):
+        if isinstance(text, str):
+            text = text.encode()
+        assert self.L.xe_ht_add_iplist(self.h, name.encode(), text, len(text)) == 0
+
+    def load_iplists(self, d):
+        return self.L.xe_ht_load_iplists(self.h, d.encode())
+
+    def filter_dump(self, text):
+        """(rc, dump, err)"""
+        out = C.create_string_buffer(1 << 16)
+        err = C.create_string_buffer(1024)
+        rc = self.L.xe_ht_filter_dump(self.h, text.encode(), out, len(out), err, len(err))
+        return rc, out.value.decode(), err.value.decode(errors="replace")
+
+    def flatten(self):
+        n = self.L.xe_ht_nlists(self.h)
+        dev = (ListDev * max(n, 1))()
+        words = C.POINTER(C.c_uint32)()
+        nw = C.c_size_t()
+        assert self.L.xe_ht_flatten(self.h, C.byref(words), C.byref(nw), dev, n) == 0
+        arr = np.ctypeslib.as_array(words, shape=(max(nw.value, 1),)).copy() if nw.value else np.zeros(1, np.uint32)
+        self.L.xe_ht_release(words)
+        return arr, [(d.root4, d.root6, d.nodes4, d.nodes6) for d in dev[:n]]
+
+    def prepass(self, batch):
+        data, offs, src, kinds = batch.packed()
+        rc = C.c_int()
+        p = self.L.xe_ht_prepass(self.h, data.ctypes.data, offs.ctypes.data, src.ctypes.data, kinds.ctypes.data,
+                                 len(offs) - 1, C.byref(rc))
+        assert rc.value == 0 and p, "pre-pass failed: %d" % rc.value
+        L = self.L
+        ns = L.xe_ht_plan_nsets(p)
+        sets = [L.xe_ht_plan_sets(p)[i] for i in range(ns)]
+        out = dict(nrec=L.xe_ht_plan_nrec(p), nsf=L.xe_ht_plan_nsf(p), skipped=L.xe_ht_plan_skipped(p),
+                   sets=[dict(first_rec=s.first_rec, nrec=s.nrec, avail=s.avail, stride=s.stride, tmpl=s.tmpl,
+                              flags=s.flags, data_off=s.data_off, exporter=s.exporter) for s in sets],
+                   exporters=[dict(dev_ip=bytes(e.dev_ip), dev_id=bytes(e.dev_id), rate=e.sampling_rate,
+                                   device=e.device)
+                              for e in (L.xe_ht_plan_exporters(p)[i] for i in range(L.xe_ht_plan_nexporters(p)))])
+        L.xe_ht_plan_free(p)
+        return out
+
+    def list_mos(self, d):
+        out = C.create_string_buffer(1 << 18)
+        rc = self.L.xe_ht_list_mos(d.encode(), out, len(out))
+        rows = [ln.split("\t") for ln in out.value.decode().splitlines()]
+        return rc, [(r[0], int(r[1]), r[2]) for r in rows]
+
+    def list_devices(self, path):
+        out = C.create_string_buffer(1 << 16)
+        rc = self.L.xe_ht_list_devices(path.encode(), out, len(out))
+        return rc, [ln.split("\t") for ln in out.value.decode().splitlines()]
+
+
+def walk_flat(words, root, nodes, addr_bytes):
+    """Reference walker of the flattened list format (tests only): root table
+    over the first 16 bits, then one 16-byte group per 8-bit chunk."""
+    if not root:
+        return 0
+    e = int(words[root + ((addr_bytes[0] << 8) | addr_bytes[1])])
+    for b in addr_bytes[2:]:
+        if e & TERM:
+            return e & 1
+        g = nodes + e * NODE_WORDS + 4 * (b >> 5)
+        child, res, base = int(words[g]), int(words[g + 1]), int(words[g + 2])
+        bit = b & 31
+        if (child >> bit) & 1:
+            e = base + bin(child & ((1 << bit) - 1)).count("1")
+        else:
+            return (res >> bit) & 1
+    return (e & 1) if (e & TERM) else 0

@@ -1,0 +1,261 @@
+"""The CPU oracle against the reference's own translation units (compiled
+unmodified into oracle/_ref) and against recorded known answers."""
+import json
+import os
+import socket
+import struct
+import tempfile
+
+import numpy as np
+import pytest
+
+from oracle_binding import Oracle, RefIplist, RefSflow, RefUtils, have_ref, FLOW_INFO_SIZE
+from xenoeye_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KNOWN = json.load(open(os.path.join(HERE, "golden", "known_answers.json")))
+
+needs_ref_iplist = pytest.mark.skipif(not have_ref("libref_iplist.so"), reason="oracle/_ref not built")
+needs_ref_sflow = pytest.mark.skipif(not have_ref("libref_sflow.so"), reason="oracle/_ref not built")
+needs_ref_utils = pytest.mark.skipif(not have_ref("libref_utils.so"), reason="oracle/_ref not built")
+
+_uniq = [0]
+
+
+def _ref_lists(texts):
+    """load list texts into the reference's registry under fresh names"""
+    ref = RefIplist()
+    d = tempfile.mkdtemp(prefix="xe_lists_")
+    names = []
+    for t in texts:
+        _uniq[0] += 1
+        n = "l%d_%d" % (os.getpid(), _uniq[0])
+        with open(os.path.join(d, n), "wb") as f:
+            f.write(t if isinstance(t, bytes) else t.encode())
+        names.append(n)
+    assert ref.load_dir(d) == 1
+    return ref, names
+
+
+@needs_ref_iplist
+def test_iplist_loader_quirks_match_reference(orc):
+    texts = [
+        "10.0.0.0/8\n10.1.0.0/16\n",                        # nested: deepest node, not longest prefix
+        "192.168.0.0/16\n172.16.0.0/12",                    # last line without newline is dropped
+        "# comment\n\n  8.8.8.8  \n1.2.3.0/24 # trailing\n2001:db8::/32\nfe80::1\n::/0\n",   # v6 default /32
+        "0.0.0.0/0\n10.0.0.0/x\n300.1.1.1/8\n7.7.7.7/33\n1.1.1.1/0\n",
+        "",
+        "\n",
+        "9.9.9.9/32\n9.9.9.8/31\n9.9.9.0/24\n9.9.0.0/16\n9.0.0.0/8\n",
+    ]
+    ref, names = _ref_lists(texts)
+    rng = np.random.default_rng(7)
+    probes4 = [socket.inet_aton(a) for a in ("10.1.2.3", "10.128.0.1", "10.0.0.1", "10.2.0.1", "192.168.1.1",
+                                             "172.16.5.5", "8.8.8.8", "8.8.8.9", "1.2.3.77", "9.9.9.9", "9.9.9.8",
+                                             "9.9.9.1", "9.9.1.1", "9.1.1.1", "0.0.0.0", "255.255.255.255",
+                                             "1.1.1.1", "7.7.7.7")]
+    probes4 += [bytes(rng.integers(0, 256, 4, dtype=np.uint8)) for _ in range(300)]
+    probes6 = [socket.inet_pton(socket.AF_INET6, a) for a in ("2001:db8::1", "2001:db9::1", "fe80::1", "fe80::2",
+                                                                "::", "ffff::")]
+    probes6 += [bytes(rng.integers(0, 256, 16, dtype=np.uint8)) for _ in range(100)]
+    for t, n in zip(texts, names):
+        orc.iplist_add(n, t)
+        h = ref.get(n)
+        assert h, n
+        for a in probes4:
+            assert orc.match4(n, a) == ref.match4(h, a), (t, a)
+        for a in probes6:
+            assert orc.match6(n, a) == ref.match6(h, a), (t, a)
+
+
+@needs_ref_iplist
+def test_iplist_random_prefixes_match_reference(orc):
+    rng = synth.Rng(99)
+    v4 = synth.prefix_list_v4(rng, 3000, np.arange(0, 33), nested_frac=0.3)
+    v6 = synth.prefix_list_v6(rng, 1500, lo=1, hi=128)
+    text = synth.iplist_text(v4, v6)
+    ref, (name,) = _ref_lists([text])
+    orc.iplist_add(name, text)
+    h = ref.get(name)
+    a4 = np.concatenate([synth.addrs_in_prefixes_v4(rng, 3000, *v4), (rng.u64(3000) & np.uint64(0xFFFFFFFF)).astype(np.uint32)])
+    for x in a4.tolist():
+        b = struct.pack(">I", x)
+        assert orc.match4(name, b) == ref.match4(h, b)
+    a6 = np.concatenate([synth.addrs_in_prefixes_v6(rng, 1500, *v6), rng.bytes(1500 * 16).reshape(-1, 16)])
+    for row in a6:
+        b = bytes(row)
+        assert orc.match6(name, b) == ref.match6(h, b)
+
+
+def test_iplist_known_answers(orc):
+    for case in KNOWN["iplist"]:
+        orc.reset()
+        orc.iplist_add("l", case["text"])
+        for addr, want in case["v4"].items():
+            assert orc.match4("l", socket.inet_aton(addr)) == want, (case["text"], addr)
+        for addr, want in case.get("v6", {}).items():
+            assert orc.match6("l", socket.inet_pton(socket.AF_INET6, addr)) == want, (case["text"], addr)
+
+
+@needs_ref_utils
+def test_mac_addr_read_matches_reference(orc):
+    import ctypes as C
+    ref = RefUtils()
+    cases = ["00:11:22:33:44:55", "aa:BB:cc:DD:ee:ff", "zz:11:22:33:44:55", "00-11-22-33-44-55", "0:1:2:3:4:5",
+             "00:11:22:33:44:5", "00:11:22:33:44:555", "1234567890123456-", "12:45:78:01:34:67", "::::::::::::::::-",
+             "gg:hh:ii:jj:kk:ll", "10.0.0.0/8xxxxxxx:"]
+    for s in cases:
+        a = C.create_string_buffer(6)
+        b = C.create_string_buffer(6)
+        ra = ref.L.mac_addr_read(s.encode(), a)
+        rb = orc.L.xo_mac_addr_read(s.encode(), b)
+        assert ra == rb, s
+        if ra:
+            assert a.raw == b.raw, s
+
+
+def _flow_sets(flows, fields):
+    """per record: {field: (size, bytes)} of the fields that are set"""
+    out = []
+    for r in flows:
+        d = {}
+        for f in fields:
+            if int.from_bytes(r[f["off_has"]:f["off_has"] + 4].tobytes(), "little"):
+                d[f["name"]] = (int.from_bytes(r[f["off_size"]:f["off_size"] + 4].tobytes(), "little"),
+                                bytes(r[f["off"]:f["off"] + f["max"]]))
+        out.append(d)
+    return out
+
+
+@needs_ref_sflow
+def test_sflow_walk_matches_reference_on_synthetic_mix(orc):
+    ref = RefSflow()
+    w = synth.workload_c3(350)
+    orc.mo_add("")
+    orc.log_config(keep_flows=True)
+    total = 0
+    for pkt, src in zip(w["batch"].pkts, w["batch"].src):
+        n0 = orc.nrecords()
+        rc = orc.sflow(pkt, src)
+        rrc, recs = ref.process(pkt)
+        assert rc == rrc
+        mine = orc.flows()[n0:]
+        assert mine.shape == recs.shape
+        assert np.array_equal(mine, recs)
+        total += len(recs)
+    assert total > 300
+
+
+@needs_ref_sflow
+def test_sflow_walk_matches_reference_on_special_cases(orc):
+    ref = RefSflow()
+    rng = synth.Rng(5)
+    agent = bytes([10, 0, 0, 1])
+    pkts = []
+    for kind in ["ipip", "6in6", "4in6", "frag", "arp", "v6udp", "v4icmp", "v4tcp", "v6tcp", "v4udp"]:
+        for vm in (0, 1, 2):
+            for cutlen in (128, 96, 70, 58, 54, 40, 20, 14):
+                hdr = (synth.sflow_header_sample(rng, kind, vm) + rng.bytes(128).tobytes())[:128]
+                el = synth.sflow_raw_element(hdr, 777, header_len=cutlen)
+                els = [el, synth.sflow_ipv4_element(rng, proto=int(rng.below(1, 3)[0]) * 5 + 1), (1001, bytes(16))]
+                s1 = synth.sflow_flow_sample(1, 33, 0x40000005, 0x80000006, els, expanded=False)
+                s2 = synth.sflow_flow_sample(2, 34, 5, 6, [el], expanded=True)
+                pkts.append(synth.sflow_datagram(agent, 3, [s1, s2]))
+    pkts.append(synth.sflow_datagram(None, 3, [s1], agent6=bytes(range(1, 17))))
+    pkts.append(pkts[0][:100])
+    pkts.append(pkts[1][:37])
+    pkts.append(b"")
+    orc.mo_add("")
+    orc.log_config(keep_flows=True)
+    for pkt in pkts:
+        n0 = orc.nrecords()
+        rc = orc.sflow(pkt, agent)
+        rrc, recs = ref.process(pkt)
+        assert rc == rrc
+        assert np.array_equal(orc.flows()[n0:], recs)
+
+
+@needs_ref_sflow
+def test_sflow_walk_matches_reference_on_mutated_datagrams(orc):
+    """byte-level mutations of valid datagrams: lengths, tags and counts go
+    wrong in every way; both walkers must deliver the same records"""
+    ref = RefSflow()
+    w = synth.workload_c3(140)
+    rng = np.random.default_rng(11)
+    orc.mo_add("")
+    orc.log_config(keep_flows=True)
+    checked = 0
+    for pkt in w["batch"].pkts:
+        for _ in range(25):
+            b = bytearray(pkt)
+            for _ in range(int(rng.integers(1, 4))):
+                pos = int(rng.integers(0, min(len(b), 200)))
+                b[pos] = int(rng.integers(0, 256)) if rng.integers(0, 2) else (b[pos] ^ (1 << int(rng.integers(0, 8))))
+            if rng.integers(0, 4) == 0:
+                b = b[:int(rng.integers(0, len(b)))]
+            n0 = orc.nrecords()
+            rc = orc.sflow(bytes(b), b"\0\0\0\0")
+            rrc, recs = ref.process(bytes(b))
+            assert rc == rrc
+            assert np.array_equal(orc.flows()[n0:], recs)
+            checked += 1
+        orc.log_clear()
+    assert checked == 500
+
+
+def test_filter_dump_known_answers(orc):
+    orc.iplist_add("mynet", "10.0.0.0/8\n")
+    for case in KNOWN["filter_dump"]:
+        h = orc.filter_parse(case["filter"])
+        assert orc.filter_dump(h) == case["dump"], case["filter"]
+
+
+def test_filter_parse_errors(orc):
+    for text in KNOWN["filter_errors"]:
+        with pytest.raises(ValueError):
+            orc.filter_parse(text)
+
+
+def test_v9_decode_known_answers(orc):
+    """the record counts and field presence the reference showed on these
+    datagrams (template = 7 fields / 21 bytes)"""
+    exp = bytes([192, 0, 2, 1])
+    fields = orc.fields()
+    for case in KNOWN["v9_decode"]:
+        orc.reset()
+        orc.mo_add("")
+        orc.log_config(keep_flows=True)
+        orc.netflow(synth.v9_template_packet(256, synth.TMPL_V9_C1, 77), exp)
+        body = bytes.fromhex(case["body_hex"])
+        assert orc.netflow(synth.v9_header(case["count"], 77) + body, exp) == 1
+        sets = _flow_sets(orc.flows(), fields)
+        assert len(sets) == case["records"], case["name"]
+        for i, want in enumerate(case["present"]):
+            got = sorted(k for k in sets[i] if k not in ("dev_ip", "dev_id"))
+            assert got == sorted(want), (case["name"], i)
+        for i, vals in case.get("values", {}).items():
+            for k, hexv in vals.items():
+                assert sets[int(i)][k][1].hex() == hexv, (case["name"], i, k)
+
+
+def test_struct_layout_known_offsets(orc):
+    off = {f["name"]: f["off"] for f in orc.fields()}
+    for name, want in KNOWN["flow_info_offsets"].items():
+        if name in off:
+            assert off[name] == want, name
+    assert orc.L.xo_off_sampling_rate() == KNOWN["flow_info_offsets"]["sampling_rate"]
+    assert orc.L.xo_off_payload_ptr() == KNOWN["flow_info_offsets"]["payload_ptr"]
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/netflow.def"), reason="reference checkout absent")
+def test_field_table_matches_reference_definition(orc):
+    import re
+    want = []
+    for line in open("/root/reference/netflow.def"):
+        m = re.match(r'FIELD\((\w+),\s*"[^"]*",\s*NF_FIELD_(\w+),\s*(\d+),\s*(\d+),\s*(\w+)\)', line)
+        if m:
+            mx = 32 if m.group(5) == "CLASS_NAME_MAX" else int(m.group(5))
+            want.append((m.group(1), {"IP_ADDR": 0, "INT": 1, "MAC": 2, "STRING": 3}[m.group(2)], int(m.group(3)),
+                         int(m.group(4)), mx))
+    got = [(f["name"], f["type"], f["id"], f["min"], f["max"]) for f in orc.fields()[:63]]
+    assert got == want

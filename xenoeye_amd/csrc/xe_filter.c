@@ -116,6 +116,7 @@ struct pctx
 	const struct xe_iplists *reg;
 	struct xe_blob ops, terms, opnds, notes;
 	int device_ok;
+	int other_func;      /* a function this library does not compile was met */
 	char why[128];
 };
 
@@ -560,7 +561,8 @@ parse_rule(struct pctx *p)
 {
 	if (func_rule(p)) return 1;
 	if (p->lx.t == T_OTHERFUNC) {
-		fail(&p->lx, "mfreq/tfstr/portstr/ppstr/geoip/asn/asd terms are not supported by this build");
+		p->other_func = 1;
+		fail(&p->lx, "function is not compiled");
 		return 0;
 	}
 	if (plain_rule(p, XE_DIR_BOTH)) return 1;
@@ -577,6 +579,12 @@ parse_factor(struct pctx *p)
 	if (parse_rule(p)) {
 		/* done */
 	} else if (take(p, T_LP)) {
+		if (p->lx.at_end) {
+			/* '(' was the last token and stays current: the reference
+			 * recurses without bound here; this is an error instead */
+			fail(&p->lx, "Unexpected end of input after '('");
+			return 0;
+		}
 		if (!parse_expr(p)) return 0;
 		if (!take(p, T_RP)) {
 			fail(&p->lx, "Expected ')' after expression");
@@ -650,8 +658,15 @@ xe_filter_compile(const struct xe_iplists *reg, const char *text, struct xe_filt
 	out->device_ok = p.device_ok;
 	memcpy(out->why, p.why, sizeof(out->why));
 	if (p.lx.failed) {
-		if (err && errlen) snprintf(err, errlen, "%s", p.lx.msg);
 		xe_filter_free(out);
+		if (p.other_func) {
+			/* valid in the reference (filter-parser-funcs.c:285-560), but
+			 * these need its geoip / string tables */
+			if (err && errlen) snprintf(err, errlen, "mfreq/tfstr/portstr/ppstr/geoip/asn/asd "
+				"functions are not supported by this library");
+			return XE_EUNSUPPORTED;
+		}
+		if (err && errlen) snprintf(err, errlen, "%s", p.lx.msg);
 		return XE_EPARSE;
 	}
 	return XE_OK;

@@ -41,7 +41,7 @@ xe_blob_push(struct xe_blob *b, const void *item, size_t sz)
 
 /* insert a prefix: iplist.c:52-158 */
 static int
-bt_add(struct xe_bnode **nodes, size_t *cnt, size_t *cap, const uint8_t *addr, int plen)
+bt_add(struct xe_bnode **nodes, size_t *cnt, size_t *cap, const uint8_t *addr, int plen, int maxbits)
 {
 	uint32_t cur = 0;
 	int i;
@@ -52,7 +52,7 @@ bt_add(struct xe_bnode **nodes, size_t *cnt, size_t *cap, const uint8_t *addr, i
 		if (!*nodes) return 0;
 		*cnt = 1;
 	}
-	for (i = 0; i < plen; i++) {
+	for (i = 0; (i < plen) && (i < maxbits); i++) {
 		int b = (addr[i >> 3] >> (7 - (i & 7))) & 1;
 		uint32_t nx = (*nodes)[cur].next[b];
 		if (!nx) {
@@ -68,7 +68,9 @@ bt_add(struct xe_bnode **nodes, size_t *cnt, size_t *cap, const uint8_t *addr, i
 		}
 		cur = nx;
 	}
-	(*nodes)[cur].is_leaf = 1;
+	/* a length beyond the address width puts the reference's leaf flag below
+	 * the depth any lookup reaches: the path exists, the leaf is invisible */
+	if (plen <= maxbits) (*nodes)[cur].is_leaf = 1;
 	return 1;
 }
 
@@ -116,13 +118,9 @@ load_stream(struct xe_iplists *reg, FILE *f, const char *name)
 			if (*end) continue;
 		}
 		if (inet_pton(AF_INET, txt, a) == 1) {
-			/* lengths past the address width make the reference read
-			 * beyond the address; such lines are rejected here */
-			if (plen > 32) continue;
-			if (!bt_add(&l->n4, &l->c4, &l->cap4, a, plen)) return XE_ENOMEM;
+			if (!bt_add(&l->n4, &l->c4, &l->cap4, a, plen, 32)) return XE_ENOMEM;
 		} else if (inet_pton(AF_INET6, txt, a) == 1) {
-			if (plen > 128) continue;
-			if (!bt_add(&l->n6, &l->c6, &l->cap6, a, plen)) return XE_ENOMEM;
+			if (!bt_add(&l->n6, &l->c6, &l->cap6, a, plen, 128)) return XE_ENOMEM;
 		}
 	}
 	reg->n++;
