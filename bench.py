@@ -35,7 +35,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--records", type=int, default=1 << 22, help="records per GPU per step")
     ap.add_argument("--workload", default="c2", choices=["c1", "c2"])
-    ap.add_argument("--cpu-sample", type=int, default=2000000, help="records timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=12000000, help="records timed on the CPU oracle (0 = skip)")
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch from a rocprofv3 --pmc pass (reported as roofline.traffic)")
     return ap.parse_args()
@@ -51,7 +51,8 @@ def build_workload(name, nrec, rank):
 
 
 def cpu_baseline(w, sample):
-    """Time the oracle on the first datagrams that hold about `sample` records."""
+    """Time the oracle on about `sample` records: whole passes over the batch's
+    datagrams (templates stay learnt between passes, as on a live collector)."""
     from oracle_binding import Oracle
     orc = Oracle()
     for name, text in w["iplists"].items():
@@ -59,17 +60,36 @@ def cpu_baseline(w, sample):
     for filt, parent in w["mos"]:
         orc.mo_add(filt, parent)
     orc.log_config(keep_flows=False)
-    pkts, srcs = w["batch"].pkts, w["batch"].src
+    pkts, srcs = w["batch"].pkts, [int.from_bytes(s, "little") for s in w["batch"].src]
     per_dgram = max(1.0, w["nrec"] / max(1, len(pkts)))
-    nd = min(len(pkts), int(sample / per_dgram) + 1)
+    todo = int(sample / per_dgram) + 1
     L = orc.L
+    nd = 0
+    nrec = 0
     t0 = time.perf_counter()
-    for p, s in zip(pkts[:nd], srcs[:nd]):
-        L.xo_netflow_process(p, len(p), int.from_bytes(s, "little"))
+    while nd < todo:
+        k = min(len(pkts), todo - nd)
+        for p, s in zip(pkts[:k], srcs[:k]):
+            L.xo_netflow_process(p, len(p), s)
+        nd += k
+        nrec += orc.nrecords()
+        L.xo_log_clear()
     dt = time.perf_counter() - t0
-    nrec = orc.nrecords()
     orc.reset()
     return nrec / dt, nrec, nd, dt
+
+
+def measured_traffic(workload, nrec):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3
+    --pmc passes (profiles/traffic.json), when they were taken at this size"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f).get(workload)
+        if t and int(t["records"]) == int(nrec):
+            return float(t["bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def main():
@@ -102,6 +122,7 @@ def main():
     t_prep = time.perf_counter() - t_prep0
     nrec = batch.records
     stream = torch.cuda.current_stream().cuda_stream
+    batch.timing(True)     # HIP events on the launch stream around each kernel
 
     def barrier():
         if world > 1:
@@ -119,7 +140,14 @@ def main():
         b.record()
     barrier()
     dt = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    step_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    # the dominant kernel alone: separate untimed-for-throughput launches, one sync each
+    kms = []
+    for _ in range(min(args.steps, 10)):
+        batch.run(stream)
+        kms.append(batch.kernel_ms())
+    kms = np.array(kms, dtype=np.float64)
+    kernel_ms = float(kms[:, 0].mean())
 
     # end-to-end including host pre-pass + H2D + D2H of masks and counters (one pass, reported only)
     t1 = time.perf_counter()
@@ -131,18 +159,13 @@ def main():
     b2.free()
     del m
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    tot = torch.tensor([float(nrec)], dtype=torch.float64, device="cuda")
-    pay = torch.tensor([float(batch.payload_bytes)], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dist.all_reduce(pay, op=dist.ReduceOp.SUM)
-        # per-object counters are merged across shards by plain u64 addition
-        ctr = torch.from_numpy(c.astype(np.int64)).cuda()
-        dist.all_reduce(ctr, op=dist.ReduceOp.SUM)
-    dt_all = float(tmax.item())
-    value = float(tot.item()) * args.steps / dt_all
+    from xenoeye_amd import shard
+    dev = torch.device("cuda", local_rank)
+    dt_all, tot, pay = shard.reduce_scalars([dt, nrec, batch.payload_bytes], ["max", "sum", "sum"],
+                                            dist if world > 1 else None, dev)
+    # per-object counters of the shards merge by wrapping u64 addition
+    ctr = shard.merge_counters(c, dist if world > 1 else None, dev)
+    value = tot * args.steps / dt_all
 
     if rank == 0:
         alg = batch.algorithmic_bytes
@@ -163,10 +186,11 @@ def main():
             "config": {"workload": wl_name, "records_per_gpu_per_step": nrec,
                        "datagrams_per_gpu": len(w["batch"]), "objects": len(w["mos"]),
                        "sharding": "exporters per rank, no data-path collective"},
-            "payload_GBps": float(pay.item()) * args.steps / dt_all / 1e9,
+            "payload_GBps": pay * args.steps / dt_all / 1e9,
+            "merged_counters_object0": [int(x) for x in ctr[0]] if len(ctr) else [],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": args.traffic,
-                         "kernel": "xe_nf_kernel", "kernel_ms": kernel_ms,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": args.traffic if args.traffic is not None else measured_traffic(args.workload, nrec),
+                         "kernel": "xe_nf_fast_kernel", "kernel_ms": kernel_ms, "step_ms_events": step_ms,
                          "algorithmic_bytes_per_launch": alg,
                          "algorithmic_bytes_per_record": alg / max(nrec, 1)},
             "host_inclusive": {"prepare_s": t_prep, "prepare_run_fetch_s": t_e2e,
@@ -175,7 +199,7 @@ def main():
         if args.cpu_sample > 0:
             rps, n_cpu, nd, secs = cpu_baseline(w, args.cpu_sample)
             out["cpu_baseline"] = {"value": rps, "unit": "records/s", "cores": 1, "kind": "port",
-                                   "sample": "first %d datagrams (%d records) of the same batch, %.1f s, "
+                                   "sample": "%d datagrams (%d records) of the same batch, %.1f s, "
                                              "oracle/xe_oracle.c single thread" % (nd, n_cpu, secs)}
         print(json.dumps(out), flush=True)
     if world > 1:

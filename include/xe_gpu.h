@@ -113,6 +113,14 @@ int xe_gpu_batch_run(xe_batch *b, void *stream);
 /* blocks until the batch's last run has finished */
 int xe_gpu_batch_sync(xe_batch *b);
 
+/* instrumentation (no counterpart in the reference): with timing enabled every
+ * run records HIP events on its stream around each kernel launch;
+ * xe_gpu_batch_kernel_ms() then gives the last run's duration of the
+ * template-grouped Netflow kernel, the general Netflow kernel and the sFlow
+ * kernel in milliseconds (-1 for a kernel the batch does not need) */
+int xe_gpu_batch_timing(xe_batch *b, int enable);
+int xe_gpu_batch_kernel_ms(xe_batch *b, float ms[3]);
+
 /* sizes */
 size_t xe_gpu_batch_records(const xe_batch *b);      /* records reaching classification */
 size_t xe_gpu_batch_mask_words(const xe_batch *b);   /* 64-bit words per record */

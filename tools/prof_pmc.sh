@@ -16,6 +16,8 @@ run waits SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ
 run fetch TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum || exit 1
 run write TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum || exit 1
 run l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum || exit 1
+run fetchsize FETCH_SIZE || exit 1
+run writesize WRITE_SIZE || exit 1
 python3 - "$out" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
@@ -28,5 +30,5 @@ for d in sorted(glob.glob(out + "/*/")):
             k = (row["Kernel_Name"].split("(")[0], row["Counter_Name"])
             acc[k][0] += float(row["Counter_Value"]); acc[k][1] += 1
         for (kn, cn), (v, n) in sorted(acc.items()):
-            print("%-24s %-28s per-launch %.4g (n=%d)" % (kn, cn, v / n, n))
+            print("%-24s %-28s per-launch %.6g (n=%d)" % (kn, cn, v / n, n))
 PY

@@ -56,6 +56,8 @@ def load_library(path=LIB_PATH):
         "xe_gpu_batch_free": (None, [vp]),
         "xe_gpu_batch_run": (i32, [vp, vp]),
         "xe_gpu_batch_sync": (i32, [vp]),
+        "xe_gpu_batch_timing": (i32, [vp, i32]),
+        "xe_gpu_batch_kernel_ms": (i32, [vp, C.POINTER(C.c_float)]),
         "xe_gpu_batch_records": (sz, [vp]),
         "xe_gpu_batch_mask_words": (sz, [vp]),
         "xe_gpu_batch_payload_bytes": (sz, [vp]),
@@ -220,6 +222,15 @@ class PreparedBatch:
 
     def sync(self):
         self.eng._chk(self.L.xe_gpu_batch_sync(self._b))
+
+    def timing(self, enable=True):
+        self.eng._chk(self.L.xe_gpu_batch_timing(self._b, int(enable)))
+
+    def kernel_ms(self):
+        """(fast netflow, general netflow, sflow) kernel time of the last run, -1 = not launched"""
+        ms = (C.c_float * 3)()
+        self.eng._chk(self.L.xe_gpu_batch_kernel_ms(self._b, ms))
+        return tuple(ms)
 
     def masks(self):
         out = np.zeros((self.records, self.mask_words), dtype=np.uint64)

@@ -44,6 +44,8 @@ struct xe_batch
 	struct xe_kparams kp;
 	hipStream_t last_stream;
 	int ran;
+	int timing;              /* record events around each kernel launch */
+	hipEvent_t ev[6];
 };
 
 #define ALIGN_UP(x, a) (((x) + (a) - 1) / (a) * (a))
@@ -641,6 +643,7 @@ xe_gpu_batch_free(xe_batch *b)
 	if (b->d_exps) (void)hipFree(b->d_exps);
 	if (b->d_sfrecs) (void)hipFree(b->d_sfrecs);
 	if (b->d_out) (void)hipFree(b->d_out);
+	for (int i = 0; i < 6; i++) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
 	{
 		void *extra[] = { b->d_fsets, b->d_fwstart, b->d_tile_first, b->d_tile_tmpl, b->d_ssets, b->d_swstart,
 			b->d_tentx };
@@ -931,7 +934,7 @@ xe_gpu_batch_run(xe_batch *b, void *stream)
 	/* templates learnt by later batches may have moved the device tables */
 	b->kp.tmpls = (const struct xe_tmpl *)b->h->d_tmpls;
 	b->kp.tents = (const struct xe_tent *)b->h->d_tents;
-	rc = xe_launch_batch(&b->kp, stream);
+	rc = xe_launch_batch(&b->kp, stream, b->timing ? (void **)b->ev : NULL);
 	if (rc != XE_OK) {
 		snprintf(b->h->err, sizeof(b->h->err), "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
 		return rc;
@@ -947,6 +950,34 @@ xe_gpu_batch_sync(xe_batch *b)
 	if (!b) return XE_EINVAL;
 	if (!b->ran) return XE_ESTATE;
 	HIPCHK(b->h, hipStreamSynchronize(b->last_stream));
+	return XE_OK;
+}
+
+extern "C" int
+xe_gpu_batch_timing(xe_batch *b, int enable)
+{
+	if (!b) return XE_EINVAL;
+	if (enable && !b->ev[0]) {
+		for (int i = 0; i < 6; i++) HIPCHK(b->h, hipEventCreate(&b->ev[i]));
+	}
+	b->timing = enable ? 1 : 0;
+	return XE_OK;
+}
+
+extern "C" int
+xe_gpu_batch_kernel_ms(xe_batch *b, float ms[3])
+{
+	int rc;
+	const uint32_t launched[3] = { b ? b->kp.ntiles : 0, b ? b->kp.nslowrec : 0, b ? b->kp.nsf : 0 };
+
+	if (!b || !ms) return XE_EINVAL;
+	if (!b->timing) return XE_ESTATE;
+	rc = xe_gpu_batch_sync(b);
+	if (rc != XE_OK) return rc;
+	for (int k = 0; k < 3; k++) {
+		ms[k] = -1.0f;
+		if (launched[k]) HIPCHK(b->h, hipEventElapsedTime(&ms[k], b->ev[2 * k], b->ev[2 * k + 1]));
+	}
 	return XE_OK;
 }
 

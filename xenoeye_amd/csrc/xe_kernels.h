@@ -95,7 +95,9 @@ struct xe_kparams
 extern "C" {
 #endif
 /* enqueue decode+classify of the whole batch on `stream` (hipStream_t) */
-int xe_launch_batch(const struct xe_kparams *kp, void *stream);
+/* events: NULL, or 6 hipEvent_t = start/stop pairs recorded on `stream` around
+ * the fast, general and sFlow kernel launches (only around those that run) */
+int xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events);
 /* n addresses (4 or 16 bytes each) against one flattened list */
 int xe_launch_trie_probe(const uint32_t *trie, struct xe_list_dev list, int family,
 	const uint8_t *addrs, uint32_t n, uint8_t *out, void *stream);

@@ -1396,9 +1396,10 @@ xe_launch_init_tables(void)
 }
 
 extern "C" int
-xe_launch_batch(const struct xe_kparams *kp, void *stream)
+xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 {
 	hipStream_t st = (hipStream_t)stream;
+	hipEvent_t *ev = (hipEvent_t *)events;   /* NULL or 3 start/stop pairs */
 	struct xe_kparams kcopy;
 
 	if (!g_tables_ready) return XE_ESTATE;
@@ -1422,17 +1423,23 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream)
 		size_t shmem = (size_t)(kp->nslots + kp->nslots_hi) * XE_BLOCK * 8
 			+ (kp->lds_counters ? (size_t)kp->nmo * 24 : 0);
 		if (blocks > 4096) blocks = 4096;
+		if (ev) (void)hipEventRecord(ev[0], st);
 		hipLaunchKernelGGL(xe_nf_fast_kernel, dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
+		if (ev) (void)hipEventRecord(ev[1], st);
 		if (hipGetLastError() != hipSuccess) return XE_EHIP;
 	}
 	if (kp->nslowrec) {
 		uint32_t blocks = (kp->nslowrec + XE_BLOCK - 1) / XE_BLOCK;
+		if (ev) (void)hipEventRecord(ev[2], st);
 		hipLaunchKernelGGL(xe_nf_general_kernel, dim3(blocks), dim3(XE_BLOCK), 0, st, *kp);
+		if (ev) (void)hipEventRecord(ev[3], st);
 		if (hipGetLastError() != hipSuccess) return XE_EHIP;
 	}
 	if (kp->nsf) {
 		uint32_t blocks = (kp->nsf + XE_BLOCK - 1) / XE_BLOCK;
+		if (ev) (void)hipEventRecord(ev[4], st);
 		hipLaunchKernelGGL(xe_sf_kernel, dim3(blocks), dim3(XE_BLOCK), 0, st, *kp);
+		if (ev) (void)hipEventRecord(ev[5], st);
 		if (hipGetLastError() != hipSuccess) return XE_EHIP;
 	}
 	return XE_OK;
