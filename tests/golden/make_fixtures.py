@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Writes the golden fixtures of this directory.  Run in the build container
+(the reference checkout must be present and oracle/_ref built):
+
+    python tests/golden/make_fixtures.py
+
+sflow_reference.npz   sFlow datagrams and the struct flow_info records the
+                      REFERENCE's own walker (sflow-impl.h + rawparse.h,
+                      compiled unmodified into oracle/_ref/libref_sflow.so)
+                      delivered for them.
+iplist_reference.npz  list files, probe addresses and the answers of the
+                      REFERENCE's iplist.c (oracle/_ref/libref_iplist.so).
+netflow_oracle.npz    Netflow v9 / IPFIX / v5 datagrams with the records, match
+                      masks and counters of the CPU oracle.  The reference's
+                      netflow.c cannot be built in this image (it needs the
+                      absent pcap, tkvdb and aajson headers), so these are
+                      regression pins of the restatement, not reference output.
+
+Fixtures are data only: inputs and expected outputs.
+"""
+import os
+import struct
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle_binding import Oracle, RefIplist, RefSflow, have_ref  # noqa: E402
+from xenoeye_amd import synth  # noqa: E402
+from helpers import configure, run_oracle  # noqa: E402
+
+
+def pack(pkts):
+    offs = np.zeros(len(pkts) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(p) for p in pkts])
+    return np.frombuffer(b"".join(pkts), dtype=np.uint8).copy(), offs
+
+
+def sflow_cases():
+    rng = synth.Rng(0x601D)
+    agent = bytes([10, 0, 0, 1])
+    pkts = list(synth.workload_c3(210, seed=0x601D0003)["batch"].pkts)
+    for kind in ["ipip", "6in6", "4in6", "frag", "arp", "v6udp", "v4icmp", "v4tcp", "v6tcp", "v4udp"]:
+        for vm in (0, 1, 2):
+            for cutlen in (128, 58, 54, 34, 14):
+                hdr = (synth.sflow_header_sample(rng, kind, vm) + rng.bytes(128).tobytes())[:128]
+                el = synth.sflow_raw_element(hdr, 777, header_len=cutlen)
+                els = [el, synth.sflow_ipv4_element(rng, proto=6), (1001, bytes(16))]
+                s1 = synth.sflow_flow_sample(1, 33, 0x40000005, 0x80000006, els, expanded=False)
+                s2 = synth.sflow_flow_sample(2, 34, 5, 6, [el], expanded=True)
+                pkts.append(synth.sflow_datagram(agent, 3, [s1, s2]))
+    pkts.append(synth.sflow_datagram(None, 3, [s1], agent6=bytes(range(1, 17))))
+    pkts.append(pkts[0][:100])
+    pkts.append(pkts[1][:37])
+    return pkts
+
+
+def make_sflow():
+    ref = RefSflow()
+    pkts = sflow_cases()
+    recs, counts, rcs = [], [], []
+    for p in pkts:
+        rc, r = ref.process(p)
+        rcs.append(rc)
+        counts.append(len(r))
+        recs.append(r)
+    flows = np.concatenate(recs, axis=0)
+    data, offs = pack(pkts)
+    np.savez_compressed(os.path.join(HERE, "sflow_reference.npz"), data=data, offsets=offs,
+                        counts=np.array(counts, dtype=np.int32), rcs=np.array(rcs, dtype=np.int32), flows=flows)
+    print("sflow_reference: %d datagrams, %d records" % (len(pkts), len(flows)))
+
+
+def make_iplist():
+    ref = RefIplist()
+    rng = synth.Rng(0x601D1)
+    v4 = synth.prefix_list_v4(rng, 1500, np.arange(0, 33), nested_frac=0.3)
+    v6 = synth.prefix_list_v6(rng, 700, lo=1, hi=128)
+    texts = [
+        "10.0.0.0/8\n10.1.0.0/16\n",
+        "192.168.0.0/16\n172.16.0.0/12",
+        "# comment\n\n  8.8.8.8  \n1.2.3.0/24 # trailing\n2001:db8::/32\nfe80::1\n::/0\n",
+        "0.0.0.0/0\n10.0.0.0/x\n300.1.1.1/8\n7.7.7.7/33\n1.1.1.1/0\n2001:db8::/200\n",
+        "\n",
+        "9.9.9.9/32\n9.9.9.8/31\n9.9.9.0/24\n9.9.0.0/16\n9.0.0.0/8\n",
+        synth.iplist_text(v4, v6),
+    ]
+    d = tempfile.mkdtemp(prefix="xe_fix_")
+    names = ["fx%d_%d" % (os.getpid(), i) for i in range(len(texts))]
+    for n, t in zip(names, texts):
+        with open(os.path.join(d, n), "w") as f:
+            f.write(t)
+    assert ref.load_dir(d) == 1
+    p4 = [bytes(x) for x in ([10, 1, 2, 3], [10, 128, 0, 1], [10, 0, 0, 1], [10, 2, 0, 1], [192, 168, 1, 1], [172, 16, 5, 5],
+                             [8, 8, 8, 8], [8, 8, 8, 9], [1, 2, 3, 77], [9, 9, 9, 9], [9, 9, 9, 8], [9, 9, 9, 1], [9, 9, 1, 1],
+                             [9, 1, 1, 1], [0, 0, 0, 0], [255, 255, 255, 255], [1, 1, 1, 1], [7, 7, 7, 7], [7, 7, 7, 6])]
+    p4 += [struct.pack(">I", int(x)) for x in synth.addrs_in_prefixes_v4(rng, 1200, *v4)]
+    p4 += [struct.pack(">I", int(x)) for x in (rng.u64(800) & np.uint64(0xFFFFFFFF))]
+    p6 = [bytes(16), bytes([255] * 16), bytes.fromhex("20010db8000000000000000000000001"),
+          bytes.fromhex("20010db9000000000000000000000001"), bytes.fromhex("fe800000000000000000000000000001"),
+          bytes.fromhex("fe800000000000000000000000000002")]
+    p6 += [bytes(r) for r in synth.addrs_in_prefixes_v6(rng, 600, *v6)]
+    p6 += [bytes(r) for r in rng.bytes(400 * 16).reshape(-1, 16)]
+    want4 = np.zeros((len(texts), len(p4)), dtype=np.uint8)
+    want6 = np.zeros((len(texts), len(p6)), dtype=np.uint8)
+    for i, n in enumerate(names):
+        h = ref.get(n)
+        assert h
+        want4[i] = [ref.match4(h, a) for a in p4]
+        want6[i] = [ref.match6(h, a) for a in p6]
+    np.savez_compressed(os.path.join(HERE, "iplist_reference.npz"),
+                        texts=np.array([t.encode() for t in texts], dtype=object).astype("S"),
+                        probes4=np.frombuffer(b"".join(p4), dtype=np.uint8).reshape(-1, 4),
+                        probes6=np.frombuffer(b"".join(p6), dtype=np.uint8).reshape(-1, 16),
+                        want4=want4, want6=want6)
+    print("iplist_reference: %d lists, %d + %d probes, %d + %d hits" %
+          (len(texts), len(p4), len(p6), int(want4.sum()), int(want6.sum())))
+
+
+def netflow_cases():
+    """(name, iplists, mos, devices, batch)"""
+    EXP = bytes([192, 0, 2, 1])
+    t = synth.TMPL_V9_C1
+    rng = synth.Rng(0x601D2)
+    out = []
+    w = synth.workload_c1(640)
+    out.append(("c1", w["iplists"], w["mos"], [], w["batch"]))
+    w = synth.workload_c2(600, prefixes=300)
+    out.append(("c2", w["iplists"], w["mos"], [], w["batch"]))
+    rec = synth.flow_columns(rng, 4, t)
+    # datagram-wide count beyond the records of the set; trailing bytes; a second set
+    b = synth.Batch()
+    b.add(synth.v9_template_packet(256, t, 77), EXP)
+    b.add(synth.v9_header(4, 77) + struct.pack(">HH", 256, 4 + 42) + rec[:2].tobytes(), EXP)
+    b.add(synth.v9_header(2, 77) + struct.pack(">HH", 256, 4 + 21) + rec[:1].tobytes() + bytes([192, 168, 1, 1]), EXP)
+    b.add(synth.v9_header(1, 77) + struct.pack(">HH", 256, 4 + 21) + rec[2:3].tobytes()
+          + struct.pack(">HH", 256, 4 + 21) + rec[3:4].tobytes(), EXP)
+    t3 = [(8, 4), (7, 2), (4, 1)]
+    r3 = synth.flow_columns(rng, 2, t3)
+    b.add(synth.ipfix_template_packet(300, t3, 9), EXP)
+    body = struct.pack(">HH", 300, 4 + 14 + 1) + r3.tobytes() + b"\0"
+    b.add(synth.ipfix_header(16 + len(body), 9) + body, EXP)
+    b.add(synth.v5_packet(rng, 7), EXP)
+    mos = [("", -1), ("src net 192.168.0.0/16", -1), ("not proto 6", -1), ("proto 6 or 17", -1), ("dst port 0-1023", 3)]
+    out.append(("edges", {}, mos, [dict(ip="192.0.2.1", sampling_rate=100)], b))
+    return out
+
+
+def make_netflow():
+    arrays = {}
+    names = []
+    for name, iplists, mos, devices, batch in netflow_cases():
+        orc = Oracle()
+        configure(None, orc, iplists, mos, devices)
+        run_oracle(orc, batch, keep_flows=True)
+        data, offs, src, kinds = batch.packed()
+        arrays[name + "_data"] = data
+        arrays[name + "_offsets"] = offs
+        arrays[name + "_src"] = src
+        arrays[name + "_masks"] = orc.masks().copy()
+        arrays[name + "_flows"] = orc.flows().copy()
+        arrays[name + "_counters"] = orc.counters().copy()
+        arrays[name + "_dropped"] = orc.dropped().copy()
+        arrays[name + "_mos"] = np.array([("%d\t%s" % (p, f)).encode() for f, p in mos]).astype("S")
+        arrays[name + "_lists"] = np.array([(n + "\t" + t).encode() for n, t in iplists.items()] or [b""]).astype("S")
+        arrays[name + "_devices"] = np.array([repr(d).encode() for d in devices] or [b""]).astype("S")
+        names.append(name)
+        print("netflow_oracle/%s: %d datagrams, %d records" % (name, len(offs) - 1, orc.nrecords()))
+        orc.reset()
+    arrays["cases"] = np.array([n.encode() for n in names]).astype("S")
+    np.savez_compressed(os.path.join(HERE, "netflow_oracle.npz"), **arrays)
+
+
+if __name__ == "__main__":
+    if not (have_ref("libref_sflow.so") and have_ref("libref_iplist.so")):
+        raise SystemExit("oracle/_ref is not built (needs the reference checkout): run `make -C oracle ref`")
+    make_sflow()
+    make_iplist()
+    make_netflow()
