@@ -9,7 +9,8 @@ import xenoeye_amd
 
 
 class ListDev(C.Structure):
-    _fields_ = [("root4", C.c_uint32), ("root6", C.c_uint32), ("nodes4", C.c_uint32), ("nodes6", C.c_uint32)]
+    _fields_ = [("root4", C.c_uint32), ("root6", C.c_uint32), ("nodes4", C.c_uint32), ("nodes6", C.c_uint32),
+                ("bit", C.c_uint32), ("pad", C.c_uint32 * 3)]
 
 
 class Set(C.Structure):
@@ -24,7 +25,8 @@ class Exporter(C.Structure):
 
 
 TERM = 0x80000000
-NODE_WORDS = 32
+NODE_WORDS = 128
+GROUP_WORDS = 16
 
 
 class Host:
@@ -85,7 +87,7 @@ class Host:
         assert self.L.xe_ht_flatten(self.h, C.byref(words), C.byref(nw), dev, n) == 0
         arr = np.ctypeslib.as_array(words, shape=(max(nw.value, 1),)).copy() if nw.value else np.zeros(1, np.uint32)
         self.L.xe_ht_release(words)
-        return arr, [(d.root4, d.root6, d.nodes4, d.nodes6) for d in dev[:n]]
+        return arr, [(d.root4, d.root6, d.nodes4, d.nodes6, d.bit) for d in dev[:n]]
 
     def prepass(self, batch):
         data, offs, src, kinds = batch.packed()
@@ -117,20 +119,22 @@ class Host:
         return rc, [ln.split("\t") for ln in out.value.decode().splitlines()]
 
 
-def walk_flat(words, root, nodes, addr_bytes):
-    """Reference walker of the flattened list format (tests only): root table
-    over the first 16 bits, then one 16-byte group per 8-bit chunk."""
+def walk_flat(words, root, nodes, addr_bytes, bit=0):
+    """Reference walker of the flattened list format (tests only): the
+    group's root table over the first 16 bits, then one 64-byte group per
+    8-bit chunk; `bit` selects the list inside the group's answer bytes."""
     if not root:
         return 0
     e = int(words[root + ((addr_bytes[0] << 8) | addr_bytes[1])])
     for b in addr_bytes[2:]:
         if e & TERM:
-            return e & 1
-        g = nodes + e * NODE_WORDS + 4 * (b >> 5)
-        child, res, base = int(words[g]), int(words[g + 1]), int(words[g + 2])
-        bit = b & 31
-        if (child >> bit) & 1:
-            e = base + bin(child & ((1 << bit) - 1)).count("1")
+            return (e >> bit) & 1
+        g = nodes + e * NODE_WORDS + GROUP_WORDS * (b >> 5)
+        child, base = int(words[g]), int(words[g + 1])
+        k = b & 31
+        if (child >> k) & 1:
+            e = base + bin(child & ((1 << k) - 1)).count("1")
         else:
-            return (res >> bit) & 1
-    return (e & 1) if (e & TERM) else 0
+            ans = (int(words[g + 2 + (k >> 2)]) >> (8 * (k & 3))) & 0xFF
+            return (ans >> bit) & 1
+    return ((e >> bit) & 1) if (e & TERM) else 0

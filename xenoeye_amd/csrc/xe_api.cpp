@@ -529,47 +529,14 @@ xe_gpu_commit(xe_gpu *h)
 		if (!h->h_lists) rc = XE_ENOMEM;
 		else rc = xe_iplists_flatten(&h->hs.lists, &trie, h->h_lists);
 	}
-	/* interleaved root tables of the probes' groups, appended to the trie array */
+	if ((rc == XE_OK) && (trie.n > 0xFFFFFFF0u)) rc = XE_EUNSUPPORTED;
 	if (rc == XE_OK) {
-		struct xe_probe *pp = (struct xe_probe *)lookups.p;
-		for (size_t i = 0; (i < lookups.n) && (rc == XE_OK); i++) {
-			uint32_t done = 0;
-			for (size_t j = 0; j < i; j++) {
-				if ((pp[j].group == pp[i].group) && (pp[j].family == pp[i].family)) { pp[i].root_off = pp[j].root_off; done = 1; break; }
-			}
-			if (done) continue;
-			while (trie.n % 8) { uint32_t z = 0; if (!xe_blob_push(&trie, &z, 4)) { rc = XE_ENOMEM; break; } }
-			if (rc != XE_OK) break;
-			pp[i].root_off = (uint32_t)trie.n;
-			{
-				size_t need = (trie.n + 65536 * XE_LIST_GROUP) * 4;
-				if (need > trie.cap) {
-					void *np = realloc(trie.p, need * 2);
-					if (!np) { rc = XE_ENOMEM; break; }
-					trie.p = np;
-					trie.cap = need * 2;
-				}
-				uint32_t *dst = (uint32_t *)trie.p + trie.n;
-				for (uint32_t idx = 0; idx < 65536; idx++) {
-					for (uint32_t l = 0; l < XE_LIST_GROUP; l++) {
-						size_t li = (size_t)pp[i].group * XE_LIST_GROUP + l;
-						uint32_t ro = (li < h->hs.lists.n) ? ((pp[i].family == 4) ? h->h_lists[li].root4 : h->h_lists[li].root6) : 0;
-						dst[idx * XE_LIST_GROUP + l] = ro ? ((const uint32_t *)trie.p)[ro + idx] : XE_TRIE_TERM;
-					}
-				}
-				trie.n += 65536 * XE_LIST_GROUP;
-			}
-		}
-		if ((rc == XE_OK) && (trie.n > 0xFFFFFFF0u)) rc = XE_EUNSUPPORTED;
-	}
-	if (rc == XE_OK) {
+		/* a probe walks the merged tables of its group of lists */
 		struct xe_probe *pp = (struct xe_probe *)lookups.p;
 		for (size_t i = 0; i < lookups.n; i++) {
-			for (uint32_t l = 0; l < XE_LIST_GROUP; l++) {
-				size_t li = (size_t)pp[i].group * XE_LIST_GROUP + l;
-				pp[i].nodes_off[l] = (li < h->hs.lists.n)
-					? ((pp[i].family == 4) ? h->h_lists[li].nodes4 : h->h_lists[li].nodes6) : 0;
-			}
+			const struct xe_list_dev *ld = &h->h_lists[(size_t)pp[i].group * XE_LIST_GROUP];
+			pp[i].root_off = (pp[i].family == 4) ? ld->root4 : ld->root6;
+			pp[i].nodes_off = (pp[i].family == 4) ? ld->nodes4 : ld->nodes6;
 		}
 	}
 	if (rc == XE_OK) {

@@ -170,18 +170,22 @@ struct xe_prog
 	uint16_t cval;
 };
 
-/* flattened IP list: per family a 65536-entry root over the first 16 address
- * bits, then 8-bit-stride nodes.  Root entry: bit31 set = terminal, bit0 =
- * result; else node index.  A node is one 128-byte line of 8 groups, group g
- * covering the 32 chunk values [32g, 32g+32):
- *   word 0  child map   (bit set: the walk continues into a child node)
- *   word 1  result map  (where the walk stops: leaf flag of the stop node)
- *   word 2  index of the group's first child node (children of a node are
- *           consecutive, in chunk order)
- *   word 3  unused
- * so a visit is a single 16-byte load. */
+/* Flattened IP lists.  Lists are merged in groups of XE_LIST_GROUP (registry
+ * order); per group and address family: a 65536-entry root over the first 16
+ * address bits, then 8-bit-stride nodes.  Root entry: bit 31 set = terminal
+ * and bits 0..7 = the answers of the group's lists (bit l = list l); else the
+ * index of a node.  A node is 8 groups of 64 bytes, group g covering the 32
+ * chunk values [32g, 32g+32):
+ *   word 0      child map (bit set: the walk continues into a child node)
+ *   word 1      index of the group's first child node (children of a node
+ *               are consecutive, in chunk order)
+ *   bytes 8-39  one answer byte per chunk value (valid where the walk stops)
+ *   bytes 40-63 unused
+ * so a visit touches one 64-byte line. */
 #define XE_TRIE_TERM 0x80000000u
-#define XE_NODE_WORDS 32
+#define XE_LIST_GROUP 8
+#define XE_GROUP_WORDS 16
+#define XE_NODE_WORDS 128
 /* one distinct (list, address family, field) membership test; the fast kernel
  * resolves all of them for a tile in batches before any term is evaluated */
 struct xe_lookup
@@ -193,22 +197,17 @@ struct xe_lookup
 	uint8_t pad;
 };
 
-/* Lists are handled in groups of XE_LIST_GROUP; per group and address family
- * the 16-bit root tables of its lists are interleaved ([top 16 bits][list]) so
- * that one 32-byte load yields the root entries of all lists of the group for
- * an address.  A probe = all membership tests of one field against one group;
- * its results occupy lookup bits [8 * probe, 8 * probe + 8). */
-#define XE_LIST_GROUP 8
+/* A probe = all membership tests of one field against one group of lists: one
+ * walk; its answers occupy lookup bits [8 * probe, 8 * probe + 8). */
 struct xe_probe
 {
-	uint32_t root_off;   /* word offset of the interleaved root table */
+	uint32_t root_off;   /* word offset of the group's root table (this family), 0 = empty */
 	uint8_t family;      /* 4 or 6 */
 	uint8_t field;
-	uint8_t wide4;
+	uint8_t wide4;       /* IPv4 test over the first 4 bytes of a 16-byte field */
 	uint8_t used;        /* bit l: list (8 * group + l) is tested on this field */
 	uint32_t group;
-	uint32_t pad;
-	uint32_t nodes_off[XE_LIST_GROUP];   /* word offset of node 0 of each list (this family) */
+	uint32_t nodes_off;  /* word offset of node 0 */
 };
 
 /* per-batch resolved form of a template field for the fast kernel */
@@ -233,8 +232,10 @@ struct xe_fterm
 
 struct xe_list_dev
 {
-	uint32_t root4, root6;   /* word offsets into the trie array, 0 = family empty */
+	uint32_t root4, root6;   /* word offsets of the list's GROUP tables, 0 = family empty */
 	uint32_t nodes4, nodes6; /* word offsets of node 0 */
+	uint32_t bit;            /* the list's bit in the group's answer bytes */
+	uint32_t pad[3];
 };
 
 /* ------------------------------------------------------------------ host side */

@@ -7,11 +7,12 @@
  * is dropped) and the lookup of :160-216, which returns the leaf flag of the
  * DEEPEST trie node the address reaches -- not a longest-prefix match.
  *
- * The device form replaces the one-bit-per-step pointer chase with a
- * 65536-entry root table over the first 16 address bits followed by
- * 8-bit-stride nodes of one 128-byte line each (child map / result map /
- * popcount-indexed child base per 32 chunk values), so a lookup is one root
- * load plus at most (bits-16)/8 node visits of one 16-byte load each.
+ * The device form replaces the one-bit-per-step pointer chase of up to 8
+ * lists at once with a 65536-entry root table over the first 16 address bits
+ * followed by 8-bit-stride nodes (per 32 chunk values one 64-byte line: child
+ * map, first-child index, one answer byte per value with one bit per list),
+ * so a lookup is one 4-byte root load plus at most (bits-16)/8 node visits,
+ * whatever the number of lists.
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -193,106 +194,133 @@ xe_iplists_free(struct xe_iplists *reg)
 /* ------------------------------------------------------------------ flatten */
 
 /*
- * Expand `depth` more bits below binary node `bn`.  For every value of those
- * bits the bit-by-bit walk either stops early at some node (the entry is then
- * terminal with that node's leaf flag) or arrives at a node `depth` levels
- * down (terminal if that node has no children, else a child entry).
- * cb(ctx, first_index, count, kind, value): kind 0 = terminal(value = leaf
- * flag) for `count` consecutive chunk values, kind 1 = child (value = binary
- * node id, count = 1).
+ * Lists are flattened in groups of XE_LIST_GROUP (registry order): the tries
+ * of a group are walked together, so that ONE device walk per address answers
+ * all lists of the group.  Per list the answer must stay the reference's: the
+ * leaf flag of the deepest node of THAT list's trie on the address's path.
+ *
+ * gstate = where each list of the group stands after some address bits:
+ * still walking (at binary node cur[l]) or stopped with a final answer.
  */
-typedef void (*expand_cb)(void *ctx, uint32_t first, uint32_t count, int kind, uint32_t value);
-
-static void
-expand(const struct xe_bnode *bt, uint32_t bn, int depth, uint32_t prefix, expand_cb cb, void *ctx)
+struct gstate
 {
-	int b;
-
-	if (depth == 0) {
-		if (bt[bn].next[0] || bt[bn].next[1]) {
-			cb(ctx, prefix, 1, 1, bn);
-		} else {
-			cb(ctx, prefix, 1, 0, (uint32_t)(bt[bn].is_leaf != 0));
-		}
-		return;
-	}
-	for (b = 0; b < 2; b++) {
-		uint32_t nx = bt[bn].next[b];
-		uint32_t base = ((prefix << 1) | (uint32_t)b) << (depth - 1);
-		if (!nx) {
-			/* prefix here counts bits already fixed; the block of
-			 * values below shares the stop node bn */
-			cb(ctx, base, 1u << (depth - 1), 0, (uint32_t)(bt[bn].is_leaf != 0));
-		} else {
-			expand(bt, nx, depth - 1, (prefix << 1) | (uint32_t)b, cb, ctx);
-		}
-	}
-}
-
-struct pending { uint32_t bnode; uint32_t dnode; };
-
-struct fl_ctx
-{
-	uint32_t *entries;        /* root: 65536 entries; node: unused */
-	uint32_t *node;           /* current device node words */
-	struct xe_blob *queue;    /* struct pending */
-	uint32_t *next_dnode;
-	int is_root;
-	uint32_t child_bnodes[256];
-	uint32_t child_chunk[256];
-	uint32_t nchild;
+	uint32_t cur[XE_LIST_GROUP];
+	uint8_t walking;     /* bit l: list l has not stopped yet */
+	uint8_t res;         /* bit l: answer of a stopped list */
 };
 
-static void
-root_cb(void *vctx, uint32_t first, uint32_t count, int kind, uint32_t value)
-{
-	struct fl_ctx *c = vctx;
-	uint32_t i;
+/* cb(ctx, first, count, res, child): `count` consecutive chunk values starting
+ * at `first` end with answers `res`; child != NULL (count == 1): some list can
+ * go deeper, its state is *child and the final answers come from below */
+typedef int (*gexpand_cb)(void *ctx, uint32_t first, uint32_t count, uint8_t res, const struct gstate *child);
 
-	if (kind == 0) {
-		for (i = 0; i < count; i++) c->entries[first + i] = XE_TRIE_TERM | value;
-	} else {
-		struct pending p;
-		p.bnode = value;
-		p.dnode = (*c->next_dnode)++;
-		c->entries[first] = p.dnode;
-		xe_blob_push(c->queue, &p, sizeof(p));
-	}
-}
-
-static void
-node_cb(void *vctx, uint32_t first, uint32_t count, int kind, uint32_t value)
-{
-	struct fl_ctx *c = vctx;
-	uint32_t i;
-
-	if (kind == 0) {
-		if (value) {
-			for (i = first; i < first + count; i++) c->node[4 * (i >> 5) + 1] |= 1u << (i & 31);
-		}
-	} else {
-		c->node[4 * (first >> 5)] |= 1u << (first & 31);
-		c->child_bnodes[c->nchild] = value;
-		c->child_chunk[c->nchild] = first;
-		c->nchild++;
-	}
-}
-
-/* one family of one list; returns 0 on allocation failure */
 static int
-flatten_family(const struct xe_bnode *bt, struct xe_blob *words, uint32_t *root_off, uint32_t *nodes_off)
+gexpand(const struct xe_bnode *const *bt, const struct gstate *st, int depth, uint32_t prefix,
+	gexpand_cb cb, void *ctx)
+{
+	int b, l;
+
+	if (depth == 0) {
+		struct gstate ch = *st;
+		ch.walking = 0;
+		for (l = 0; l < XE_LIST_GROUP; l++) {
+			const struct xe_bnode *n;
+			if (!((st->walking >> l) & 1)) continue;
+			n = &bt[l][st->cur[l]];
+			if (n->next[0] || n->next[1]) {
+				ch.walking |= (uint8_t)(1u << l);
+			} else if (n->is_leaf) {
+				ch.res |= (uint8_t)(1u << l);
+			}
+		}
+		return cb(ctx, prefix, 1, ch.res, ch.walking ? &ch : NULL);
+	}
+	for (b = 0; b < 2; b++) {
+		struct gstate ns = *st;
+		uint32_t np = (prefix << 1) | (uint32_t)b;
+		for (l = 0; l < XE_LIST_GROUP; l++) {
+			const struct xe_bnode *n;
+			if (!((st->walking >> l) & 1)) continue;
+			n = &bt[l][st->cur[l]];
+			if (n->next[b]) {
+				ns.cur[l] = n->next[b];
+			} else {
+				/* the list's walk stops at n */
+				ns.walking &= (uint8_t)~(1u << l);
+				if (n->is_leaf) ns.res |= (uint8_t)(1u << l);
+			}
+		}
+		if (!ns.walking) {
+			if (!cb(ctx, np << (depth - 1), 1u << (depth - 1), ns.res, NULL)) return 0;
+		} else if (!gexpand(bt, &ns, depth - 1, np, cb, ctx)) {
+			return 0;
+		}
+	}
+	return 1;
+}
+
+struct gpending { struct gstate st; };
+
+struct gfl_ctx
+{
+	uint32_t *root;           /* 65536 entries while the root is expanded */
+	uint32_t *node;           /* XE_NODE_WORDS words while a node is expanded */
+	struct xe_blob *queue;    /* struct gpending; queue index = device node index */
+};
+
+static int
+groot_cb(void *vctx, uint32_t first, uint32_t count, uint8_t res, const struct gstate *child)
+{
+	struct gfl_ctx *c = vctx;
+	uint32_t i;
+
+	if (!child) {
+		for (i = 0; i < count; i++) c->root[first + i] = XE_TRIE_TERM | res;
+		return 1;
+	}
+	if (c->queue->n >= 0x7FFFFFF0u) return 0;
+	c->root[first] = (uint32_t)c->queue->n;
+	return xe_blob_push(c->queue, child, sizeof(struct gpending));
+}
+
+static int
+gnode_cb(void *vctx, uint32_t first, uint32_t count, uint8_t res, const struct gstate *child)
+{
+	struct gfl_ctx *c = vctx;
+	uint32_t i;
+
+	for (i = first; i < first + count; i++) {
+		((uint8_t *)&c->node[XE_GROUP_WORDS * (i >> 5) + 2])[i & 31] = res;
+	}
+	if (child) {
+		/* children are queued in increasing chunk order = rank order of the map */
+		c->node[XE_GROUP_WORDS * (first >> 5)] |= 1u << (first & 31);
+		if (c->queue->n >= 0x7FFFFFF0u) return 0;
+		return xe_blob_push(c->queue, child, sizeof(struct gpending));
+	}
+	return 1;
+}
+
+/* one address family of one group of lists; bt[l] == NULL: list l has no
+ * entries of this family (answers 0).  Returns 0 on allocation failure. */
+static int
+flatten_group(const struct xe_bnode *const *bt, struct xe_blob *words,
+	uint32_t *root_off, uint32_t *nodes_off)
 {
 	struct xe_blob queue = {0};
-	struct fl_ctx c;
-	uint32_t next_dnode = 0;
-	uint32_t *root;
-	size_t qi, i;
-	size_t root_pos, nodes_pos;
+	struct gfl_ctx c;
+	struct gstate st0;
+	size_t qi, i, root_pos, nodes_pos;
 	uint32_t zero = 0;
+	int l, any = 0;
 
 	*root_off = 0;
 	*nodes_off = 0;
-	if (!bt) return 1;
+	memset(&st0, 0, sizeof(st0));
+	for (l = 0; l < XE_LIST_GROUP; l++) {
+		if (bt[l]) { st0.walking |= (uint8_t)(1u << l); any = 1; }
+	}
+	if (!any) return 1;
 
 	/* word 0 of the array is reserved so that offset 0 means "empty" */
 	if (words->n == 0) {
@@ -302,42 +330,28 @@ flatten_family(const struct xe_bnode *bt, struct xe_blob *words, uint32_t *root_
 	for (i = 0; i < 65536; i++) {
 		if (!xe_blob_push(words, &zero, 4)) return 0;
 	}
-	memset(&c, 0, sizeof(c));
 	c.queue = &queue;
-	c.next_dnode = &next_dnode;
-	c.is_root = 1;
-	root = (uint32_t *)words->p + root_pos;
-	c.entries = root;
-	expand(bt, 0, 16, 0, root_cb, &c);
+	c.node = NULL;
+	c.root = (uint32_t *)words->p + root_pos;
+	if (!gexpand(bt, &st0, 16, 0, groot_cb, &c)) { free(queue.p); return 0; }
 
-	/* breadth-first so that the children of a node get consecutive ids;
-	 * node k of the family lives at nodes_pos + k * XE_NODE_WORDS, and ids
-	 * are handed out in queue order, so the queue index IS the node id */
-	while (words->n % XE_NODE_WORDS) {
+	while (words->n % XE_GROUP_WORDS) {
 		if (!xe_blob_push(words, &zero, 4)) { free(queue.p); return 0; }
 	}
 	nodes_pos = words->n;
 	for (qi = 0; qi < queue.n; qi++) {
-		struct pending p = ((struct pending *)queue.p)[qi];
+		struct gstate st = ((struct gpending *)queue.p)[qi].st;
 		uint32_t nw[XE_NODE_WORDS];
 		uint32_t k, cum = 0;
+		size_t first_child = queue.n;
 
 		memset(nw, 0, sizeof(nw));
 		c.node = nw;
-		c.nchild = 0;
-		expand(bt, p.bnode, 8, 0, node_cb, &c);
+		if (!gexpand(bt, &st, 8, 0, gnode_cb, &c)) { free(queue.p); return 0; }
 		for (k = 0; k < 8; k++) {
-			nw[4 * k + 2] = next_dnode + cum;   /* first child of this group */
-			cum += (uint32_t)__builtin_popcount(nw[4 * k]);
+			nw[XE_GROUP_WORDS * k + 1] = (uint32_t)first_child + cum;
+			cum += (uint32_t)__builtin_popcount(nw[XE_GROUP_WORDS * k]);
 		}
-		/* children in increasing chunk order = rank order of the bitmap */
-		for (k = 0; k < c.nchild; k++) {
-			struct pending ch;
-			ch.bnode = c.child_bnodes[k];
-			ch.dnode = next_dnode++;
-			if (!xe_blob_push(&queue, &ch, sizeof(ch))) { free(queue.p); return 0; }
-		}
-		if (p.dnode != qi) { free(queue.p); return 0; }
 		for (k = 0; k < XE_NODE_WORDS; k++) {
 			if (!xe_blob_push(words, &nw[k], 4)) { free(queue.p); return 0; }
 		}
@@ -352,10 +366,26 @@ flatten_family(const struct xe_bnode *bt, struct xe_blob *words, uint32_t *root_
 int
 xe_iplists_flatten(const struct xe_iplists *reg, struct xe_blob *words, struct xe_list_dev *dev)
 {
-	size_t i;
-	for (i = 0; i < reg->n; i++) {
-		if (!flatten_family(reg->l[i].n4, words, &dev[i].root4, &dev[i].nodes4)) return XE_ENOMEM;
-		if (!flatten_family(reg->l[i].n6, words, &dev[i].root6, &dev[i].nodes6)) return XE_ENOMEM;
+	size_t g, l;
+
+	for (g = 0; g * XE_LIST_GROUP < reg->n; g++) {
+		const struct xe_bnode *b4[XE_LIST_GROUP], *b6[XE_LIST_GROUP];
+		uint32_t r4, n4, r6, n6;
+
+		for (l = 0; l < XE_LIST_GROUP; l++) {
+			size_t li = g * XE_LIST_GROUP + l;
+			b4[l] = (li < reg->n) ? reg->l[li].n4 : NULL;
+			b6[l] = (li < reg->n) ? reg->l[li].n6 : NULL;
+		}
+		if (!flatten_group(b4, words, &r4, &n4)) return XE_ENOMEM;
+		if (!flatten_group(b6, words, &r6, &n6)) return XE_ENOMEM;
+		for (l = 0; (l < XE_LIST_GROUP) && (g * XE_LIST_GROUP + l < reg->n); l++) {
+			struct xe_list_dev *d = &dev[g * XE_LIST_GROUP + l];
+			memset(d, 0, sizeof(*d));
+			d->root4 = r4; d->nodes4 = n4;
+			d->root6 = r6; d->nodes6 = n6;
+			d->bit = (uint32_t)l;
+		}
 	}
 	return XE_OK;
 }

@@ -53,49 +53,54 @@ pkt_be(const pkt_src &s, int32_t off, uint32_t len)
 }
 
 /* ------------------------------------------------------------------ flattened IP list */
+/* one node visit of a group walk: entry for the next level (node index, or
+ * terminal | answer byte) */
 __device__ __forceinline__ uint32_t
-node_step(const uint32_t *N, uint32_t chunk, bool *stop, uint32_t *result)
+node_step(const uint32_t *nodes, uint32_t node, uint32_t chunk)
 {
-	const uint4 gq = *(const uint4 *)(N + 4 * (chunk >> 5));
-	uint32_t b = chunk & 31;
-	if ((gq.x >> b) & 1) {
-		*stop = false;
-		return gq.z + __popc(gq.x & ((1u << b) - 1u));
-	}
-	*stop = true;
-	*result = (gq.y >> b) & 1;
-	return 0;
+	const uint32_t *g = nodes + (size_t)node * XE_NODE_WORDS + XE_GROUP_WORDS * (chunk >> 5);
+	const uint2 hd = *(const uint2 *)g;
+	const uint32_t b = chunk & 31;
+	const uint32_t ans = ((const uint8_t *)(g + 2))[b];
+	if ((hd.x >> b) & 1) return hd.y + __popc(hd.x & ((1u << b) - 1u));
+	return XE_TRIE_TERM | ans;
 }
 
+/* answers of all lists of the group: bit l = list l (iplist_match4, iplist.c:160-186) */
 __device__ uint32_t
+group_match4(const uint32_t *T, uint32_t root, uint32_t nodes, uint32_t a)
+{
+	if (!root) return 0;
+	uint32_t e = T[root + (a >> 16)];
+	for (int lvl = 0; (lvl < 2) && !(e & XE_TRIE_TERM); lvl++) {
+		e = node_step(T + nodes, e, (a >> (8 - 8 * lvl)) & 255);
+	}
+	return (e & XE_TRIE_TERM) ? (e & 0xFF) : 0;
+}
+
+/* iplist_match6, iplist.c:188-216 */
+__device__ uint32_t
+group_match6(const uint32_t *T, uint32_t root, uint32_t nodes, uint64_t hi, uint64_t lo)
+{
+	if (!root) return 0;
+	uint32_t e = T[root + (uint32_t)(hi >> 48)];
+	for (int k = 2; (k < 16) && !(e & XE_TRIE_TERM); k++) {
+		uint32_t chunk = (k < 8) ? (uint32_t)(hi >> (56 - 8 * k)) & 255 : (uint32_t)(lo >> (56 - 8 * (k - 8))) & 255;
+		e = node_step(T + nodes, e, chunk);
+	}
+	return (e & XE_TRIE_TERM) ? (e & 0xFF) : 0;
+}
+
+__device__ __forceinline__ uint32_t
 trie_match4(const uint32_t *T, const xe_list_dev &L, uint32_t a)
 {
-	if (!L.root4) return 0;
-	uint32_t e = T[L.root4 + (a >> 16)];
-	for (int lvl = 0; lvl < 2; lvl++) {
-		if (e & XE_TRIE_TERM) return e & 1;
-		bool stop;
-		uint32_t res = 0;
-		e = node_step(T + L.nodes4 + (size_t)e * XE_NODE_WORDS, (a >> (8 - 8 * lvl)) & 255, &stop, &res);
-		if (stop) return res;
-	}
-	return (e & XE_TRIE_TERM) ? (e & 1) : 0;
+	return (group_match4(T, L.root4, L.nodes4, a) >> L.bit) & 1;
 }
 
-__device__ uint32_t
+__device__ __forceinline__ uint32_t
 trie_match6(const uint32_t *T, const xe_list_dev &L, uint64_t hi, uint64_t lo)
 {
-	if (!L.root6) return 0;
-	uint32_t e = T[L.root6 + (uint32_t)(hi >> 48)];
-	for (int k = 2; k < 16; k++) {
-		if (e & XE_TRIE_TERM) return e & 1;
-		uint32_t chunk = (k < 8) ? (uint32_t)(hi >> (56 - 8 * k)) & 255 : (uint32_t)(lo >> (56 - 8 * (k - 8))) & 255;
-		bool stop;
-		uint32_t res = 0;
-		e = node_step(T + L.nodes6 + (size_t)e * XE_NODE_WORDS, chunk, &stop, &res);
-		if (stop) return res;
-	}
-	return (e & XE_TRIE_TERM) ? (e & 1) : 0;
+	return (group_match6(T, L.root6, L.nodes6, hi, lo) >> L.bit) & 1;
 }
 
 /* ------------------------------------------------------------------ field sources */
@@ -656,16 +661,19 @@ typedef const XE_CONST uint64_t *cu64;
 typedef const XE_CONST uint8_t *cu8;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-/* one node visit: the 16-byte group of the chunk (read-only data, so the
- * load may be scheduled freely among the stores to the output columns) */
+/* one node visit through read-only (constant address space) loads, so that
+ * they may be scheduled freely among the stores to the output columns */
 __device__ __forceinline__ uint32_t
 node_walk(const uint32_t *nodes, uint32_t node, uint32_t chunk)
 {
-	const XE_CONST u32x4 *gp = (const XE_CONST u32x4 *)(nodes + (size_t)node * XE_NODE_WORDS) + (chunk >> 5);
-	const u32x4 gq = *gp;
-	uint32_t b = chunk & 31;
-	if ((gq.x >> b) & 1) return gq.z + __popc(gq.x & ((1u << b) - 1u));
-	return XE_TRIE_TERM | ((gq.y >> b) & 1);
+	const XE_CONST uint32_t *g = (const XE_CONST uint32_t *)(nodes + (size_t)node * XE_NODE_WORDS
+		+ XE_GROUP_WORDS * (chunk >> 5));
+	const uint64_t hd = *(const XE_CONST uint64_t *)g;
+	const uint32_t b = chunk & 31;
+	const uint32_t ans = ((const XE_CONST uint8_t *)(g + 2))[b];
+	const uint32_t map = (uint32_t)hd;
+	if ((map >> b) & 1) return (uint32_t)(hd >> 32) + __popc(map & ((1u << b) - 1u));
+	return XE_TRIE_TERM | ans;
 }
 
 struct tent_s { uint32_t len, field, flags, off; };
@@ -713,17 +721,16 @@ ld_list(const xe_kparams &kp, uint32_t idx)
 {
 	cu32 q = (cu32)(kp.lists + idx);
 	xe_list_dev L;
-	L.root4 = q[0]; L.root6 = q[1]; L.nodes4 = q[2]; L.nodes6 = q[3];
+	L.root4 = q[0]; L.root6 = q[1]; L.nodes4 = q[2]; L.nodes6 = q[3]; L.bit = q[4];
 	return L;
 }
 
 /*
  * All IP-list membership tests of a tile.  Per probe (one field against one
- * group of up to 8 lists) a single 32-byte gather fetches the root entries of
- * all lists of the group; then, level by level, the lists that still have
- * lanes walking visit one node each, all visits of a level in flight
- * together.  Bit (8 * probe + l) of the result = list l of the probe's group
- * matched (0 where the lane's field is absent).
+ * group of up to 8 lists) ONE walk of the group's merged tables: a 4-byte root
+ * gather, then one 64-byte-line node visit per further address byte while any
+ * list of the group can still go deeper.  Bit (8 * probe + l) of the result =
+ * list l of the probe's group matched (0 where the lane's field is absent).
  */
 __device__ uint64_t
 fast_lookups(const xe_kparams &kp, const fast_lane &L)
@@ -732,55 +739,34 @@ fast_lookups(const xe_kparams &kp, const fast_lane &L)
 
 	for (uint32_t pr = 0; pr < kp.nprobes; pr++) {
 		cu32 q = (cu32)(kp.probes + pr);
-		const uint32_t root_off = q[0], w1 = q[1];
-		uint32_t nodes[XE_LIST_GROUP];
-#pragma unroll
-		for (int l = 0; l < XE_LIST_GROUP; l++) nodes[l] = q[4 + l];
+		const uint32_t root_off = q[0], w1 = q[1], nodes_off = q[3];
 		const uint32_t family = w1 & 0xFF, field = (w1 >> 8) & 0xFF, wide4 = (w1 >> 16) & 1, used = w1 >> 24;
 		bool has;
 		uint64_t hi, lo;
-		uint32_t e[XE_LIST_GROUP];
 
 		slot_get(kp, L, field, has, hi, lo);
-		if (!__ballot(has)) continue;
+		if (!root_off || !__ballot(has)) continue;
 		const uint32_t a4 = wide4 ? (uint32_t)(hi >> 32) : (uint32_t)lo;
-		u32x4 r0 = { XE_TRIE_TERM, XE_TRIE_TERM, XE_TRIE_TERM, XE_TRIE_TERM }, r1 = r0;
+		uint32_t e = XE_TRIE_TERM;
 		if (has) {
 			uint32_t top = (family == 6) ? (uint32_t)(hi >> 48) : (a4 >> 16);
-			const XE_CONST u32x4 *rp = (const XE_CONST u32x4 *)(kp.trie + root_off) + (size_t)top * 2;
-			r0 = rp[0];
-			r1 = rp[1];
+			e = ((const XE_CONST uint32_t *)(kp.trie + root_off))[top];
 		}
-		e[0] = r0.x; e[1] = r0.y; e[2] = r0.z; e[3] = r0.w;
-		e[4] = r1.x; e[5] = r1.y; e[6] = r1.z; e[7] = r1.w;
-#pragma unroll
-		for (int l = 0; l < XE_LIST_GROUP; l++) {
-			if (!((used >> l) & 1)) e[l] = XE_TRIE_TERM;
-		}
-		for (uint32_t lvl = 0; lvl < 14; lvl++) {
-			bool any = false;
+		const uint32_t nlvl = (family == 4) ? 2 : 14;
+		for (uint32_t lvl = 0; lvl < nlvl; lvl++) {
+			const bool walk = !(e & XE_TRIE_TERM);
+			if (!__ballot(walk)) break;
 			uint32_t chunk;
 			if (family == 4) {
-				chunk = (a4 >> (8 - 8 * (lvl & 1))) & 255;
+				chunk = (a4 >> (8 - 8 * lvl)) & 255;
 			} else {
 				uint32_t byte = lvl + 2;
 				chunk = (byte < 8) ? (uint32_t)(hi >> (56 - 8 * byte)) & 255
 					: (uint32_t)(lo >> (56 - 8 * (byte - 8))) & 255;
 			}
-#pragma unroll
-			for (int l = 0; l < XE_LIST_GROUP; l++) {
-				const bool walk = !(e[l] & XE_TRIE_TERM);
-				if (__ballot(walk)) {
-					any = true;
-					if (walk) e[l] = node_walk(kp.trie + nodes[l], e[l], chunk);
-				}
-			}
-			if (!any) break;
+			if (walk) e = node_walk(kp.trie + nodes_off, e, chunk);
 		}
-#pragma unroll
-		for (int l = 0; l < XE_LIST_GROUP; l++) {
-			bits |= (uint64_t)(((e[l] & XE_TRIE_TERM) ? e[l] : 0u) & 1u) << (pr * XE_LIST_GROUP + l);
-		}
+		bits |= (uint64_t)(((e & XE_TRIE_TERM) ? e : 0u) & used & 0xFFu) << (pr * XE_LIST_GROUP);
 	}
 	return bits;
 }
