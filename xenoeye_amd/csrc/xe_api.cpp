@@ -20,7 +20,7 @@ struct xe_gpu
 	int device;
 	struct xe_host hs;
 	int committed;
-	void *d_progs, *d_ops, *d_terms, *d_opnds, *d_trie, *d_lists, *d_devrules, *d_lookups, *d_fterms;
+	void *d_progs, *d_ops, *d_terms, *d_opnds, *d_trie, *d_lists, *d_devrules, *d_lookups, *d_fterms, *d_fprogs;
 	uint32_t nmo, mask_words, nprogs_total, nlookups;
 	struct xe_list_dev *h_lists;
 	void *d_tmpls, *d_tents;
@@ -39,7 +39,7 @@ struct xe_batch
 	struct xe_plan plan;
 	size_t ntot, payload_bytes;
 	void *d_pkt, *d_sets, *d_exps, *d_sfrecs, *d_out;
-	void *d_fsets, *d_fwstart, *d_tile_first, *d_tile_tmpl, *d_ssets, *d_swstart, *d_tentx;
+	void *d_fruns, *d_tile_first, *d_tile_tmpl, *d_ssets, *d_swstart, *d_fplans, *d_fops;
 	size_t out_bytes, masks_off, nparsed_off, marks_off, counters_off, sfhas_off;
 	struct xe_kparams kp;
 	hipStream_t last_stream;
@@ -113,7 +113,7 @@ static void
 free_config_dev(xe_gpu *h)
 {
 	void **p[] = { &h->d_progs, &h->d_ops, &h->d_terms, &h->d_opnds, &h->d_trie, &h->d_lists, &h->d_devrules,
-		&h->d_lookups, &h->d_fterms };
+		&h->d_lookups, &h->d_fterms, &h->d_fprogs };
 	for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); i++) {
 		if (*p[i]) (void)hipFree(*p[i]);
 		*p[i] = NULL;
@@ -540,11 +540,14 @@ xe_gpu_commit(xe_gpu *h)
 		}
 	}
 	if (rc == XE_OK) {
-		/* fast-kernel view of the object programs' terms */
+		/* fast-kernel view of the object programs and their terms */
 		const struct xe_term *tt = (const struct xe_term *)terms.p;
 		const struct xe_dopnd *oo = (const struct xe_dopnd *)opnds.p;
+		const struct xe_prog *pg = (const struct xe_prog *)progs.p;
+		const uint32_t *op = (const uint32_t *)ops.p;
 		struct xe_fterm *ft = (struct xe_fterm *)calloc(h->nterms ? h->nterms : 1, sizeof(*ft));
-		if (!ft) rc = XE_ENOMEM;
+		struct xe_fprog *fp = (struct xe_fprog *)calloc(h->hs.nmos ? h->hs.nmos : 1, sizeof(*fp));
+		if (!ft || !fp) rc = XE_ENOMEM;
 		for (uint32_t t = 0; (rc == XE_OK) && (t < h->nterms); t++) {
 			int all_lists = (tt[t].func == XE_FN_NONE) && (tt[t].nopnd > 0)
 				&& ((tt[t].type == XE_BT_ADDR4) || (tt[t].type == XE_BT_ADDR6));
@@ -558,8 +561,31 @@ xe_gpu_commit(xe_gpu *h)
 			ft[t].kind = all_lists ? 1 : 0;
 			ft[t].mask = all_lists ? m : 0;
 		}
+		for (size_t m = 0; (rc == XE_OK) && (m < h->hs.nmos); m++) {
+			if (pg[m].flags & XE_PROG_CONST) {
+				fp[m].kind = XE_FPROG_CONST;
+			} else if ((pg[m].nops == 1) && ((op[pg[m].op_base] & 3) == XE_OP_BASIC)) {
+				uint32_t t = op[pg[m].op_base] >> 2;
+				if (ft[t].kind & 1) {
+					fp[m].kind = XE_FPROG_MASK;
+					fp[m].mask = ft[t].mask;
+				} else {
+					fp[m].kind = XE_FPROG_TERM;
+					fp[m].term = t;
+					ft[t].kind |= 2;
+				}
+			} else {
+				fp[m].kind = XE_FPROG_GENERAL;
+				for (uint32_t k = 0; k < pg[m].nops; k++) {
+					uint32_t w = op[pg[m].op_base + k];
+					if ((w & 3) == XE_OP_BASIC) ft[w >> 2].kind |= 2;
+				}
+			}
+		}
 		if (rc == XE_OK) rc = upload(h, &h->d_fterms, ft, (size_t)h->nterms * sizeof(*ft));
+		if (rc == XE_OK) rc = upload(h, &h->d_fprogs, fp, h->hs.nmos * sizeof(*fp));
 		free(ft);
+		free(fp);
 	}
 	if (rc == XE_OK) rc = upload(h, &h->d_progs, progs.p, progs.n * sizeof(struct xe_prog));
 	if (rc == XE_OK) rc = upload(h, &h->d_ops, ops.p, ops.n * 4);
@@ -612,8 +638,8 @@ xe_gpu_batch_free(xe_batch *b)
 	if (b->d_out) (void)hipFree(b->d_out);
 	for (int i = 0; i < 6; i++) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
 	{
-		void *extra[] = { b->d_fsets, b->d_fwstart, b->d_tile_first, b->d_tile_tmpl, b->d_ssets, b->d_swstart,
-			b->d_tentx };
+		void *extra[] = { b->d_fruns, b->d_tile_first, b->d_tile_tmpl, b->d_ssets, b->d_swstart,
+			b->d_fplans, b->d_fops };
 		for (size_t i = 0; i < sizeof(extra) / sizeof(extra[0]); i++) if (extra[i]) (void)hipFree(extra[i]);
 	}
 	xe_plan_free(&b->plan);
@@ -627,7 +653,7 @@ xe_gpu_batch_free(xe_batch *b)
  * (stable, so arrival order is kept inside a group) and each group is padded
  * to whole 64-record tiles: a wave then works on one template only. */
 static int
-build_work_lists(xe_gpu *h, xe_batch *b)
+build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 {
 	const struct xe_set *sets = (const struct xe_set *)b->plan.sets.p;
 	const struct xe_tmpl *tm = (const struct xe_tmpl *)h->hs.dev_tmpls.p;
@@ -636,9 +662,12 @@ build_work_lists(xe_gpu *h, xe_batch *b)
 	size_t ns = b->plan.sets.n, nt = h->hs.dev_tmpls.n, i;
 	uint8_t *tfast = NULL, *is_fast = NULL;
 	uint64_t *gcount = NULL, *gpos = NULL;
-	struct xe_set *fs = NULL, *ss = NULL;
-	uint32_t *fw = NULL, *sw = NULL, *tfirst = NULL, *ttmpl = NULL;
+	struct xe_frun *fr = NULL;
+	struct xe_set *ss = NULL;
+	uint32_t *sw = NULL, *tfirst = NULL, *ttmpl = NULL, *rtmpl = NULL;
 	size_t nfast = 0, nslow = 0, ntiles = 0, work = 0, slowrec = 0;
+	/* the fast kernel addresses packet bytes with 32-bit offsets */
+	const int small = (total_bytes + 64) < 0xFFFF0000ull;
 	int rc = XE_ENOMEM;
 
 	tfast = (uint8_t *)calloc(nt + 1, 1);
@@ -647,24 +676,25 @@ build_work_lists(xe_gpu *h, xe_batch *b)
 	gpos = (uint64_t *)calloc(nt + 1, sizeof(uint64_t));
 	if (!tfast || !is_fast || !gcount || !gpos) goto out;
 	for (i = 0; i < nt; i++) {
-		int ok = h->fast_ok && !tm[i].varlen && !tm[i].repeats;
+		int ok = h->fast_ok && small && !tm[i].varlen && !tm[i].repeats;
 		for (uint32_t j = 0; ok && (j < tm[i].nfields); j++) {
 			if ((te[tm[i].ent_base + j].field != XE_F_NONE) && (te[tm[i].ent_base + j].flags & XE_TE_STR)) ok = 0;
-			if (te[tm[i].ent_base + j].len > 16 && (te[tm[i].ent_base + j].flags & XE_TE_VALID)
+			if (((te[tm[i].ent_base + j].len > 16) || (te[tm[i].ent_base + j].len == 0))
+				&& (te[tm[i].ent_base + j].flags & XE_TE_VALID)
 				&& (te[tm[i].ent_base + j].field != XE_F_NONE)) ok = 0;
 		}
 		tfast[i] = (uint8_t)ok;
 	}
 	for (i = 0; i < ns; i++) {
-		int ok = tfast[sets[i].tmpl] && !(sets[i].flags & XE_SET_CHECKED) && (ex[sets[i].exporter].device < 0);
+		int ok = tfast[sets[i].tmpl] && !(sets[i].flags & (XE_SET_CHECKED | XE_SET_PARTIAL))
+			&& (ex[sets[i].exporter].device < 0);
 		is_fast[i] = (uint8_t)ok;
 		if (ok) { nfast++; gcount[sets[i].tmpl]++; } else { nslow++; slowrec += sets[i].nrec; }
 	}
-	fs = (struct xe_set *)malloc((nfast + 1) * sizeof(*fs));
-	fw = (uint32_t *)malloc((nfast + 1) * sizeof(uint32_t));
+	fr = (struct xe_frun *)malloc((nfast + 1) * sizeof(*fr));
 	ss = (struct xe_set *)malloc((nslow + 1) * sizeof(*ss));
 	sw = (uint32_t *)malloc((nslow + 1) * sizeof(uint32_t));
-	if (!fs || !fw || !ss || !sw) goto out;
+	if (!fr || !ss || !sw) goto out;
 	/* group positions */
 	{
 		uint64_t acc = 0;
@@ -674,17 +704,34 @@ build_work_lists(xe_gpu *h, xe_batch *b)
 		size_t k = 0;
 		uint64_t w = 0;
 		for (i = 0; i < ns; i++) {
-			if (is_fast[i]) fs[gpos[sets[i].tmpl]++] = sets[i];
-			else { ss[k] = sets[i]; sw[k] = (uint32_t)w; w += sets[i].nrec; k++; }
+			if (is_fast[i]) {
+				struct xe_frun *r = &fr[gpos[sets[i].tmpl]++];
+				const struct xe_exporter *e = &ex[sets[i].exporter];
+				uint32_t ipw, idw;
+				memcpy(&ipw, e->dev_ip, 4);
+				memcpy(&idw, e->dev_id, 4);
+				r->data_off = (uint32_t)sets[i].data_off;
+				r->first_rec = sets[i].first_rec;
+				r->start = sets[i].tmpl;   /* template for now, position below */
+				r->nrec = sets[i].nrec;
+				r->stride = sets[i].stride;
+				r->rate = e->sampling_rate;
+				r->dev_ip = ntohl(ipw);
+				r->dev_id = ntohl(idw);
+			} else { ss[k] = sets[i]; sw[k] = (uint32_t)w; w += sets[i].nrec; k++; }
 		}
 	}
-	/* work indices with per-group padding, then the tile tables */
+	/* positions with per-group padding (r->start holds the template so far),
+	 * then the tile tables */
+	rtmpl = (uint32_t *)malloc((nfast + 1) * sizeof(uint32_t));
+	if (!rtmpl) goto out;
 	for (i = 0; i < nfast; i++) {
-		if (i && (fs[i].tmpl != fs[i - 1].tmpl)) work = (work + 63) / 64 * 64;
-		fw[i] = (uint32_t)work;
-		work += fs[i].nrec;
+		rtmpl[i] = fr[i].start;
+		if (i && (rtmpl[i] != rtmpl[i - 1])) work = (work + 63) / 64 * 64;
+		if (work + fr[i].nrec > 0xFFFFFF00u) { rc = XE_EUNSUPPORTED; goto out; }
+		fr[i].start = (uint32_t)work;
+		work += fr[i].nrec;
 	}
-	if (work > 0xFFFFFF00u) { rc = XE_EUNSUPPORTED; goto out; }
 	ntiles = (work + 63) / 64;
 	tfirst = (uint32_t *)malloc((ntiles + 1) * sizeof(uint32_t));
 	ttmpl = (uint32_t *)malloc((ntiles + 1) * sizeof(uint32_t));
@@ -693,23 +740,21 @@ build_work_lists(xe_gpu *h, xe_batch *b)
 		size_t sidx = 0;
 		for (size_t t = 0; t < ntiles; t++) {
 			uint64_t g0 = (uint64_t)t * 64;
-			while ((sidx + 1 < nfast) && (fw[sidx + 1] <= g0)) sidx++;
+			while ((sidx + 1 < nfast) && (fr[sidx + 1].start <= g0)) sidx++;
 			tfirst[t] = (uint32_t)sidx;
-			ttmpl[t] = fs[sidx].tmpl;
+			ttmpl[t] = rtmpl[sidx];
 		}
 	}
-	rc = upload(h, &b->d_fsets, fs, nfast * sizeof(*fs));
-	if (rc == XE_OK) rc = upload(h, &b->d_fwstart, fw, nfast * 4);
+	rc = upload(h, &b->d_fruns, fr, nfast * sizeof(*fr));
 	if (rc == XE_OK) rc = upload(h, &b->d_tile_first, tfirst, ntiles * 4);
 	if (rc == XE_OK) rc = upload(h, &b->d_tile_tmpl, ttmpl, ntiles * 4);
 	if (rc == XE_OK) rc = upload(h, &b->d_ssets, ss, nslow * sizeof(*ss));
 	if (rc == XE_OK) rc = upload(h, &b->d_swstart, sw, nslow * 4);
 	if (rc == XE_OK) {
-		b->kp.fsets = (const struct xe_set *)b->d_fsets;
-		b->kp.fwstart = (const uint32_t *)b->d_fwstart;
+		b->kp.fruns = (const struct xe_frun *)b->d_fruns;
 		b->kp.tile_first = (const uint32_t *)b->d_tile_first;
 		b->kp.tile_tmpl = (const uint32_t *)b->d_tile_tmpl;
-		b->kp.nfsets = (uint32_t)nfast;
+		b->kp.nfruns = (uint32_t)nfast;
 		b->kp.ntiles = (uint32_t)ntiles;
 		b->kp.ssets = (const struct xe_set *)b->d_ssets;
 		b->kp.swstart = (const uint32_t *)b->d_swstart;
@@ -721,13 +766,14 @@ build_work_lists(xe_gpu *h, xe_batch *b)
 		b->kp.nslots_hi = h->nslots_hi;
 		b->kp.nterms = h->nterms;
 		b->kp.fterms = (const struct xe_fterm *)h->d_fterms;
+		b->kp.fprogs = (const struct xe_fprog *)h->d_fprogs;
 		b->kp.probes = (const struct xe_probe *)h->d_lookups;
 		b->kp.nprobes = h->nlookups;
 		b->kp.lds_counters = (h->hs.nmos <= XE_MAX_LDS_COUNTER_MOS) ? 1u : 0u;
 	}
 out:
 	free(tfast); free(is_fast); free(gcount); free(gpos);
-	free(fs); free(fw); free(ss); free(sw); free(tfirst); free(ttmpl);
+	free(fr); free(ss); free(sw); free(tfirst); free(ttmpl); free(rtmpl);
 	return rc;
 }
 
@@ -780,7 +826,7 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 	if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
 
 	memset(&b->kp, 0, sizeof(b->kp));
-	rc = build_work_lists(h, b);
+	rc = build_work_lists(h, b, total);
 	if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
 
 	/* output layout */
@@ -836,32 +882,50 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 		if (e != hipSuccess) { xe_gpu_batch_free(b); return hip_fail(h, e, "hipMalloc(outputs)"); }
 	}
 
-	/* per-batch resolved template fields for the fast kernel */
+	/* decode plans of the fast kernel: per template the micro-ops of its
+	 * known, valid fields with this batch's column addresses */
 	{
+		const struct xe_tmpl *tm = (const struct xe_tmpl *)h->hs.dev_tmpls.p;
 		const struct xe_tent *te = (const struct xe_tent *)h->hs.dev_tents.p;
-		size_t ne = h->hs.dev_tents.n;
-		struct xe_tentx *tx = (struct xe_tentx *)calloc(ne ? ne : 1, sizeof(*tx));
-		if (!tx) { xe_gpu_batch_free(b); return XE_ENOMEM; }
-		for (size_t i = 0; i < ne; i++) {
-			int f = te[i].field;
-			tx[i].off = te[i].off;
-			tx[i].len = (uint8_t)((te[i].len > 255) ? 255 : te[i].len);
-			tx[i].field = te[i].field;
-			tx[i].slot = 0xFF;
-			if ((f != XE_F_NONE) && (te[i].flags & XE_TE_VALID) && (te[i].len <= 16)
-				&& (b->kp.col_off[f] != ~0ull)) {
-				tx[i].flags = XE_TE_VALID;
-				tx[i].slot = h->fslot[f];
-				tx[i].colw = (uint8_t)xe_fields[f].col_width;
-				tx[i].special = (uint8_t)(((f == XF_in_bytes) ? 1 : 0) | ((f == XF_in_pkts) ? 2 : 0)
-					| ((xe_fields[f].size_max == 6) ? 4 : 0));
-				tx[i].col = (uint64_t)(uintptr_t)((uint8_t *)b->d_out + b->kp.col_off[f]);
+		size_t nt = h->hs.dev_tmpls.n, ne = h->hs.dev_tents.n, nops = 0;
+		struct xe_fplan *pl = (struct xe_fplan *)calloc(nt ? nt : 1, sizeof(*pl));
+		struct xe_fop *fo = (struct xe_fop *)calloc(ne ? ne : 1, sizeof(*fo));
+		if (!pl || !fo) { free(pl); free(fo); xe_gpu_batch_free(b); return XE_ENOMEM; }
+		for (size_t t = 0; t < nt; t++) {
+			pl[t].op_base = (uint32_t)nops;
+			pl[t].nparsed = tm[t].nfields;
+			if (h->fslot[XF_dev_ip] != 0xFF) pl[t].present |= 1ull << h->fslot[XF_dev_ip];
+			if (h->fslot[XF_dev_id] != 0xFF) pl[t].present |= 1ull << h->fslot[XF_dev_id];
+			for (uint32_t j = 0; j < tm[t].nfields; j++) {
+				const struct xe_tent *e = &te[tm[t].ent_base + j];
+				int f = e->field;
+				uint32_t cw, lg = 0, kind, slot, hsl;
+				if ((f == XE_F_NONE) || !(e->flags & XE_TE_VALID) || (e->len > 16) || (e->len == 0)
+					|| (b->kp.col_off[f] == ~0ull)) continue;
+				cw = xe_fields[f].col_width;
+				while ((1u << lg) < cw) lg++;
+				kind = lg;
+				if (e->len == cw) kind |= XE_FOP_COPY;
+				if (f == XF_in_bytes) kind |= XE_FOP_BYTES;
+				if (f == XF_in_pkts) kind |= XE_FOP_PKTS;
+				if (xe_fields[f].size_max == 6) kind |= XE_FOP_MAC;
+				slot = h->fslot[f];
+				hsl = (slot != 0xFF) ? h->slot_hi[slot] : 0xFF;
+				if (slot != 0xFF) pl[t].present |= 1ull << slot;
+				fo[nops].w0 = (uint64_t)e->off | ((uint64_t)e->len << 16) | ((uint64_t)kind << 24)
+					| ((uint64_t)slot << 32) | ((uint64_t)hsl << 40);
+				fo[nops].w1 = (uint64_t)(uintptr_t)((uint8_t *)b->d_out + b->kp.col_off[f]);
+				nops++;
 			}
+			pl[t].nops = (uint32_t)nops - pl[t].op_base;
 		}
-		rc = upload(h, &b->d_tentx, tx, ne * sizeof(*tx));
-		free(tx);
+		rc = upload(h, &b->d_fplans, pl, nt * sizeof(*pl));
+		if (rc == XE_OK) rc = upload(h, &b->d_fops, fo, nops * sizeof(*fo));
+		free(pl);
+		free(fo);
 		if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
-		b->kp.tentx = (const struct xe_tentx *)b->d_tentx;
+		b->kp.fplans = (const struct xe_fplan *)b->d_fplans;
+		b->kp.fops = (const struct xe_fop *)b->d_fops;
 	}
 
 	b->kp.progs = (const struct xe_prog *)h->d_progs;

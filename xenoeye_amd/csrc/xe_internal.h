@@ -108,6 +108,7 @@ struct xe_set
 	uint32_t flags;      /* XE_SET_* */
 };
 #define XE_SET_CHECKED 1 /* a read may pass the datagram end: bounds-check bytes */
+#define XE_SET_PARTIAL 2 /* some record of the run does not get all template fields */
 
 struct xe_exporter
 {
@@ -210,25 +211,57 @@ struct xe_probe
 	uint32_t nodes_off;  /* word offset of node 0 */
 };
 
-/* per-batch resolved form of a template field for the fast kernel */
-struct xe_tentx
+/* ---- fast kernel tables (built per batch: they hold output addresses) ---- */
+
+/* one run of complete records, with what the kernel needs of its exporter */
+struct xe_frun
 {
-	uint16_t off;
-	uint8_t len;
-	uint8_t field;
-	uint8_t flags;       /* XE_TE_VALID only when the field is known and its length valid */
-	uint8_t slot;        /* operand slot, 0xFF none */
-	uint8_t colw;        /* column width in bytes */
-	uint8_t special;     /* 1 in_bytes, 2 in_pkts, 4 six-byte value in an 8-byte column */
-	uint64_t col;        /* device address of the field's column */
+	uint32_t data_off;   /* first record, byte offset in the batch buffer (< 4 GiB) */
+	uint32_t first_rec;  /* batch index of its first record */
+	uint32_t start;      /* position of its first record in the template-grouped order */
+	uint32_t nrec;
+	uint32_t stride;
+	uint32_t rate;       /* sampling rate */
+	uint32_t dev_ip;     /* exporter address / source id as big-endian numbers */
+	uint32_t dev_id;
+};
+
+/* decode micro-op: one known, valid template field.
+ * w0: bits 0-15 offset in the record, 16-23 wire length, 24-31 kind,
+ *     32-39 operand slot (0xFF none), 40-47 index of the slot's upper half
+ * w1: device address of the field's column */
+struct xe_fop { uint64_t w0, w1; };
+#define XE_FOP_LGW 7       /* kind bits 0-2: log2(column width) */
+#define XE_FOP_COPY 8      /* wire length == column width: the bytes are stored as they are */
+#define XE_FOP_BYTES 16    /* in_bytes: value feeds the octet counter */
+#define XE_FOP_PKTS 32     /* in_pkts */
+#define XE_FOP_MAC 64      /* 6-byte value kept in an 8-byte column */
+
+/* per template */
+struct xe_fplan
+{
+	uint32_t op_base, nops;
+	uint32_t nparsed;    /* fields a complete record parses (all of the template's) */
+	uint32_t pad;
+	uint64_t present;    /* operand slots every complete record fills */
 };
 
 /* fast-kernel view of a distinct term */
 struct xe_fterm
 {
-	uint64_t kind;       /* bit 0: every operand is an IP list -> result = lookup bits & mask */
+	uint64_t kind;       /* bit 0: every operand is an IP list -> result = lookup bits & mask;
+	                        bit 1: some program needs the term's bit */
 	uint64_t mask;
 };
+
+/* fast-kernel view of an object program */
+struct xe_fprog
+{
+	uint64_t mask;       /* XE_FPROG_MASK: lookup bits that make it match */
+	uint32_t kind;
+	uint32_t term;       /* XE_FPROG_TERM: the one term */
+};
+enum { XE_FPROG_GENERAL = 0, XE_FPROG_CONST = 1, XE_FPROG_MASK = 2, XE_FPROG_TERM = 3 };
 
 struct xe_list_dev
 {

@@ -62,15 +62,17 @@ struct xe_kparams
 	uint64_t vsize_off[XE_NFIELDS]; /* u16 per record, ~0 = absent */
 	uint32_t *sf_has;            /* sflow: presence bits of the fields its parser can set */
 
-	/* fast path: regular runs (fixed-length template without repeated or
-	 * string elements, every read inside the datagram, exporter without a
-	 * devices.conf entry), grouped by template so that a wave decodes one
-	 * template; 64 records per tile */
-	const struct xe_set *fsets;
-	const uint32_t *fwstart;     /* work index of each grouped set's first record */
-	const uint32_t *tile_first;  /* per tile: first grouped set that may hold its records */
+	/* fast path: runs of complete records (fixed-length template without
+	 * repeated or string elements, every read inside the datagram, exporter
+	 * without a devices.conf entry), grouped by template so that a wave
+	 * decodes one template; 64 records per tile */
+	const struct xe_frun *fruns;
+	const uint32_t *tile_first;  /* per tile: first run that may hold its records */
 	const uint32_t *tile_tmpl;   /* per tile: template slot */
-	uint32_t nfsets, ntiles;
+	const struct xe_fplan *fplans;  /* per template slot */
+	const struct xe_fop *fops;
+	const struct xe_fprog *fprogs;  /* parallel to progs[0, nmo) */
+	uint32_t nfruns, ntiles;
 	/* everything else goes through the general kernel */
 	const struct xe_set *ssets;
 	const uint32_t *swstart;
@@ -80,7 +82,6 @@ struct xe_kparams
 	uint8_t slot_hi[XE_MAX_SLOTS]; /* slot -> index of its upper 8 bytes, 0xFF = field <= 8 bytes */
 	uint32_t nslots, nslots_hi;
 	uint32_t nterms;             /* distinct terms */
-	const struct xe_tentx *tentx;   /* parallel to tents */
 	const struct xe_fterm *fterms;  /* parallel to terms[0, nterms) */
 	const struct xe_probe *probes;
 	uint32_t nprobes, pad2;

@@ -565,10 +565,12 @@ xe_nf_general_kernel(const xe_kparams kp)
 
 /* ------------------------------------------------------------------ fast kernel */
 /*
- * One wave = one tile of 64 records that share a template, so the walk over
- * the template's fields, over the distinct filter terms and over the object
- * programs is wave-uniform (scalar loads, scalar branches); only packet
- * bytes, field values, IP-list lookups and match bits are per lane.
+ * One wave = one tile of 64 complete records that share a template, so the
+ * walk over the template's fields, over the filter terms and over the object
+ * programs is wave-uniform (scalar loads, scalar branches); only packet bytes,
+ * field values, IP-list walks and match bits are per lane.  Every record of a
+ * tile carries all fields of its template (runs with cut-short records go to
+ * the general kernel), so field presence is wave-uniform too.
  *
  * Per lane state kept in LDS: the value of every field some program reads
  * ("operand slots", laid out [slot][lane] so that lanes hit distinct banks).
@@ -577,7 +579,7 @@ xe_nf_general_kernel(const xe_kparams kp)
  */
 struct fast_lane
 {
-	uint64_t present;     /* bit per operand slot: the field is set in this record */
+	uint64_t present;     /* wave-uniform: bit per operand slot the template fills */
 	uint64_t *lo, *hi;    /* LDS: lo[slot * XE_BLOCK + tid], hi[hi_index * XE_BLOCK + tid] */
 	uint32_t tid;
 };
@@ -596,56 +598,13 @@ slot_get(const xe_kparams &kp, const fast_lane &L, uint32_t field, bool &has, ui
 }
 
 __device__ __forceinline__ void
-slot_put(const xe_kparams &kp, fast_lane &L, uint32_t field, bool act, uint64_t hi, uint64_t lo)
+slot_put(const xe_kparams &kp, fast_lane &L, uint32_t field, uint64_t hi, uint64_t lo)
 {
 	uint32_t s = kp.fslot[field];
 	if (s == 0xFF) return;
-	if (act) {
-		L.lo[s * XE_BLOCK + L.tid] = lo;
-		uint32_t h = kp.slot_hi[s];
-		if (h != 0xFF) L.hi[h * XE_BLOCK + L.tid] = hi;
-		L.present |= 1ull << s;
-	}
-}
-
-/* len (wave-uniform, 1..16) wire bytes at p as a big-endian number.  Odd
- * lengths read up to 7 bytes past the field and shift them out; the batch
- * buffer is padded so that such a read stays inside the allocation. */
-__device__ __forceinline__ void
-load_be(const uint8_t *p, uint32_t len, uint64_t &hi, uint64_t &lo)
-{
-	hi = 0;
-	if (len <= 2) {
-		if (len == 1) {
-			lo = *p;
-		} else {
-			uint16_t v;
-			__builtin_memcpy(&v, p, 2);
-			lo = __builtin_bswap16(v);
-		}
-	} else if (len <= 4) {
-		uint32_t v;
-		__builtin_memcpy(&v, p, 4);
-		lo = __builtin_bswap32(v) >> (8 * (4 - len));
-	} else if (len <= 8) {
-		uint64_t v;
-		__builtin_memcpy(&v, p, 8);
-		lo = __builtin_bswap64(v) >> (8 * (8 - len));
-	} else {
-		uint64_t a, b;
-		__builtin_memcpy(&a, p, 8);
-		__builtin_memcpy(&b, p + 8, 8);
-		a = __builtin_bswap64(a);
-		b = __builtin_bswap64(b);
-		uint32_t sh = 8 * (16 - len);
-		if (sh == 0) {
-			hi = a;
-			lo = b;
-		} else {
-			lo = (b >> sh) | (a << (64 - sh));
-			hi = a >> sh;
-		}
-	}
+	L.lo[s * XE_BLOCK + L.tid] = lo;
+	uint32_t h = kp.slot_hi[s];
+	if (h != 0xFF) L.hi[h * XE_BLOCK + L.tid] = hi;
 }
 
 /*
@@ -659,34 +618,28 @@ load_be(const uint8_t *p, uint32_t len, uint64_t &hi, uint64_t &lo)
 typedef const XE_CONST uint32_t *cu32;
 typedef const XE_CONST uint64_t *cu64;
 typedef const XE_CONST uint8_t *cu8;
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-/* one node visit through read-only (constant address space) loads, so that
- * they may be scheduled freely among the stores to the output columns */
-__device__ __forceinline__ uint32_t
-node_walk(const uint32_t *nodes, uint32_t node, uint32_t chunk)
+/* what one node visit loads: the group's child map + first-child index, and
+ * the answer byte of the chunk (same 64-byte line) */
+struct node_ld { uint64_t hd; uint32_t ans; };
+
+__device__ __forceinline__ node_ld
+node_fetch(const uint32_t *nodes, uint32_t node, uint32_t chunk)
 {
 	const XE_CONST uint32_t *g = (const XE_CONST uint32_t *)(nodes + (size_t)node * XE_NODE_WORDS
 		+ XE_GROUP_WORDS * (chunk >> 5));
-	const uint64_t hd = *(const XE_CONST uint64_t *)g;
-	const uint32_t b = chunk & 31;
-	const uint32_t ans = ((const XE_CONST uint8_t *)(g + 2))[b];
-	const uint32_t map = (uint32_t)hd;
-	if ((map >> b) & 1) return (uint32_t)(hd >> 32) + __popc(map & ((1u << b) - 1u));
-	return XE_TRIE_TERM | ans;
+	node_ld r;
+	r.hd = *(const XE_CONST uint64_t *)g;
+	r.ans = ((const XE_CONST uint8_t *)(g + 2))[chunk & 31];
+	return r;
 }
 
-struct tent_s { uint32_t len, field, flags, off; };
-__device__ __forceinline__ tent_s
-ld_tent(const xe_tent *E, uint32_t j)
+__device__ __forceinline__ uint32_t
+node_next(const node_ld &r, uint32_t chunk)
 {
-	uint64_t w = ((cu64)E)[j];
-	tent_s e;
-	e.len = (uint32_t)w & 0xFFFF;
-	e.field = (uint32_t)(w >> 16) & 0xFF;
-	e.flags = (uint32_t)(w >> 24) & 0xFF;
-	e.off = (uint32_t)(w >> 32) & 0xFFFF;
-	return e;
+	const uint32_t b = chunk & 31, map = (uint32_t)r.hd;
+	if ((map >> b) & 1) return (uint32_t)(r.hd >> 32) + __popc(map & ((1u << b) - 1u));
+	return XE_TRIE_TERM | r.ans;
 }
 
 struct term_s { uint32_t type, dir, fsrc, fdst, func, fa, fb, nopnd; int32_t k; const xe_dopnd *o; };
@@ -716,57 +669,80 @@ in_ranges_u(const xe_dopnd *o, uint32_t n, int64_t v)
 	return r;
 }
 
-__device__ __forceinline__ xe_list_dev
-ld_list(const xe_kparams &kp, uint32_t idx)
+/* address chunk `lvl` levels below the 16-bit root */
+__device__ __forceinline__ uint32_t
+addr_chunk(uint32_t family, uint32_t lvl, uint32_t a4, uint64_t hi, uint64_t lo)
 {
-	cu32 q = (cu32)(kp.lists + idx);
-	xe_list_dev L;
-	L.root4 = q[0]; L.root6 = q[1]; L.nodes4 = q[2]; L.nodes6 = q[3]; L.bit = q[4];
-	return L;
+	if (family == 4) return (a4 >> (8 - 8 * (lvl & 1))) & 255;
+	const uint32_t byte = lvl + 2;
+	return (byte < 8) ? (uint32_t)(hi >> (56 - 8 * byte)) & 255 : (uint32_t)(lo >> (56 - 8 * (byte - 8))) & 255;
 }
 
 /*
  * All IP-list membership tests of a tile.  Per probe (one field against one
  * group of up to 8 lists) ONE walk of the group's merged tables: a 4-byte root
- * gather, then one 64-byte-line node visit per further address byte while any
- * list of the group can still go deeper.  Bit (8 * probe + l) of the result =
- * list l of the probe's group matched (0 where the lane's field is absent).
+ * gather, then one node visit (one 64-byte line) per further address byte
+ * while any list of the group can still go deeper.  Probes are walked two at
+ * a time so that their dependent gathers overlap.  Bit (8 * probe + l) of the
+ * result = list l of the probe's group matched.
  */
+struct probe_s { uint32_t root, nodes, family, used, a4, e; uint64_t hi, lo; };
+
+__device__ __forceinline__ bool
+probe_open(const xe_kparams &kp, const fast_lane &L, uint32_t pr, bool live, probe_s &P)
+{
+	cu32 q = (cu32)(kp.probes + pr);
+	const uint32_t w1 = q[1];
+	bool has;
+
+	P.root = q[0];
+	P.nodes = q[3];
+	P.family = w1 & 0xFF;
+	P.used = w1 >> 24;
+	slot_get(kp, L, (w1 >> 8) & 0xFF, has, P.hi, P.lo);
+	if (!P.root || !has) return false;
+	P.a4 = ((w1 >> 16) & 1) ? (uint32_t)(P.hi >> 32) : (uint32_t)P.lo;
+	P.e = XE_TRIE_TERM;
+	if (live) {
+		const uint32_t top = (P.family == 6) ? (uint32_t)(P.hi >> 48) : (P.a4 >> 16);
+		P.e = ((const XE_CONST uint32_t *)(kp.trie + P.root))[top];
+	}
+	return true;
+}
+
 __device__ uint64_t
-fast_lookups(const xe_kparams &kp, const fast_lane &L)
+fast_lookups(const xe_kparams &kp, const fast_lane &L, bool live)
 {
 	uint64_t bits = 0;
+	uint32_t pr = 0;
 
-	for (uint32_t pr = 0; pr < kp.nprobes; pr++) {
-		cu32 q = (cu32)(kp.probes + pr);
-		const uint32_t root_off = q[0], w1 = q[1], nodes_off = q[3];
-		const uint32_t family = w1 & 0xFF, field = (w1 >> 8) & 0xFF, wide4 = (w1 >> 16) & 1, used = w1 >> 24;
-		bool has;
-		uint64_t hi, lo;
+	while (pr < kp.nprobes) {
+		probe_s A, B;
+		uint32_t ia = 0, ib = 0;
+		bool okA = false, okB = false;
 
-		slot_get(kp, L, field, has, hi, lo);
-		if (!root_off || !__ballot(has)) continue;
-		const uint32_t a4 = wide4 ? (uint32_t)(hi >> 32) : (uint32_t)lo;
-		uint32_t e = XE_TRIE_TERM;
-		if (has) {
-			uint32_t top = (family == 6) ? (uint32_t)(hi >> 48) : (a4 >> 16);
-			e = ((const XE_CONST uint32_t *)(kp.trie + root_off))[top];
+		/* next two probes whose field the template carries */
+		for (; (pr < kp.nprobes) && !okA; pr++) { okA = probe_open(kp, L, pr, live, A); ia = pr; }
+		for (; (pr < kp.nprobes) && !okB; pr++) { okB = probe_open(kp, L, pr, live, B); ib = pr; }
+		if (!okA) break;
+		if (!okB) { B = A; B.e = XE_TRIE_TERM; }
+
+		for (uint32_t lvl = 0; lvl < 14; lvl++) {
+			const bool wa = !(A.e & XE_TRIE_TERM) && (lvl < ((A.family == 4) ? 2u : 14u));
+			const bool wb = !(B.e & XE_TRIE_TERM) && (lvl < ((B.family == 4) ? 2u : 14u));
+			const bool anyA = __ballot(wa) != 0, anyB = __ballot(wb) != 0;
+			if (!anyA && !anyB) break;
+			/* lanes that are done re-read node 0 of the table: one shared line */
+			const uint32_t ca = wa ? addr_chunk(A.family, lvl, A.a4, A.hi, A.lo) : 0;
+			const uint32_t cb = wb ? addr_chunk(B.family, lvl, B.a4, B.hi, B.lo) : 0;
+			node_ld ra = {0, 0}, rb = {0, 0};
+			if (anyA) ra = node_fetch(kp.trie + A.nodes, wa ? A.e : 0, ca);
+			if (anyB) rb = node_fetch(kp.trie + B.nodes, wb ? B.e : 0, cb);
+			if (wa) A.e = node_next(ra, ca);
+			if (wb) B.e = node_next(rb, cb);
 		}
-		const uint32_t nlvl = (family == 4) ? 2 : 14;
-		for (uint32_t lvl = 0; lvl < nlvl; lvl++) {
-			const bool walk = !(e & XE_TRIE_TERM);
-			if (!__ballot(walk)) break;
-			uint32_t chunk;
-			if (family == 4) {
-				chunk = (a4 >> (8 - 8 * lvl)) & 255;
-			} else {
-				uint32_t byte = lvl + 2;
-				chunk = (byte < 8) ? (uint32_t)(hi >> (56 - 8 * byte)) & 255
-					: (uint32_t)(lo >> (56 - 8 * (byte - 8))) & 255;
-			}
-			if (walk) e = node_walk(kp.trie + nodes_off, e, chunk);
-		}
-		bits |= (uint64_t)(((e & XE_TRIE_TERM) ? e : 0u) & used & 0xFFu) << (pr * XE_LIST_GROUP);
+		bits |= (uint64_t)(((A.e & XE_TRIE_TERM) ? A.e : 0u) & A.used & 0xFFu) << (ia * XE_LIST_GROUP);
+		if (okB) bits |= (uint64_t)(((B.e & XE_TRIE_TERM) ? B.e : 0u) & B.used & 0xFFu) << (ib * XE_LIST_GROUP);
 	}
 	return bits;
 }
@@ -801,7 +777,7 @@ fast_term(const xe_kparams &kp, const fast_lane &L, const term_s &t, uint64_t lk
 		if (!(t.dir & side)) continue;
 		uint32_t f = (side == XE_DIR_SRC) ? t.fsrc : t.fdst;
 		slot_get(kp, L, f, has, hi, lo);
-		if (((t.type == XE_BT_ADDR4) || (t.type == XE_BT_ADDR6)) && !__ballot(has)) continue;
+		if (((t.type == XE_BT_ADDR4) || (t.type == XE_BT_ADDR6)) && !has) continue;
 		switch (t.type) {
 			case XE_BT_ADDR4: {
 				uint32_t a = (c_fmax[f] == 16) ? (uint32_t)(hi >> 32) : (uint32_t)lo;
@@ -811,7 +787,7 @@ fast_term(const xe_kparams &kp, const fast_lane &L, const term_s &t, uint64_t lk
 					bool m;
 					if (q[0]) m = ((lkbits >> q[(side == XE_DIR_SRC) ? 2 : 3]) & 1) != 0;
 					else m = (a & (uint32_t)r[5]) == (uint32_t)r[3];
-					res |= has && m;
+					res |= m;
 				}
 				break;
 			}
@@ -822,7 +798,7 @@ fast_term(const xe_kparams &kp, const fast_lane &L, const term_s &t, uint64_t lk
 					bool m;
 					if (q[0]) m = ((lkbits >> q[(side == XE_DIR_SRC) ? 2 : 3]) & 1) != 0;
 					else m = ((hi & r[4]) == r[2]) && ((lo & r[5]) == r[3]);
-					res |= has && m;
+					res |= m;
 				}
 				break;
 			case XE_BT_RANGE: {
@@ -841,6 +817,31 @@ fast_term(const xe_kparams &kp, const fast_lane &L, const term_s &t, uint64_t lk
 	return res;
 }
 
+/* `hit` lanes add their octets and packets to object m's counters: few hits
+ * go one by one (same-address atomics serialise, but there are few), many go
+ * through a wave reduction first */
+__device__ __forceinline__ void
+count_hits(unsigned long long *dst, bool hit, unsigned long long ball, uint32_t lane,
+	unsigned long long bxr, unsigned long long pxr)
+{
+	const uint32_t n = (uint32_t)__popcll(ball);
+	if (n <= 6) {
+		if (hit) {
+			atomicAdd(dst + 1, bxr);
+			atomicAdd(dst + 2, pxr);
+		}
+		if (lane == 0) atomicAdd(dst + 0, (unsigned long long)n);
+	} else {
+		unsigned long long sb = wave_sum(hit ? bxr : 0ull);
+		unsigned long long sp = wave_sum(hit ? pxr : 0ull);
+		if (lane == 0) {
+			atomicAdd(dst + 0, (unsigned long long)n);
+			atomicAdd(dst + 1, sb);
+			atomicAdd(dst + 2, sp);
+		}
+	}
+}
+
 __global__ void __launch_bounds__(XE_BLOCK)
 xe_nf_fast_kernel(const xe_kparams kp)
 {
@@ -848,6 +849,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 	fast_lane L;
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	unsigned long long *lcnt = (unsigned long long *)(lds + (size_t)(kp.nslots + kp.nslots_hi) * XE_BLOCK);
+	const bool want_dev = (kp.fslot[XF_dev_ip] != 0xFF) || (kp.fslot[XF_dev_id] != 0xFF);
 
 	L.tid = threadIdx.x;
 	L.lo = lds;
@@ -860,45 +862,76 @@ xe_nf_fast_kernel(const xe_kparams kp)
 	const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (XE_BLOCK / 64) + wave);
 	for (uint32_t tile = wave0; tile < kp.ntiles; tile += gridDim.x * (XE_BLOCK / 64)) {
 		const uint32_t tmpl = ((cu32)kp.tile_tmpl)[tile];
-		cu32 TQ = (cu32)(kp.tmpls + tmpl);
-		const uint32_t ent_base = TQ[0];
-		const uint32_t nf = TQ[1] & 0xFFFF;
-		const bool ipfix = (TQ[2] & 0xFF) == XE_MODE_IPFIX;
+		cu32 PL = (cu32)(kp.fplans + tmpl);
+		const uint32_t op_base = PL[0], nops = PL[1], nparsed = PL[2];
+		L.present = ((cu64)PL)[2];
 
-		/* which run, which record */
-		uint32_t g = tile * 64 + lane;
-		uint32_t s = ((cu32)kp.tile_first)[tile];
-		while ((s + 1 < kp.nfsets) && (kp.fwstart[s + 1] <= g)) s++;
-		const xe_set S = kp.fsets[s];
-		uint32_t i = g - kp.fwstart[s];
-		const bool live = (S.tmpl == tmpl) && (i < S.nrec);
-		const uint32_t ridx = S.first_rec + i;
-		const uint8_t *p = kp.pkt + S.data_off + (uint64_t)i * S.stride;
-		/* (packet bytes are read-only: constant-address-space loads below may
-		 * be scheduled across the column stores) */
-		const int32_t avail = live ? (S.avail - (int32_t)(i * S.stride)) : -0x7fffffff;
+		/* which run, which record: the runs that overlap the tile are walked
+		 * with scalar loads, each lane keeps the one it falls into */
+		const uint32_t g = tile * 64 + lane;
+		bool live = false;
+		uint32_t voff = 0, ridx = 0, rate = 0, dev_ip = 0, dev_id = 0;
+		for (uint32_t s = ((cu32)kp.tile_first)[tile]; s < kp.nfruns; s++) {
+			cu32 R = (cu32)(kp.fruns + s);
+			const uint32_t start = R[2];
+			if (start >= tile * 64 + 64) break;
+			const uint32_t i = g - start;
+			const bool in = (g >= start) && (i < R[3]);
+			voff = in ? (R[0] + i * R[4]) : voff;
+			ridx = in ? (R[1] + i) : ridx;
+			rate = in ? R[5] : rate;
+			if (want_dev) {
+				dev_ip = in ? R[6] : dev_ip;
+				dev_id = in ? R[7] : dev_id;
+			}
+			live |= in;
+		}
 
-		L.present = 0;
+		/* decode: one micro-op per known field of the template (16 bytes,
+		 * one scalar load): copy the wire bytes into the field's column,
+		 * keep the value where a filter or a counter needs it */
 		uint64_t bytes = 0, pkts = 0;
-		uint32_t np = 0;
+		if (live) {
+			for (uint32_t j = 0; j < nops; j++) {
+				cu64 xq = (cu64)(kp.fops + op_base + j);
+				const uint64_t w0 = xq[0];
+				const uint32_t off = (uint32_t)w0 & 0xFFFF, len = (uint32_t)(w0 >> 16) & 0xFF;
+				const uint32_t kind = (uint32_t)(w0 >> 24) & 0xFF, slot = (uint32_t)(w0 >> 32) & 0xFF;
+				const uint32_t hsl = (uint32_t)(w0 >> 40) & 0xFF;
+				const uint32_t lg = kind & XE_FOP_LGW;
+				uint8_t *col = (uint8_t *)xq[1];
+				/* packet bytes are read-only: constant-address-space loads may be
+				 * scheduled across the column stores */
+				const XE_CONST uint8_t *src = (const XE_CONST uint8_t *)(kp.pkt + off) + voff;
+				const bool need_val = (slot != 0xFF) || (kind & (XE_FOP_BYTES | XE_FOP_PKTS));
 
-		/* decode: one pre-resolved micro-op per template field (offset, length,
-		 * column address and width, operand slot), 16 bytes, one scalar load */
-#pragma unroll 4
-		for (uint32_t j = 0; j < nf; j++) {
-			cu64 xq = (cu64)(kp.tentx + ent_base + j);
-			const uint64_t w0 = xq[0];
-			const uint32_t off = (uint32_t)w0 & 0xFFFF, len = (uint32_t)(w0 >> 16) & 0xFF;
-			const uint32_t flags = (uint32_t)(w0 >> 32) & 0xFF, slot = (uint32_t)(w0 >> 40) & 0xFF;
-			const uint32_t colw = (uint32_t)(w0 >> 48) & 0xFF, special = (uint32_t)(w0 >> 56);
-			bool act = ipfix ? (live && ((j == 0) || ((int32_t)off < avail)))
-				: (((int32_t)off + (int32_t)len) <= avail);
-			np += act ? 1u : 0u;
-			if (!(flags & XE_TE_VALID)) continue;
-			uint8_t *col = (uint8_t *)xq[1] + (size_t)ridx * colw;
-			const XE_CONST uint8_t *src = (const XE_CONST uint8_t *)(p + off);
-			uint64_t hi = 0, lo = 0;
-			if (act) {
+				if ((kind & XE_FOP_COPY) && !need_val) {
+					/* column bytes = wire bytes */
+					if (lg == 0) {
+						col[ridx] = *src;
+					} else if (lg == 1) {
+						uint16_t v;
+						__builtin_memcpy(&v, src, 2);
+						((uint16_t *)col)[ridx] = v;
+					} else if (lg == 2) {
+						uint32_t v;
+						__builtin_memcpy(&v, src, 4);
+						((uint32_t *)col)[ridx] = v;
+					} else if (lg == 3) {
+						uint64_t v;
+						__builtin_memcpy(&v, src, 8);
+						((uint64_t *)col)[ridx] = v;
+					} else {
+						uint64_t a, b;
+						__builtin_memcpy(&a, src, 8);
+						__builtin_memcpy(&b, src + 8, 8);
+						((uint64_t *)col)[2 * (size_t)ridx] = a;
+						((uint64_t *)col)[2 * (size_t)ridx + 1] = b;
+					}
+					continue;
+				}
+				/* the value as a big-endian number, right-aligned */
+				uint64_t hi = 0, lo;
 				if (len <= 4) {
 					uint32_t raw;
 					__builtin_memcpy(&raw, src, 4);
@@ -919,56 +952,42 @@ xe_nf_fast_kernel(const xe_kparams kp)
 				}
 				/* column bytes = the field as the reference stores it: value
 				 * right-aligned in its maximum size, big-endian */
-				if (colw <= 2) {
-					if (colw == 1) *col = (uint8_t)lo;
-					else *(uint16_t *)col = __builtin_bswap16((uint16_t)lo);
-				} else if (colw == 4) {
-					*(uint32_t *)col = __builtin_bswap32((uint32_t)lo);
-				} else if (colw == 8) {
-					*(uint64_t *)col = __builtin_bswap64(lo << ((special & 4) ? 16 : 0));
-				} else {
-					((uint64_t *)col)[0] = __builtin_bswap64(hi);
-					((uint64_t *)col)[1] = __builtin_bswap64(lo);
+				if (lg == 0) col[ridx] = (uint8_t)lo;
+				else if (lg == 1) ((uint16_t *)col)[ridx] = __builtin_bswap16((uint16_t)lo);
+				else if (lg == 2) ((uint32_t *)col)[ridx] = __builtin_bswap32((uint32_t)lo);
+				else if (lg == 3) ((uint64_t *)col)[ridx] = __builtin_bswap64(lo << ((kind & XE_FOP_MAC) ? 16 : 0));
+				else {
+					((uint64_t *)col)[2 * (size_t)ridx] = __builtin_bswap64(hi);
+					((uint64_t *)col)[2 * (size_t)ridx + 1] = __builtin_bswap64(lo);
 				}
 				if (slot != 0xFF) {
 					L.lo[slot * XE_BLOCK + L.tid] = lo;
-					const uint32_t h = kp.slot_hi[slot];
-					if (h != 0xFF) L.hi[h * XE_BLOCK + L.tid] = hi;
-					L.present |= 1ull << slot;
+					if (hsl != 0xFF) L.hi[hsl * XE_BLOCK + L.tid] = hi;
 				}
+				if (kind & XE_FOP_BYTES) bytes = lo;
+				if (kind & XE_FOP_PKTS) pkts = lo;
 			}
-			if (special & 1) bytes = act ? lo : bytes;
-			if (special & 2) pkts = act ? lo : pkts;
-		}
-		if (live) {
-			kp.nparsed[ridx] = (uint8_t)np;
+			kp.nparsed[ridx] = (uint8_t)nparsed;
 			if (kp.marks) kp.marks[ridx] = 0;
-		}
-
-		/* virtual fields (netflow.c:112-124) and what the counters add */
-		uint64_t rate = 0;
-		if (live) {
-			const xe_exporter *ex = kp.exps + S.exporter;
-			uint32_t ipw, idw;
-			__builtin_memcpy(&ipw, ex->dev_ip, 4);
-			__builtin_memcpy(&idw, ex->dev_id, 4);
-			rate = ex->sampling_rate;
-			slot_put(kp, L, XF_dev_ip, true, 0, __builtin_bswap32(ipw));
-			slot_put(kp, L, XF_dev_id, true, 0, __builtin_bswap32(idw));
+			/* virtual fields (netflow.c:112-124) */
+			if (want_dev) {
+				slot_put(kp, L, XF_dev_ip, 0, dev_ip);
+				slot_put(kp, L, XF_dev_id, 0, dev_id);
+			}
 		}
 		const unsigned long long bxr = bytes * rate, pxr = pkts * rate;
 
-		/* every IP-list membership, then every distinct term, once */
-		const uint64_t lkbits = (kp.pad2 & 1) ? 0 : fast_lookups(kp, L);
+		/* every IP-list membership, then every term some program needs, once */
+		const uint64_t lkbits = (kp.pad2 & 1) ? 0 : fast_lookups(kp, L, live);
 		uint64_t tb0 = 0, tb1 = 0, tb2 = 0, tb3 = 0;
 		for (uint32_t t = 0; (t < kp.nterms) && !(kp.pad2 & 2); t++) {
-			/* a term whose operands are all IP lists is a mask over the
-			 * lookup bits (absent fields already read 0 there) */
 			cu64 fq = (cu64)(kp.fterms + t);
-			const uint64_t fmask = fq[1];
+			const uint64_t fkind = fq[0];
 			bool r;
-			if (fq[0] & 1) {
-				r = (lkbits & fmask) != 0;
+			if (!(fkind & 2)) continue;
+			if (fkind & 1) {
+				/* all operands are IP lists: a mask over the lookup bits */
+				r = (lkbits & fq[1]) != 0;
 			} else {
 				const term_s tm = ld_term(kp, t);
 				r = fast_term(kp, L, tm, lkbits);
@@ -982,21 +1001,30 @@ xe_nf_fast_kernel(const xe_kparams kp)
 			}
 		}
 
-		/* object programs over the term bits */
+		/* object programs */
 		for (uint32_t w = 0; (w < kp.mask_words) && !(kp.pad2 & 8); w++) {
 			uint64_t bits = 0;
 			uint32_t m0 = w * 64, m1 = (m0 + 64 < kp.nmo) ? m0 + 64 : kp.nmo;
 			for (uint32_t m = m0; m < m1; m++) {
+				cu64 FP = (cu64)(kp.fprogs + m);
+				const uint64_t fmask = FP[0], fw = FP[1];
+				const uint32_t fkind = (uint32_t)fw, fterm = (uint32_t)(fw >> 32);
 				cu32 PQ = (cu32)(kp.progs + m);
-				const uint32_t op_base = PQ[0], nops = PQ[1], pflags = PQ[3];
 				const int32_t parent = (int32_t)PQ[2];
 				bool hit;
-				if (pflags & XE_PROG_CONST) {
-					hit = (pflags >> 16) != 0;
+				if (fkind == XE_FPROG_MASK) {
+					hit = (lkbits & fmask) != 0;
+				} else if (fkind == XE_FPROG_TERM) {
+					const uint32_t wsel = fterm >> 6;
+					const uint64_t word = (wsel == 0) ? tb0 : (wsel == 1) ? tb1 : (wsel == 2) ? tb2 : tb3;
+					hit = ((word >> (fterm & 63)) & 1) != 0;
+				} else if (fkind == XE_FPROG_CONST) {
+					hit = (PQ[3] >> 16) != 0;
 				} else {
+					const uint32_t pbase = PQ[0], pn = PQ[1];
 					uint64_t st = 0;
-					for (uint32_t k = 0; k < nops; k++) {
-						uint32_t op = ((cu32)kp.ops)[op_base + k];
+					for (uint32_t k = 0; k < pn; k++) {
+						uint32_t op = ((cu32)kp.ops)[pbase + k];
 						uint32_t code = op & 3;
 						if (code == XE_OP_BASIC) {
 							uint32_t id = op >> 2, wsel = id >> 6;
@@ -1022,16 +1050,9 @@ xe_nf_fast_kernel(const xe_kparams kp)
 					hit = hit && pok;
 				}
 				if (hit) bits |= 1ull << (m - m0);
-				unsigned long long ball = (kp.pad2 & 4) ? 0 : __ballot(hit);
+				const unsigned long long ball = (kp.pad2 & 4) ? 0 : __ballot(hit);
 				if (ball) {
-					unsigned long long sb = wave_sum(hit ? bxr : 0ull);
-					unsigned long long sp = wave_sum(hit ? pxr : 0ull);
-					if (lane == 0) {
-						unsigned long long *dst = kp.lds_counters ? (lcnt + 3 * m) : (kp.counters + 3 * m);
-						atomicAdd(dst + 0, (unsigned long long)__popcll(ball));
-						atomicAdd(dst + 1, sb);
-						atomicAdd(dst + 2, sp);
-					}
+					count_hits(kp.lds_counters ? (lcnt + 3 * m) : (kp.counters + 3 * m), hit, ball, lane, bxr, pxr);
 				}
 			}
 			if (live) kp.masks[(size_t)ridx * kp.mask_words + w] = bits;

@@ -340,7 +340,7 @@ tmpl_put(struct xe_host *hs, const struct xe_tkey *k, const uint8_t *raw, size_t
 /* ------------------------------------------------------------------ set emission */
 static int
 emit_set(struct xe_plan *plan, const struct xe_host *hs, const struct dgram *d, long rel_off,
-	uint32_t nrec, long avail, uint32_t stride, uint32_t tmpl, long extent)
+	uint32_t nrec, long avail, uint32_t stride, uint32_t tmpl, long extent, uint32_t flags)
 {
 	struct xe_set s;
 	const struct xe_tmpl *t = (const struct xe_tmpl *)hs->dev_tmpls.p + tmpl;
@@ -358,6 +358,7 @@ emit_set(struct xe_plan *plan, const struct xe_host *hs, const struct dgram *d, 
 	s.tmpl = tmpl;
 	s.dgram_left = (int32_t)(d->len - rel_off);
 	s.exporter = d->exporter;
+	s.flags = flags;
 	/* extent = the furthest byte (relative to rel_off) any record of the run
 	 * may look at; past the datagram end the kernels must substitute zeros */
 	if ((extent < 0) || ((rel_off + extent) > d->len) || (rel_off < 0) || t->varlen) s.flags |= XE_SET_CHECKED;
@@ -395,11 +396,11 @@ v9_data_set(struct xe_host *hs, struct xe_plan *plan, struct dgram *d, long *ptr
 	if (nfull > count) nfull = count;
 	if (S == 0) {
 		/* every field is empty: `count` records, all at the set start */
-		if (!emit_set(plan, hs, d, *ptr, (uint32_t)count, length, 0, ts->dev_slot, 0)) return -1;
+		if (!emit_set(plan, hs, d, *ptr, (uint32_t)count, length, 0, ts->dev_slot, 0, XE_SET_PARTIAL)) return -1;
 		*ptr += length;
 		return 1;
 	}
-	if (!emit_set(plan, hs, d, *ptr, (uint32_t)nfull, length, (uint32_t)S, ts->dev_slot, nfull * S)) return -1;
+	if (!emit_set(plan, hs, d, *ptr, (uint32_t)nfull, length, (uint32_t)S, ts->dev_slot, nfull * S, 0)) return -1;
 	done = nfull;
 	start = nfull * S;
 	/* the remaining iterations each start where the previous one stopped
@@ -414,10 +415,11 @@ v9_data_set(struct xe_host *hs, struct xe_plan *plan, struct dgram *d, long *ptr
 		if (pos == start) {
 			/* nothing consumed: all later iterations are identical */
 			if (!emit_set(plan, hs, d, *ptr + start, (uint32_t)(count - done), length - start, 0,
-				ts->dev_slot, 0)) return -1;
+				ts->dev_slot, 0, XE_SET_PARTIAL)) return -1;
 			break;
 		}
-		if (!emit_set(plan, hs, d, *ptr + start, 1, length - start, 0, ts->dev_slot, pos - start)) return -1;
+		if (!emit_set(plan, hs, d, *ptr + start, 1, length - start, 0, ts->dev_slot, pos - start,
+			XE_SET_PARTIAL)) return -1;
 		start = pos;
 		done++;
 	}
@@ -539,7 +541,16 @@ ipfix_data_set(struct xe_host *hs, struct xe_plan *plan, struct dgram *d, long p
 		 * reaches `length` ends the loop but is itself delivered */
 		if (length < fc) return 1;
 		nrec = (length - fc) / S + 1;
-		if (!emit_set(plan, hs, d, ptr, (uint32_t)nrec, length, (uint32_t)S, ts->dev_slot, nrec * S)) return -1;
+		/* record k gets every field iff its last field starts before
+		 * `length` (netflow.c:596-600); the rest of the run is cut short */
+		{
+			long off_last = t->nfields ? e[t->nfields - 1].off : 0;
+			long nfull = (length > off_last) ? ((length - off_last - 1) / S + 1) : 0;
+			if (nfull > nrec) nfull = nrec;
+			if (!emit_set(plan, hs, d, ptr, (uint32_t)nfull, length, (uint32_t)S, ts->dev_slot, nfull * S, 0)) return -1;
+			if (!emit_set(plan, hs, d, ptr + nfull * S, (uint32_t)(nrec - nfull), length - nfull * S, (uint32_t)S,
+				ts->dev_slot, (nrec - nfull) * S, XE_SET_PARTIAL)) return -1;
+		}
 		return 1;
 	}
 	/* variable-length elements (netflow.c:367-383): find each record's start */
@@ -560,7 +571,7 @@ ipfix_data_set(struct xe_host *hs, struct xe_plan *plan, struct dgram *d, long p
 				pos += fl + adj;
 				if (pos >= length) { stop = 1; break; }
 			}
-			if (!emit_set(plan, hs, d, ptr + start, 1, length - start, 0, ts->dev_slot, -1)) return -1;
+			if (!emit_set(plan, hs, d, ptr + start, 1, length - start, 0, ts->dev_slot, -1, XE_SET_PARTIAL)) return -1;
 			/* a template cut at 65535 bytes never gets here without stop */
 			if (!stop && (pos == start)) { plan->skipped_datagrams++; break; }
 		}
@@ -632,7 +643,7 @@ walk_v5(struct xe_host *hs, struct xe_plan *plan, struct dgram *d)
 		if (rc != XE_OK) return rc;
 		hs->v5_slot_plus1 = slot + 1;
 	}
-	if (!emit_set(plan, hs, d, 24, (uint32_t)n, 48 * n, 48, slot, 48 * n)) return XE_ENOMEM;
+	if (!emit_set(plan, hs, d, 24, (uint32_t)n, 48 * n, 48, slot, 48 * n, 0)) return XE_ENOMEM;
 	return XE_OK;
 }
 
