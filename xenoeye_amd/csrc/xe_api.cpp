@@ -25,11 +25,8 @@ struct xe_gpu
 	struct xe_list_dev *h_lists;
 	void *d_tmpls, *d_tents;
 	size_t up_tmpls, up_tents;
-	/* operand slots and distinct terms (see xe_kernels.h) */
-	uint8_t fslot[XE_NFIELDS];
-	uint8_t slot_hi[XE_MAX_SLOTS];
-	uint32_t nslots, nslots_hi, nterms;
-	int fast_ok;
+	uint32_t nterms;           /* distinct terms of the object programs */
+	int fast_ok, want_dev;     /* want_dev: some object program reads dev_ip / dev_id */
 	char err[512];
 };
 
@@ -39,7 +36,7 @@ struct xe_batch
 	struct xe_plan plan;
 	size_t ntot, payload_bytes;
 	void *d_pkt, *d_sets, *d_exps, *d_sfrecs, *d_out;
-	void *d_fruns, *d_tile_first, *d_tile_tmpl, *d_ssets, *d_swstart, *d_fplans, *d_fops;
+	void *d_fruns, *d_tile_first, *d_tile_tmpl, *d_ssets, *d_swstart, *d_fplans, *d_fops, *d_fflds;
 	size_t out_bytes, masks_off, nparsed_off, marks_off, counters_off, sfhas_off;
 	struct xe_kparams kp;
 	hipStream_t last_stream;
@@ -462,32 +459,22 @@ append_prog(struct xe_blob *progs, struct xe_blob *ops, struct xe_blob *terms, s
 	return xe_blob_push(progs, &pr, sizeof(pr)) ? XE_OK : XE_ENOMEM;
 }
 
-/* give every field some object program reads a slot in the per-lane operand file */
-static void
-assign_slots(xe_gpu *h, const struct xe_term *terms, size_t nobj_terms)
+/* does some object program read the exporter's address or source id? */
+static int
+reads_device_fields(const struct xe_term *terms, size_t n)
 {
-	memset(h->fslot, 0xFF, sizeof(h->fslot));
-	memset(h->slot_hi, 0xFF, sizeof(h->slot_hi));
-	h->nslots = h->nslots_hi = 0;
-	h->fast_ok = 1;
-	for (size_t i = 0; i < nobj_terms; i++) {
+	for (size_t i = 0; i < n; i++) {
 		const struct xe_term *t = &terms[i];
 		uint8_t fl[2];
-		int n = 0;
-		if (t->func != XE_FN_NONE) { fl[n++] = t->fa; fl[n++] = t->fb; }
+		int k = 0;
+		if (t->func != XE_FN_NONE) { fl[k++] = t->fa; fl[k++] = t->fb; }
 		else {
-			if (t->dir & XE_DIR_SRC) fl[n++] = t->fsrc;
-			if (t->dir & XE_DIR_DST) fl[n++] = t->fdst;
+			if (t->dir & XE_DIR_SRC) fl[k++] = t->fsrc;
+			if (t->dir & XE_DIR_DST) fl[k++] = t->fdst;
 		}
-		for (int k = 0; k < n; k++) {
-			uint8_t f = fl[k];
-			if (h->fslot[f] != 0xFF) continue;
-			if (h->nslots >= XE_MAX_SLOTS) { h->fast_ok = 0; return; }
-			h->fslot[f] = (uint8_t)h->nslots;
-			if (xe_fields[f].size_max > 8) h->slot_hi[h->nslots] = (uint8_t)h->nslots_hi++;
-			h->nslots++;
-		}
+		for (int j = 0; j < k; j++) if ((fl[j] == XF_dev_ip) || (fl[j] == XF_dev_id)) return 1;
 	}
+	return 0;
 }
 
 extern "C" int
@@ -507,11 +494,11 @@ xe_gpu_commit(xe_gpu *h)
 		/* the fast kernel evaluates the object programs' terms [0, nterms);
 		 * terms used only by device mark filters follow them */
 		h->nterms = (uint32_t)terms.n;
-		assign_slots(h, (const struct xe_term *)terms.p, terms.n);
+		h->fast_ok = 1;
+		h->want_dev = reads_device_fields((const struct xe_term *)terms.p, terms.n);
 		if (h->nterms > XE_MAX_FAST_TERMS) h->fast_ok = 0;
 		h->nlookups = (uint32_t)lookups.n;
 		if (h->nlookups > XE_MAX_PROBES) h->fast_ok = 0;
-		if ((size_t)(h->nslots + h->nslots_hi) * 256 * 8 + (size_t)h->hs.nmos * 24 > 60 * 1024) h->fast_ok = 0;
 	}
 	for (size_t d = 0; (d < h->hs.ndevs) && (rc == XE_OK); d++) {
 		struct xe_devrule r;
@@ -639,7 +626,7 @@ xe_gpu_batch_free(xe_batch *b)
 	for (int i = 0; i < 6; i++) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
 	{
 		void *extra[] = { b->d_fruns, b->d_tile_first, b->d_tile_tmpl, b->d_ssets, b->d_swstart,
-			b->d_fplans, b->d_fops };
+			b->d_fplans, b->d_fops, b->d_fflds };
 		for (size_t i = 0; i < sizeof(extra) / sizeof(extra[0]); i++) if (extra[i]) (void)hipFree(extra[i]);
 	}
 	xe_plan_free(&b->plan);
@@ -668,6 +655,8 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 	size_t nfast = 0, nslow = 0, ntiles = 0, work = 0, slowrec = 0;
 	/* the fast kernel addresses packet bytes with 32-bit offsets */
 	const int small = (total_bytes + 64) < 0xFFFF0000ull;
+	uint32_t maxchunk = 1, R, tilesz;
+	size_t cnt_bytes = (h->hs.nmos <= XE_MAX_LDS_COUNTER_MOS) ? h->hs.nmos * 24 : 0;
 	int rc = XE_ENOMEM;
 
 	tfast = (uint8_t *)calloc(nt + 1, 1);
@@ -676,7 +665,8 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 	gpos = (uint64_t *)calloc(nt + 1, sizeof(uint64_t));
 	if (!tfast || !is_fast || !gcount || !gpos) goto out;
 	for (i = 0; i < nt; i++) {
-		int ok = h->fast_ok && small && !tm[i].varlen && !tm[i].repeats;
+		int ok = h->fast_ok && small && !tm[i].varlen && !tm[i].repeats
+			&& (tm[i].stride > 0) && (tm[i].stride <= XE_FAST_MAX_STRIDE);
 		for (uint32_t j = 0; ok && (j < tm[i].nfields); j++) {
 			if ((te[tm[i].ent_base + j].field != XE_F_NONE) && (te[tm[i].ent_base + j].flags & XE_TE_STR)) ok = 0;
 			if (((te[tm[i].ent_base + j].len > 16) || (te[tm[i].ent_base + j].len == 0))
@@ -689,8 +679,22 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 		int ok = tfast[sets[i].tmpl] && !(sets[i].flags & (XE_SET_CHECKED | XE_SET_PARTIAL))
 			&& (ex[sets[i].exporter].device < 0);
 		is_fast[i] = (uint8_t)ok;
-		if (ok) { nfast++; gcount[sets[i].tmpl]++; } else { nslow++; slowrec += sets[i].nrec; }
+		if (ok) {
+			uint32_t nc = ((uint32_t)tm[sets[i].tmpl].stride + 15) / 16;
+			if (nc > maxchunk) maxchunk = nc;
+			nfast++;
+			gcount[sets[i].tmpl]++;
+		} else { nslow++; slowrec += sets[i].nrec; }
 	}
+	/* records per lane: as many as keep the block's staging area (4 waves x
+	 * R x 64 records x 16 * maxchunk bytes) within the LDS budget */
+	R = 4;
+	while ((R > 1) && ((size_t)4 * R * 64 * 16 * maxchunk + cnt_bytes > XE_FAST_LDS_BUDGET)) R >>= 1;
+	if (getenv("XE_FAST_R")) {
+		int want = atoi(getenv("XE_FAST_R"));   /* diagnostic override */
+		if ((want == 1) || (want == 2) || (want == 4)) R = (uint32_t)want;
+	}
+	tilesz = 64 * R;
 	fr = (struct xe_frun *)malloc((nfast + 1) * sizeof(*fr));
 	ss = (struct xe_set *)malloc((nslow + 1) * sizeof(*ss));
 	sw = (uint32_t *)malloc((nslow + 1) * sizeof(uint32_t));
@@ -727,19 +731,19 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 	if (!rtmpl) goto out;
 	for (i = 0; i < nfast; i++) {
 		rtmpl[i] = fr[i].start;
-		if (i && (rtmpl[i] != rtmpl[i - 1])) work = (work + 63) / 64 * 64;
+		if (i && (rtmpl[i] != rtmpl[i - 1])) work = (work + tilesz - 1) / tilesz * tilesz;
 		if (work + fr[i].nrec > 0xFFFFFF00u) { rc = XE_EUNSUPPORTED; goto out; }
 		fr[i].start = (uint32_t)work;
 		work += fr[i].nrec;
 	}
-	ntiles = (work + 63) / 64;
+	ntiles = (work + tilesz - 1) / tilesz;
 	tfirst = (uint32_t *)malloc((ntiles + 1) * sizeof(uint32_t));
 	ttmpl = (uint32_t *)malloc((ntiles + 1) * sizeof(uint32_t));
 	if (!tfirst || !ttmpl) goto out;
 	{
 		size_t sidx = 0;
 		for (size_t t = 0; t < ntiles; t++) {
-			uint64_t g0 = (uint64_t)t * 64;
+			uint64_t g0 = (uint64_t)t * tilesz;
 			while ((sidx + 1 < nfast) && (fr[sidx + 1].start <= g0)) sidx++;
 			tfirst[t] = (uint32_t)sidx;
 			ttmpl[t] = rtmpl[sidx];
@@ -760,10 +764,9 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 		b->kp.swstart = (const uint32_t *)b->d_swstart;
 		b->kp.nssets = (uint32_t)nslow;
 		b->kp.nslowrec = (uint32_t)slowrec;
-		memcpy(b->kp.fslot, h->fslot, sizeof(h->fslot));
-		memcpy(b->kp.slot_hi, h->slot_hi, sizeof(h->slot_hi));
-		b->kp.nslots = h->nslots;
-		b->kp.nslots_hi = h->nslots_hi;
+		b->kp.fast_r = R;
+		b->kp.fast_dwords = 4 * maxchunk;
+		b->kp.fast_want_dev = (uint32_t)h->want_dev;
 		b->kp.nterms = h->nterms;
 		b->kp.fterms = (const struct xe_fterm *)h->d_fterms;
 		b->kp.fprogs = (const struct xe_fprog *)h->d_fprogs;
@@ -883,23 +886,31 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 	}
 
 	/* decode plans of the fast kernel: per template the micro-ops of its
-	 * known, valid fields with this batch's column addresses */
+	 * known, valid fields with this batch's column addresses, and the
+	 * location of every field for the filter terms */
 	{
 		const struct xe_tmpl *tm = (const struct xe_tmpl *)h->hs.dev_tmpls.p;
 		const struct xe_tent *te = (const struct xe_tent *)h->hs.dev_tents.p;
 		size_t nt = h->hs.dev_tmpls.n, ne = h->hs.dev_tents.n, nops = 0;
 		struct xe_fplan *pl = (struct xe_fplan *)calloc(nt ? nt : 1, sizeof(*pl));
 		struct xe_fop *fo = (struct xe_fop *)calloc(ne ? ne : 1, sizeof(*fo));
-		if (!pl || !fo) { free(pl); free(fo); xe_gpu_batch_free(b); return XE_ENOMEM; }
+		uint32_t *ff = (uint32_t *)calloc((nt ? nt : 1) * XE_NFIELDS, sizeof(uint32_t));
+		if (!pl || !fo || !ff) { free(pl); free(fo); free(ff); xe_gpu_batch_free(b); return XE_ENOMEM; }
 		for (size_t t = 0; t < nt; t++) {
+			uint32_t *fld = ff + t * XE_NFIELDS;
 			pl[t].op_base = (uint32_t)nops;
 			pl[t].nparsed = tm[t].nfields;
-			if (h->fslot[XF_dev_ip] != 0xFF) pl[t].present |= 1ull << h->fslot[XF_dev_ip];
-			if (h->fslot[XF_dev_id] != 0xFF) pl[t].present |= 1ull << h->fslot[XF_dev_id];
+			pl[t].nchunk = ((uint32_t)tm[t].stride + 15) / 16;
+			for (int f = 0; f < XE_NFIELDS; f++) {
+				uint32_t mx = xe_fields[f].size_max;
+				fld[f] = ((mx > 31) ? 31u : mx) << 21;
+			}
+			fld[XF_dev_ip] |= XE_FFLD_PRESENT | XE_FFLD_VIRTUAL;
+			fld[XF_dev_id] |= XE_FFLD_PRESENT | XE_FFLD_VIRTUAL;
 			for (uint32_t j = 0; j < tm[t].nfields; j++) {
 				const struct xe_tent *e = &te[tm[t].ent_base + j];
 				int f = e->field;
-				uint32_t cw, lg = 0, kind, slot, hsl;
+				uint32_t cw, lg = 0, kind;
 				if ((f == XE_F_NONE) || !(e->flags & XE_TE_VALID) || (e->len > 16) || (e->len == 0)
 					|| (b->kp.col_off[f] == ~0ull)) continue;
 				cw = xe_fields[f].col_width;
@@ -909,11 +920,8 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 				if (f == XF_in_bytes) kind |= XE_FOP_BYTES;
 				if (f == XF_in_pkts) kind |= XE_FOP_PKTS;
 				if (xe_fields[f].size_max == 6) kind |= XE_FOP_MAC;
-				slot = h->fslot[f];
-				hsl = (slot != 0xFF) ? h->slot_hi[slot] : 0xFF;
-				if (slot != 0xFF) pl[t].present |= 1ull << slot;
-				fo[nops].w0 = (uint64_t)e->off | ((uint64_t)e->len << 16) | ((uint64_t)kind << 24)
-					| ((uint64_t)slot << 32) | ((uint64_t)hsl << 40);
+				fld[f] = (fld[f] & (31u << 21)) | XE_FFLD_PRESENT | ((uint32_t)e->len << 16) | e->off;
+				fo[nops].w0 = (uint64_t)e->off | ((uint64_t)e->len << 16) | ((uint64_t)kind << 24);
 				fo[nops].w1 = (uint64_t)(uintptr_t)((uint8_t *)b->d_out + b->kp.col_off[f]);
 				nops++;
 			}
@@ -921,11 +929,14 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 		}
 		rc = upload(h, &b->d_fplans, pl, nt * sizeof(*pl));
 		if (rc == XE_OK) rc = upload(h, &b->d_fops, fo, nops * sizeof(*fo));
+		if (rc == XE_OK) rc = upload(h, &b->d_fflds, ff, nt * XE_NFIELDS * sizeof(uint32_t));
 		free(pl);
 		free(fo);
+		free(ff);
 		if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
 		b->kp.fplans = (const struct xe_fplan *)b->d_fplans;
 		b->kp.fops = (const struct xe_fop *)b->d_fops;
+		b->kp.fflds = (const uint32_t *)b->d_fflds;
 	}
 
 	b->kp.progs = (const struct xe_prog *)h->d_progs;

@@ -242,9 +242,15 @@ struct xe_fplan
 {
 	uint32_t op_base, nops;
 	uint32_t nparsed;    /* fields a complete record parses (all of the template's) */
-	uint32_t pad;
-	uint64_t present;    /* operand slots every complete record fills */
+	uint32_t nchunk;     /* 16-byte pieces that cover one record */
 };
+
+/* per template and field (XE_NFIELDS words per template): where the field's
+ * bytes are in the record, for filter operands.
+ * bits 0-15 offset, 16-20 wire length, 21-25 maximum size of the field,
+ * 30 virtual (dev_ip / dev_id: value comes from the exporter), 31 present */
+#define XE_FFLD_VIRTUAL 0x40000000u
+#define XE_FFLD_PRESENT 0x80000000u
 
 /* fast-kernel view of a distinct term */
 struct xe_fterm

@@ -25,7 +25,6 @@ struct xe_dopnd
 	uint64_t mask_hi, mask_lo;
 };
 
-#define XE_MAX_SLOTS 32
 #define XE_MARK_DROPPED 0x80000000u
 #define XE_MARK_HAS 0x40000000u
 
@@ -72,15 +71,15 @@ struct xe_kparams
 	const struct xe_fplan *fplans;  /* per template slot */
 	const struct xe_fop *fops;
 	const struct xe_fprog *fprogs;  /* parallel to progs[0, nmo) */
+	const uint32_t *fflds;       /* [template slot][XE_NFIELDS] XE_FFLD_* words */
 	uint32_t nfruns, ntiles;
+	uint32_t fast_r;             /* records per lane and tile: 1, 2 or 4 */
+	uint32_t fast_dwords;        /* LDS dwords staged per record (largest fast template) */
+	uint32_t fast_want_dev, pad3;/* some program reads dev_ip / dev_id */
 	/* everything else goes through the general kernel */
 	const struct xe_set *ssets;
 	const uint32_t *swstart;
 	uint32_t nssets, nslowrec;
-	/* filter operand slots: the fields some program reads, kept per lane in LDS */
-	uint8_t fslot[XE_NFIELDS];   /* field -> slot, 0xFF = not read by any program */
-	uint8_t slot_hi[XE_MAX_SLOTS]; /* slot -> index of its upper 8 bytes, 0xFF = field <= 8 bytes */
-	uint32_t nslots, nslots_hi;
 	uint32_t nterms;             /* distinct terms */
 	const struct xe_fterm *fterms;  /* parallel to terms[0, nterms) */
 	const struct xe_probe *probes;
@@ -89,6 +88,8 @@ struct xe_kparams
 };
 
 #define XE_MAX_FAST_TERMS 256
+#define XE_FAST_MAX_STRIDE 256       /* longest record the fast kernel stages in LDS */
+#define XE_FAST_LDS_BUDGET (64 * 1024) /* LDS bytes per 256-thread block (2 blocks per CU) */
 #define XE_MAX_PROBES 8
 #define XE_MAX_LDS_COUNTER_MOS 1024
 

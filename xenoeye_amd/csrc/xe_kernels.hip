@@ -565,59 +565,31 @@ xe_nf_general_kernel(const xe_kparams kp)
 
 /* ------------------------------------------------------------------ fast kernel */
 /*
- * One wave = one tile of 64 complete records that share a template, so the
- * walk over the template's fields, over the filter terms and over the object
- * programs is wave-uniform (scalar loads, scalar branches); only packet bytes,
- * field values, IP-list walks and match bits are per lane.  Every record of a
- * tile carries all fields of its template (runs with cut-short records go to
- * the general kernel), so field presence is wave-uniform too.
+ * One wave = one tile of 64 * R complete records that share a template (lane l
+ * owns records l, 64 + l, ... of the tile), so the walk over the template's
+ * fields, over the filter terms and over the object programs is wave-uniform:
+ * scalar loads and scalar branches, paid once per 64 * R records.  Every
+ * record of a tile carries all fields of its template (runs with cut-short
+ * records go to the general kernel), so field presence is wave-uniform too.
  *
- * Per lane state kept in LDS: the value of every field some program reads
- * ("operand slots", laid out [slot][lane] so that lanes hit distinct banks).
- * A block walks tiles grid-stride and stages its per-object counters in LDS;
- * they reach HBM with one atomic per block and counter.
- */
-struct fast_lane
-{
-	uint64_t present;     /* wave-uniform: bit per operand slot the template fills */
-	uint64_t *lo, *hi;    /* LDS: lo[slot * XE_BLOCK + tid], hi[hi_index * XE_BLOCK + tid] */
-	uint32_t tid;
-};
-
-__device__ __forceinline__ void
-slot_get(const xe_kparams &kp, const fast_lane &L, uint32_t field, bool &has, uint64_t &hi, uint64_t &lo)
-{
-	uint32_t s = kp.fslot[field];
-	has = false;
-	hi = lo = 0;
-	if (s == 0xFF) return;
-	has = ((L.present >> s) & 1) != 0;
-	if (has) lo = L.lo[s * XE_BLOCK + L.tid];
-	uint32_t h = kp.slot_hi[s];
-	if ((h != 0xFF) && has) hi = L.hi[h * XE_BLOCK + L.tid];
-}
-
-__device__ __forceinline__ void
-slot_put(const xe_kparams &kp, fast_lane &L, uint32_t field, uint64_t hi, uint64_t lo)
-{
-	uint32_t s = kp.fslot[field];
-	if (s == 0xFF) return;
-	L.lo[s * XE_BLOCK + L.tid] = lo;
-	uint32_t h = kp.slot_hi[s];
-	if (h != 0xFF) L.hi[h * XE_BLOCK + L.tid] = hi;
-}
-
-/*
- * Configuration data (templates, terms, operands, programs, list
- * descriptors, tile tables) is read with wave-uniform indices.  Reading it
- * through constant-address-space pointers makes those loads scalar (s_load,
- * served by the scalar cache) instead of 64-lane vector loads that all fetch
- * the same address; the arrays are never written while a kernel runs.
+ * Phases per tile:
+ *   runs     the runs overlapping the tile are walked with scalar loads; each
+ *            lane keeps packet offset, record index and exporter data of its
+ *            records;
+ *   stage    every lane copies its records into LDS with 16-byte loads that
+ *            are all in flight together (layout [dword][r][lane]: conflict
+ *            free, aligned); everything later reads record bytes from LDS;
+ *   decode   per known template field one 16-byte micro-op: bytes go from LDS
+ *            to the field's column, consecutive lanes = consecutive records;
+ *   classify IP-list walks (R at a time per probe), terms, object programs,
+ *            match masks; counters are staged in LDS per block.
  */
 #define XE_CONST __attribute__((address_space(4)))
+#define XE_GLOBAL __attribute__((address_space(1)))
 typedef const XE_CONST uint32_t *cu32;
 typedef const XE_CONST uint64_t *cu64;
 typedef const XE_CONST uint8_t *cu8;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 /* what one node visit loads: the group's child map + first-child index, and
  * the answer byte of the chunk (same 64-byte line) */
@@ -669,6 +641,82 @@ in_ranges_u(const xe_dopnd *o, uint32_t n, int64_t v)
 	return r;
 }
 
+/* per wave and tile */
+template <int R>
+struct fast_tile
+{
+	const uint32_t *stg;       /* LDS: record dword d of record r of this lane at stg[(d * R + r) * 64] */
+	cu32 fld;                  /* per field of the template: XE_FFLD_* word */
+	uint32_t dev_ip[R], dev_id[R];
+	bool live[R];
+};
+
+/* `len` wire bytes at record offset `off` (both wave-uniform) of the lane's
+ * record r, as little-endian words a[0..3] (bytes beyond len are not cleared) */
+template <int R>
+__device__ __forceinline__ void
+stage_read(const uint32_t *stg, uint32_t r, uint32_t off, uint32_t len, uint32_t a[4])
+{
+	const uint32_t d0 = off >> 2, sh = off & 3;
+	const uint32_t nd = (sh + len + 3) >> 2;
+	const uint32_t *p = stg + (d0 * R + r) * 64;
+	uint32_t w0 = p[0], w1 = 0, w2 = 0, w3 = 0, w4 = 0;
+
+	if (nd > 1) w1 = p[R * 64];
+	if (nd > 2) {
+		w2 = p[2 * R * 64];
+		if (nd > 3) w3 = p[3 * R * 64];
+		if (nd > 4) w4 = p[4 * R * 64];
+	}
+	if (sh) {
+		a[0] = __builtin_amdgcn_alignbyte(w1, w0, sh);
+		a[1] = __builtin_amdgcn_alignbyte(w2, w1, sh);
+		a[2] = __builtin_amdgcn_alignbyte(w3, w2, sh);
+		a[3] = __builtin_amdgcn_alignbyte(w4, w3, sh);
+	} else {
+		a[0] = w0; a[1] = w1; a[2] = w2; a[3] = w3;
+	}
+}
+
+/* little-endian wire words -> the value as a big-endian number */
+__device__ __forceinline__ void
+wire_number(const uint32_t a[4], uint32_t len, uint64_t &hi, uint64_t &lo)
+{
+	hi = 0;
+	if (len <= 4) {
+		lo = __builtin_bswap32(a[0]) >> (8 * (4 - len));
+	} else if (len <= 8) {
+		lo = __builtin_bswap64((uint64_t)a[0] | ((uint64_t)a[1] << 32)) >> (8 * (8 - len));
+	} else {
+		const uint64_t A = __builtin_bswap64((uint64_t)a[0] | ((uint64_t)a[1] << 32));
+		const uint64_t B = __builtin_bswap64((uint64_t)a[2] | ((uint64_t)a[3] << 32));
+		const uint32_t sh = 8 * (16 - len);
+		lo = sh ? ((B >> sh) | (A << (64 - sh))) : B;
+		hi = A >> sh;
+	}
+}
+
+/* presence and value of a field of the lane's record r, as the filter terms
+ * see it (flow_info bytes read as a big-endian number) */
+template <int R>
+__device__ __forceinline__ void
+fld_get(const fast_tile<R> &T, uint32_t field, uint32_t r, bool &has, uint32_t &fmax, uint64_t &hi, uint64_t &lo)
+{
+	const uint32_t fe = T.fld[field];
+	has = (fe >> 31) != 0;
+	fmax = (fe >> 21) & 31;
+	hi = lo = 0;
+	if (!has) return;
+	if (fe & XE_FFLD_VIRTUAL) {
+		lo = (field == XF_dev_ip) ? T.dev_ip[r] : T.dev_id[r];
+		return;
+	}
+	uint32_t a[4];
+	const uint32_t len = (fe >> 16) & 31;
+	stage_read<R>(T.stg, r, fe & 0xFFFF, len, a);
+	wire_number(a, len, hi, lo);
+}
+
 /* address chunk `lvl` levels below the 16-bit root */
 __device__ __forceinline__ uint32_t
 addr_chunk(uint32_t family, uint32_t lvl, uint32_t a4, uint64_t hi, uint64_t lo)
@@ -680,88 +728,84 @@ addr_chunk(uint32_t family, uint32_t lvl, uint32_t a4, uint64_t hi, uint64_t lo)
 
 /*
  * All IP-list membership tests of a tile.  Per probe (one field against one
- * group of up to 8 lists) ONE walk of the group's merged tables: a 4-byte root
- * gather, then one node visit (one 64-byte line) per further address byte
- * while any list of the group can still go deeper.  Probes are walked two at
- * a time so that their dependent gathers overlap.  Bit (8 * probe + l) of the
- * result = list l of the probe's group matched.
+ * group of up to 8 lists) ONE walk of the group's merged tables per record: a
+ * 4-byte root gather, then one node visit (one 64-byte line) per further
+ * address byte while any list of the group can still go deeper.  The R records
+ * of a lane walk together so that their dependent gathers overlap.  Bit
+ * (8 * probe + l) of lk[r] = list l of the probe's group matched.
  */
-struct probe_s { uint32_t root, nodes, family, used, a4, e; uint64_t hi, lo; };
-
-__device__ __forceinline__ bool
-probe_open(const xe_kparams &kp, const fast_lane &L, uint32_t pr, bool live, probe_s &P)
+template <int R>
+__device__ void
+fast_lookups(const xe_kparams &kp, const fast_tile<R> &T, uint64_t lk[R])
 {
-	cu32 q = (cu32)(kp.probes + pr);
-	const uint32_t w1 = q[1];
-	bool has;
+#pragma unroll
+	for (int r = 0; r < R; r++) lk[r] = 0;
 
-	P.root = q[0];
-	P.nodes = q[3];
-	P.family = w1 & 0xFF;
-	P.used = w1 >> 24;
-	slot_get(kp, L, (w1 >> 8) & 0xFF, has, P.hi, P.lo);
-	if (!P.root || !has) return false;
-	P.a4 = ((w1 >> 16) & 1) ? (uint32_t)(P.hi >> 32) : (uint32_t)P.lo;
-	P.e = XE_TRIE_TERM;
-	if (live) {
-		const uint32_t top = (P.family == 6) ? (uint32_t)(P.hi >> 48) : (P.a4 >> 16);
-		P.e = ((const XE_CONST uint32_t *)(kp.trie + P.root))[top];
-	}
-	return true;
-}
+	for (uint32_t pr = 0; pr < kp.nprobes; pr++) {
+		cu32 q = (cu32)(kp.probes + pr);
+		const uint32_t root = q[0], w1 = q[1], nodes = q[3];
+		const uint32_t family = w1 & 0xFF, field = (w1 >> 8) & 0xFF, wide4 = (w1 >> 16) & 1, used = w1 >> 24;
+		const uint32_t nlvl = (family == 4) ? 2u : 14u;
+		uint32_t e[R], a4[R];
+		uint64_t hi[R], lo[R];
 
-__device__ uint64_t
-fast_lookups(const xe_kparams &kp, const fast_lane &L, bool live)
-{
-	uint64_t bits = 0;
-	uint32_t pr = 0;
-
-	while (pr < kp.nprobes) {
-		probe_s A, B;
-		uint32_t ia = 0, ib = 0;
-		bool okA = false, okB = false;
-
-		/* next two probes whose field the template carries */
-		for (; (pr < kp.nprobes) && !okA; pr++) { okA = probe_open(kp, L, pr, live, A); ia = pr; }
-		for (; (pr < kp.nprobes) && !okB; pr++) { okB = probe_open(kp, L, pr, live, B); ib = pr; }
-		if (!okA) break;
-		if (!okB) { B = A; B.e = XE_TRIE_TERM; }
-
-		for (uint32_t lvl = 0; lvl < 14; lvl++) {
-			const bool wa = !(A.e & XE_TRIE_TERM) && (lvl < ((A.family == 4) ? 2u : 14u));
-			const bool wb = !(B.e & XE_TRIE_TERM) && (lvl < ((B.family == 4) ? 2u : 14u));
-			const bool anyA = __ballot(wa) != 0, anyB = __ballot(wb) != 0;
-			if (!anyA && !anyB) break;
-			/* lanes that are done re-read node 0 of the table: one shared line */
-			const uint32_t ca = wa ? addr_chunk(A.family, lvl, A.a4, A.hi, A.lo) : 0;
-			const uint32_t cb = wb ? addr_chunk(B.family, lvl, B.a4, B.hi, B.lo) : 0;
-			node_ld ra = {0, 0}, rb = {0, 0};
-			if (anyA) ra = node_fetch(kp.trie + A.nodes, wa ? A.e : 0, ca);
-			if (anyB) rb = node_fetch(kp.trie + B.nodes, wb ? B.e : 0, cb);
-			if (wa) A.e = node_next(ra, ca);
-			if (wb) B.e = node_next(rb, cb);
+		if (!root || !(T.fld[field] >> 31)) continue;
+#pragma unroll
+		for (int r = 0; r < R; r++) {
+			bool has;
+			uint32_t fmax;
+			fld_get<R>(T, field, r, has, fmax, hi[r], lo[r]);
+			a4[r] = wide4 ? (uint32_t)(hi[r] >> 32) : (uint32_t)lo[r];
+			e[r] = XE_TRIE_TERM;
+			if (T.live[r]) {
+				const uint32_t top = (family == 6) ? (uint32_t)(hi[r] >> 48) : (a4[r] >> 16);
+				e[r] = ((const XE_CONST uint32_t *)(kp.trie + root))[top];
+			}
 		}
-		bits |= (uint64_t)(((A.e & XE_TRIE_TERM) ? A.e : 0u) & A.used & 0xFFu) << (ia * XE_LIST_GROUP);
-		if (okB) bits |= (uint64_t)(((B.e & XE_TRIE_TERM) ? B.e : 0u) & B.used & 0xFFu) << (ib * XE_LIST_GROUP);
+		for (uint32_t lvl = 0; lvl < nlvl; lvl++) {
+			bool walk[R], any = false;
+			uint32_t c[R];
+			node_ld nl[R];
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				walk[r] = !(e[r] & XE_TRIE_TERM);
+				any |= walk[r];
+			}
+			if (!__ballot(any)) break;
+			/* lanes that are done re-read node 0 of the table: one shared line */
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				c[r] = walk[r] ? addr_chunk(family, lvl, a4[r], hi[r], lo[r]) : 0;
+				nl[r] = node_fetch(kp.trie + nodes, walk[r] ? e[r] : 0, c[r]);
+			}
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				if (walk[r]) e[r] = node_next(nl[r], c[r]);
+			}
+		}
+#pragma unroll
+		for (int r = 0; r < R; r++) {
+			lk[r] |= (uint64_t)(((e[r] & XE_TRIE_TERM) ? e[r] : 0u) & used & 0xFFu) << (pr * XE_LIST_GROUP);
+		}
 	}
-	return bits;
 }
 
-/* one distinct term for all lanes; same semantics as term_match(), with the
+/* one term for record r of all lanes; same semantics as term_match(), with the
  * list memberships taken from fast_lookups() */
+template <int R>
 __device__ bool
-fast_term(const xe_kparams &kp, const fast_lane &L, const term_s &t, uint64_t lkbits)
+fast_term(const xe_kparams &kp, const fast_tile<R> &T, const term_s &t, uint32_t r, uint64_t lkbits)
 {
 	const xe_dopnd *o = t.o;
 	bool has;
+	uint32_t fmax;
 	uint64_t hi, lo;
 
 	if (t.func != XE_FN_NONE) {
-		uint32_t sa = c_fmax[t.fa], sb = c_fmax[t.fb];
-		slot_get(kp, L, t.fa, has, hi, lo);
-		uint64_t a = ((sa == 1) || (sa == 2) || (sa == 4) || (sa == 8)) ? lo : 0;
-		slot_get(kp, L, t.fb, has, hi, lo);
-		uint64_t b = ((sb == 1) || (sb == 2) || (sb == 4) || (sb == 8)) ? lo : 0;
+		fld_get<R>(T, t.fa, r, has, fmax, hi, lo);
+		uint64_t a = ((fmax == 1) || (fmax == 2) || (fmax == 4) || (fmax == 8)) ? lo : 0;
+		fld_get<R>(T, t.fb, r, has, fmax, hi, lo);
+		uint64_t b = ((fmax == 1) || (fmax == 2) || (fmax == 4) || (fmax == 8)) ? lo : 0;
 		if (t.func == XE_FN_MIN) return in_ranges_u(o, t.nopnd, (int64_t)((a < b) ? a : b));
 		int32_t q = 0;
 		if (b != 0) {
@@ -776,17 +820,17 @@ fast_term(const xe_kparams &kp, const fast_lane &L, const term_s &t, uint64_t lk
 	for (uint32_t side = XE_DIR_SRC; side <= XE_DIR_DST; side <<= 1) {
 		if (!(t.dir & side)) continue;
 		uint32_t f = (side == XE_DIR_SRC) ? t.fsrc : t.fdst;
-		slot_get(kp, L, f, has, hi, lo);
+		fld_get<R>(T, f, r, has, fmax, hi, lo);
 		if (((t.type == XE_BT_ADDR4) || (t.type == XE_BT_ADDR6)) && !has) continue;
 		switch (t.type) {
 			case XE_BT_ADDR4: {
-				uint32_t a = (c_fmax[f] == 16) ? (uint32_t)(hi >> 32) : (uint32_t)lo;
+				uint32_t a = (fmax == 16) ? (uint32_t)(hi >> 32) : (uint32_t)lo;
 				for (uint32_t i = 0; i < t.nopnd; i++) {
 					cu32 q = (cu32)(o + i);
-					cu64 r = (cu64)(o + i);
+					cu64 w = (cu64)(o + i);
 					bool m;
 					if (q[0]) m = ((lkbits >> q[(side == XE_DIR_SRC) ? 2 : 3]) & 1) != 0;
-					else m = (a & (uint32_t)r[5]) == (uint32_t)r[3];
+					else m = (a & (uint32_t)w[5]) == (uint32_t)w[3];
 					res |= m;
 				}
 				break;
@@ -794,17 +838,17 @@ fast_term(const xe_kparams &kp, const fast_lane &L, const term_s &t, uint64_t lk
 			case XE_BT_ADDR6:
 				for (uint32_t i = 0; i < t.nopnd; i++) {
 					cu32 q = (cu32)(o + i);
-					cu64 r = (cu64)(o + i);
+					cu64 w = (cu64)(o + i);
 					bool m;
 					if (q[0]) m = ((lkbits >> q[(side == XE_DIR_SRC) ? 2 : 3]) & 1) != 0;
-					else m = ((hi & r[4]) == r[2]) && ((lo & r[5]) == r[3]);
+					else m = ((hi & w[4]) == w[2]) && ((lo & w[5]) == w[3]);
 					res |= m;
 				}
 				break;
 			case XE_BT_RANGE: {
 				/* absent fields compare as 0; only 1/2/4-byte fields carry a value */
-				int32_t r = (c_fmax[f] <= 4) ? (int32_t)(uint32_t)lo : 0;
-				res |= in_ranges_u(o, t.nopnd, r);
+				int32_t v = (fmax <= 4) ? (int32_t)(uint32_t)lo : 0;
+				res |= in_ranges_u(o, t.nopnd, v);
 				break;
 			}
 			case XE_BT_MAC:
@@ -817,43 +861,41 @@ fast_term(const xe_kparams &kp, const fast_lane &L, const term_s &t, uint64_t lk
 	return res;
 }
 
-/* `hit` lanes add their octets and packets to object m's counters: few hits
+/* `hit` lanes add their octets and packets to an object's counters: few hits
  * go one by one (same-address atomics serialise, but there are few), many go
  * through a wave reduction first */
 __device__ __forceinline__ void
-count_hits(unsigned long long *dst, bool hit, unsigned long long ball, uint32_t lane,
+count_hits(unsigned long long *dst, bool hit, uint32_t n, uint32_t lane,
 	unsigned long long bxr, unsigned long long pxr)
 {
-	const uint32_t n = (uint32_t)__popcll(ball);
 	if (n <= 6) {
 		if (hit) {
 			atomicAdd(dst + 1, bxr);
 			atomicAdd(dst + 2, pxr);
 		}
-		if (lane == 0) atomicAdd(dst + 0, (unsigned long long)n);
 	} else {
 		unsigned long long sb = wave_sum(hit ? bxr : 0ull);
 		unsigned long long sp = wave_sum(hit ? pxr : 0ull);
 		if (lane == 0) {
-			atomicAdd(dst + 0, (unsigned long long)n);
 			atomicAdd(dst + 1, sb);
 			atomicAdd(dst + 2, sp);
 		}
 	}
+	if (lane == 0) atomicAdd(dst + 0, (unsigned long long)n);
 }
 
+template <int R>
 __global__ void __launch_bounds__(XE_BLOCK)
 xe_nf_fast_kernel(const xe_kparams kp)
 {
-	extern __shared__ uint64_t lds[];
-	fast_lane L;
+	extern __shared__ uint32_t lds32[];
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	unsigned long long *lcnt = (unsigned long long *)(lds + (size_t)(kp.nslots + kp.nslots_hi) * XE_BLOCK);
-	const bool want_dev = (kp.fslot[XF_dev_ip] != 0xFF) || (kp.fslot[XF_dev_id] != 0xFF);
+	/* staging: kp.fast_dwords dwords per record, [wave][dword][r][lane] */
+	uint32_t *stg = lds32 + (size_t)wave * kp.fast_dwords * R * 64 + lane;
+	unsigned long long *lcnt = (unsigned long long *)(lds32 + (size_t)(XE_BLOCK / 64) * kp.fast_dwords * R * 64);
+	const bool want_dev = kp.fast_want_dev != 0;
+	const XE_GLOBAL uint8_t *pkt = (const XE_GLOBAL uint8_t *)kp.pkt;
 
-	L.tid = threadIdx.x;
-	L.lo = lds;
-	L.hi = lds + (size_t)kp.nslots * XE_BLOCK;
 	if (kp.lds_counters) {
 		for (uint32_t i = threadIdx.x; i < kp.nmo * 3; i += XE_BLOCK) lcnt[i] = 0;
 		__syncthreads();
@@ -863,199 +905,228 @@ xe_nf_fast_kernel(const xe_kparams kp)
 	for (uint32_t tile = wave0; tile < kp.ntiles; tile += gridDim.x * (XE_BLOCK / 64)) {
 		const uint32_t tmpl = ((cu32)kp.tile_tmpl)[tile];
 		cu32 PL = (cu32)(kp.fplans + tmpl);
-		const uint32_t op_base = PL[0], nops = PL[1], nparsed = PL[2];
-		L.present = ((cu64)PL)[2];
+		const uint32_t op_base = PL[0], nops = PL[1], nparsed = PL[2], nchunk = PL[3];
+		const uint32_t tbase = tile * (64 * R);
+		fast_tile<R> T;
+		uint32_t voff[R], ridx[R], rate[R];
 
-		/* which run, which record: the runs that overlap the tile are walked
-		 * with scalar loads, each lane keeps the one it falls into */
-		const uint32_t g = tile * 64 + lane;
-		bool live = false;
-		uint32_t voff = 0, ridx = 0, rate = 0, dev_ip = 0, dev_id = 0;
+		T.stg = stg;
+		T.fld = (cu32)(kp.fflds + (size_t)tmpl * XE_NFIELDS);
+#pragma unroll
+		for (int r = 0; r < R; r++) {
+			T.live[r] = false;
+			voff[r] = ridx[r] = rate[r] = 0;
+			T.dev_ip[r] = T.dev_id[r] = 0;
+		}
+
+		/* which run, which record */
 		for (uint32_t s = ((cu32)kp.tile_first)[tile]; s < kp.nfruns; s++) {
-			cu32 R = (cu32)(kp.fruns + s);
-			const uint32_t start = R[2];
-			if (start >= tile * 64 + 64) break;
-			const uint32_t i = g - start;
-			const bool in = (g >= start) && (i < R[3]);
-			voff = in ? (R[0] + i * R[4]) : voff;
-			ridx = in ? (R[1] + i) : ridx;
-			rate = in ? R[5] : rate;
-			if (want_dev) {
-				dev_ip = in ? R[6] : dev_ip;
-				dev_id = in ? R[7] : dev_id;
+			cu32 RN = (cu32)(kp.fruns + s);
+			const uint32_t start = RN[2], nrec = RN[3];
+			if (start >= tbase + 64 * R) break;
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				const uint32_t sub0 = tbase + 64 * r;
+				if ((start + nrec <= sub0) || (start >= sub0 + 64)) continue;
+				const uint32_t g = sub0 + lane, i = g - start;
+				const bool in = (g >= start) && (i < nrec);
+				voff[r] = in ? (RN[0] + i * RN[4]) : voff[r];
+				ridx[r] = in ? (RN[1] + i) : ridx[r];
+				rate[r] = in ? RN[5] : rate[r];
+				if (want_dev) {
+					T.dev_ip[r] = in ? RN[6] : T.dev_ip[r];
+					T.dev_id[r] = in ? RN[7] : T.dev_id[r];
+				}
+				T.live[r] |= in;
 			}
-			live |= in;
 		}
 
-		/* decode: one micro-op per known field of the template (16 bytes,
-		 * one scalar load): copy the wire bytes into the field's column,
-		 * keep the value where a filter or a counter needs it */
-		uint64_t bytes = 0, pkts = 0;
-		if (live) {
-			for (uint32_t j = 0; j < nops; j++) {
-				cu64 xq = (cu64)(kp.fops + op_base + j);
-				const uint64_t w0 = xq[0];
-				const uint32_t off = (uint32_t)w0 & 0xFFFF, len = (uint32_t)(w0 >> 16) & 0xFF;
-				const uint32_t kind = (uint32_t)(w0 >> 24) & 0xFF, slot = (uint32_t)(w0 >> 32) & 0xFF;
-				const uint32_t hsl = (uint32_t)(w0 >> 40) & 0xFF;
-				const uint32_t lg = kind & XE_FOP_LGW;
-				uint8_t *col = (uint8_t *)xq[1];
-				/* packet bytes are read-only: constant-address-space loads may be
-				 * scheduled across the column stores */
-				const XE_CONST uint8_t *src = (const XE_CONST uint8_t *)(kp.pkt + off) + voff;
-				const bool need_val = (slot != 0xFF) || (kind & (XE_FOP_BYTES | XE_FOP_PKTS));
+		/* stage the records: all 16-byte loads of a lane are independent */
+		for (uint32_t k = 0; k < nchunk; k++) {
+			u32x4 q[R];
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				q[r] = (u32x4){0, 0, 0, 0};
+				if (T.live[r]) __builtin_memcpy(&q[r], (const uint8_t *)pkt + voff[r] + 16 * k, 16);
+			}
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				uint32_t *d = stg + ((4 * k) * R + r) * 64;
+				d[0] = q[r].x;
+				d[R * 64] = q[r].y;
+				d[2 * R * 64] = q[r].z;
+				d[3 * R * 64] = q[r].w;
+			}
+		}
 
-				if ((kind & XE_FOP_COPY) && !need_val) {
-					/* column bytes = wire bytes */
-					if (lg == 0) {
-						col[ridx] = *src;
-					} else if (lg == 1) {
-						uint16_t v;
-						__builtin_memcpy(&v, src, 2);
-						((uint16_t *)col)[ridx] = v;
-					} else if (lg == 2) {
-						uint32_t v;
-						__builtin_memcpy(&v, src, 4);
-						((uint32_t *)col)[ridx] = v;
-					} else if (lg == 3) {
-						uint64_t v;
-						__builtin_memcpy(&v, src, 8);
-						((uint64_t *)col)[ridx] = v;
-					} else {
-						uint64_t a, b;
-						__builtin_memcpy(&a, src, 8);
-						__builtin_memcpy(&b, src + 8, 8);
-						((uint64_t *)col)[2 * (size_t)ridx] = a;
-						((uint64_t *)col)[2 * (size_t)ridx + 1] = b;
-					}
-					continue;
-				}
-				/* the value as a big-endian number, right-aligned */
-				uint64_t hi = 0, lo;
-				if (len <= 4) {
-					uint32_t raw;
-					__builtin_memcpy(&raw, src, 4);
-					lo = __builtin_bswap32(raw) >> (8 * (4 - len));
-				} else if (len <= 8) {
-					uint64_t raw;
-					__builtin_memcpy(&raw, src, 8);
-					lo = __builtin_bswap64(raw) >> (8 * (8 - len));
+		/* decode: one micro-op per known field of the template */
+		uint64_t bytes[R], pkts[R];
+#pragma unroll
+		for (int r = 0; r < R; r++) bytes[r] = pkts[r] = 0;
+		for (uint32_t j = 0; j < nops; j++) {
+			cu64 xq = (cu64)(kp.fops + op_base + j);
+			const uint64_t w0 = xq[0];
+			const uint32_t off = (uint32_t)w0 & 0xFFFF, len = (uint32_t)(w0 >> 16) & 0xFF;
+			const uint32_t kind = (uint32_t)(w0 >> 24) & 0xFF;
+			const uint32_t lg = kind & XE_FOP_LGW;
+			XE_GLOBAL uint8_t *col = (XE_GLOBAL uint8_t *)xq[1];
+			const uint32_t pad = (kind & (XE_FOP_COPY | XE_FOP_MAC)) ? 0 : (8 * ((1u << lg) - len));
+
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				uint32_t a[4];
+				stage_read<R>(stg, r, off, len, a);
+				if (!T.live[r]) continue;
+				/* column bytes = the field as the reference stores it: the wire
+				 * bytes right-aligned in the field's maximum size */
+				if (lg <= 2) {
+					uint32_t v = a[0];
+					if (!(kind & XE_FOP_COPY)) v = (v & (0xFFFFFFFFu >> (32 - 8 * len))) << pad;
+					if (lg == 0) col[ridx[r]] = (uint8_t)v;
+					else if (lg == 1) ((XE_GLOBAL uint16_t *)col)[ridx[r]] = (uint16_t)v;
+					else ((XE_GLOBAL uint32_t *)col)[ridx[r]] = v;
+				} else if (lg == 3) {
+					uint64_t v = (uint64_t)a[0] | ((uint64_t)a[1] << 32);
+					if (!(kind & XE_FOP_COPY)) v = (v & (~0ull >> (64 - 8 * len))) << pad;
+					((XE_GLOBAL uint64_t *)col)[ridx[r]] = v;
 				} else {
-					uint64_t a, b;
-					__builtin_memcpy(&a, src, 8);
-					__builtin_memcpy(&b, src + 8, 8);
-					a = __builtin_bswap64(a);
-					b = __builtin_bswap64(b);
-					const uint32_t sh = 8 * (16 - len);
-					lo = sh ? ((b >> sh) | (a << (64 - sh))) : b;
-					hi = a >> sh;
+					uint64_t v0 = (uint64_t)a[0] | ((uint64_t)a[1] << 32);
+					uint64_t v1 = (uint64_t)a[2] | ((uint64_t)a[3] << 32);
+					if (!(kind & XE_FOP_COPY)) {
+						/* len < 16: shift the 128-bit little-endian value up by pad bits */
+						if (len <= 8) { v1 = 0; v0 &= ~0ull >> (64 - 8 * len); }
+						else v1 &= ~0ull >> (128 - 8 * len);
+						if (pad >= 64) { v1 = v0 << (pad - 64); v0 = 0; }
+						else if (pad) { v1 = (v1 << pad) | (v0 >> (64 - pad)); v0 <<= pad; }
+					}
+					((XE_GLOBAL uint64_t *)col)[2 * (size_t)ridx[r]] = v0;
+					((XE_GLOBAL uint64_t *)col)[2 * (size_t)ridx[r] + 1] = v1;
 				}
-				/* column bytes = the field as the reference stores it: value
-				 * right-aligned in its maximum size, big-endian */
-				if (lg == 0) col[ridx] = (uint8_t)lo;
-				else if (lg == 1) ((uint16_t *)col)[ridx] = __builtin_bswap16((uint16_t)lo);
-				else if (lg == 2) ((uint32_t *)col)[ridx] = __builtin_bswap32((uint32_t)lo);
-				else if (lg == 3) ((uint64_t *)col)[ridx] = __builtin_bswap64(lo << ((kind & XE_FOP_MAC) ? 16 : 0));
-				else {
-					((uint64_t *)col)[2 * (size_t)ridx] = __builtin_bswap64(hi);
-					((uint64_t *)col)[2 * (size_t)ridx + 1] = __builtin_bswap64(lo);
+				if (kind & (XE_FOP_BYTES | XE_FOP_PKTS)) {
+					uint64_t hi, lo;
+					wire_number(a, len, hi, lo);
+					if (kind & XE_FOP_BYTES) bytes[r] = lo;
+					if (kind & XE_FOP_PKTS) pkts[r] = lo;
 				}
-				if (slot != 0xFF) {
-					L.lo[slot * XE_BLOCK + L.tid] = lo;
-					if (hsl != 0xFF) L.hi[hsl * XE_BLOCK + L.tid] = hi;
-				}
-				if (kind & XE_FOP_BYTES) bytes = lo;
-				if (kind & XE_FOP_PKTS) pkts = lo;
-			}
-			kp.nparsed[ridx] = (uint8_t)nparsed;
-			if (kp.marks) kp.marks[ridx] = 0;
-			/* virtual fields (netflow.c:112-124) */
-			if (want_dev) {
-				slot_put(kp, L, XF_dev_ip, 0, dev_ip);
-				slot_put(kp, L, XF_dev_id, 0, dev_id);
 			}
 		}
-		const unsigned long long bxr = bytes * rate, pxr = pkts * rate;
+		unsigned long long bxr[R], pxr[R];
+#pragma unroll
+		for (int r = 0; r < R; r++) {
+			if (T.live[r]) {
+				((XE_GLOBAL uint8_t *)kp.nparsed)[ridx[r]] = (uint8_t)nparsed;
+				if (kp.marks) ((XE_GLOBAL uint32_t *)kp.marks)[ridx[r]] = 0;
+			}
+			bxr[r] = bytes[r] * rate[r];
+			pxr[r] = pkts[r] * rate[r];
+		}
 
 		/* every IP-list membership, then every term some program needs, once */
-		const uint64_t lkbits = (kp.pad2 & 1) ? 0 : fast_lookups(kp, L, live);
-		uint64_t tb0 = 0, tb1 = 0, tb2 = 0, tb3 = 0;
+		uint64_t lk[R];
+		if (kp.pad2 & 1) {
+#pragma unroll
+			for (int r = 0; r < R; r++) lk[r] = 0;
+		} else {
+			fast_lookups<R>(kp, T, lk);
+		}
+		uint64_t tb[R][4];
+#pragma unroll
+		for (int r = 0; r < R; r++) tb[r][0] = tb[r][1] = tb[r][2] = tb[r][3] = 0;
 		for (uint32_t t = 0; (t < kp.nterms) && !(kp.pad2 & 2); t++) {
 			cu64 fq = (cu64)(kp.fterms + t);
 			const uint64_t fkind = fq[0];
-			bool r;
 			if (!(fkind & 2)) continue;
-			if (fkind & 1) {
-				/* all operands are IP lists: a mask over the lookup bits */
-				r = (lkbits & fq[1]) != 0;
-			} else {
-				const term_s tm = ld_term(kp, t);
-				r = fast_term(kp, L, tm, lkbits);
-			}
-			uint64_t bit = (uint64_t)(live && r) << (t & 63);
-			switch (t >> 6) {
-				case 0: tb0 |= bit; break;
-				case 1: tb1 |= bit; break;
-				case 2: tb2 |= bit; break;
-				default: tb3 |= bit; break;
+			const term_s tm = ld_term(kp, t);
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				bool res;
+				/* all operands IP lists: a mask over the lookup bits */
+				if (fkind & 1) res = (lk[r] & fq[1]) != 0;
+				else res = fast_term<R>(kp, T, tm, r, lk[r]);
+				const uint64_t bit = (uint64_t)(T.live[r] && res) << (t & 63);
+				switch (t >> 6) {
+					case 0: tb[r][0] |= bit; break;
+					case 1: tb[r][1] |= bit; break;
+					case 2: tb[r][2] |= bit; break;
+					default: tb[r][3] |= bit; break;
+				}
 			}
 		}
 
 		/* object programs */
 		for (uint32_t w = 0; (w < kp.mask_words) && !(kp.pad2 & 8); w++) {
-			uint64_t bits = 0;
-			uint32_t m0 = w * 64, m1 = (m0 + 64 < kp.nmo) ? m0 + 64 : kp.nmo;
+			uint64_t bits[R];
+			const uint32_t m0 = w * 64, m1 = (m0 + 64 < kp.nmo) ? m0 + 64 : kp.nmo;
+#pragma unroll
+			for (int r = 0; r < R; r++) bits[r] = 0;
 			for (uint32_t m = m0; m < m1; m++) {
 				cu64 FP = (cu64)(kp.fprogs + m);
 				const uint64_t fmask = FP[0], fw = FP[1];
 				const uint32_t fkind = (uint32_t)fw, fterm = (uint32_t)(fw >> 32);
 				cu32 PQ = (cu32)(kp.progs + m);
 				const int32_t parent = (int32_t)PQ[2];
-				bool hit;
-				if (fkind == XE_FPROG_MASK) {
-					hit = (lkbits & fmask) != 0;
-				} else if (fkind == XE_FPROG_TERM) {
-					const uint32_t wsel = fterm >> 6;
-					const uint64_t word = (wsel == 0) ? tb0 : (wsel == 1) ? tb1 : (wsel == 2) ? tb2 : tb3;
-					hit = ((word >> (fterm & 63)) & 1) != 0;
-				} else if (fkind == XE_FPROG_CONST) {
-					hit = (PQ[3] >> 16) != 0;
-				} else {
-					const uint32_t pbase = PQ[0], pn = PQ[1];
-					uint64_t st = 0;
-					for (uint32_t k = 0; k < pn; k++) {
-						uint32_t op = ((cu32)kp.ops)[pbase + k];
-						uint32_t code = op & 3;
-						if (code == XE_OP_BASIC) {
-							uint32_t id = op >> 2, wsel = id >> 6;
-							uint64_t word = (wsel == 0) ? tb0 : (wsel == 1) ? tb1 : (wsel == 2) ? tb2 : tb3;
-							st = (st << 1) | ((word >> (id & 63)) & 1);
-						} else if (code == XE_OP_NOT) {
-							st ^= 1;
-						} else {
-							uint64_t top = st & 1;
-							st >>= 1;
-							if (code == XE_OP_AND) st &= (top | ~1ull);
-							else st |= top;
+				bool hit[R];
+				uint32_t nhit = 0;
+#pragma unroll
+				for (int r = 0; r < R; r++) {
+					bool h;
+					if (fkind == XE_FPROG_MASK) {
+						h = (lk[r] & fmask) != 0;
+					} else if (fkind == XE_FPROG_TERM) {
+						const uint32_t wsel = fterm >> 6;
+						const uint64_t word = (wsel == 0) ? tb[r][0] : (wsel == 1) ? tb[r][1] : (wsel == 2) ? tb[r][2] : tb[r][3];
+						h = ((word >> (fterm & 63)) & 1) != 0;
+					} else if (fkind == XE_FPROG_CONST) {
+						h = (PQ[3] >> 16) != 0;
+					} else {
+						const uint32_t pbase = PQ[0], pn = PQ[1];
+						uint64_t st = 0;
+						for (uint32_t k = 0; k < pn; k++) {
+							uint32_t op = ((cu32)kp.ops)[pbase + k];
+							uint32_t code = op & 3;
+							if (code == XE_OP_BASIC) {
+								uint32_t id = op >> 2, wsel = id >> 6;
+								uint64_t word = (wsel == 0) ? tb[r][0] : (wsel == 1) ? tb[r][1] : (wsel == 2) ? tb[r][2] : tb[r][3];
+								st = (st << 1) | ((word >> (id & 63)) & 1);
+							} else if (code == XE_OP_NOT) {
+								st ^= 1;
+							} else {
+								uint64_t top = st & 1;
+								st >>= 1;
+								if (code == XE_OP_AND) st &= (top | ~1ull);
+								else st |= top;
+							}
 						}
+						h = (st & 1) != 0;
 					}
-					hit = (st & 1) != 0;
+					h = h && T.live[r];
+					if (parent >= 0) {
+						const uint32_t par = (uint32_t)parent;
+						bool pok;
+						if (par >= m0) pok = ((bits[r] >> (par - m0)) & 1) != 0;
+						else pok = T.live[r] && (((kp.masks[(size_t)ridx[r] * kp.mask_words + (par >> 6)] >> (par & 63)) & 1) != 0);
+						h = h && pok;
+					}
+					if (h) bits[r] |= 1ull << (m - m0);
+					hit[r] = h;
+					nhit += (uint32_t)__popcll(__ballot(h));
 				}
-				hit = hit && live;
-				if (parent >= 0) {
-					uint32_t par = (uint32_t)parent;
-					bool pok;
-					if (par >= m0) pok = ((bits >> (par - m0)) & 1) != 0;
-					else pok = live && (((kp.masks[(size_t)ridx * kp.mask_words + (par >> 6)] >> (par & 63)) & 1) != 0);
-					hit = hit && pok;
-				}
-				if (hit) bits |= 1ull << (m - m0);
-				const unsigned long long ball = (kp.pad2 & 4) ? 0 : __ballot(hit);
-				if (ball) {
-					count_hits(kp.lds_counters ? (lcnt + 3 * m) : (kp.counters + 3 * m), hit, ball, lane, bxr, pxr);
+				if (nhit && !(kp.pad2 & 4)) {
+					unsigned long long sb = 0, sp = 0;
+					bool anyhit = false;
+#pragma unroll
+					for (int r = 0; r < R; r++) {
+						sb += hit[r] ? bxr[r] : 0ull;
+						sp += hit[r] ? pxr[r] : 0ull;
+						anyhit |= hit[r];
+					}
+					count_hits(kp.lds_counters ? (lcnt + 3 * m) : (kp.counters + 3 * m), anyhit, nhit, lane, sb, sp);
 				}
 			}
-			if (live) kp.masks[(size_t)ridx * kp.mask_words + w] = bits;
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				if (T.live[r]) ((XE_GLOBAL uint64_t *)kp.masks)[(size_t)ridx[r] * kp.mask_words + w] = bits[r];
+			}
 		}
 	}
 
@@ -1427,11 +1498,13 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 		 * over, few enough that the per-block counter flush stays cheap */
 		uint32_t per_block = XE_BLOCK / 64;
 		uint32_t blocks = (kp->ntiles + per_block - 1) / per_block;
-		size_t shmem = (size_t)(kp->nslots + kp->nslots_hi) * XE_BLOCK * 8
+		size_t shmem = (size_t)per_block * kp->fast_dwords * kp->fast_r * 64 * 4
 			+ (kp->lds_counters ? (size_t)kp->nmo * 24 : 0);
 		if (blocks > 4096) blocks = 4096;
 		if (ev) (void)hipEventRecord(ev[0], st);
-		hipLaunchKernelGGL(xe_nf_fast_kernel, dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
+		if (kp->fast_r == 4) hipLaunchKernelGGL(xe_nf_fast_kernel<4>, dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
+		else if (kp->fast_r == 2) hipLaunchKernelGGL(xe_nf_fast_kernel<2>, dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
+		else hipLaunchKernelGGL(xe_nf_fast_kernel<1>, dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
 		if (ev) (void)hipEventRecord(ev[1], st);
 		if (hipGetLastError() != hipSuccess) return XE_EHIP;
 	}
