@@ -46,6 +46,7 @@ const char *xe_gpu_last_error(const xe_gpu *h);
 /* device: HIP device ordinal.  Fails with XE_EHIP when no GPU is usable:
  * there is no CPU fallback. */
 int xe_gpu_create(xe_gpu **out, int device);
+/* every batch prepared on the handle must have been freed before */
 void xe_gpu_destroy(xe_gpu *h);
 
 /* ---- configuration (load-time, host) ---- */

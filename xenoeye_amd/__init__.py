@@ -8,6 +8,7 @@ without a GPU) every entry point raises.
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -113,9 +114,14 @@ class Engine:
             raise XeError(rc, "xe_gpu_create(device=%d): %s (no GPU, no fallback)" %
                           (device, self.L.xe_gpu_strerror(rc).decode()))
         self._h = h
+        self._batches = weakref.WeakSet()
 
     def close(self):
+        """Destroys the handle; batches made from it are freed first (a batch
+        must not outlive its handle)."""
         if self._h:
+            for b in list(self._batches):
+                b.free()
             self.L.xe_gpu_destroy(self._h)
             self._h = None
 
@@ -193,7 +199,9 @@ class Engine:
         b = C.c_void_p()
         self._chk(self.L.xe_gpu_batch_prepare(self._h, data.ctypes.data, offs.ctypes.data, src.ctypes.data,
                                               kinds.ctypes.data if kinds is not None else None, n, C.byref(b)))
-        return PreparedBatch(self, b)
+        pb = PreparedBatch(self, b)
+        self._batches.add(pb)
+        return pb
 
 
 class PreparedBatch:

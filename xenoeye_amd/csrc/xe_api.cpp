@@ -36,7 +36,7 @@ struct xe_batch
 	struct xe_plan plan;
 	size_t ntot, payload_bytes;
 	void *d_pkt, *d_sets, *d_exps, *d_sfrecs, *d_out;
-	void *d_fruns, *d_tile_first, *d_tile_tmpl, *d_ssets, *d_swstart, *d_fplans, *d_fops, *d_fflds;
+	void *d_fruns, *d_ftiles, *d_ssets, *d_swstart, *d_fplans, *d_fops, *d_fflds;
 	size_t out_bytes, masks_off, nparsed_off, marks_off, counters_off, sfhas_off;
 	struct xe_kparams kp;
 	hipStream_t last_stream;
@@ -625,7 +625,7 @@ xe_gpu_batch_free(xe_batch *b)
 	if (b->d_out) (void)hipFree(b->d_out);
 	for (int i = 0; i < 6; i++) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
 	{
-		void *extra[] = { b->d_fruns, b->d_tile_first, b->d_tile_tmpl, b->d_ssets, b->d_swstart,
+		void *extra[] = { b->d_fruns, b->d_ftiles, b->d_ssets, b->d_swstart,
 			b->d_fplans, b->d_fops, b->d_fflds };
 		for (size_t i = 0; i < sizeof(extra) / sizeof(extra[0]); i++) if (extra[i]) (void)hipFree(extra[i]);
 	}
@@ -640,6 +640,13 @@ xe_gpu_batch_free(xe_batch *b)
  * (stable, so arrival order is kept inside a group) and each group is padded
  * to whole 64-record tiles: a wave then works on one template only. */
 static int
+ftile_cmp(const void *a, const void *b)
+{
+	const struct xe_ftile *x = (const struct xe_ftile *)a, *y = (const struct xe_ftile *)b;
+	return (x->pad > y->pad) - (x->pad < y->pad);
+}
+
+static int
 build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 {
 	const struct xe_set *sets = (const struct xe_set *)b->plan.sets.p;
@@ -651,7 +658,8 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 	uint64_t *gcount = NULL, *gpos = NULL;
 	struct xe_frun *fr = NULL;
 	struct xe_set *ss = NULL;
-	uint32_t *sw = NULL, *tfirst = NULL, *ttmpl = NULL, *rtmpl = NULL;
+	uint32_t *sw = NULL, *rtmpl = NULL;
+	struct xe_ftile *ft = NULL;
 	size_t nfast = 0, nslow = 0, ntiles = 0, work = 0, slowrec = 0;
 	/* the fast kernel addresses packet bytes with 32-bit offsets */
 	const int small = (total_bytes + 64) < 0xFFFF0000ull;
@@ -686,13 +694,15 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 			gcount[sets[i].tmpl]++;
 		} else { nslow++; slowrec += sets[i].nrec; }
 	}
-	/* records per lane: as many as keep the block's staging area (4 waves x
-	 * R x 64 records x 16 * maxchunk bytes) within the LDS budget */
-	R = 4;
-	while ((R > 1) && ((size_t)4 * R * 64 * 16 * maxchunk + cnt_bytes > XE_FAST_LDS_BUDGET)) R >>= 1;
+	/* records per lane: one measured fastest on MI355X (more records per lane
+	 * amortise the scalar work but lengthen every dependent chain); 2 and 4
+	 * stay available while they fit the LDS budget (4 waves x R x 64 records
+	 * x 16 * maxchunk bytes) */
+	R = 1;
 	if (getenv("XE_FAST_R")) {
 		int want = atoi(getenv("XE_FAST_R"));   /* diagnostic override */
 		if ((want == 1) || (want == 2) || (want == 4)) R = (uint32_t)want;
+		while ((R > 1) && ((size_t)4 * R * 64 * 16 * maxchunk + cnt_bytes > XE_FAST_LDS_BUDGET)) R >>= 1;
 	}
 	tilesz = 64 * R;
 	fr = (struct xe_frun *)malloc((nfast + 1) * sizeof(*fr));
@@ -737,27 +747,29 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 		work += fr[i].nrec;
 	}
 	ntiles = (work + tilesz - 1) / tilesz;
-	tfirst = (uint32_t *)malloc((ntiles + 1) * sizeof(uint32_t));
-	ttmpl = (uint32_t *)malloc((ntiles + 1) * sizeof(uint32_t));
-	if (!tfirst || !ttmpl) goto out;
+	ft = (struct xe_ftile *)calloc(ntiles + 1, sizeof(*ft));
+	if (!ft) goto out;
 	{
 		size_t sidx = 0;
 		for (size_t t = 0; t < ntiles; t++) {
 			uint64_t g0 = (uint64_t)t * tilesz;
 			while ((sidx + 1 < nfast) && (fr[sidx + 1].start <= g0)) sidx++;
-			tfirst[t] = (uint32_t)sidx;
-			ttmpl[t] = rtmpl[sidx];
+			ft[t].first_run = (uint32_t)sidx;
+			ft[t].tmpl = rtmpl[sidx];
+			ft[t].base = (uint32_t)g0;
+			/* sort key: batch index of the tile's first record */
+			ft[t].pad = fr[sidx].first_rec + (uint32_t)(g0 - fr[sidx].start);
 		}
+		/* groups are in arrival order already; merge them by that key */
+		qsort(ft, ntiles, sizeof(*ft), ftile_cmp);
 	}
 	rc = upload(h, &b->d_fruns, fr, nfast * sizeof(*fr));
-	if (rc == XE_OK) rc = upload(h, &b->d_tile_first, tfirst, ntiles * 4);
-	if (rc == XE_OK) rc = upload(h, &b->d_tile_tmpl, ttmpl, ntiles * 4);
+	if (rc == XE_OK) rc = upload(h, &b->d_ftiles, ft, ntiles * sizeof(*ft));
 	if (rc == XE_OK) rc = upload(h, &b->d_ssets, ss, nslow * sizeof(*ss));
 	if (rc == XE_OK) rc = upload(h, &b->d_swstart, sw, nslow * 4);
 	if (rc == XE_OK) {
 		b->kp.fruns = (const struct xe_frun *)b->d_fruns;
-		b->kp.tile_first = (const uint32_t *)b->d_tile_first;
-		b->kp.tile_tmpl = (const uint32_t *)b->d_tile_tmpl;
+		b->kp.ftiles = (const struct xe_ftile *)b->d_ftiles;
 		b->kp.nfruns = (uint32_t)nfast;
 		b->kp.ntiles = (uint32_t)ntiles;
 		b->kp.ssets = (const struct xe_set *)b->d_ssets;
@@ -776,7 +788,7 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 	}
 out:
 	free(tfast); free(is_fast); free(gcount); free(gpos);
-	free(fr); free(ss); free(sw); free(tfirst); free(ttmpl); free(rtmpl);
+	free(fr); free(ss); free(sw); free(ft); free(rtmpl);
 	return rc;
 }
 
@@ -883,6 +895,9 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 	{
 		hipError_t e = hipMalloc(&b->d_out, b->out_bytes);
 		if (e != hipSuccess) { xe_gpu_batch_free(b); return hip_fail(h, e, "hipMalloc(outputs)"); }
+		/* records the kernels do not reach (none by construction) read as empty */
+		e = hipMemset(b->d_out, 0, b->out_bytes);
+		if (e != hipSuccess) { xe_gpu_batch_free(b); return hip_fail(h, e, "hipMemset(outputs)"); }
 	}
 
 	/* decode plans of the fast kernel: per template the micro-ops of its
@@ -1224,9 +1239,10 @@ xe_gpu_batch_flow_info(xe_batch *b, size_t first, size_t count, void *out)
 			t = &tm[sets[si].tmpl];
 			en = &te[t->ent_base];
 			e = &ex[sets[si].exporter];
+			if (np > t->nfields) np = t->nfields;   /* never trust a count beyond the template */
 			for (uint32_t j = 0; j < np; j++) {
 				int f = en[j].field;
-				if (f == XE_F_NONE) continue;
+				if ((f == XE_F_NONE) || !s.col[f]) continue;
 				if (s.vsize[f]) {
 					uint16_t vs = s.vsize[f][k];
 					if (vs == 0xFFFF) continue;

@@ -226,6 +226,18 @@ struct xe_frun
 	uint32_t dev_id;
 };
 
+/* one tile of the fast kernel: 64 * R consecutive positions of one template
+ * group.  Tiles are listed in the order of the batch index of their first
+ * record, whatever their template, so that neighbours in the list write
+ * neighbouring parts of the output columns. */
+struct xe_ftile
+{
+	uint32_t first_run;  /* first run that may hold its records */
+	uint32_t tmpl;       /* template slot */
+	uint32_t base;       /* first position in the template-grouped order */
+	uint32_t pad;
+};
+
 /* decode micro-op: one known, valid template field.
  * w0: bits 0-15 offset in the record, 16-23 wire length, 24-31 kind,
  *     32-39 operand slot (0xFF none), 40-47 index of the slot's upper half

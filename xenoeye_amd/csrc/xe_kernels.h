@@ -66,8 +66,7 @@ struct xe_kparams
 	 * without a devices.conf entry), grouped by template so that a wave
 	 * decodes one template; 64 records per tile */
 	const struct xe_frun *fruns;
-	const uint32_t *tile_first;  /* per tile: first run that may hold its records */
-	const uint32_t *tile_tmpl;   /* per tile: template slot */
+	const struct xe_ftile *ftiles;
 	const struct xe_fplan *fplans;  /* per template slot */
 	const struct xe_fop *fops;
 	const struct xe_fprog *fprogs;  /* parallel to progs[0, nmo) */

@@ -901,12 +901,22 @@ xe_nf_fast_kernel(const xe_kparams kp)
 		__syncthreads();
 	}
 
-	const uint32_t wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * (XE_BLOCK / 64) + wave);
-	for (uint32_t tile = wave0; tile < kp.ntiles; tile += gridDim.x * (XE_BLOCK / 64)) {
-		const uint32_t tmpl = ((cu32)kp.tile_tmpl)[tile];
+	/* The tile list is cut into 8 contiguous parts, one per XCD (blocks are
+	 * dealt to the XCDs round-robin), so that tiles which write neighbouring
+	 * parts of the same output lines run behind the same L2 and their partial
+	 * lines merge there.  Only speed depends on the dealing order: every
+	 * tile belongs to exactly one (block, wave, iteration). */
+	const uint32_t part = blockIdx.x & 7, lblk = blockIdx.x >> 3;
+	const uint32_t nblk = (gridDim.x + 7 - part) >> 3;
+	const uint32_t per = (kp.ntiles + 7) >> 3;
+	const uint32_t p0 = part * per, p1 = (p0 + per < kp.ntiles) ? p0 + per : kp.ntiles;
+	const uint32_t wave0 = __builtin_amdgcn_readfirstlane(p0 + lblk * (XE_BLOCK / 64) + wave);
+	for (uint32_t tile = wave0; tile < p1; tile += nblk * (XE_BLOCK / 64)) {
+		cu32 TQ = (cu32)(kp.ftiles + tile);
+		const uint32_t tmpl = TQ[1];
 		cu32 PL = (cu32)(kp.fplans + tmpl);
 		const uint32_t op_base = PL[0], nops = PL[1], nparsed = PL[2], nchunk = PL[3];
-		const uint32_t tbase = tile * (64 * R);
+		const uint32_t tbase = TQ[2];
 		fast_tile<R> T;
 		uint32_t voff[R], ridx[R], rate[R];
 
@@ -920,7 +930,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 		}
 
 		/* which run, which record */
-		for (uint32_t s = ((cu32)kp.tile_first)[tile]; s < kp.nfruns; s++) {
+		for (uint32_t s = TQ[0]; s < kp.nfruns; s++) {
 			cu32 RN = (cu32)(kp.fruns + s);
 			const uint32_t start = RN[2], nrec = RN[3];
 			if (start >= tbase + 64 * R) break;
@@ -947,7 +957,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 #pragma unroll
 			for (int r = 0; r < R; r++) {
 				q[r] = (u32x4){0, 0, 0, 0};
-				if (T.live[r]) __builtin_memcpy(&q[r], (const uint8_t *)pkt + voff[r] + 16 * k, 16);
+				if (T.live[r] && !(kp.pad2 & 32)) __builtin_memcpy(&q[r], (const uint8_t *)pkt + voff[r] + 16 * k, 16);
 			}
 #pragma unroll
 			for (int r = 0; r < R; r++) {
@@ -976,7 +986,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 			for (int r = 0; r < R; r++) {
 				uint32_t a[4];
 				stage_read<R>(stg, r, off, len, a);
-				if (!T.live[r]) continue;
+				if (!T.live[r] || (kp.pad2 & 16)) continue;
 				/* column bytes = the field as the reference stores it: the wire
 				 * bytes right-aligned in the field's maximum size */
 				if (lg <= 2) {
@@ -1482,7 +1492,8 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 
 	if (!g_tables_ready) return XE_ESTATE;
 	/* XE_ABLATE (diagnostic): bit 0 skip list lookups, 1 terms, 2 counters,
-	 * 3 programs, 4 decode stores.  Results are wrong with any bit set. */
+	 * 3 programs, 4 column stores, 5 packet loads.  Results are wrong with
+	 * any bit set. */
 	if (getenv("XE_ABLATE")) {
 		kcopy = *kp;
 		kcopy.pad2 = (uint32_t)atoi(getenv("XE_ABLATE"));
@@ -1501,6 +1512,9 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 		size_t shmem = (size_t)per_block * kp->fast_dwords * kp->fast_r * 64 * 4
 			+ (kp->lds_counters ? (size_t)kp->nmo * 24 : 0);
 		if (blocks > 4096) blocks = 4096;
+		/* the kernel deals the tile list to 8 groups of blocks (blockIdx % 8):
+		 * every group needs at least one block */
+		if (blocks < 8) blocks = 8;
 		if (ev) (void)hipEventRecord(ev[0], st);
 		if (kp->fast_r == 4) hipLaunchKernelGGL(xe_nf_fast_kernel<4>, dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
 		else if (kp->fast_r == 2) hipLaunchKernelGGL(xe_nf_fast_kernel<2>, dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
