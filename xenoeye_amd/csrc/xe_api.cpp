@@ -20,12 +20,14 @@ struct xe_gpu
 	int device;
 	struct xe_host hs;
 	int committed;
-	void *d_progs, *d_ops, *d_terms, *d_opnds, *d_trie, *d_lists, *d_devrules, *d_lookups, *d_fterms, *d_fprogs;
+	void *d_progs, *d_ops, *d_terms, *d_opnds, *d_trie, *d_lists, *d_devrules, *d_lookups, *d_fterms, *d_fprogs, *d_motab;
 	uint32_t nmo, mask_words, nprogs_total, nlookups;
 	struct xe_list_dev *h_lists;
+	struct xe_probe *h_probes;   /* host copy of the probe table (nlookups entries) */
 	void *d_tmpls, *d_tents;
 	size_t up_tmpls, up_tents;
 	uint32_t nterms;           /* distinct terms of the object programs */
+	uint32_t nfprogs;          /* objects the fast kernel evaluates one by one */
 	int fast_ok, want_dev;     /* want_dev: some object program reads dev_ip / dev_id */
 	char err[512];
 };
@@ -110,13 +112,15 @@ static void
 free_config_dev(xe_gpu *h)
 {
 	void **p[] = { &h->d_progs, &h->d_ops, &h->d_terms, &h->d_opnds, &h->d_trie, &h->d_lists, &h->d_devrules,
-		&h->d_lookups, &h->d_fterms, &h->d_fprogs };
+		&h->d_lookups, &h->d_fterms, &h->d_fprogs, &h->d_motab };
 	for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); i++) {
 		if (*p[i]) (void)hipFree(*p[i]);
 		*p[i] = NULL;
 	}
 	free(h->h_lists);
 	h->h_lists = NULL;
+	free(h->h_probes);
+	h->h_probes = NULL;
 }
 
 extern "C" void
@@ -548,29 +552,60 @@ xe_gpu_commit(xe_gpu *h)
 			ft[t].kind = all_lists ? 1 : 0;
 			ft[t].mask = all_lists ? m : 0;
 		}
-		for (size_t m = 0; (rc == XE_OK) && (m < h->hs.nmos); m++) {
-			if (pg[m].flags & XE_PROG_CONST) {
-				fp[m].kind = XE_FPROG_CONST;
-			} else if ((pg[m].nops == 1) && ((op[pg[m].op_base] & 3) == XE_OP_BASIC)) {
-				uint32_t t = op[pg[m].op_base] >> 2;
-				if (ft[t].kind & 1) {
-					fp[m].kind = XE_FPROG_MASK;
-					fp[m].mask = ft[t].mask;
+		{
+			/* objects resolved through the atom table, the rest listed */
+			size_t words = h->hs.nmos ? (h->hs.nmos + 63) / 64 : 1, nb = 0;
+			uint64_t *mt = (uint64_t *)calloc(words * XE_MOTAB_ROWS, sizeof(uint64_t));
+			if (!mt) rc = XE_ENOMEM;
+			for (size_t m = 0; (rc == XE_OK) && (m < h->hs.nmos); m++) {
+				struct xe_fprog q;
+				memset(&q, 0, sizeof(q));
+				q.op_base = pg[m].op_base;
+				q.nops = pg[m].nops;
+				q.parent = pg[m].parent;
+				q.cval = pg[m].cval;
+				q.mo = (uint32_t)m;
+				if (pg[m].flags & XE_PROG_CONST) {
+					q.kind = XE_FPROG_CONST;
+				} else if ((pg[m].nops == 1) && ((op[pg[m].op_base] & 3) == XE_OP_BASIC)) {
+					uint32_t t = op[pg[m].op_base] >> 2;
+					if (ft[t].kind & 1) {
+						q.kind = XE_FPROG_MASK;
+						q.mask = ft[t].mask;
+					} else {
+						q.kind = XE_FPROG_TERM;
+						q.term = t;
+					}
 				} else {
-					fp[m].kind = XE_FPROG_TERM;
-					fp[m].term = t;
-					ft[t].kind |= 2;
+					q.kind = XE_FPROG_GENERAL;
 				}
-			} else {
-				fp[m].kind = XE_FPROG_GENERAL;
-				for (uint32_t k = 0; k < pg[m].nops; k++) {
-					uint32_t w = op[pg[m].op_base + k];
-					if ((w & 3) == XE_OP_BASIC) ft[w >> 2].kind |= 2;
+				if ((q.parent < 0) && (q.kind == XE_FPROG_MASK)) {
+					for (int bit = 0; bit < 64; bit++) {
+						if ((q.mask >> bit) & 1) mt[(m / 64) * XE_MOTAB_ROWS + bit] |= 1ull << (m % 64);
+					}
+					continue;
 				}
+				if ((q.parent < 0) && (q.kind == XE_FPROG_TERM) && (q.term < 64)) {
+					mt[(m / 64) * XE_MOTAB_ROWS + 64 + q.term] |= 1ull << (m % 64);
+					ft[q.term].kind |= 2;
+					continue;
+				}
+				/* evaluated one by one: mark the terms it needs */
+				if (q.kind == XE_FPROG_TERM) ft[q.term].kind |= 2;
+				if (q.kind == XE_FPROG_GENERAL) {
+					for (uint32_t k = 0; k < pg[m].nops; k++) {
+						uint32_t w = op[pg[m].op_base + k];
+						if ((w & 3) == XE_OP_BASIC) ft[w >> 2].kind |= 2;
+					}
+				}
+				fp[nb++] = q;
 			}
+			h->nfprogs = (uint32_t)nb;
+			if (rc == XE_OK) rc = upload(h, &h->d_motab, mt, words * XE_MOTAB_ROWS * sizeof(uint64_t));
+			if (rc == XE_OK) rc = upload(h, &h->d_fprogs, fp, nb * sizeof(*fp));
+			free(mt);
 		}
 		if (rc == XE_OK) rc = upload(h, &h->d_fterms, ft, (size_t)h->nterms * sizeof(*ft));
-		if (rc == XE_OK) rc = upload(h, &h->d_fprogs, fp, h->hs.nmos * sizeof(*fp));
 		free(ft);
 		free(fp);
 	}
@@ -582,6 +617,11 @@ xe_gpu_commit(xe_gpu *h)
 	if (rc == XE_OK) rc = upload(h, &h->d_lists, h->h_lists, h->hs.lists.n * sizeof(struct xe_list_dev));
 	if (rc == XE_OK) rc = upload(h, &h->d_devrules, rules.p, rules.n * sizeof(struct xe_devrule));
 	if (rc == XE_OK) rc = upload(h, &h->d_lookups, lookups.p, lookups.n * sizeof(struct xe_probe));
+	if (rc == XE_OK) {
+		h->h_probes = (struct xe_probe *)calloc(lookups.n ? lookups.n : 1, sizeof(struct xe_probe));
+		if (!h->h_probes) rc = XE_ENOMEM;
+		else if (lookups.n) memcpy(h->h_probes, lookups.p, lookups.n * sizeof(struct xe_probe));
+	}
 	if (rc == XE_OK) {
 		h->nmo = (uint32_t)h->hs.nmos;
 		h->mask_words = h->nmo ? (h->nmo + 63) / 64 : 1;
@@ -702,7 +742,7 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 	if (getenv("XE_FAST_R")) {
 		int want = atoi(getenv("XE_FAST_R"));   /* diagnostic override */
 		if ((want == 1) || (want == 2) || (want == 4)) R = (uint32_t)want;
-		while ((R > 1) && ((size_t)4 * R * 64 * 16 * maxchunk + cnt_bytes > XE_FAST_LDS_BUDGET)) R >>= 1;
+		while ((R > 1) && ((size_t)4 * R * 64 * 4 * (4 * maxchunk + 1) + cnt_bytes + 8192 > XE_FAST_LDS_BUDGET)) R >>= 1;
 	}
 	tilesz = 64 * R;
 	fr = (struct xe_frun *)malloc((nfast + 1) * sizeof(*fr));
@@ -777,11 +817,14 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 		b->kp.nssets = (uint32_t)nslow;
 		b->kp.nslowrec = (uint32_t)slowrec;
 		b->kp.fast_r = R;
-		b->kp.fast_dwords = 4 * maxchunk;
+		b->kp.fast_dwords = 4 * maxchunk + 1;   /* + 1: field reads look one dword ahead */
 		b->kp.fast_want_dev = (uint32_t)h->want_dev;
 		b->kp.nterms = h->nterms;
 		b->kp.fterms = (const struct xe_fterm *)h->d_fterms;
 		b->kp.fprogs = (const struct xe_fprog *)h->d_fprogs;
+		b->kp.nfprogs = h->nfprogs;
+		b->kp.motab = (const uint64_t *)h->d_motab;
+		b->kp.motab_lds = ((size_t)h->mask_words * XE_MOTAB_ROWS * 8 <= 8192) ? 1u : 0u;
 		b->kp.probes = (const struct xe_probe *)h->d_lookups;
 		b->kp.nprobes = h->nlookups;
 		b->kp.lds_counters = (h->hs.nmos <= XE_MAX_LDS_COUNTER_MOS) ? 1u : 0u;
@@ -922,25 +965,40 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 			}
 			fld[XF_dev_ip] |= XE_FFLD_PRESENT | XE_FFLD_VIRTUAL;
 			fld[XF_dev_id] |= XE_FFLD_PRESENT | XE_FFLD_VIRTUAL;
-			for (uint32_t j = 0; j < tm[t].nfields; j++) {
-				const struct xe_tent *e = &te[tm[t].ent_base + j];
-				int f = e->field;
-				uint32_t cw, lg = 0, kind;
-				if ((f == XE_F_NONE) || !(e->flags & XE_TE_VALID) || (e->len > 16) || (e->len == 0)
-					|| (b->kp.col_off[f] == ~0ull)) continue;
-				cw = xe_fields[f].col_width;
-				while ((1u << lg) < cw) lg++;
-				kind = lg;
-				if (e->len == cw) kind |= XE_FOP_COPY;
-				if (f == XF_in_bytes) kind |= XE_FOP_BYTES;
-				if (f == XF_in_pkts) kind |= XE_FOP_PKTS;
-				if (xe_fields[f].size_max == 6) kind |= XE_FOP_MAC;
-				fld[f] = (fld[f] & (31u << 21)) | XE_FFLD_PRESENT | ((uint32_t)e->len << 16) | e->off;
-				fo[nops].w0 = (uint64_t)e->off | ((uint64_t)e->len << 16) | ((uint64_t)kind << 24);
-				fo[nops].w1 = (uint64_t)(uintptr_t)((uint8_t *)b->d_out + b->kp.col_off[f]);
-				nops++;
+			for (int pass = 0; pass < 6; pass++) {
+				for (uint32_t j = 0; j < tm[t].nfields; j++) {
+					const struct xe_tent *e = &te[tm[t].ent_base + j];
+					int f = e->field;
+					uint32_t cw, lg = 0, kind, cls;
+					if ((f == XE_F_NONE) || !(e->flags & XE_TE_VALID) || (e->len > 16) || (e->len == 0)
+						|| (b->kp.col_off[f] == ~0ull)) continue;
+					cw = xe_fields[f].col_width;
+					while ((1u << lg) < cw) lg++;
+					kind = lg;
+					if (e->len == cw) kind |= XE_FOP_COPY;
+					if (xe_fields[f].size_max == 6) kind |= XE_FOP_MAC;
+					cls = (kind & XE_FOP_COPY) ? lg : 5;
+					if ((int)cls != pass) continue;
+					fld[f] = (fld[f] & (31u << 21)) | XE_FFLD_PRESENT | ((uint32_t)e->len << 16) | e->off;
+					fo[nops].w0 = (uint64_t)e->off | ((uint64_t)e->len << 16) | ((uint64_t)kind << 24);
+					fo[nops].w1 = (uint64_t)(uintptr_t)((uint8_t *)b->d_out + b->kp.col_off[f]);
+					nops++;
+					pl[t].cnt[pass]++;
+				}
 			}
-			pl[t].nops = (uint32_t)nops - pl[t].op_base;
+			/* probes that can match at all: the field is there, the tables are not empty */
+			{
+				uint64_t list = ~0ull;
+				uint32_t k = 0;
+				for (uint32_t pr = 0; (pr < h->nlookups) && (k < 8); pr++) {
+					const struct xe_probe *q = &h->h_probes[pr];
+					if (q->root_off && (fld[q->field] & XE_FFLD_PRESENT)) {
+						list = (list & ~(0xFFull << (8 * k))) | ((uint64_t)pr << (8 * k));
+						k++;
+					}
+				}
+				pl[t].probes = list;
+			}
 		}
 		rc = upload(h, &b->d_fplans, pl, nt * sizeof(*pl));
 		if (rc == XE_OK) rc = upload(h, &b->d_fops, fo, nops * sizeof(*fo));

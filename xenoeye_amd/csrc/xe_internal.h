@@ -249,12 +249,16 @@ struct xe_fop { uint64_t w0, w1; };
 #define XE_FOP_PKTS 32     /* in_pkts */
 #define XE_FOP_MAC 64      /* 6-byte value kept in an 8-byte column */
 
-/* per template */
+/* per template.  The micro-ops are sorted by kind: plain copies of 1, 2, 4, 8
+ * and 16 bytes (wire length == column width), then everything else. */
 struct xe_fplan
 {
-	uint32_t op_base, nops;
+	uint32_t op_base;
+	uint32_t cnt[6];     /* copies of 1, 2, 4, 8, 16 bytes; general ops */
 	uint32_t nparsed;    /* fields a complete record parses (all of the template's) */
 	uint32_t nchunk;     /* 16-byte pieces that cover one record */
+	uint32_t pad;
+	uint64_t probes;     /* byte i = i-th probe whose field the template carries, 0xFF = end */
 };
 
 /* per template and field (XE_NFIELDS words per template): where the field's
@@ -272,12 +276,24 @@ struct xe_fterm
 	uint64_t mask;
 };
 
-/* fast-kernel view of an object program */
+/* Fast-kernel view of the object programs.
+ *
+ * Objects without a parent whose program is a single term are resolved through
+ * a table: "atom" a (0-63: lookup bit a; 64-127: term a - 64) -> the set of
+ * such objects that match when the atom is true; a record's match bits are the
+ * OR of the rows of its true atoms (xe_kparams.motab[word][128]).
+ * All other objects are listed, in index order, as xe_fprog entries. */
+#define XE_MOTAB_ROWS 128
 struct xe_fprog
 {
 	uint64_t mask;       /* XE_FPROG_MASK: lookup bits that make it match */
 	uint32_t kind;
 	uint32_t term;       /* XE_FPROG_TERM: the one term */
+	uint32_t op_base, nops;   /* XE_FPROG_GENERAL: the postfix program */
+	int32_t parent;      /* object that must have matched too, -1 none */
+	uint32_t cval;       /* XE_FPROG_CONST: the result */
+	uint32_t mo;         /* the object's index */
+	uint32_t pad[3];
 };
 enum { XE_FPROG_GENERAL = 0, XE_FPROG_CONST = 1, XE_FPROG_MASK = 2, XE_FPROG_TERM = 3 };
 

@@ -69,7 +69,9 @@ struct xe_kparams
 	const struct xe_ftile *ftiles;
 	const struct xe_fplan *fplans;  /* per template slot */
 	const struct xe_fop *fops;
-	const struct xe_fprog *fprogs;  /* parallel to progs[0, nmo) */
+	const struct xe_fprog *fprogs;  /* objects not resolved through motab, in index order */
+	const uint64_t *motab;       /* [mask word][XE_MOTAB_ROWS] */
+	uint32_t nfprogs, motab_lds; /* motab_lds: the table is small enough to be copied to LDS */
 	const uint32_t *fflds;       /* [template slot][XE_NFIELDS] XE_FFLD_* words */
 	uint32_t nfruns, ntiles;
 	uint32_t fast_r;             /* records per lane and tile: 1, 2 or 4 */

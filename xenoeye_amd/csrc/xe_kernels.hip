@@ -730,63 +730,100 @@ addr_chunk(uint32_t family, uint32_t lvl, uint32_t a4, uint64_t hi, uint64_t lo)
  * All IP-list membership tests of a tile.  Per probe (one field against one
  * group of up to 8 lists) ONE walk of the group's merged tables per record: a
  * 4-byte root gather, then one node visit (one 64-byte line) per further
- * address byte while any list of the group can still go deeper.  The R records
- * of a lane walk together so that their dependent gathers overlap.  Bit
+ * address byte while any list of the group can still go deeper.  The walks
+ * are dependent gathers, so several are kept in flight: PC probes x R
+ * records advance level by level together.  `plist` names the probes whose
+ * field the template carries (byte i = probe index, 0xFF = end).  Bit
  * (8 * probe + l) of lk[r] = list l of the probe's group matched.
  */
 template <int R>
 __device__ void
-fast_lookups(const xe_kparams &kp, const fast_tile<R> &T, uint64_t lk[R])
+fast_lookups(const xe_kparams &kp, const fast_tile<R> &T, uint64_t plist, uint64_t lk[R])
 {
+	constexpr int PC = (R == 1) ? 4 : 2;
+
 #pragma unroll
 	for (int r = 0; r < R; r++) lk[r] = 0;
 
-	for (uint32_t pr = 0; pr < kp.nprobes; pr++) {
-		cu32 q = (cu32)(kp.probes + pr);
-		const uint32_t root = q[0], w1 = q[1], nodes = q[3];
-		const uint32_t family = w1 & 0xFF, field = (w1 >> 8) & 0xFF, wide4 = (w1 >> 16) & 1, used = w1 >> 24;
-		const uint32_t nlvl = (family == 4) ? 2u : 14u;
-		uint32_t e[R], a4[R];
-		uint64_t hi[R], lo[R];
+	while ((plist & 0xFF) != 0xFF) {
+		uint32_t root[PC], nodes[PC], family[PC], used[PC], pidx[PC], nlvl[PC];
+		bool act[PC];
+		uint32_t e[PC][R], a4[PC][R];
+		uint64_t hi[PC][R], lo[PC][R];
+		uint32_t maxlvl = 0;
 
-		if (!root || !(T.fld[field] >> 31)) continue;
 #pragma unroll
-		for (int r = 0; r < R; r++) {
-			bool has;
-			uint32_t fmax;
-			fld_get<R>(T, field, r, has, fmax, hi[r], lo[r]);
-			a4[r] = wide4 ? (uint32_t)(hi[r] >> 32) : (uint32_t)lo[r];
-			e[r] = XE_TRIE_TERM;
-			if (T.live[r]) {
-				const uint32_t top = (family == 6) ? (uint32_t)(hi[r] >> 48) : (a4[r] >> 16);
-				e[r] = ((const XE_CONST uint32_t *)(kp.trie + root))[top];
-			}
-		}
-		for (uint32_t lvl = 0; lvl < nlvl; lvl++) {
-			bool walk[R], any = false;
-			uint32_t c[R];
-			node_ld nl[R];
+		for (int c = 0; c < PC; c++) {
+			const uint32_t pr = (uint32_t)(plist >> (8 * c)) & 0xFF;
+			/* the list ends with 0xFF bytes: once inactive, always inactive */
+			act[c] = (pr != 0xFF);
+			cu32 q = (cu32)(kp.probes + (act[c] ? pr : 0));
+			const uint32_t w1 = q[1];
+			root[c] = q[0];
+			nodes[c] = q[3];
+			family[c] = w1 & 0xFF;
+			used[c] = w1 >> 24;
+			pidx[c] = pr;
+			nlvl[c] = act[c] ? ((family[c] == 4) ? 2u : 14u) : 0u;
+			if (nlvl[c] > maxlvl) maxlvl = nlvl[c];
 #pragma unroll
 			for (int r = 0; r < R; r++) {
-				walk[r] = !(e[r] & XE_TRIE_TERM);
-				any |= walk[r];
+				bool has;
+				uint32_t fmax;
+				e[c][r] = XE_TRIE_TERM;
+				a4[c][r] = 0;
+				hi[c][r] = lo[c][r] = 0;
+				if (!act[c]) continue;
+				fld_get<R>(T, (w1 >> 8) & 0xFF, r, has, fmax, hi[c][r], lo[c][r]);
+				a4[c][r] = ((w1 >> 16) & 1) ? (uint32_t)(hi[c][r] >> 32) : (uint32_t)lo[c][r];
+				if (T.live[r]) {
+					const uint32_t top = (family[c] == 6) ? (uint32_t)(hi[c][r] >> 48) : (a4[c][r] >> 16);
+					e[c][r] = ((const XE_CONST uint32_t *)(kp.trie + root[c]))[top];
+				}
+			}
+		}
+		for (uint32_t lvl = 0; lvl < maxlvl; lvl++) {
+			bool walk[PC][R], any = false;
+			uint32_t ch[PC][R];
+			node_ld nl[PC][R];
+#pragma unroll
+			for (int c = 0; c < PC; c++) {
+#pragma unroll
+				for (int r = 0; r < R; r++) {
+					walk[c][r] = act[c] && (lvl < nlvl[c]) && !(e[c][r] & XE_TRIE_TERM);
+					any |= walk[c][r];
+				}
 			}
 			if (!__ballot(any)) break;
 			/* lanes that are done re-read node 0 of the table: one shared line */
 #pragma unroll
-			for (int r = 0; r < R; r++) {
-				c[r] = walk[r] ? addr_chunk(family, lvl, a4[r], hi[r], lo[r]) : 0;
-				nl[r] = node_fetch(kp.trie + nodes, walk[r] ? e[r] : 0, c[r]);
+			for (int c = 0; c < PC; c++) {
+				if (!act[c] || (lvl >= nlvl[c])) continue;
+#pragma unroll
+				for (int r = 0; r < R; r++) {
+					ch[c][r] = walk[c][r] ? addr_chunk(family[c], lvl, a4[c][r], hi[c][r], lo[c][r]) : 0;
+					nl[c][r] = node_fetch(kp.trie + nodes[c], walk[c][r] ? e[c][r] : 0, ch[c][r]);
+				}
 			}
 #pragma unroll
-			for (int r = 0; r < R; r++) {
-				if (walk[r]) e[r] = node_next(nl[r], c[r]);
+			for (int c = 0; c < PC; c++) {
+				if (!act[c] || (lvl >= nlvl[c])) continue;
+#pragma unroll
+				for (int r = 0; r < R; r++) {
+					if (walk[c][r]) e[c][r] = node_next(nl[c][r], ch[c][r]);
+				}
 			}
 		}
 #pragma unroll
-		for (int r = 0; r < R; r++) {
-			lk[r] |= (uint64_t)(((e[r] & XE_TRIE_TERM) ? e[r] : 0u) & used & 0xFFu) << (pr * XE_LIST_GROUP);
+		for (int c = 0; c < PC; c++) {
+			if (!act[c]) continue;
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				lk[r] |= (uint64_t)(((e[c][r] & XE_TRIE_TERM) ? e[c][r] : 0u) & used[c] & 0xFFu)
+					<< (pidx[c] * XE_LIST_GROUP);
+			}
 		}
+		plist = (PC >= 8) ? ~0ull : ((plist >> (8 * PC)) | (~0ull << (64 - 8 * PC)));
 	}
 }
 
@@ -861,27 +898,134 @@ fast_term(const xe_kparams &kp, const fast_tile<R> &T, const term_s &t, uint32_t
 	return res;
 }
 
-/* `hit` lanes add their octets and packets to an object's counters: few hits
- * go one by one (same-address atomics serialise, but there are few), many go
- * through a wave reduction first */
+/* Plain copies of 2^LG wire bytes into a column (wire length == column
+ * width): n micro-ops starting at fops[j0].  The next micro-op is fetched
+ * while the current one is applied. */
+template <int R, int LG>
 __device__ __forceinline__ void
-count_hits(unsigned long long *dst, bool hit, uint32_t n, uint32_t lane,
-	unsigned long long bxr, unsigned long long pxr)
+copy_ops(const xe_kparams &kp, const uint32_t *stg, uint32_t j0, uint32_t n,
+	const uint32_t (&ridx)[R], const bool (&live)[R])
 {
-	if (n <= 6) {
-		if (hit) {
-			atomicAdd(dst + 1, bxr);
-			atomicAdd(dst + 2, pxr);
-		}
-	} else {
-		unsigned long long sb = wave_sum(hit ? bxr : 0ull);
-		unsigned long long sp = wave_sum(hit ? pxr : 0ull);
-		if (lane == 0) {
-			atomicAdd(dst + 1, sb);
-			atomicAdd(dst + 2, sp);
+	typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+	if (!n) return;
+	u64x2 opn = *(const XE_CONST u64x2 *)(kp.fops + j0);
+	for (uint32_t j = 0; j < n; j++) {
+		const u64x2 opc = opn;
+		opn = *(const XE_CONST u64x2 *)(kp.fops + j0 + ((j + 1 < n) ? j + 1 : j));
+		const uint32_t off = (uint32_t)opc[0] & 0xFFFF, sh = off & 3;
+		const uint32_t *p = stg + (off >> 2) * (R * 64);
+		XE_GLOBAL uint8_t *col = (XE_GLOBAL uint8_t *)opc[1];
+#pragma unroll
+		for (int r = 0; r < R; r++) {
+			const uint32_t *q = p + r * 64;
+			if (LG == 0) {
+				const uint32_t w0 = q[0];
+				if (live[r]) col[ridx[r]] = (uint8_t)__builtin_amdgcn_alignbyte(w0, w0, sh);
+			} else if (LG <= 2) {
+				const uint32_t w0 = q[0], w1 = q[R * 64];
+				const uint32_t v = __builtin_amdgcn_alignbyte(w1, w0, sh);
+				if (live[r]) {
+					if (LG == 1) ((XE_GLOBAL uint16_t *)col)[ridx[r]] = (uint16_t)v;
+					else ((XE_GLOBAL uint32_t *)col)[ridx[r]] = v;
+				}
+			} else if (LG == 3) {
+				const uint32_t w0 = q[0], w1 = q[R * 64], w2 = q[2 * R * 64];
+				const uint32_t v0 = __builtin_amdgcn_alignbyte(w1, w0, sh);
+				const uint32_t v1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+				if (live[r]) ((XE_GLOBAL uint64_t *)col)[ridx[r]] = (uint64_t)v0 | ((uint64_t)v1 << 32);
+			} else {
+				const uint32_t w0 = q[0], w1 = q[R * 64], w2 = q[2 * R * 64], w3 = q[3 * R * 64], w4 = q[4 * R * 64];
+				u32x4 v;
+				v.x = __builtin_amdgcn_alignbyte(w1, w0, sh);
+				v.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
+				v.z = __builtin_amdgcn_alignbyte(w3, w2, sh);
+				v.w = __builtin_amdgcn_alignbyte(w4, w3, sh);
+				if (live[r]) ((XE_GLOBAL u32x4 *)col)[ridx[r]] = v;
+			}
 		}
 	}
-	if (lane == 0) atomicAdd(dst + 0, (unsigned long long)n);
+}
+
+/* Micro-ops whose wire length differs from the column width (and 6-byte MAC
+ * values kept in 8-byte columns): mask, shift, store. */
+template <int R>
+__device__ void
+general_ops(const xe_kparams &kp, const uint32_t *stg, uint32_t j0, uint32_t n,
+	const uint32_t (&ridx)[R], const bool (&live)[R])
+{
+	for (uint32_t j = 0; j < n; j++) {
+		cu64 xq = (cu64)(kp.fops + j0 + j);
+		const uint64_t w0 = xq[0];
+		const uint32_t off = (uint32_t)w0 & 0xFFFF, len = (uint32_t)(w0 >> 16) & 0xFF;
+		const uint32_t kind = (uint32_t)(w0 >> 24) & 0xFF;
+		const uint32_t lg = kind & XE_FOP_LGW;
+		XE_GLOBAL uint8_t *col = (XE_GLOBAL uint8_t *)xq[1];
+		const uint32_t pad = (kind & (XE_FOP_COPY | XE_FOP_MAC)) ? 0 : (8 * ((1u << lg) - len));
+
+#pragma unroll
+		for (int r = 0; r < R; r++) {
+			uint32_t a[4];
+			stage_read<R>(stg, r, off, len, a);
+			if (!live[r]) continue;
+			/* column bytes = the field as the reference stores it: the wire
+			 * bytes right-aligned in the field's maximum size */
+			if (lg <= 2) {
+				uint32_t v = a[0];
+				if (!(kind & XE_FOP_COPY)) v = (v & (0xFFFFFFFFu >> (32 - 8 * len))) << pad;
+				if (lg == 0) col[ridx[r]] = (uint8_t)v;
+				else if (lg == 1) ((XE_GLOBAL uint16_t *)col)[ridx[r]] = (uint16_t)v;
+				else ((XE_GLOBAL uint32_t *)col)[ridx[r]] = v;
+			} else if (lg == 3) {
+				uint64_t v = (uint64_t)a[0] | ((uint64_t)a[1] << 32);
+				if (!(kind & XE_FOP_COPY)) v = (v & (~0ull >> (64 - 8 * len))) << pad;
+				((XE_GLOBAL uint64_t *)col)[ridx[r]] = v;
+			} else {
+				uint64_t v0 = (uint64_t)a[0] | ((uint64_t)a[1] << 32);
+				uint64_t v1 = (uint64_t)a[2] | ((uint64_t)a[3] << 32);
+				if (!(kind & XE_FOP_COPY)) {
+					/* len < 16: shift the 128-bit little-endian value up by pad bits */
+					if (len <= 8) { v1 = 0; v0 &= ~0ull >> (64 - 8 * len); }
+					else v1 &= ~0ull >> (128 - 8 * len);
+					if (pad >= 64) { v1 = v0 << (pad - 64); v0 = 0; }
+					else if (pad) { v1 = (v1 << pad) | (v0 >> (64 - pad)); v0 <<= pad; }
+				}
+				((XE_GLOBAL uint64_t *)col)[2 * (size_t)ridx[r]] = v0;
+				((XE_GLOBAL uint64_t *)col)[2 * (size_t)ridx[r] + 1] = v1;
+			}
+		}
+	}
+}
+
+/* one listed object program for record r of all lanes */
+template <int R>
+__device__ __forceinline__ bool
+prog_eval(const xe_kparams &kp, const uint32_t (&FP)[12], uint64_t lkbits, const uint64_t (&tb)[4])
+{
+	const uint32_t fkind = FP[2];
+	if (fkind == XE_FPROG_MASK) return (lkbits & ((uint64_t)FP[0] | ((uint64_t)FP[1] << 32))) != 0;
+	if (fkind == XE_FPROG_TERM) {
+		const uint32_t t = FP[3], wsel = t >> 6;
+		const uint64_t word = (wsel == 0) ? tb[0] : (wsel == 1) ? tb[1] : (wsel == 2) ? tb[2] : tb[3];
+		return ((word >> (t & 63)) & 1) != 0;
+	}
+	if (fkind == XE_FPROG_CONST) return FP[7] != 0;
+	uint64_t st = 0;
+	for (uint32_t k = 0; k < FP[5]; k++) {
+		const uint32_t op = ((cu32)kp.ops)[FP[4] + k], code = op & 3;
+		if (code == XE_OP_BASIC) {
+			const uint32_t id = op >> 2, wsel = id >> 6;
+			const uint64_t word = (wsel == 0) ? tb[0] : (wsel == 1) ? tb[1] : (wsel == 2) ? tb[2] : tb[3];
+			st = (st << 1) | ((word >> (id & 63)) & 1);
+		} else if (code == XE_OP_NOT) {
+			st ^= 1;
+		} else {
+			const uint64_t top = st & 1;
+			st >>= 1;
+			if (code == XE_OP_AND) st &= (top | ~1ull);
+			else st |= top;
+		}
+	}
+	return (st & 1) != 0;
 }
 
 template <int R>
@@ -890,16 +1034,21 @@ xe_nf_fast_kernel(const xe_kparams kp)
 {
 	extern __shared__ uint32_t lds32[];
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	/* staging: kp.fast_dwords dwords per record, [wave][dword][r][lane] */
+	/* staging: kp.fast_dwords dwords per record, [wave][dword][r][lane]; then
+	 * the block's counters and its copy of the atom table */
 	uint32_t *stg = lds32 + (size_t)wave * kp.fast_dwords * R * 64 + lane;
 	unsigned long long *lcnt = (unsigned long long *)(lds32 + (size_t)(XE_BLOCK / 64) * kp.fast_dwords * R * 64);
+	uint64_t *lmt = (uint64_t *)(lcnt + (kp.lds_counters ? (size_t)kp.nmo * 3 : 0));
 	const bool want_dev = kp.fast_want_dev != 0;
 	const XE_GLOBAL uint8_t *pkt = (const XE_GLOBAL uint8_t *)kp.pkt;
 
 	if (kp.lds_counters) {
 		for (uint32_t i = threadIdx.x; i < kp.nmo * 3; i += XE_BLOCK) lcnt[i] = 0;
-		__syncthreads();
 	}
+	if (kp.motab_lds) {
+		for (uint32_t i = threadIdx.x; i < kp.mask_words * XE_MOTAB_ROWS; i += XE_BLOCK) lmt[i] = kp.motab[i];
+	}
+	__syncthreads();
 
 	/* The tile list is cut into 8 contiguous parts, one per XCD (blocks are
 	 * dealt to the XCDs round-robin), so that tiles which write neighbouring
@@ -915,7 +1064,8 @@ xe_nf_fast_kernel(const xe_kparams kp)
 		cu32 TQ = (cu32)(kp.ftiles + tile);
 		const uint32_t tmpl = TQ[1];
 		cu32 PL = (cu32)(kp.fplans + tmpl);
-		const uint32_t op_base = PL[0], nops = PL[1], nparsed = PL[2], nchunk = PL[3];
+		const uint32_t op_base = PL[0], nparsed = PL[7], nchunk = PL[8];
+		const uint64_t plist = ((cu64)PL)[5];
 		const uint32_t tbase = TQ[2];
 		fast_tile<R> T;
 		uint32_t voff[R], ridx[R], rate[R];
@@ -929,106 +1079,90 @@ xe_nf_fast_kernel(const xe_kparams kp)
 			T.dev_ip[r] = T.dev_id[r] = 0;
 		}
 
-		/* which run, which record */
-		for (uint32_t s = TQ[0]; s < kp.nfruns; s++) {
-			cu32 RN = (cu32)(kp.fruns + s);
-			const uint32_t start = RN[2], nrec = RN[3];
-			if (start >= tbase + 64 * R) break;
+		/* which run, which record (the next run's descriptor is fetched while
+		 * the current one is applied) */
+		{
+			typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+			const uint32_t s_end = kp.nfruns - 1;
+			uint32_t s = TQ[0];
+			u32x8 RN = *(const XE_CONST u32x8 *)(kp.fruns + s);
+			for (;;) {
+				const uint32_t start = RN[2], nrec = RN[3];
+				if (start >= tbase + 64 * R) break;
+				const u32x8 NX = *(const XE_CONST u32x8 *)(kp.fruns + ((s < s_end) ? s + 1 : s_end));
 #pragma unroll
-			for (int r = 0; r < R; r++) {
-				const uint32_t sub0 = tbase + 64 * r;
-				if ((start + nrec <= sub0) || (start >= sub0 + 64)) continue;
-				const uint32_t g = sub0 + lane, i = g - start;
-				const bool in = (g >= start) && (i < nrec);
-				voff[r] = in ? (RN[0] + i * RN[4]) : voff[r];
-				ridx[r] = in ? (RN[1] + i) : ridx[r];
-				rate[r] = in ? RN[5] : rate[r];
-				if (want_dev) {
-					T.dev_ip[r] = in ? RN[6] : T.dev_ip[r];
-					T.dev_id[r] = in ? RN[7] : T.dev_id[r];
-				}
-				T.live[r] |= in;
-			}
-		}
-
-		/* stage the records: all 16-byte loads of a lane are independent */
-		for (uint32_t k = 0; k < nchunk; k++) {
-			u32x4 q[R];
-#pragma unroll
-			for (int r = 0; r < R; r++) {
-				q[r] = (u32x4){0, 0, 0, 0};
-				if (T.live[r] && !(kp.pad2 & 32)) __builtin_memcpy(&q[r], (const uint8_t *)pkt + voff[r] + 16 * k, 16);
-			}
-#pragma unroll
-			for (int r = 0; r < R; r++) {
-				uint32_t *d = stg + ((4 * k) * R + r) * 64;
-				d[0] = q[r].x;
-				d[R * 64] = q[r].y;
-				d[2 * R * 64] = q[r].z;
-				d[3 * R * 64] = q[r].w;
-			}
-		}
-
-		/* decode: one micro-op per known field of the template */
-		uint64_t bytes[R], pkts[R];
-#pragma unroll
-		for (int r = 0; r < R; r++) bytes[r] = pkts[r] = 0;
-		for (uint32_t j = 0; j < nops; j++) {
-			cu64 xq = (cu64)(kp.fops + op_base + j);
-			const uint64_t w0 = xq[0];
-			const uint32_t off = (uint32_t)w0 & 0xFFFF, len = (uint32_t)(w0 >> 16) & 0xFF;
-			const uint32_t kind = (uint32_t)(w0 >> 24) & 0xFF;
-			const uint32_t lg = kind & XE_FOP_LGW;
-			XE_GLOBAL uint8_t *col = (XE_GLOBAL uint8_t *)xq[1];
-			const uint32_t pad = (kind & (XE_FOP_COPY | XE_FOP_MAC)) ? 0 : (8 * ((1u << lg) - len));
-
-#pragma unroll
-			for (int r = 0; r < R; r++) {
-				uint32_t a[4];
-				stage_read<R>(stg, r, off, len, a);
-				if (!T.live[r] || (kp.pad2 & 16)) continue;
-				/* column bytes = the field as the reference stores it: the wire
-				 * bytes right-aligned in the field's maximum size */
-				if (lg <= 2) {
-					uint32_t v = a[0];
-					if (!(kind & XE_FOP_COPY)) v = (v & (0xFFFFFFFFu >> (32 - 8 * len))) << pad;
-					if (lg == 0) col[ridx[r]] = (uint8_t)v;
-					else if (lg == 1) ((XE_GLOBAL uint16_t *)col)[ridx[r]] = (uint16_t)v;
-					else ((XE_GLOBAL uint32_t *)col)[ridx[r]] = v;
-				} else if (lg == 3) {
-					uint64_t v = (uint64_t)a[0] | ((uint64_t)a[1] << 32);
-					if (!(kind & XE_FOP_COPY)) v = (v & (~0ull >> (64 - 8 * len))) << pad;
-					((XE_GLOBAL uint64_t *)col)[ridx[r]] = v;
-				} else {
-					uint64_t v0 = (uint64_t)a[0] | ((uint64_t)a[1] << 32);
-					uint64_t v1 = (uint64_t)a[2] | ((uint64_t)a[3] << 32);
-					if (!(kind & XE_FOP_COPY)) {
-						/* len < 16: shift the 128-bit little-endian value up by pad bits */
-						if (len <= 8) { v1 = 0; v0 &= ~0ull >> (64 - 8 * len); }
-						else v1 &= ~0ull >> (128 - 8 * len);
-						if (pad >= 64) { v1 = v0 << (pad - 64); v0 = 0; }
-						else if (pad) { v1 = (v1 << pad) | (v0 >> (64 - pad)); v0 <<= pad; }
+				for (int r = 0; r < R; r++) {
+					const uint32_t sub0 = tbase + 64 * r;
+					if ((start + nrec <= sub0) || (start >= sub0 + 64)) continue;
+					const uint32_t g = sub0 + lane, i = g - start;
+					const bool in = (g >= start) && (i < nrec);
+					voff[r] = in ? (RN[0] + i * RN[4]) : voff[r];
+					ridx[r] = in ? (RN[1] + i) : ridx[r];
+					rate[r] = in ? RN[5] : rate[r];
+					if (want_dev) {
+						T.dev_ip[r] = in ? RN[6] : T.dev_ip[r];
+						T.dev_id[r] = in ? RN[7] : T.dev_id[r];
 					}
-					((XE_GLOBAL uint64_t *)col)[2 * (size_t)ridx[r]] = v0;
-					((XE_GLOBAL uint64_t *)col)[2 * (size_t)ridx[r] + 1] = v1;
+					T.live[r] |= in;
 				}
-				if (kind & (XE_FOP_BYTES | XE_FOP_PKTS)) {
-					uint64_t hi, lo;
-					wire_number(a, len, hi, lo);
-					if (kind & XE_FOP_BYTES) bytes[r] = lo;
-					if (kind & XE_FOP_PKTS) pkts[r] = lo;
+				if (s >= s_end) break;
+				s++;
+				RN = NX;
+			}
+		}
+
+		/* stage the records: the 16-byte loads of a lane are independent, four
+		 * pieces per record are in flight before the first is written to LDS */
+		for (uint32_t k0 = 0; k0 < nchunk; k0 += 4) {
+			u32x4 q[4][R];
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+#pragma unroll
+				for (int r = 0; r < R; r++) {
+					q[i][r] = (u32x4){0, 0, 0, 0};
+					if (T.live[r] && (k0 + i < nchunk) && !(kp.pad2 & 32))
+						__builtin_memcpy(&q[i][r], (const uint8_t *)pkt + voff[r] + 16 * (k0 + i), 16);
 				}
 			}
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				if (k0 + i >= nchunk) break;
+#pragma unroll
+				for (int r = 0; r < R; r++) {
+					uint32_t *d = stg + ((4 * (k0 + i)) * R + r) * 64;
+					d[0] = q[i][r].x;
+					d[R * 64] = q[i][r].y;
+					d[2 * R * 64] = q[i][r].z;
+					d[3 * R * 64] = q[i][r].w;
+				}
+			}
+		}
+
+		/* decode: the template's micro-ops, sorted by kind */
+		if (!(kp.pad2 & 16)) {
+			uint32_t j = op_base;
+			copy_ops<R, 0>(kp, stg, j, PL[1], ridx, T.live); j += PL[1];
+			copy_ops<R, 1>(kp, stg, j, PL[2], ridx, T.live); j += PL[2];
+			copy_ops<R, 2>(kp, stg, j, PL[3], ridx, T.live); j += PL[3];
+			copy_ops<R, 3>(kp, stg, j, PL[4], ridx, T.live); j += PL[4];
+			copy_ops<R, 4>(kp, stg, j, PL[5], ridx, T.live); j += PL[5];
+			if (PL[6]) general_ops<R>(kp, stg, j, PL[6], ridx, T.live);
 		}
 		unsigned long long bxr[R], pxr[R];
 #pragma unroll
 		for (int r = 0; r < R; r++) {
+			bool has;
+			uint32_t fmax;
+			uint64_t hi, b, p;
 			if (T.live[r]) {
 				((XE_GLOBAL uint8_t *)kp.nparsed)[ridx[r]] = (uint8_t)nparsed;
 				if (kp.marks) ((XE_GLOBAL uint32_t *)kp.marks)[ridx[r]] = 0;
 			}
-			bxr[r] = bytes[r] * rate[r];
-			pxr[r] = pkts[r] * rate[r];
+			/* what the counters add (monit-objects.c:995-1007, scale 1) */
+			fld_get<R>(T, XF_in_bytes, r, has, fmax, hi, b);
+			fld_get<R>(T, XF_in_pkts, r, has, fmax, hi, p);
+			bxr[r] = b * rate[r];
+			pxr[r] = p * rate[r];
 		}
 
 		/* every IP-list membership, then every term some program needs, once */
@@ -1037,7 +1171,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 #pragma unroll
 			for (int r = 0; r < R; r++) lk[r] = 0;
 		} else {
-			fast_lookups<R>(kp, T, lk);
+			fast_lookups<R>(kp, T, plist, lk);
 		}
 		uint64_t tb[R][4];
 #pragma unroll
@@ -1063,53 +1197,42 @@ xe_nf_fast_kernel(const xe_kparams kp)
 			}
 		}
 
-		/* object programs */
+		/* object programs: the atom table first, then the listed objects */
+		uint32_t bi = 0;
 		for (uint32_t w = 0; (w < kp.mask_words) && !(kp.pad2 & 8); w++) {
 			uint64_t bits[R];
 			const uint32_t m0 = w * 64, m1 = (m0 + 64 < kp.nmo) ? m0 + 64 : kp.nmo;
 #pragma unroll
-			for (int r = 0; r < R; r++) bits[r] = 0;
-			for (uint32_t m = m0; m < m1; m++) {
-				cu64 FP = (cu64)(kp.fprogs + m);
-				const uint64_t fmask = FP[0], fw = FP[1];
-				const uint32_t fkind = (uint32_t)fw, fterm = (uint32_t)(fw >> 32);
-				cu32 PQ = (cu32)(kp.progs + m);
-				const int32_t parent = (int32_t)PQ[2];
-				bool hit[R];
-				uint32_t nhit = 0;
+			for (int r = 0; r < R; r++) {
+				uint64_t acc = 0;
+				if (T.live[r]) {
+					uint64_t x = lk[r];
+					while (x) {
+						const uint32_t a = (uint32_t)__builtin_ctzll(x);
+						x &= x - 1;
+						acc |= kp.motab_lds ? lmt[w * XE_MOTAB_ROWS + a] : kp.motab[w * XE_MOTAB_ROWS + a];
+					}
+					x = tb[r][0];
+					while (x) {
+						const uint32_t a = 64 + (uint32_t)__builtin_ctzll(x);
+						x &= x - 1;
+						acc |= kp.motab_lds ? lmt[w * XE_MOTAB_ROWS + a] : kp.motab[w * XE_MOTAB_ROWS + a];
+					}
+				}
+				bits[r] = acc;
+			}
+			while (bi < kp.nfprogs) {
+				typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+				const XE_CONST u32x4v *fq = (const XE_CONST u32x4v *)(kp.fprogs + bi);
+				const u32x4v f0 = fq[0], f1 = fq[1], f2 = fq[2];
+				const uint32_t FP[12] = { f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w };
+				const uint32_t m = FP[8];
+				const int32_t parent = (int32_t)FP[6];
+				if (m >= m1) break;
+				bi++;
 #pragma unroll
 				for (int r = 0; r < R; r++) {
-					bool h;
-					if (fkind == XE_FPROG_MASK) {
-						h = (lk[r] & fmask) != 0;
-					} else if (fkind == XE_FPROG_TERM) {
-						const uint32_t wsel = fterm >> 6;
-						const uint64_t word = (wsel == 0) ? tb[r][0] : (wsel == 1) ? tb[r][1] : (wsel == 2) ? tb[r][2] : tb[r][3];
-						h = ((word >> (fterm & 63)) & 1) != 0;
-					} else if (fkind == XE_FPROG_CONST) {
-						h = (PQ[3] >> 16) != 0;
-					} else {
-						const uint32_t pbase = PQ[0], pn = PQ[1];
-						uint64_t st = 0;
-						for (uint32_t k = 0; k < pn; k++) {
-							uint32_t op = ((cu32)kp.ops)[pbase + k];
-							uint32_t code = op & 3;
-							if (code == XE_OP_BASIC) {
-								uint32_t id = op >> 2, wsel = id >> 6;
-								uint64_t word = (wsel == 0) ? tb[r][0] : (wsel == 1) ? tb[r][1] : (wsel == 2) ? tb[r][2] : tb[r][3];
-								st = (st << 1) | ((word >> (id & 63)) & 1);
-							} else if (code == XE_OP_NOT) {
-								st ^= 1;
-							} else {
-								uint64_t top = st & 1;
-								st >>= 1;
-								if (code == XE_OP_AND) st &= (top | ~1ull);
-								else st |= top;
-							}
-						}
-						h = (st & 1) != 0;
-					}
-					h = h && T.live[r];
+					bool h = prog_eval<R>(kp, FP, lk[r], tb[r]) && T.live[r];
 					if (parent >= 0) {
 						const uint32_t par = (uint32_t)parent;
 						bool pok;
@@ -1118,24 +1241,27 @@ xe_nf_fast_kernel(const xe_kparams kp)
 						h = h && pok;
 					}
 					if (h) bits[r] |= 1ull << (m - m0);
-					hit[r] = h;
-					nhit += (uint32_t)__popcll(__ballot(h));
-				}
-				if (nhit && !(kp.pad2 & 4)) {
-					unsigned long long sb = 0, sp = 0;
-					bool anyhit = false;
-#pragma unroll
-					for (int r = 0; r < R; r++) {
-						sb += hit[r] ? bxr[r] : 0ull;
-						sp += hit[r] ? pxr[r] : 0ull;
-						anyhit |= hit[r];
-					}
-					count_hits(kp.lds_counters ? (lcnt + 3 * m) : (kp.counters + 3 * m), anyhit, nhit, lane, sb, sp);
 				}
 			}
 #pragma unroll
 			for (int r = 0; r < R; r++) {
-				if (T.live[r]) ((XE_GLOBAL uint64_t *)kp.masks)[(size_t)ridx[r] * kp.mask_words + w] = bits[r];
+				if (!T.live[r]) continue;
+				((XE_GLOBAL uint64_t *)kp.masks)[(size_t)ridx[r] * kp.mask_words + w] = bits[r];
+				/* counters: every lane adds for each object it matched */
+				uint64_t x = (kp.pad2 & 4) ? 0 : bits[r];
+				while (x) {
+					const uint32_t m = m0 + (uint32_t)__builtin_ctzll(x);
+					x &= x - 1;
+					if (kp.lds_counters) {
+						atomicAdd(lcnt + 3 * m + 0, 1ull);
+						atomicAdd(lcnt + 3 * m + 1, bxr[r]);
+						atomicAdd(lcnt + 3 * m + 2, pxr[r]);
+					} else {
+						atomicAdd(kp.counters + 3 * m + 0, 1ull);
+						atomicAdd(kp.counters + 3 * m + 1, bxr[r]);
+						atomicAdd(kp.counters + 3 * m + 2, pxr[r]);
+					}
+				}
 			}
 		}
 	}
@@ -1510,7 +1636,8 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 		uint32_t per_block = XE_BLOCK / 64;
 		uint32_t blocks = (kp->ntiles + per_block - 1) / per_block;
 		size_t shmem = (size_t)per_block * kp->fast_dwords * kp->fast_r * 64 * 4
-			+ (kp->lds_counters ? (size_t)kp->nmo * 24 : 0);
+			+ (kp->lds_counters ? (size_t)kp->nmo * 24 : 0)
+			+ (kp->motab_lds ? (size_t)kp->mask_words * XE_MOTAB_ROWS * 8 : 0);
 		if (blocks > 4096) blocks = 4096;
 		/* the kernel deals the tile list to 8 groups of blocks (blockIdx % 8):
 		 * every group needs at least one block */
