@@ -10,7 +10,7 @@ import xenoeye_amd
 
 class ListDev(C.Structure):
     _fields_ = [("root4", C.c_uint32), ("root6", C.c_uint32), ("nodes4", C.c_uint32), ("nodes6", C.c_uint32),
-                ("bit", C.c_uint32), ("pad", C.c_uint32 * 3)]
+                ("bit", C.c_uint32), ("chains4", C.c_uint32), ("chains6", C.c_uint32), ("pad", C.c_uint32)]
 
 
 class Set(C.Structure):
@@ -25,8 +25,7 @@ class Exporter(C.Structure):
 
 
 TERM = 0x80000000
-NODE_WORDS = 128
-GROUP_WORDS = 16
+NODE_WORDS = 256
 
 
 class Host:
@@ -87,7 +86,7 @@ class Host:
         assert self.L.xe_ht_flatten(self.h, C.byref(words), C.byref(nw), dev, n) == 0
         arr = np.ctypeslib.as_array(words, shape=(max(nw.value, 1),)).copy() if nw.value else np.zeros(1, np.uint32)
         self.L.xe_ht_release(words)
-        return arr, [(d.root4, d.root6, d.nodes4, d.nodes6, d.bit) for d in dev[:n]]
+        return arr, [(d.root4, d.root6, d.nodes4, d.nodes6, d.bit, d.chains4, d.chains6) for d in dev[:n]]
 
     def prepass(self, batch):
         data, offs, src, kinds = batch.packed()
@@ -119,22 +118,32 @@ class Host:
         return rc, [ln.split("\t") for ln in out.value.decode().splitlines()]
 
 
-def walk_flat(words, root, nodes, addr_bytes, bit=0):
+CHAIN = 0x40000000
+CHAIN_WORDS = 8
+
+
+def walk_flat(words, root, nodes, addr_bytes, bit=0, chains=0):
     """Reference walker of the flattened list format (tests only): the
-    group's root table over the first 16 bits, then one 64-byte group per
-    8-bit chunk; `bit` selects the list inside the group's answer bytes."""
+    group's root table over the first 16 bits, then one directly indexed
+    256-entry node per address byte, or a chain record that settles the rest
+    of the walk with one comparison; `bit` selects the list inside the group's
+    answer bits."""
     if not root:
         return 0
-    e = int(words[root + ((addr_bytes[0] << 8) | addr_bytes[1])])
-    for b in addr_bytes[2:]:
-        if e & TERM:
-            return (e >> bit) & 1
-        g = nodes + e * NODE_WORDS + GROUP_WORDS * (b >> 5)
-        child, base = int(words[g]), int(words[g + 1])
-        k = b & 31
-        if (child >> k) & 1:
-            e = base + bin(child & ((1 << k) - 1)).count("1")
+    nbits = 8 * len(addr_bytes)
+    addr = int.from_bytes(addr_bytes, "big")
+    e = int(words[root + (addr >> (nbits - 16))])
+    depth = 16
+    while not (e & TERM) and depth < nbits:
+        if e & CHAIN:
+            c = chains + (e & ~CHAIN) * CHAIN_WORDS
+            meta = int(words[c])
+            ln, lst = (meta >> 11) & 127, (meta >> 8) & 7
+            pat = (int(words[c + 3]) << 96) | (int(words[c + 2]) << 64) | (int(words[c + 5]) << 32) | int(words[c + 4])
+            rest = (addr << (128 - nbits + depth)) & ((1 << 128) - 1)   # address bits from `depth`, left-aligned
+            m = ((rest ^ pat) >> (128 - ln)) == 0
+            e = TERM | (meta & 0xFF) | (int(m) << lst)
         else:
-            ans = (int(words[g + 2 + (k >> 2)]) >> (8 * (k & 3))) & 0xFF
-            return (ans >> bit) & 1
+            e = int(words[nodes + e * NODE_WORDS + ((addr >> (nbits - depth - 8)) & 0xFF)])
+        depth += 8
     return ((e >> bit) & 1) if (e & TERM) else 0

@@ -39,9 +39,9 @@ def test_flattened_lists_equal_reference_answers():
     for i, t in enumerate(texts):
         h.add_iplist("l%d" % i, t)
     words, devs = h.flatten()
-    for i, (root4, root6, nodes4, nodes6, bit) in enumerate(devs):
-        got4 = [walk_flat(words, root4, nodes4, bytes(a), bit) for a in p4]
-        got6 = [walk_flat(words, root6, nodes6, bytes(a), bit) for a in p6]
+    for i, (root4, root6, nodes4, nodes6, bit, chains4, chains6) in enumerate(devs):
+        got4 = [walk_flat(words, root4, nodes4, bytes(a), bit, chains4) for a in p4]
+        got6 = [walk_flat(words, root6, nodes6, bytes(a), bit, chains6) for a in p6]
         assert got4 == want4[i].tolist(), i
         assert got6 == want6[i].tolist(), i
     h.close()

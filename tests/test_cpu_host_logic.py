@@ -173,11 +173,11 @@ def test_flattened_lists_match_oracle(host, orc):
     probe4 += [struct.pack(">I", int(x)) for x in synth.addrs_in_prefixes_v4(rng, 3000, *v4)]
     probe6 = [bytes(16), bytes([255] * 16), bytes.fromhex("20010db8000000000000000000000001")]
     probe6 += [bytes(r) for r in rng.bytes(1500 * 16).reshape(-1, 16)]
-    for (name, _), (root4, root6, nodes4, nodes6, bit) in zip(lists.items(), devs):
+    for (name, _), (root4, root6, nodes4, nodes6, bit, chains4, chains6) in zip(lists.items(), devs):
         for a in probe4:
-            assert walk_flat(words, root4, nodes4, a, bit) == orc.match4(name, a), (name, a.hex())
+            assert walk_flat(words, root4, nodes4, a, bit, chains4) == orc.match4(name, a), (name, a.hex())
         for a in probe6:
-            assert walk_flat(words, root6, nodes6, a, bit) == orc.match6(name, a), (name, a.hex())
+            assert walk_flat(words, root6, nodes6, a, bit, chains6) == orc.match6(name, a), (name, a.hex())
 
 
 def _count_cases():

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Memory-pipeline counters of the benchmark kernel (vector L1 <-> L2 requests,
+# their latencies, stall cycles).  Usage: tools/pmc_mem.sh <tag> [XE_ABLATE value]
+set -u
+tag=$1; export XE_ABLATE=${2:-0}
+out=gpurun_out/$tag
+mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+run() {
+  name=$1; shift
+  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 ${BENCH_ARGS:-} > "$out/$name.log" 2>&1 || { tail -5 "$out/$name.log"; exit 1; }
+}
+run p1 TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_WRITE_REQ_LATENCY_sum TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE
+run p2 TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum
+run p3 TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
+run p4 TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TD_TCP_STALL_CYCLES_sum TCP_LFIFO_STALL_CYCLES_sum TCP_RFIFO_STALL_CYCLES_sum
+python3 - "$out" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+for f in sorted(glob.glob(out + "/**/*counter_collection.csv", recursive=True)):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for row in csv.DictReader(open(f)):
+        if "xe_nf" not in row["Kernel_Name"]:
+            continue
+        acc[row["Counter_Name"]][0] += float(row["Counter_Value"]); acc[row["Counter_Name"]][1] += 1
+    for cn, (v, n) in sorted(acc.items()):
+        print("%-44s per-launch %.6g" % (cn, v / n))
+PY

@@ -528,6 +528,7 @@ xe_gpu_commit(xe_gpu *h)
 			const struct xe_list_dev *ld = &h->h_lists[(size_t)pp[i].group * XE_LIST_GROUP];
 			pp[i].root_off = (pp[i].family == 4) ? ld->root4 : ld->root6;
 			pp[i].nodes_off = (pp[i].family == 4) ? ld->nodes4 : ld->nodes6;
+			pp[i].chains_off = (pp[i].family == 4) ? ld->chains4 : ld->chains6;
 		}
 	}
 	if (rc == XE_OK) {

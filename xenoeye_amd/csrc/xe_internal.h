@@ -173,20 +173,21 @@ struct xe_prog
 
 /* Flattened IP lists.  Lists are merged in groups of XE_LIST_GROUP (registry
  * order); per group and address family: a 65536-entry root over the first 16
- * address bits, then 8-bit-stride nodes.  Root entry: bit 31 set = terminal
- * and bits 0..7 = the answers of the group's lists (bit l = list l); else the
- * index of a node.  A node is 8 groups of 64 bytes, group g covering the 32
- * chunk values [32g, 32g+32):
- *   word 0      child map (bit set: the walk continues into a child node)
- *   word 1      index of the group's first child node (children of a node
- *               are consecutive, in chunk order)
- *   bytes 8-39  one answer byte per chunk value (valid where the walk stops)
- *   bytes 40-63 unused
- * so a visit touches one 64-byte line. */
+ * address bits, then 8-bit-stride nodes of 256 entries, one per chunk value.
+ * An entry (root and node alike): bit 31 set = the walk ends here and bits
+ * 0..7 are the answers of the group's lists (bit l = list l); bit 30 set =
+ * index of a chain record; else the index of the node for the next address
+ * byte.  A visit is one 4-byte load.
+ * Chain record (XE_CHAIN_WORDS words): only list `l` can still go deeper, along
+ * one path of `len` bits that ends in a prefix:
+ *   word 0      answers of the other lists (bits 0-7) | l << 8 | len << 11
+ *   words 2-5   the path, left-aligned in 128 bits (hi word pair first)
+ * the list's answer is 1 iff the next `len` address bits equal the path. */
 #define XE_TRIE_TERM 0x80000000u
+#define XE_TRIE_CHAIN 0x40000000u
+#define XE_CHAIN_WORDS 8
 #define XE_LIST_GROUP 8
-#define XE_GROUP_WORDS 16
-#define XE_NODE_WORDS 128
+#define XE_NODE_WORDS 256
 /* one distinct (list, address family, field) membership test; the fast kernel
  * resolves all of them for a tile in batches before any term is evaluated */
 struct xe_lookup
@@ -209,6 +210,8 @@ struct xe_probe
 	uint8_t used;        /* bit l: list (8 * group + l) is tested on this field */
 	uint32_t group;
 	uint32_t nodes_off;  /* word offset of node 0 */
+	uint32_t chains_off; /* word offset of chain record 0 */
+	uint32_t pad[3];
 };
 
 /* ---- fast kernel tables (built per batch: they hold output addresses) ---- */
@@ -302,7 +305,8 @@ struct xe_list_dev
 	uint32_t root4, root6;   /* word offsets of the list's GROUP tables, 0 = family empty */
 	uint32_t nodes4, nodes6; /* word offsets of node 0 */
 	uint32_t bit;            /* the list's bit in the group's answer bytes */
-	uint32_t pad[3];
+	uint32_t chains4, chains6; /* word offsets of chain record 0 */
+	uint32_t pad;
 };
 
 /* ------------------------------------------------------------------ host side */

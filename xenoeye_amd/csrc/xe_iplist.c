@@ -9,10 +9,11 @@
  *
  * The device form replaces the one-bit-per-step pointer chase of up to 8
  * lists at once with a 65536-entry root table over the first 16 address bits
- * followed by 8-bit-stride nodes (per 32 chunk values one 64-byte line: child
- * map, first-child index, one answer byte per value with one bit per list),
- * so a lookup is one 4-byte root load plus at most (bits-16)/8 node visits,
- * whatever the number of lists.
+ * followed by 8-bit-stride nodes of 256 directly indexed entries (terminal
+ * with one answer bit per list, or the index of the next node), so a lookup
+ * is one 4-byte load per level, at most 1 + (bits-16)/8 of them, whatever the
+ * number of lists; tails along which only one prefix of one list is left
+ * are collapsed into one comparison (chain records).
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -263,10 +264,85 @@ struct gpending { struct gstate st; };
 
 struct gfl_ctx
 {
+	const struct xe_bnode *const *bt;
 	uint32_t *root;           /* 65536 entries while the root is expanded */
 	uint32_t *node;           /* XE_NODE_WORDS words while a node is expanded */
 	struct xe_blob *queue;    /* struct gpending; queue index = device node index */
+	struct xe_blob *chains;   /* XE_CHAIN_WORDS words per record */
 };
+
+/*
+ * Where the walk can only go on in ONE list, along a single path that ends in
+ * a prefix with nothing below and no prefix on the way, the rest of the walk
+ * is one comparison: the address follows the path to its end (answer 1 for
+ * that list: the deepest node is the prefix's) or leaves it at an inner node
+ * (answer 0).  Such a tail becomes a chain record instead of a node per
+ * address byte.  Returns 1 and fills rec[] when `st` is such a state, 0 when
+ * it is not, and 2 when the path ends without a prefix (answer 0 always).
+ */
+static int
+chain_of(const struct xe_bnode *const *bt, const struct gstate *st, uint32_t rec[XE_CHAIN_WORDS])
+{
+	int l = -1, k;
+	uint32_t n, len = 0;
+	uint64_t pat[2] = { 0, 0 };
+
+	for (k = 0; k < XE_LIST_GROUP; k++) {
+		if ((st->walking >> k) & 1) {
+			if (l >= 0) return 0;
+			l = k;
+		}
+	}
+	if (l < 0) return 0;
+	n = st->cur[l];
+	for (;;) {
+		const struct xe_bnode *b = &bt[l][n];
+		int c0 = b->next[0] != 0, c1 = b->next[1] != 0;
+		if (!c0 && !c1) break;
+		if ((c0 && c1) || b->is_leaf || (len >= 112)) return 0;
+		if (c1) pat[len >> 6] |= 1ull << (63 - (len & 63));
+		n = c1 ? b->next[1] : b->next[0];
+		len++;
+	}
+	memset(rec, 0, XE_CHAIN_WORDS * sizeof(uint32_t));
+	if (!bt[l][n].is_leaf) {
+		rec[0] = st->res & (uint8_t)~(1u << l);
+		return 2;
+	}
+	rec[0] = (uint32_t)(st->res & (uint8_t)~(1u << l)) | ((uint32_t)l << 8) | (len << 11);
+	rec[2] = (uint32_t)pat[0];
+	rec[3] = (uint32_t)(pat[0] >> 32);
+	rec[4] = (uint32_t)pat[1];
+	rec[5] = (uint32_t)(pat[1] >> 32);
+	return 1;
+}
+
+/* entry for a state some list can leave deeper: chain record, plain answer or
+ * a node of its own */
+static int
+child_entry(struct gfl_ctx *c, const struct gstate *child, uint32_t *entry)
+{
+	uint32_t rec[XE_CHAIN_WORDS];
+	int kind = chain_of(c->bt, child, rec);
+	size_t k;
+
+	if (kind == 2) {
+		*entry = XE_TRIE_TERM | (rec[0] & 0xFF);
+		return 1;
+	}
+	if (kind == 1) {
+		size_t idx = c->chains->n / XE_CHAIN_WORDS;
+		if (idx >= 0x3FFFFFF0u) return 0;
+		for (k = 0; k < XE_CHAIN_WORDS; k++) {
+			if (!xe_blob_push(c->chains, &rec[k], 4)) return 0;
+		}
+		*entry = XE_TRIE_CHAIN | (uint32_t)idx;
+		return 1;
+	}
+	if (c->queue->n >= 0x3FFFFFF0u) return 0;
+	*entry = (uint32_t)c->queue->n;
+	return xe_blob_push(c->queue, child, sizeof(struct gpending));
+}
 
 static int
 groot_cb(void *vctx, uint32_t first, uint32_t count, uint8_t res, const struct gstate *child)
@@ -278,9 +354,7 @@ groot_cb(void *vctx, uint32_t first, uint32_t count, uint8_t res, const struct g
 		for (i = 0; i < count; i++) c->root[first + i] = XE_TRIE_TERM | res;
 		return 1;
 	}
-	if (c->queue->n >= 0x7FFFFFF0u) return 0;
-	c->root[first] = (uint32_t)c->queue->n;
-	return xe_blob_push(c->queue, child, sizeof(struct gpending));
+	return child_entry(c, child, &c->root[first]);
 }
 
 static int
@@ -289,33 +363,29 @@ gnode_cb(void *vctx, uint32_t first, uint32_t count, uint8_t res, const struct g
 	struct gfl_ctx *c = vctx;
 	uint32_t i;
 
-	for (i = first; i < first + count; i++) {
-		((uint8_t *)&c->node[XE_GROUP_WORDS * (i >> 5) + 2])[i & 31] = res;
+	if (!child) {
+		for (i = first; i < first + count; i++) c->node[i] = XE_TRIE_TERM | res;
+		return 1;
 	}
-	if (child) {
-		/* children are queued in increasing chunk order = rank order of the map */
-		c->node[XE_GROUP_WORDS * (first >> 5)] |= 1u << (first & 31);
-		if (c->queue->n >= 0x7FFFFFF0u) return 0;
-		return xe_blob_push(c->queue, child, sizeof(struct gpending));
-	}
-	return 1;
+	return child_entry(c, child, &c->node[first]);
 }
 
 /* one address family of one group of lists; bt[l] == NULL: list l has no
  * entries of this family (answers 0).  Returns 0 on allocation failure. */
 static int
 flatten_group(const struct xe_bnode *const *bt, struct xe_blob *words,
-	uint32_t *root_off, uint32_t *nodes_off)
+	uint32_t *root_off, uint32_t *nodes_off, uint32_t *chains_off)
 {
-	struct xe_blob queue = {0};
+	struct xe_blob queue = {0}, chains = {0};
 	struct gfl_ctx c;
 	struct gstate st0;
-	size_t qi, i, root_pos, nodes_pos;
+	size_t qi, i, root_pos, nodes_pos, chains_pos;
 	uint32_t zero = 0;
-	int l, any = 0;
+	int l, any = 0, ok = 0;
 
 	*root_off = 0;
 	*nodes_off = 0;
+	*chains_off = 0;
 	memset(&st0, 0, sizeof(st0));
 	for (l = 0; l < XE_LIST_GROUP; l++) {
 		if (bt[l]) { st0.walking |= (uint8_t)(1u << l); any = 1; }
@@ -330,37 +400,50 @@ flatten_group(const struct xe_bnode *const *bt, struct xe_blob *words,
 	for (i = 0; i < 65536; i++) {
 		if (!xe_blob_push(words, &zero, 4)) return 0;
 	}
+	c.bt = bt;
 	c.queue = &queue;
+	c.chains = &chains;
 	c.node = NULL;
-	c.root = (uint32_t *)words->p + root_pos;
-	if (!gexpand(bt, &st0, 16, 0, groot_cb, &c)) { free(queue.p); return 0; }
-
-	while (words->n % XE_GROUP_WORDS) {
-		if (!xe_blob_push(words, &zero, 4)) { free(queue.p); return 0; }
+	{
+		/* the root lives in `words`, which does not grow while it is expanded */
+		c.root = (uint32_t *)words->p + root_pos;
+		if (!gexpand(bt, &st0, 16, 0, groot_cb, &c)) goto out;
+	}
+	while (words->n % 16) {
+		if (!xe_blob_push(words, &zero, 4)) goto out;
 	}
 	nodes_pos = words->n;
 	for (qi = 0; qi < queue.n; qi++) {
 		struct gstate st = ((struct gpending *)queue.p)[qi].st;
 		uint32_t nw[XE_NODE_WORDS];
-		uint32_t k, cum = 0;
-		size_t first_child = queue.n;
+		uint32_t k;
 
-		memset(nw, 0, sizeof(nw));
 		c.node = nw;
-		if (!gexpand(bt, &st, 8, 0, gnode_cb, &c)) { free(queue.p); return 0; }
-		for (k = 0; k < 8; k++) {
-			nw[XE_GROUP_WORDS * k + 1] = (uint32_t)first_child + cum;
-			cum += (uint32_t)__builtin_popcount(nw[XE_GROUP_WORDS * k]);
-		}
+		if (!gexpand(bt, &st, 8, 0, gnode_cb, &c)) goto out;
 		for (k = 0; k < XE_NODE_WORDS; k++) {
-			if (!xe_blob_push(words, &nw[k], 4)) { free(queue.p); return 0; }
+			if (!xe_blob_push(words, &nw[k], 4)) goto out;
 		}
 	}
-	free(queue.p);
-	if (words->n > 0xFFFFFFF0u) return 0;
+	while (words->n % XE_CHAIN_WORDS) {
+		if (!xe_blob_push(words, &zero, 4)) goto out;
+	}
+	chains_pos = words->n;
+	for (i = 0; i < chains.n; i++) {
+		if (!xe_blob_push(words, (uint32_t *)chains.p + i, 4)) goto out;
+	}
+	/* one spare record so that a wide load of the last one stays inside */
+	for (i = 0; i < XE_CHAIN_WORDS; i++) {
+		if (!xe_blob_push(words, &zero, 4)) goto out;
+	}
+	if (words->n > 0xFFFFFFF0u) goto out;
 	*root_off = (uint32_t)root_pos;
 	*nodes_off = (uint32_t)nodes_pos;
-	return 1;
+	*chains_off = (uint32_t)chains_pos;
+	ok = 1;
+out:
+	free(queue.p);
+	free(chains.p);
+	return ok;
 }
 
 int
@@ -370,20 +453,20 @@ xe_iplists_flatten(const struct xe_iplists *reg, struct xe_blob *words, struct x
 
 	for (g = 0; g * XE_LIST_GROUP < reg->n; g++) {
 		const struct xe_bnode *b4[XE_LIST_GROUP], *b6[XE_LIST_GROUP];
-		uint32_t r4, n4, r6, n6;
+		uint32_t r4, n4, c4, r6, n6, c6;
 
 		for (l = 0; l < XE_LIST_GROUP; l++) {
 			size_t li = g * XE_LIST_GROUP + l;
 			b4[l] = (li < reg->n) ? reg->l[li].n4 : NULL;
 			b6[l] = (li < reg->n) ? reg->l[li].n6 : NULL;
 		}
-		if (!flatten_group(b4, words, &r4, &n4)) return XE_ENOMEM;
-		if (!flatten_group(b6, words, &r6, &n6)) return XE_ENOMEM;
+		if (!flatten_group(b4, words, &r4, &n4, &c4)) return XE_ENOMEM;
+		if (!flatten_group(b6, words, &r6, &n6, &c6)) return XE_ENOMEM;
 		for (l = 0; (l < XE_LIST_GROUP) && (g * XE_LIST_GROUP + l < reg->n); l++) {
 			struct xe_list_dev *d = &dev[g * XE_LIST_GROUP + l];
 			memset(d, 0, sizeof(*d));
-			d->root4 = r4; d->nodes4 = n4;
-			d->root6 = r6; d->nodes6 = n6;
+			d->root4 = r4; d->nodes4 = n4; d->chains4 = c4;
+			d->root6 = r6; d->nodes6 = n6; d->chains6 = c6;
 			d->bit = (uint32_t)l;
 		}
 	}

@@ -18,6 +18,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include "xe_kernels.h"
 
@@ -53,40 +54,45 @@ pkt_be(const pkt_src &s, int32_t off, uint32_t len)
 }
 
 /* ------------------------------------------------------------------ flattened IP list */
-/* one node visit of a group walk: entry for the next level (node index, or
- * terminal | answer byte) */
+/* address byte that starts `depth` bits into the left-aligned 128-bit address
+ * (depth is a multiple of 8) */
 __device__ __forceinline__ uint32_t
-node_step(const uint32_t *nodes, uint32_t node, uint32_t chunk)
+addr_byte(uint64_t hi, uint64_t lo, uint32_t depth)
 {
-	const uint32_t *g = nodes + (size_t)node * XE_NODE_WORDS + XE_GROUP_WORDS * (chunk >> 5);
-	const uint2 hd = *(const uint2 *)g;
-	const uint32_t b = chunk & 31;
-	const uint32_t ans = ((const uint8_t *)(g + 2))[b];
-	if ((hd.x >> b) & 1) return hd.y + __popc(hd.x & ((1u << b) - 1u));
-	return XE_TRIE_TERM | ans;
+	return (depth < 64) ? (uint32_t)((hi << depth) >> 56) : (uint32_t)((lo << (depth - 64)) >> 56);
 }
 
-/* answers of all lists of the group: bit l = list l (iplist_match4, iplist.c:160-186) */
-__device__ uint32_t
-group_match4(const uint32_t *T, uint32_t root, uint32_t nodes, uint32_t a)
+/* chain record: the answers of the group's lists when the rest of the walk is
+ * a single path of one list (see XE_CHAIN_WORDS); w[0..5] = its first six
+ * words, depth = address bits consumed so far (16..120) */
+__device__ __forceinline__ uint32_t
+chain_answer(const uint32_t w[6], uint64_t hi, uint64_t lo, uint32_t depth)
 {
-	if (!root) return 0;
-	uint32_t e = T[root + (a >> 16)];
-	for (int lvl = 0; (lvl < 2) && !(e & XE_TRIE_TERM); lvl++) {
-		e = node_step(T + nodes, e, (a >> (8 - 8 * lvl)) & 255);
-	}
-	return (e & XE_TRIE_TERM) ? (e & 0xFF) : 0;
+	const uint32_t meta = w[0], len = (meta >> 11) & 127, l = (meta >> 8) & 7;
+	const uint64_t ph = (uint64_t)w[2] | ((uint64_t)w[3] << 32), pl = (uint64_t)w[4] | ((uint64_t)w[5] << 32);
+	uint64_t sh, sl;
+	if (depth >= 64) { sh = lo << (depth - 64); sl = 0; }
+	else { sh = (hi << depth) | (lo >> (64 - depth)); sl = lo << depth; }
+	const uint64_t dh = sh ^ ph, dl = sl ^ pl;
+	const bool m = (len <= 64) ? ((dh >> (64 - len)) == 0) : ((dh == 0) && ((dl >> (128 - len)) == 0));
+	return XE_TRIE_TERM | (meta & 0xFF) | ((uint32_t)m << l);
 }
 
-/* iplist_match6, iplist.c:188-216 */
+/* answers of all lists of a group for one address (left-aligned in hi:lo,
+ * `bits` wide): bit l = list l.  iplist_match4/6, iplist.c:160-216 */
 __device__ uint32_t
-group_match6(const uint32_t *T, uint32_t root, uint32_t nodes, uint64_t hi, uint64_t lo)
+group_match(const uint32_t *T, uint32_t root, uint32_t nodes, uint32_t chains, uint64_t hi, uint64_t lo, uint32_t bits)
 {
 	if (!root) return 0;
 	uint32_t e = T[root + (uint32_t)(hi >> 48)];
-	for (int k = 2; (k < 16) && !(e & XE_TRIE_TERM); k++) {
-		uint32_t chunk = (k < 8) ? (uint32_t)(hi >> (56 - 8 * k)) & 255 : (uint32_t)(lo >> (56 - 8 * (k - 8))) & 255;
-		e = node_step(T + nodes, e, chunk);
+	for (uint32_t depth = 16; !(e & XE_TRIE_TERM) && (depth < bits); depth += 8) {
+		if (e & XE_TRIE_CHAIN) {
+			const uint32_t *c = T + chains + (size_t)(e & ~XE_TRIE_CHAIN) * XE_CHAIN_WORDS;
+			const uint32_t w[6] = { c[0], c[1], c[2], c[3], c[4], c[5] };
+			e = chain_answer(w, hi, lo, depth);
+		} else {
+			e = T[nodes + (size_t)e * XE_NODE_WORDS + addr_byte(hi, lo, depth)];
+		}
 	}
 	return (e & XE_TRIE_TERM) ? (e & 0xFF) : 0;
 }
@@ -94,13 +100,13 @@ group_match6(const uint32_t *T, uint32_t root, uint32_t nodes, uint64_t hi, uint
 __device__ __forceinline__ uint32_t
 trie_match4(const uint32_t *T, const xe_list_dev &L, uint32_t a)
 {
-	return (group_match4(T, L.root4, L.nodes4, a) >> L.bit) & 1;
+	return (group_match(T, L.root4, L.nodes4, L.chains4, (uint64_t)a << 32, 0, 32) >> L.bit) & 1;
 }
 
 __device__ __forceinline__ uint32_t
 trie_match6(const uint32_t *T, const xe_list_dev &L, uint64_t hi, uint64_t lo)
 {
-	return (group_match6(T, L.root6, L.nodes6, hi, lo) >> L.bit) & 1;
+	return (group_match(T, L.root6, L.nodes6, L.chains6, hi, lo, 128) >> L.bit) & 1;
 }
 
 /* ------------------------------------------------------------------ field sources */
@@ -591,29 +597,6 @@ typedef const XE_CONST uint64_t *cu64;
 typedef const XE_CONST uint8_t *cu8;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-/* what one node visit loads: the group's child map + first-child index, and
- * the answer byte of the chunk (same 64-byte line) */
-struct node_ld { uint64_t hd; uint32_t ans; };
-
-__device__ __forceinline__ node_ld
-node_fetch(const uint32_t *nodes, uint32_t node, uint32_t chunk)
-{
-	const XE_CONST uint32_t *g = (const XE_CONST uint32_t *)(nodes + (size_t)node * XE_NODE_WORDS
-		+ XE_GROUP_WORDS * (chunk >> 5));
-	node_ld r;
-	r.hd = *(const XE_CONST uint64_t *)g;
-	r.ans = ((const XE_CONST uint8_t *)(g + 2))[chunk & 31];
-	return r;
-}
-
-__device__ __forceinline__ uint32_t
-node_next(const node_ld &r, uint32_t chunk)
-{
-	const uint32_t b = chunk & 31, map = (uint32_t)r.hd;
-	if ((map >> b) & 1) return (uint32_t)(r.hd >> 32) + __popc(map & ((1u << b) - 1u));
-	return XE_TRIE_TERM | r.ans;
-}
-
 struct term_s { uint32_t type, dir, fsrc, fdst, func, fa, fb, nopnd; int32_t k; const xe_dopnd *o; };
 __device__ __forceinline__ term_s
 ld_term(const xe_kparams &kp, uint32_t t)
@@ -717,40 +700,33 @@ fld_get(const fast_tile<R> &T, uint32_t field, uint32_t r, bool &has, uint32_t &
 	wire_number(a, len, hi, lo);
 }
 
-/* address chunk `lvl` levels below the 16-bit root */
-__device__ __forceinline__ uint32_t
-addr_chunk(uint32_t family, uint32_t lvl, uint32_t a4, uint64_t hi, uint64_t lo)
-{
-	if (family == 4) return (a4 >> (8 - 8 * (lvl & 1))) & 255;
-	const uint32_t byte = lvl + 2;
-	return (byte < 8) ? (uint32_t)(hi >> (56 - 8 * byte)) & 255 : (uint32_t)(lo >> (56 - 8 * (byte - 8))) & 255;
-}
-
 /*
  * All IP-list membership tests of a tile.  Per probe (one field against one
  * group of up to 8 lists) ONE walk of the group's merged tables per record: a
- * 4-byte root gather, then one node visit (one 64-byte line) per further
- * address byte while any list of the group can still go deeper.  The walks
- * are dependent gathers, so several are kept in flight: PC probes x R
- * records advance level by level together.  `plist` names the probes whose
- * field the template carries (byte i = probe index, 0xFF = end).  Bit
- * (8 * probe + l) of lk[r] = list l of the probe's group matched.
+ * 4-byte root gather, then per further address byte one 4-byte node visit
+ * while several prefixes are still possible, and one chain record (24 bytes)
+ * once a single prefix is left.  The walks are dependent gathers, so several
+ * are kept in flight: PC probes x R records advance level by level together,
+ * all loads of a level issued before the first result is used.  `plist` names
+ * the probes whose field the template carries (byte i = probe index, 0xFF =
+ * end).  Bit (8 * probe + l) of lk[r] = list l of the probe's group matched.
  */
 template <int R>
 __device__ void
 fast_lookups(const xe_kparams &kp, const fast_tile<R> &T, uint64_t plist, uint64_t lk[R])
 {
 	constexpr int PC = (R == 1) ? 4 : 2;
+	typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 #pragma unroll
 	for (int r = 0; r < R; r++) lk[r] = 0;
 
 	while ((plist & 0xFF) != 0xFF) {
-		uint32_t root[PC], nodes[PC], family[PC], used[PC], pidx[PC], nlvl[PC];
+		uint32_t nodes[PC], chains[PC], used[PC], pidx[PC], bits[PC];
 		bool act[PC];
-		uint32_t e[PC][R], a4[PC][R];
+		uint32_t e[PC][R];
 		uint64_t hi[PC][R], lo[PC][R];
-		uint32_t maxlvl = 0;
+		uint32_t maxbits = 0;
 
 #pragma unroll
 		for (int c = 0; c < PC; c++) {
@@ -758,59 +734,77 @@ fast_lookups(const xe_kparams &kp, const fast_tile<R> &T, uint64_t plist, uint64
 			/* the list ends with 0xFF bytes: once inactive, always inactive */
 			act[c] = (pr != 0xFF);
 			cu32 q = (cu32)(kp.probes + (act[c] ? pr : 0));
-			const uint32_t w1 = q[1];
-			root[c] = q[0];
+			const uint32_t root = q[0], w1 = q[1];
 			nodes[c] = q[3];
-			family[c] = w1 & 0xFF;
+			chains[c] = q[4];
 			used[c] = w1 >> 24;
 			pidx[c] = pr;
-			nlvl[c] = act[c] ? ((family[c] == 4) ? 2u : 14u) : 0u;
-			if (nlvl[c] > maxlvl) maxlvl = nlvl[c];
+			bits[c] = act[c] ? (((w1 & 0xFF) == 4) ? 32u : 128u) : 0u;
+			if (bits[c] > maxbits) maxbits = bits[c];
 #pragma unroll
 			for (int r = 0; r < R; r++) {
 				bool has;
 				uint32_t fmax;
 				e[c][r] = XE_TRIE_TERM;
-				a4[c][r] = 0;
 				hi[c][r] = lo[c][r] = 0;
 				if (!act[c]) continue;
 				fld_get<R>(T, (w1 >> 8) & 0xFF, r, has, fmax, hi[c][r], lo[c][r]);
-				a4[c][r] = ((w1 >> 16) & 1) ? (uint32_t)(hi[c][r] >> 32) : (uint32_t)lo[c][r];
-				if (T.live[r]) {
-					const uint32_t top = (family[c] == 6) ? (uint32_t)(hi[c][r] >> 48) : (a4[c][r] >> 16);
-					e[c][r] = ((const XE_CONST uint32_t *)(kp.trie + root[c]))[top];
+				if (bits[c] == 32) {
+					/* IPv4: the field's 4 bytes, or the first 4 of a 16-byte field */
+					const uint32_t a4 = ((w1 >> 16) & 1) ? (uint32_t)(hi[c][r] >> 32) : (uint32_t)lo[c][r];
+					hi[c][r] = (uint64_t)a4 << 32;
+					lo[c][r] = 0;
 				}
+				if (T.live[r]) e[c][r] = ((const XE_CONST uint32_t *)(kp.trie + root))[(uint32_t)(hi[c][r] >> 48)];
 			}
 		}
-		for (uint32_t lvl = 0; lvl < maxlvl; lvl++) {
+		for (uint32_t depth = 16; depth < maxbits; depth += 8) {
 			bool walk[PC][R], any = false;
-			uint32_t ch[PC][R];
-			node_ld nl[PC][R];
+			uint32_t nx[PC][R];
+			u32x4 ca[PC][R];
+			u32x2 cb[PC][R];
 #pragma unroll
 			for (int c = 0; c < PC; c++) {
 #pragma unroll
 				for (int r = 0; r < R; r++) {
-					walk[c][r] = act[c] && (lvl < nlvl[c]) && !(e[c][r] & XE_TRIE_TERM);
+					walk[c][r] = act[c] && (depth < bits[c]) && !(e[c][r] & XE_TRIE_TERM);
 					any |= walk[c][r];
 				}
 			}
 			if (!__ballot(any)) break;
-			/* lanes that are done re-read node 0 of the table: one shared line */
+			/* only lanes that still walk touch memory */
 #pragma unroll
 			for (int c = 0; c < PC; c++) {
-				if (!act[c] || (lvl >= nlvl[c])) continue;
+				if (!act[c] || (depth >= bits[c])) continue;
 #pragma unroll
 				for (int r = 0; r < R; r++) {
-					ch[c][r] = walk[c][r] ? addr_chunk(family[c], lvl, a4[c][r], hi[c][r], lo[c][r]) : 0;
-					nl[c][r] = node_fetch(kp.trie + nodes[c], walk[c][r] ? e[c][r] : 0, ch[c][r]);
+					nx[c][r] = e[c][r];
+					ca[c][r] = (u32x4){0, 0, 0, 0};
+					cb[c][r] = (u32x2){0, 0};
+					if (walk[c][r]) {
+						if (e[c][r] & XE_TRIE_CHAIN) {
+							const XE_CONST uint32_t *cp = (const XE_CONST uint32_t *)(kp.trie + chains[c])
+								+ (size_t)(e[c][r] & ~XE_TRIE_CHAIN) * XE_CHAIN_WORDS;
+							ca[c][r] = *(const XE_CONST u32x4 *)cp;
+							cb[c][r] = *(const XE_CONST u32x2 *)(cp + 4);
+						} else {
+							nx[c][r] = ((const XE_CONST uint32_t *)(kp.trie + nodes[c]))[(size_t)e[c][r] * XE_NODE_WORDS
+								+ addr_byte(hi[c][r], lo[c][r], depth)];
+						}
+					}
 				}
 			}
 #pragma unroll
 			for (int c = 0; c < PC; c++) {
-				if (!act[c] || (lvl >= nlvl[c])) continue;
+				if (!act[c] || (depth >= bits[c])) continue;
 #pragma unroll
 				for (int r = 0; r < R; r++) {
-					if (walk[c][r]) e[c][r] = node_next(nl[c][r], ch[c][r]);
+					if (walk[c][r] && (e[c][r] & XE_TRIE_CHAIN)) {
+						const uint32_t w[6] = { ca[c][r].x, ca[c][r].y, ca[c][r].z, ca[c][r].w, cb[c][r].x, cb[c][r].y };
+						e[c][r] = chain_answer(w, hi[c][r], lo[c][r], depth);
+					} else {
+						e[c][r] = nx[c][r];
+					}
 				}
 			}
 		}
@@ -1028,10 +1022,17 @@ prog_eval(const xe_kparams &kp, const uint32_t (&FP)[12], uint64_t lkbits, const
 	return (st & 1) != 0;
 }
 
+/* diagnostic phase timing (XE_ABLATE bit 6): wave-clock cycles per phase, summed
+ * over the waves' tiles into xe_fast_phase_cycles[] */
+__device__ unsigned long long xe_fast_phase_cycles[8];
+#define XE_PHASE(N) do { if (kp.pad2 & 64) { const uint64_t now_ = __builtin_readcyclecounter(); \
+	if (lane == 0) atomicAdd(&xe_fast_phase_cycles[N], (unsigned long long)(now_ - tprev)); tprev = now_; } } while (0)
+
 template <int R>
 __global__ void __launch_bounds__(XE_BLOCK)
 xe_nf_fast_kernel(const xe_kparams kp)
 {
+	uint64_t tprev = __builtin_readcyclecounter();
 	extern __shared__ uint32_t lds32[];
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	/* staging: kp.fast_dwords dwords per record, [wave][dword][r][lane]; then
@@ -1111,6 +1112,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 			}
 		}
 
+		XE_PHASE(0);
 		/* stage the records: the 16-byte loads of a lane are independent, four
 		 * pieces per record are in flight before the first is written to LDS */
 		for (uint32_t k0 = 0; k0 < nchunk; k0 += 4) {
@@ -1138,16 +1140,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 			}
 		}
 
-		/* decode: the template's micro-ops, sorted by kind */
-		if (!(kp.pad2 & 16)) {
-			uint32_t j = op_base;
-			copy_ops<R, 0>(kp, stg, j, PL[1], ridx, T.live); j += PL[1];
-			copy_ops<R, 1>(kp, stg, j, PL[2], ridx, T.live); j += PL[2];
-			copy_ops<R, 2>(kp, stg, j, PL[3], ridx, T.live); j += PL[3];
-			copy_ops<R, 3>(kp, stg, j, PL[4], ridx, T.live); j += PL[4];
-			copy_ops<R, 4>(kp, stg, j, PL[5], ridx, T.live); j += PL[5];
-			if (PL[6]) general_ops<R>(kp, stg, j, PL[6], ridx, T.live);
-		}
+		XE_PHASE(1);
 		unsigned long long bxr[R], pxr[R];
 #pragma unroll
 		for (int r = 0; r < R; r++) {
@@ -1173,6 +1166,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 		} else {
 			fast_lookups<R>(kp, T, plist, lk);
 		}
+		XE_PHASE(2);
 		uint64_t tb[R][4];
 #pragma unroll
 		for (int r = 0; r < R; r++) tb[r][0] = tb[r][1] = tb[r][2] = tb[r][3] = 0;
@@ -1197,6 +1191,20 @@ xe_nf_fast_kernel(const xe_kparams kp)
 			}
 		}
 
+		XE_PHASE(3);
+		/* decode: the template's micro-ops, sorted by kind.  The stores come
+		 * after the list walks so that no gather waits behind them (the vector
+		 * memory counter retires in order) */
+		if (!(kp.pad2 & 16)) {
+			uint32_t j = op_base;
+			copy_ops<R, 0>(kp, stg, j, PL[1], ridx, T.live); j += PL[1];
+			copy_ops<R, 1>(kp, stg, j, PL[2], ridx, T.live); j += PL[2];
+			copy_ops<R, 2>(kp, stg, j, PL[3], ridx, T.live); j += PL[3];
+			copy_ops<R, 3>(kp, stg, j, PL[4], ridx, T.live); j += PL[4];
+			copy_ops<R, 4>(kp, stg, j, PL[5], ridx, T.live); j += PL[5];
+			if (PL[6]) general_ops<R>(kp, stg, j, PL[6], ridx, T.live);
+		}
+		XE_PHASE(4);
 		/* object programs: the atom table first, then the listed objects */
 		uint32_t bi = 0;
 		for (uint32_t w = 0; (w < kp.mask_words) && !(kp.pad2 & 8); w++) {
@@ -1264,6 +1272,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 				}
 			}
 		}
+		XE_PHASE(5);
 	}
 
 	if (kp.lds_counters) {
@@ -1648,6 +1657,16 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 		else hipLaunchKernelGGL(xe_nf_fast_kernel<1>, dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
 		if (ev) (void)hipEventRecord(ev[1], st);
 		if (hipGetLastError() != hipSuccess) return XE_EHIP;
+		if (kp->pad2 & 64) {
+			/* diagnostic: print and reset the per-phase wave cycles */
+			unsigned long long pc[8], z[8] = {0};
+			(void)hipStreamSynchronize(st);
+			(void)hipMemcpyFromSymbol(pc, HIP_SYMBOL(xe_fast_phase_cycles), sizeof(pc));
+			(void)hipMemcpyToSymbol(HIP_SYMBOL(xe_fast_phase_cycles), z, sizeof(z));
+			fprintf(stderr, "phase cycles per tile: runs %.0f stage %.0f lookups %.0f terms %.0f decode %.0f programs %.0f\n",
+				(double)pc[0] / kp->ntiles, (double)pc[1] / kp->ntiles, (double)pc[2] / kp->ntiles,
+				(double)pc[3] / kp->ntiles, (double)pc[4] / kp->ntiles, (double)pc[5] / kp->ntiles);
+		}
 	}
 	if (kp->nslowrec) {
 		uint32_t blocks = (kp->nslowrec + XE_BLOCK - 1) / XE_BLOCK;
