@@ -20,7 +20,7 @@ struct xe_gpu
 	int device;
 	struct xe_host hs;
 	int committed;
-	void *d_progs, *d_ops, *d_terms, *d_opnds, *d_trie, *d_lists, *d_devrules, *d_lookups, *d_fterms, *d_fprogs, *d_motab;
+	void *d_progs, *d_ops, *d_terms, *d_opnds, *d_trie, *d_lists, *d_devrules, *d_lookups, *d_fterms, *d_fprogs, *d_motab, *d_tneed;
 	uint32_t nmo, mask_words, nprogs_total, nlookups;
 	struct xe_list_dev *h_lists;
 	struct xe_probe *h_probes;   /* host copy of the probe table (nlookups entries) */
@@ -28,6 +28,7 @@ struct xe_gpu
 	size_t up_tmpls, up_tents;
 	uint32_t nterms;           /* distinct terms of the object programs */
 	uint32_t nfprogs;          /* objects the fast kernel evaluates one by one */
+	uint32_t ntneed;           /* terms the fast kernel has to evaluate */
 	int fast_ok, want_dev;     /* want_dev: some object program reads dev_ip / dev_id */
 	char err[512];
 };
@@ -112,7 +113,7 @@ static void
 free_config_dev(xe_gpu *h)
 {
 	void **p[] = { &h->d_progs, &h->d_ops, &h->d_terms, &h->d_opnds, &h->d_trie, &h->d_lists, &h->d_devrules,
-		&h->d_lookups, &h->d_fterms, &h->d_fprogs, &h->d_motab };
+		&h->d_lookups, &h->d_fterms, &h->d_fprogs, &h->d_motab, &h->d_tneed };
 	for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); i++) {
 		if (*p[i]) (void)hipFree(*p[i]);
 		*p[i] = NULL;
@@ -607,6 +608,15 @@ xe_gpu_commit(xe_gpu *h)
 			free(mt);
 		}
 		if (rc == XE_OK) rc = upload(h, &h->d_fterms, ft, (size_t)h->nterms * sizeof(*ft));
+		if (rc == XE_OK) {
+			uint32_t *need = (uint32_t *)calloc(h->nterms ? h->nterms : 1, sizeof(uint32_t));
+			uint32_t n = 0;
+			if (!need) rc = XE_ENOMEM;
+			for (uint32_t t = 0; (rc == XE_OK) && (t < h->nterms); t++) if (ft[t].kind & 2) need[n++] = t;
+			h->ntneed = n;
+			if (rc == XE_OK) rc = upload(h, &h->d_tneed, need, (size_t)n * sizeof(uint32_t));
+			free(need);
+		}
 		free(ft);
 		free(fp);
 	}
@@ -822,6 +832,8 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 		b->kp.fast_want_dev = (uint32_t)h->want_dev;
 		b->kp.nterms = h->nterms;
 		b->kp.fterms = (const struct xe_fterm *)h->d_fterms;
+		b->kp.tneed = (const uint32_t *)h->d_tneed;
+		b->kp.ntneed = h->ntneed;
 		b->kp.fprogs = (const struct xe_fprog *)h->d_fprogs;
 		b->kp.nfprogs = h->nfprogs;
 		b->kp.motab = (const uint64_t *)h->d_motab;

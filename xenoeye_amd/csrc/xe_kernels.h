@@ -83,6 +83,8 @@ struct xe_kparams
 	uint32_t nssets, nslowrec;
 	uint32_t nterms;             /* distinct terms */
 	const struct xe_fterm *fterms;  /* parallel to terms[0, nterms) */
+	const uint32_t *tneed;       /* the terms some program needs evaluated */
+	uint32_t ntneed, pad4;
 	const struct xe_probe *probes;
 	uint32_t nprobes, pad2;
 	uint32_t lds_counters;       /* per-block counter staging fits in LDS */

@@ -715,7 +715,7 @@ template <int R>
 __device__ void
 fast_lookups(const xe_kparams &kp, const fast_tile<R> &T, uint64_t plist, uint64_t lk[R])
 {
-	constexpr int PC = (R == 1) ? 4 : 2;
+	constexpr int PC = 2;
 	typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 #pragma unroll
@@ -1022,6 +1022,78 @@ prog_eval(const xe_kparams &kp, const uint32_t (&FP)[12], uint64_t lkbits, const
 	return (st & 1) != 0;
 }
 
+/* per lane: where its records of a tile are and what their exporter says */
+template <int R>
+struct tile_lanes
+{
+	uint32_t voff[R], ridx[R], rate[R], dev_ip[R], dev_id[R];
+	bool live[R];
+	uint32_t tmpl, nchunk;    /* wave-uniform */
+};
+
+/* which run, which record: the runs that overlap the tile are walked with
+ * scalar loads (the next run's descriptor is fetched while the current one is
+ * applied); each lane keeps the run it falls into */
+template <int R>
+__device__ __forceinline__ void
+tile_setup(const xe_kparams &kp, uint32_t tile, uint32_t lane, bool want_dev, tile_lanes<R> &S)
+{
+	typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+	cu32 TQ = (cu32)(kp.ftiles + tile);
+	const uint32_t tbase = TQ[2], s_end = kp.nfruns - 1;
+	uint32_t s = TQ[0];
+	u32x8 RN = *(const XE_CONST u32x8 *)(kp.fruns + s);
+
+	S.tmpl = TQ[1];
+	S.nchunk = ((cu32)(kp.fplans + S.tmpl))[8];
+#pragma unroll
+	for (int r = 0; r < R; r++) {
+		S.live[r] = false;
+		S.voff[r] = S.ridx[r] = S.rate[r] = 0;
+		S.dev_ip[r] = S.dev_id[r] = 0;
+	}
+	for (;;) {
+		const uint32_t start = RN[2], nrec = RN[3];
+		if (start >= tbase + 64 * R) break;
+		const u32x8 NX = *(const XE_CONST u32x8 *)(kp.fruns + ((s < s_end) ? s + 1 : s_end));
+#pragma unroll
+		for (int r = 0; r < R; r++) {
+			const uint32_t sub0 = tbase + 64 * r;
+			if ((start + nrec <= sub0) || (start >= sub0 + 64)) continue;
+			const uint32_t g = sub0 + lane, i = g - start;
+			const bool in = (g >= start) && (i < nrec);
+			S.voff[r] = in ? (RN[0] + i * RN[4]) : S.voff[r];
+			S.ridx[r] = in ? (RN[1] + i) : S.ridx[r];
+			S.rate[r] = in ? RN[5] : S.rate[r];
+			if (want_dev) {
+				S.dev_ip[r] = in ? RN[6] : S.dev_ip[r];
+				S.dev_id[r] = in ? RN[7] : S.dev_id[r];
+			}
+			S.live[r] |= in;
+		}
+		if (s >= s_end) break;
+		s++;
+		RN = NX;
+	}
+}
+
+/* start the loads of the first (up to) four 16-byte pieces of every record */
+template <int R>
+__device__ __forceinline__ void
+tile_issue(const xe_kparams &kp, const tile_lanes<R> &S, u32x4 (&q)[4][R])
+{
+	const XE_GLOBAL uint8_t *pkt = (const XE_GLOBAL uint8_t *)kp.pkt;
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+#pragma unroll
+		for (int r = 0; r < R; r++) {
+			q[i][r] = (u32x4){0, 0, 0, 0};
+			if (S.live[r] && ((uint32_t)i < S.nchunk) && !(kp.pad2 & 32))
+				__builtin_memcpy(&q[i][r], (const uint8_t *)pkt + S.voff[r] + 16 * i, 16);
+		}
+	}
+}
+
 /* diagnostic phase timing (XE_ABLATE bit 6): wave-clock cycles per phase, summed
  * over the waves' tiles into xe_fast_phase_cycles[] */
 __device__ unsigned long long xe_fast_phase_cycles[8];
@@ -1061,83 +1133,66 @@ xe_nf_fast_kernel(const xe_kparams kp)
 	const uint32_t per = (kp.ntiles + 7) >> 3;
 	const uint32_t p0 = part * per, p1 = (p0 + per < kp.ntiles) ? p0 + per : kp.ntiles;
 	const uint32_t wave0 = __builtin_amdgcn_readfirstlane(p0 + lblk * (XE_BLOCK / 64) + wave);
-	for (uint32_t tile = wave0; tile < p1; tile += nblk * (XE_BLOCK / 64)) {
-		cu32 TQ = (cu32)(kp.ftiles + tile);
-		const uint32_t tmpl = TQ[1];
+	/* Tiles are pipelined: while a tile is classified and written out, the
+	 * packet loads of the wave's next tile are already in flight (they sit in
+	 * registers until the staging area is free again). */
+	const uint32_t tstride = nblk * (XE_BLOCK / 64);
+	tile_lanes<R> C, N;
+	u32x4 q[4][R];
+	if (wave0 < p1) {
+		tile_setup<R>(kp, wave0, lane, want_dev, C);
+		tile_issue<R>(kp, C, q);
+		N = C;
+	}
+	for (uint32_t tile = wave0; tile < p1; tile += tstride) {
+		const uint32_t tmpl = C.tmpl, nchunk = C.nchunk;
 		cu32 PL = (cu32)(kp.fplans + tmpl);
-		const uint32_t op_base = PL[0], nparsed = PL[7], nchunk = PL[8];
+		const uint32_t op_base = PL[0], nparsed = PL[7];
 		const uint64_t plist = ((cu64)PL)[5];
-		const uint32_t tbase = TQ[2];
 		fast_tile<R> T;
-		uint32_t voff[R], ridx[R], rate[R];
+		uint32_t ridx[R], rate[R];
 
 		T.stg = stg;
 		T.fld = (cu32)(kp.fflds + (size_t)tmpl * XE_NFIELDS);
 #pragma unroll
 		for (int r = 0; r < R; r++) {
-			T.live[r] = false;
-			voff[r] = ridx[r] = rate[r] = 0;
-			T.dev_ip[r] = T.dev_id[r] = 0;
+			T.live[r] = C.live[r];
+			T.dev_ip[r] = C.dev_ip[r];
+			T.dev_id[r] = C.dev_id[r];
+			ridx[r] = C.ridx[r];
+			rate[r] = C.rate[r];
 		}
 
-		/* which run, which record (the next run's descriptor is fetched while
-		 * the current one is applied) */
-		{
-			typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-			const uint32_t s_end = kp.nfruns - 1;
-			uint32_t s = TQ[0];
-			u32x8 RN = *(const XE_CONST u32x8 *)(kp.fruns + s);
-			for (;;) {
-				const uint32_t start = RN[2], nrec = RN[3];
-				if (start >= tbase + 64 * R) break;
-				const u32x8 NX = *(const XE_CONST u32x8 *)(kp.fruns + ((s < s_end) ? s + 1 : s_end));
+		/* stage the records in LDS: the pieces loaded ahead, then (records
+		 * longer than 64 bytes) the rest */
 #pragma unroll
-				for (int r = 0; r < R; r++) {
-					const uint32_t sub0 = tbase + 64 * r;
-					if ((start + nrec <= sub0) || (start >= sub0 + 64)) continue;
-					const uint32_t g = sub0 + lane, i = g - start;
-					const bool in = (g >= start) && (i < nrec);
-					voff[r] = in ? (RN[0] + i * RN[4]) : voff[r];
-					ridx[r] = in ? (RN[1] + i) : ridx[r];
-					rate[r] = in ? RN[5] : rate[r];
-					if (want_dev) {
-						T.dev_ip[r] = in ? RN[6] : T.dev_ip[r];
-						T.dev_id[r] = in ? RN[7] : T.dev_id[r];
-					}
-					T.live[r] |= in;
-				}
-				if (s >= s_end) break;
-				s++;
-				RN = NX;
+		for (int i = 0; i < 4; i++) {
+			if ((uint32_t)i >= nchunk) break;
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				uint32_t *d = stg + ((4 * i) * R + r) * 64;
+				d[0] = q[i][r].x;
+				d[R * 64] = q[i][r].y;
+				d[2 * R * 64] = q[i][r].z;
+				d[3 * R * 64] = q[i][r].w;
 			}
 		}
-
+		for (uint32_t k = 4; k < nchunk; k++) {
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				u32x4 x = {0, 0, 0, 0};
+				if (C.live[r] && !(kp.pad2 & 32)) __builtin_memcpy(&x, (const uint8_t *)pkt + C.voff[r] + 16 * k, 16);
+				uint32_t *d = stg + ((4 * k) * R + r) * 64;
+				d[0] = x.x;
+				d[R * 64] = x.y;
+				d[2 * R * 64] = x.z;
+				d[3 * R * 64] = x.w;
+			}
+		}
 		XE_PHASE(0);
-		/* stage the records: the 16-byte loads of a lane are independent, four
-		 * pieces per record are in flight before the first is written to LDS */
-		for (uint32_t k0 = 0; k0 < nchunk; k0 += 4) {
-			u32x4 q[4][R];
-#pragma unroll
-			for (int i = 0; i < 4; i++) {
-#pragma unroll
-				for (int r = 0; r < R; r++) {
-					q[i][r] = (u32x4){0, 0, 0, 0};
-					if (T.live[r] && (k0 + i < nchunk) && !(kp.pad2 & 32))
-						__builtin_memcpy(&q[i][r], (const uint8_t *)pkt + voff[r] + 16 * (k0 + i), 16);
-				}
-			}
-#pragma unroll
-			for (int i = 0; i < 4; i++) {
-				if (k0 + i >= nchunk) break;
-#pragma unroll
-				for (int r = 0; r < R; r++) {
-					uint32_t *d = stg + ((4 * (k0 + i)) * R + r) * 64;
-					d[0] = q[i][r].x;
-					d[R * 64] = q[i][r].y;
-					d[2 * R * 64] = q[i][r].z;
-					d[3 * R * 64] = q[i][r].w;
-				}
-			}
+		if (tile + tstride < p1) {
+			tile_setup<R>(kp, tile + tstride, lane, want_dev, N);
+			tile_issue<R>(kp, N, q);
 		}
 
 		XE_PHASE(1);
@@ -1170,10 +1225,10 @@ xe_nf_fast_kernel(const xe_kparams kp)
 		uint64_t tb[R][4];
 #pragma unroll
 		for (int r = 0; r < R; r++) tb[r][0] = tb[r][1] = tb[r][2] = tb[r][3] = 0;
-		for (uint32_t t = 0; (t < kp.nterms) && !(kp.pad2 & 2); t++) {
+		for (uint32_t ti = 0; (ti < kp.ntneed) && !(kp.pad2 & 2); ti++) {
+			const uint32_t t = ((cu32)kp.tneed)[ti];
 			cu64 fq = (cu64)(kp.fterms + t);
 			const uint64_t fkind = fq[0];
-			if (!(fkind & 2)) continue;
 			const term_s tm = ld_term(kp, t);
 #pragma unroll
 			for (int r = 0; r < R; r++) {
@@ -1273,6 +1328,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 			}
 		}
 		XE_PHASE(5);
+		C = N;
 	}
 
 	if (kp.lds_counters) {
