@@ -34,15 +34,19 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--records", type=int, default=1 << 22, help="records per GPU per step")
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2"])
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c4"])
+    ap.add_argument("--c4-prefixes", type=int, default=1000000, help="prefixes per list of the c4 workload")
     ap.add_argument("--cpu-sample", type=int, default=12000000, help="records timed on the CPU oracle (0 = skip)")
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch from a rocprofv3 --pmc pass (reported as roofline.traffic)")
     return ap.parse_args()
 
 
-def build_workload(name, nrec, rank):
+def build_workload(name, nrec, rank, c4_prefixes=1000000):
     from xenoeye_amd import synth
+    if name == "c4":
+        return synth.workload_c4(nrec, seed=synth.SEED_C4 ^ (rank << 32), prefixes=c4_prefixes), \
+            "C4 netflow-v9 29B records, 256 objects = 8 lists x %d prefixes x 32 variants (net + port/AS/proto)" % c4_prefixes
     if name == "c1":
         return synth.workload_c1(nrec, seed=synth.SEED_C1 ^ (rank << 32)), \
             "C1 netflow-v9 1 exporter 21B records 1 object (src net mynet)"
@@ -108,7 +112,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import xenoeye_amd
-    w, wl_name = build_workload(args.workload, args.records, rank)
+    w, wl_name = build_workload(args.workload, args.records, rank, args.c4_prefixes)
     eng = xenoeye_amd.Engine(device=local_rank)
     for name, text in w["iplists"].items():
         eng.add_iplist(name, text)

@@ -1,0 +1,83 @@
+"""GPU parity at larger shapes: 256 objects over big lists (multi-word masks,
+listed and table-resolved objects mixed), and size-independent properties of
+the benchmark-size batch."""
+import numpy as np
+import pytest
+
+import xenoeye_amd
+from xenoeye_amd import synth
+from helpers import configure, run_oracle, compare
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def eng():
+    e = xenoeye_amd.Engine(device=0)
+    yield e
+    e.close()
+
+
+def test_c4_shape_256_objects(eng, orc):
+    w = synth.workload_c4(20000, prefixes=30000)
+    assert len(w["mos"]) == 256
+    configure(eng, orc, w["iplists"], w["mos"])
+    b = eng.prepare(w["batch"])
+    b.run()
+    assert b.mask_words == 4
+    run_oracle(orc, w["batch"], keep_flows=True)
+    compare(b, orc)
+    c = b.counters()
+    assert (c[:, 0] > 0).sum() > 200     # nearly every object sees traffic
+
+
+def test_c4_nested_objects(eng, orc):
+    """children under table-resolved and listed parents, across mask words"""
+    w = synth.workload_c4(6000, prefixes=5000, n_lists=4, variants=4)
+    mos = list(w["mos"])
+    n0 = len(mos)
+    for i in range(n0):
+        mos.append(("proto 6", i))                 # child of every object
+    for i in range(n0):
+        mos.append(("dst port 0-1023 or src port 0-1023", n0 + i))   # grandchild
+    mos += [("", -1), ("not net big0", -1), ("src net big1 or dst net big2", 2 * n0)]
+    configure(eng, orc, w["iplists"], mos)
+    b = eng.prepare(w["batch"])
+    b.run()
+    run_oracle(orc, w["batch"], keep_flows=False)
+    compare(b, orc, flows=False)
+
+
+def test_benchmark_size_properties(eng, orc):
+    """4 Mi IPFIX records: counters = column sums over the match masks, a rerun
+    gives the same bytes, and a prefix of the batch equals the oracle."""
+    w = synth.workload_c2(1 << 22)
+    configure(eng, orc, w["iplists"], w["mos"])
+    b = eng.prepare(w["batch"])
+    b.run()
+    masks = b.masks()[:, 0]
+    c = b.counters()
+    names = [f["name"] for f in xenoeye_amd.fields()]
+    bytes_be = b.column(names.index("in_bytes"))
+    pkts_be = b.column(names.index("in_pkts"))
+    nbytes = bytes_be.view(">u8").reshape(-1).astype(np.uint64)
+    npkts = pkts_be.view(">u8").reshape(-1).astype(np.uint64)
+    for m in range(len(w["mos"])):
+        sel = ((masks >> np.uint64(m)) & np.uint64(1)).astype(bool)
+        assert int(sel.sum()) == int(c[m, 0]), m
+        assert int(nbytes[sel].sum(dtype=np.uint64)) == int(c[m, 1]), m
+        assert int(npkts[sel].sum(dtype=np.uint64)) == int(c[m, 2]), m
+    assert 0.2 < (masks != 0).mean() < 0.9
+    # idempotence
+    b.run()
+    assert np.array_equal(b.masks()[:, 0], masks)
+    assert np.array_equal(b.counters(), c)
+    # the first datagrams against the oracle (templates come first in the batch)
+    nd = 4000
+    sub = synth.Batch()
+    for p, s in zip(w["batch"].pkts[:nd], w["batch"].src[:nd]):
+        sub.add(p, s)
+    run_oracle(orc, sub, keep_flows=False)
+    n = orc.nrecords()
+    assert n > 90000
+    assert np.array_equal(masks[:n], orc.masks()[:, 0])

@@ -314,8 +314,10 @@ def workload_c2(nrec, seed=SEED_C2, n_exporters=64, n_lists=8, prefixes=10000):
     the data sets use the IPv4 template 256 (46 B/record, 30 per datagram) and
     30 % the IPv6 template 257 (62 B/record, 22 per datagram).  16 objects:
     8 x `net listK` + 8 x `net6 listK`; every list holds `prefixes` IPv4
-    (/12-/28, 10 % nested) and `prefixes` IPv6 (/29-/64) prefixes; about 30 %
-    of the addresses fall inside some list."""
+    (/12-/28, 10 % nested) and `prefixes` IPv6 (/29-/64) prefixes; a sixth of
+    the addresses of each side is drawn from inside some list, the rest is
+    uniform (the short prefixes alone cover a good part of the IPv4 space, so
+    about three quarters of the records match some object)."""
     rng = Rng(seed)
     lists4, lists6, iplists = [], [], {}
     for k in range(n_lists):
@@ -382,6 +384,56 @@ def workload_c2(nrec, seed=SEED_C2, n_exporters=64, n_lists=8, prefixes=10000):
         b.add(pkt, per_exp[e])
     mos = [("net list%d" % k, -1) for k in range(n_lists)] + [("net6 list%d" % k, -1) for k in range(n_lists)]
     return dict(batch=b, iplists=iplists, mos=mos, devices=[], nrec=n4 + n6)
+
+
+def bgp_like_lengths():
+    """candidate IPv4 prefix lengths weighted like a full routing table:
+    about 60 % /24, 10 % /23, 10 % /22, the rest /8-/21 and a few /25-/32"""
+    lens = [24] * 60 + [23] * 10 + [22] * 10
+    lens += [8, 10, 11, 12, 13, 14, 15, 16, 16, 17, 18, 19, 19, 20, 20, 21, 21]
+    lens += [25, 28, 32]
+    return np.array(lens)
+
+
+def workload_c4(nrec, seed=SEED_C4, n_lists=8, prefixes=1000000, variants=32, per_packet=50):
+    """Netflow v9 records of the C1 shape plus src/dst AS (29 B/record) against
+    n_lists x variants objects over `n_lists` big IPv4 lists with a routing
+    table like length histogram (5 % more-specifics).  About a third of the
+    source addresses and a third of the destinations fall inside some list."""
+    rng = Rng(seed)
+    tmpl = TMPL_V9_C1 + [(16, 4), (17, 4)]
+    lists, iplists = [], {}
+    for k in range(n_lists):
+        lr = Rng(seed ^ (0x2000 + k))
+        v4 = prefix_list_v4(lr, prefixes, bgp_like_lengths(), nested_frac=0.05)
+        lists.append(v4)
+        iplists["big%d" % k] = iplist_text(v4, None)
+    all4 = (np.concatenate([a for a, _ in lists]), np.concatenate([l for _, l in lists]))
+
+    def mix(n):
+        inside = addrs_in_prefixes_v4(rng, n, *all4)
+        rnd = (rng.u64(n) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        return np.where(rng.below(n, 3) == 0, inside, rnd)
+
+    rec = flow_columns(rng, nrec, tmpl, src4=mix(nrec), dst4=mix(nrec), with_as=True)
+    b = Batch()
+    exporter = bytes([192, 0, 2, 4])
+    b.add(v9_template_packet(256, tmpl, 4), exporter)
+    b.extend(v9_data_packets(256, rec, per_packet, 4), exporter)
+    mos = []
+    for k in range(n_lists):
+        for v in range(variants):
+            kind = v % 4
+            if kind == 0:
+                f = "src net big%d and (dst port 80 or 443 or %d-%d) and src as 64512-65534" % (k, 8000 + v, 8999 + v)
+            elif kind == 1:
+                f = "dst net big%d and not proto %d" % (k, 17 if v < 16 else 6)
+            elif kind == 2:
+                f = "net big%d and dst port %d-%d" % (k, 1000 * v, 1000 * v + 999)
+            else:
+                f = "src net big%d and dst as %d-%d" % (k, 1000 * v, 1000 * v + 20000)
+            mos.append((f, -1))
+    return dict(batch=b, iplists=iplists, mos=mos, devices=[], nrec=nrec)
 
 
 # ------------------------------------------------------------------ sflow v5
