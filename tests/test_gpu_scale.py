@@ -81,3 +81,36 @@ def test_benchmark_size_properties(eng, orc):
     n = orc.nrecords()
     assert n > 90000
     assert np.array_equal(masks[:n], orc.masks()[:, 0])
+
+
+def _random_filter(rng, depth=0):
+    """boolean structure of every shape: conjunctions, negated disjunctions,
+    nesting beyond what the clause form takes (those stay interpreted)"""
+    atoms = ["proto %d" % int(rng.integers(0, 3) * 5 + int(rng.integers(0, 2)) * 6 + 1),
+             "src port %d-%d" % tuple(sorted(rng.integers(0, 65536, 2))),
+             "dst port 53 or 80 or 443", "net big0", "src net big1", "dst net big2 or big3",
+             "src as %d-%d" % tuple(sorted(rng.integers(0, 400000, 2))), "dst as 64512-65534",
+             "tos 0", "dst net 10.0.0.0/8 or big1", "src port 0"]
+    r = rng.integers(0, 10)
+    if depth < 4 and r < 4:
+        return "(%s) %s (%s)" % (_random_filter(rng, depth + 1), ["and", "or"][int(rng.integers(0, 2))],
+                                 _random_filter(rng, depth + 1))
+    if depth < 4 and r < 6:
+        return "not (%s)" % _random_filter(rng, depth + 1)
+    return atoms[int(rng.integers(0, len(atoms)))]
+
+
+def test_random_boolean_structures(eng, orc):
+    rng = np.random.default_rng(2024)
+    w = synth.workload_c4(8000, prefixes=3000, n_lists=4, variants=1)
+    mos = [(_random_filter(rng), -1) for _ in range(150)]
+    # some of them nested under earlier ones
+    for i in range(40):
+        mos.append((_random_filter(rng), int(rng.integers(0, 150 + i))))
+    configure(eng, orc, w["iplists"], mos)
+    b = eng.prepare(w["batch"])
+    b.run()
+    run_oracle(orc, w["batch"], keep_flows=False)
+    compare(b, orc, flows=False)
+    c = b.counters()
+    assert 20 < (c[:, 0] > 0).sum() < 190

@@ -20,7 +20,7 @@ struct xe_gpu
 	int device;
 	struct xe_host hs;
 	int committed;
-	void *d_progs, *d_ops, *d_terms, *d_opnds, *d_trie, *d_lists, *d_devrules, *d_lookups, *d_fterms, *d_fprogs, *d_motab, *d_tneed;
+	void *d_progs, *d_ops, *d_terms, *d_opnds, *d_trie, *d_lists, *d_devrules, *d_lookups, *d_fterms, *d_fprogs, *d_motab, *d_tneed, *d_cjrows, *d_cjderived, *d_cjcand;
 	uint32_t nmo, mask_words, nprogs_total, nlookups;
 	struct xe_list_dev *h_lists;
 	struct xe_probe *h_probes;   /* host copy of the probe table (nlookups entries) */
@@ -29,6 +29,7 @@ struct xe_gpu
 	uint32_t nterms;           /* distinct terms of the object programs */
 	uint32_t nfprogs;          /* objects the fast kernel evaluates one by one */
 	uint32_t ntneed;           /* terms the fast kernel has to evaluate */
+	uint32_t ncjrows, ncjderived;
 	int fast_ok, want_dev;     /* want_dev: some object program reads dev_ip / dev_id */
 	char err[512];
 };
@@ -113,7 +114,8 @@ static void
 free_config_dev(xe_gpu *h)
 {
 	void **p[] = { &h->d_progs, &h->d_ops, &h->d_terms, &h->d_opnds, &h->d_trie, &h->d_lists, &h->d_devrules,
-		&h->d_lookups, &h->d_fterms, &h->d_fprogs, &h->d_motab, &h->d_tneed };
+		&h->d_lookups, &h->d_fterms, &h->d_fprogs, &h->d_motab, &h->d_tneed,
+		&h->d_cjrows, &h->d_cjderived, &h->d_cjcand };
 	for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); i++) {
 		if (*p[i]) (void)hipFree(*p[i]);
 		*p[i] = NULL;
@@ -464,6 +466,136 @@ append_prog(struct xe_blob *progs, struct xe_blob *ops, struct xe_blob *terms, s
 	return xe_blob_push(progs, &pr, sizeof(pr)) ? XE_OK : XE_ENOMEM;
 }
 
+/* ------------------------------------------------------------------ programs as clause sets */
+/* A postfix program as a conjunction of clauses, each an OR of literals
+ * (atom, negated?).  Small limits: what does not fit stays a general program. */
+#define CNF_MAXC 8
+#define CNF_MAXL 8
+struct cnf_lit { uint16_t atom; uint8_t neg; };
+struct cnf_clause { struct cnf_lit l[CNF_MAXL]; int n; };
+struct cnf { struct cnf_clause c[CNF_MAXC]; int n; int ok; };
+
+static int
+clause_add(struct cnf_clause *c, struct cnf_lit l, int *tautology)
+{
+	for (int i = 0; i < c->n; i++) {
+		if (c->l[i].atom == l.atom) {
+			if (c->l[i].neg != l.neg) *tautology = 1;
+			return 1;
+		}
+	}
+	if (c->n >= CNF_MAXL) return 0;
+	c->l[c->n++] = l;
+	return 1;
+}
+
+static void
+cnf_and(struct cnf *a, const struct cnf *b)
+{
+	if (!a->ok || !b->ok || (a->n + b->n > CNF_MAXC)) { a->ok = 0; return; }
+	for (int i = 0; i < b->n; i++) a->c[a->n++] = b->c[i];
+}
+
+static void
+cnf_or(struct cnf *a, const struct cnf *b)
+{
+	struct cnf r;
+	memset(&r, 0, sizeof(r));
+	r.ok = a->ok && b->ok;
+	for (int i = 0; r.ok && (i < a->n); i++) {
+		for (int j = 0; r.ok && (j < b->n); j++) {
+			struct cnf_clause c = a->c[i];
+			int taut = 0;
+			for (int k = 0; k < b->c[j].n; k++) if (!clause_add(&c, b->c[j].l[k], &taut)) r.ok = 0;
+			if (taut) continue;
+			if (r.n >= CNF_MAXC) { r.ok = 0; break; }
+			r.c[r.n++] = c;
+		}
+	}
+	*a = r;
+}
+
+/* NOT(c1 & c2 & ...) = OR over clauses of (AND of the negated literals): one
+ * clause per choice of one literal from every clause */
+static void
+cnf_not(struct cnf *a)
+{
+	struct cnf r;
+	int idx[CNF_MAXC] = {0};
+	memset(&r, 0, sizeof(r));
+	r.ok = a->ok && (a->n > 0) && (a->n <= CNF_MAXL);
+	while (r.ok) {
+		struct cnf_clause c;
+		int taut = 0, k;
+		c.n = 0;
+		for (k = 0; k < a->n; k++) {
+			struct cnf_lit l = a->c[k].l[idx[k]];
+			l.neg = !l.neg;
+			if (!clause_add(&c, l, &taut)) r.ok = 0;
+		}
+		if (!taut) {
+			if (r.n >= CNF_MAXC) { r.ok = 0; break; }
+			r.c[r.n++] = c;
+		}
+		for (k = 0; k < a->n; k++) {
+			if (++idx[k] < a->c[k].n) break;
+			idx[k] = 0;
+		}
+		if (k == a->n) break;
+	}
+	*a = r;
+}
+
+/* the program of object `pg` as clauses over atoms; 0 = not expressible */
+static int
+prog_to_cnf(const struct xe_prog *pg, const uint32_t *op, const struct xe_fterm *ft, struct cnf *out)
+{
+	struct cnf *st = (struct cnf *)calloc(64, sizeof(struct cnf));
+	int sp = 0, ok = 1;
+	if (!st) return 0;
+	for (uint32_t k = 0; ok && (k < pg->nops); k++) {
+		uint32_t w = op[pg->op_base + k], code = w & 3;
+		if (code == XE_OP_BASIC) {
+			uint32_t t = w >> 2;
+			struct cnf *c;
+			if (sp >= 64) { ok = 0; break; }
+			c = &st[sp++];
+			memset(c, 0, sizeof(*c));
+			c->ok = 1;
+			c->n = 1;
+			if (ft[t].kind & 1) {
+				/* all operands are lists: an OR of lookup bits */
+				for (int b = 0; b < 64; b++) {
+					if (!((ft[t].mask >> b) & 1)) continue;
+					if (c->c[0].n >= CNF_MAXL) { c->ok = 0; break; }
+					c->c[0].l[c->c[0].n].atom = (uint16_t)b;
+					c->c[0].l[c->c[0].n].neg = 0;
+					c->c[0].n++;
+				}
+				if (c->c[0].n == 0) c->ok = 0;   /* no lookup bit: never true; leave to the interpreter */
+			} else {
+				if (t >= 256) { c->ok = 0; }
+				c->c[0].l[0].atom = (uint16_t)(XE_ATOM_TERM0 + t);
+				c->c[0].l[0].neg = 0;
+				c->c[0].n = 1;
+			}
+		} else if (code == XE_OP_NOT) {
+			if (sp < 1) { ok = 0; break; }
+			cnf_not(&st[sp - 1]);
+		} else {
+			if (sp < 2) { ok = 0; break; }
+			if (code == XE_OP_AND) cnf_and(&st[sp - 2], &st[sp - 1]);
+			else cnf_or(&st[sp - 2], &st[sp - 1]);
+			sp--;
+		}
+		if (sp && !st[sp - 1].ok) ok = 0;
+	}
+	if (ok && (sp == 1) && st[0].ok && (st[0].n > 0)) *out = st[0];
+	else ok = 0;
+	free(st);
+	return ok;
+}
+
 /* does some object program read the exporter's address or source id? */
 static int
 reads_device_fields(const struct xe_term *terms, size_t n)
@@ -558,7 +690,12 @@ xe_gpu_commit(xe_gpu *h)
 			/* objects resolved through the atom table, the rest listed */
 			size_t words = h->hs.nmos ? (h->hs.nmos + 63) / 64 : 1, nb = 0;
 			uint64_t *mt = (uint64_t *)calloc(words * XE_MOTAB_ROWS, sizeof(uint64_t));
-			if (!mt) rc = XE_ENOMEM;
+			uint64_t *cand = (uint64_t *)calloc(words, sizeof(uint64_t));
+			struct xe_cjderived *der = (struct xe_cjderived *)calloc(XE_MAX_DERIVED, sizeof(struct xe_cjderived));
+			struct xe_cjrow *rows = NULL;
+			size_t nrows = 0, rows_cap = 0, nder = 0;
+			struct cj_obj { uint16_t atom[CNF_MAXC]; uint8_t neg[CNF_MAXC]; int n; };
+			if (!mt || !cand || !der) rc = XE_ENOMEM;
 			for (size_t m = 0; (rc == XE_OK) && (m < h->hs.nmos); m++) {
 				struct xe_fprog q;
 				memset(&q, 0, sizeof(q));
@@ -592,6 +729,78 @@ xe_gpu_commit(xe_gpu *h)
 					ft[q.term].kind |= 2;
 					continue;
 				}
+				/* a conjunction of clauses: matched through the need / forbid rows */
+				if (q.kind != XE_FPROG_CONST) {
+					struct cnf f;
+					struct cj_obj co;
+					int fits = prog_to_cnf(&pg[m], op, ft, &f);
+					memset(&co, 0, sizeof(co));
+					for (int ci = 0; fits && (ci < f.n); ci++) {
+						const struct cnf_clause *c = &f.c[ci];
+						uint32_t atom;
+						int neg = 0;
+						if (c->n == 1) {
+							atom = c->l[0].atom;
+							neg = c->l[0].neg;
+						} else {
+							struct xe_cjderived d;
+							size_t j;
+							memset(&d, 0, sizeof(d));
+							for (int li = 0; li < c->n; li++) {
+								uint32_t a = c->l[li].atom;
+								if (a < 64) { if (c->l[li].neg) d.neg_lk |= 1ull << a; else d.pos_lk |= 1ull << a; }
+								else if (a < 128) { if (c->l[li].neg) d.neg_tb |= 1ull << (a - 64); else d.pos_tb |= 1ull << (a - 64); }
+								else fits = 0;
+							}
+							if (!fits) break;
+							for (j = 0; j < nder; j++) if (!memcmp(&der[j], &d, sizeof(d))) break;
+							if (j == nder) {
+								if (nder >= XE_MAX_DERIVED) { fits = 0; break; }
+								der[nder++] = d;
+							}
+							atom = XE_ATOM_DERIVED0 + (uint32_t)j;
+						}
+						co.atom[co.n] = (uint16_t)atom;
+						co.neg[co.n] = (uint8_t)neg;
+						co.n++;
+					}
+					if (fits) {
+						for (int ci = 0; ci < co.n; ci++) {
+							/* row of (atom, word): find or add */
+							size_t j;
+							uint32_t a = co.atom[ci];
+							for (j = 0; j < nrows; j++) if ((rows[j].atom == a) && (rows[j].word == m / 64)) break;
+							if (j == nrows) {
+								if (nrows == rows_cap) {
+									struct xe_cjrow *nr = (struct xe_cjrow *)realloc(rows, (rows_cap ? rows_cap * 2 : 64) * sizeof(*rows));
+									if (!nr) { rc = XE_ENOMEM; break; }
+									rows = nr;
+									rows_cap = rows_cap ? rows_cap * 2 : 64;
+								}
+								memset(&rows[nrows], 0, sizeof(rows[0]));
+								rows[nrows].atom = a;
+								rows[nrows].word = (uint32_t)(m / 64);
+								nrows++;
+							}
+							if (co.neg[ci]) rows[j].forbid |= 1ull << (m % 64);
+							else rows[j].need |= 1ull << (m % 64);
+							/* terms the rows read must be evaluated */
+							if ((a >= XE_ATOM_TERM0) && (a < XE_ATOM_DERIVED0)) ft[a - XE_ATOM_TERM0].kind |= 2;
+							if (a >= XE_ATOM_DERIVED0) {
+								const struct xe_cjderived *d = &der[a - XE_ATOM_DERIVED0];
+								uint64_t tbm = d->pos_tb | d->neg_tb;
+								for (int b = 0; b < 64; b++) if ((tbm >> b) & 1) ft[b].kind |= 2;
+							}
+						}
+						if (rc != XE_OK) break;
+						cand[m / 64] |= 1ull << (m % 64);
+						if (q.parent >= 0) {
+							q.kind = XE_FPROG_GATE;
+							fp[nb++] = q;
+						}
+						continue;
+					}
+				}
 				/* evaluated one by one: mark the terms it needs */
 				if (q.kind == XE_FPROG_TERM) ft[q.term].kind |= 2;
 				if (q.kind == XE_FPROG_GENERAL) {
@@ -603,9 +812,24 @@ xe_gpu_commit(xe_gpu *h)
 				fp[nb++] = q;
 			}
 			h->nfprogs = (uint32_t)nb;
+			/* rows in mask-word order (stable: a simple insertion sort, few rows) */
+			for (size_t i = 1; i < nrows; i++) {
+				struct xe_cjrow x = rows[i];
+				size_t j = i;
+				while (j && (rows[j - 1].word > x.word)) { rows[j] = rows[j - 1]; j--; }
+				rows[j] = x;
+			}
+			h->ncjrows = (uint32_t)nrows;
+			h->ncjderived = (uint32_t)nder;
 			if (rc == XE_OK) rc = upload(h, &h->d_motab, mt, words * XE_MOTAB_ROWS * sizeof(uint64_t));
 			if (rc == XE_OK) rc = upload(h, &h->d_fprogs, fp, nb * sizeof(*fp));
+			if (rc == XE_OK) rc = upload(h, &h->d_cjrows, rows, nrows * sizeof(*rows));
+			if (rc == XE_OK) rc = upload(h, &h->d_cjderived, der, nder * sizeof(*der));
+			if (rc == XE_OK) rc = upload(h, &h->d_cjcand, cand, words * sizeof(uint64_t));
 			free(mt);
+			free(cand);
+			free(der);
+			free(rows);
 		}
 		if (rc == XE_OK) rc = upload(h, &h->d_fterms, ft, (size_t)h->nterms * sizeof(*ft));
 		if (rc == XE_OK) {
@@ -836,6 +1060,11 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 		b->kp.ntneed = h->ntneed;
 		b->kp.fprogs = (const struct xe_fprog *)h->d_fprogs;
 		b->kp.nfprogs = h->nfprogs;
+		b->kp.cjrows = (const struct xe_cjrow *)h->d_cjrows;
+		b->kp.cjderived = (const struct xe_cjderived *)h->d_cjderived;
+		b->kp.cjcand = (const uint64_t *)h->d_cjcand;
+		b->kp.ncjrows = h->ncjrows;
+		b->kp.ncjderived = h->ncjderived;
 		b->kp.motab = (const uint64_t *)h->d_motab;
 		b->kp.motab_lds = ((size_t)h->mask_words * XE_MOTAB_ROWS * 8 <= 8192) ? 1u : 0u;
 		b->kp.probes = (const struct xe_probe *)h->d_lookups;

@@ -298,7 +298,27 @@ struct xe_fprog
 	uint32_t mo;         /* the object's index */
 	uint32_t pad[3];
 };
-enum { XE_FPROG_GENERAL = 0, XE_FPROG_CONST = 1, XE_FPROG_MASK = 2, XE_FPROG_TERM = 3 };
+enum { XE_FPROG_GENERAL = 0, XE_FPROG_CONST = 1, XE_FPROG_MASK = 2, XE_FPROG_TERM = 3,
+	XE_FPROG_GATE = 4 };   /* GATE: matched elsewhere, only the parent condition is left */
+
+/* Objects whose program is a conjunction of clauses (each an OR of possibly
+ * negated atoms) are matched all at once: an object fails when one of the
+ * atoms it needs is false or one it forbids is true.
+ * Atoms: 0-63 lookup bits, 64-319 terms, 320-383 derived (multi-literal clauses).
+ * One xe_cjrow per (atom, mask word) with objects that care about the atom. */
+#define XE_ATOM_TERM0 64
+#define XE_ATOM_DERIVED0 320
+#define XE_MAX_DERIVED 64
+struct xe_cjrow
+{
+	uint32_t atom, word;
+	uint64_t need;       /* objects of this word that fail when the atom is false */
+	uint64_t forbid;     /* objects that fail when it is true */
+};
+/* derived atom: true iff some positive literal is true or some negative one
+ * false; literals are lookup bits and terms 0-63 */
+struct xe_cjderived { uint64_t pos_lk, pos_tb, neg_lk, neg_tb; };
+
 
 struct xe_list_dev
 {

@@ -72,6 +72,10 @@ struct xe_kparams
 	const struct xe_fprog *fprogs;  /* objects not resolved through motab, in index order */
 	const uint64_t *motab;       /* [mask word][XE_MOTAB_ROWS] */
 	uint32_t nfprogs, motab_lds; /* motab_lds: the table is small enough to be copied to LDS */
+	const struct xe_cjrow *cjrows;       /* sorted by mask word */
+	const struct xe_cjderived *cjderived;
+	const uint64_t *cjcand;      /* per mask word: the objects matched through cjrows */
+	uint32_t ncjrows, ncjderived;
 	const uint32_t *fflds;       /* [template slot][XE_NFIELDS] XE_FFLD_* words */
 	uint32_t nfruns, ntiles;
 	uint32_t fast_r;             /* records per lane and tile: 1, 2 or 4 */

@@ -1260,8 +1260,23 @@ xe_nf_fast_kernel(const xe_kparams kp)
 			if (PL[6]) general_ops<R>(kp, stg, j, PL[6], ridx, T.live);
 		}
 		XE_PHASE(4);
-		/* object programs: the atom table first, then the listed objects */
-		uint32_t bi = 0;
+		/* derived atoms: the multi-literal clauses of the conjunctive objects */
+		uint64_t dbits[R];
+#pragma unroll
+		for (int r = 0; r < R; r++) dbits[r] = 0;
+		for (uint32_t j = 0; (j < kp.ncjderived) && !(kp.pad2 & 8); j++) {
+			cu64 dq = (cu64)(kp.cjderived + j);
+			const uint64_t pl = dq[0], pt = dq[1], nl = dq[2], nt = dq[3];
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				const bool d = (((lk[r] & pl) | (tb[r][0] & pt) | (~lk[r] & nl) | (~tb[r][0] & nt)) != 0);
+				dbits[r] |= (uint64_t)d << j;
+			}
+		}
+
+		/* object programs: the atom table first, then the conjunctive objects
+		 * (need / forbid rows), then the listed objects */
+		uint32_t bi = 0, ci = 0;
 		for (uint32_t w = 0; (w < kp.mask_words) && !(kp.pad2 & 8); w++) {
 			uint64_t bits[R];
 			const uint32_t m0 = w * 64, m1 = (m0 + 64 < kp.nmo) ? m0 + 64 : kp.nmo;
@@ -1284,6 +1299,38 @@ xe_nf_fast_kernel(const xe_kparams kp)
 				}
 				bits[r] = acc;
 			}
+			if (kp.ncjrows) {
+				uint64_t fail[R];
+#pragma unroll
+				for (int r = 0; r < R; r++) fail[r] = 0;
+				while (ci < kp.ncjrows) {
+					cu32 rq = (cu32)(kp.cjrows + ci);
+					const uint32_t a = rq[0];
+					if (rq[1] != w) break;
+					const uint64_t need = (uint64_t)rq[2] | ((uint64_t)rq[3] << 32);
+					const uint64_t forbid = (uint64_t)rq[4] | ((uint64_t)rq[5] << 32);
+					ci++;
+#pragma unroll
+					for (int r = 0; r < R; r++) {
+						bool val;
+						if (a < XE_ATOM_TERM0) {
+							val = ((lk[r] >> a) & 1) != 0;
+						} else if (a < XE_ATOM_DERIVED0) {
+							const uint32_t t = a - XE_ATOM_TERM0, wsel = t >> 6;
+							const uint64_t word = (wsel == 0) ? tb[r][0] : (wsel == 1) ? tb[r][1] : (wsel == 2) ? tb[r][2] : tb[r][3];
+							val = ((word >> (t & 63)) & 1) != 0;
+						} else {
+							val = ((dbits[r] >> (a - XE_ATOM_DERIVED0)) & 1) != 0;
+						}
+						fail[r] |= val ? forbid : need;
+					}
+				}
+				const uint64_t cand = ((cu64)kp.cjcand)[w];
+#pragma unroll
+				for (int r = 0; r < R; r++) {
+					if (T.live[r]) bits[r] |= cand & ~fail[r];
+				}
+			}
 			while (bi < kp.nfprogs) {
 				typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 				const XE_CONST u32x4v *fq = (const XE_CONST u32x4v *)(kp.fprogs + bi);
@@ -1295,7 +1342,9 @@ xe_nf_fast_kernel(const xe_kparams kp)
 				bi++;
 #pragma unroll
 				for (int r = 0; r < R; r++) {
-					bool h = prog_eval<R>(kp, FP, lk[r], tb[r]) && T.live[r];
+					bool h;
+					if (FP[2] == XE_FPROG_GATE) h = ((bits[r] >> (m - m0)) & 1) != 0;   /* matched above */
+					else h = prog_eval<R>(kp, FP, lk[r], tb[r]) && T.live[r];
 					if (parent >= 0) {
 						const uint32_t par = (uint32_t)parent;
 						bool pok;
@@ -1303,7 +1352,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 						else pok = T.live[r] && (((kp.masks[(size_t)ridx[r] * kp.mask_words + (par >> 6)] >> (par & 63)) & 1) != 0);
 						h = h && pok;
 					}
-					if (h) bits[r] |= 1ull << (m - m0);
+					bits[r] = (bits[r] & ~(1ull << (m - m0))) | ((uint64_t)h << (m - m0));
 				}
 			}
 #pragma unroll
