@@ -37,6 +37,7 @@ def parse_args():
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4"])
     ap.add_argument("--c4-prefixes", type=int, default=1000000, help="prefixes per list of the c4 workload")
     ap.add_argument("--cpu-sample", type=int, default=12000000, help="records timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--replicate", type=int, default=1, help="repeat the generated datagrams this many times")
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch from a rocprofv3 --pmc pass (reported as roofline.traffic)")
     return ap.parse_args()
@@ -127,6 +128,13 @@ def main():
         eng.add_mo("mo", filt, parent)
     eng.commit()
 
+    if args.replicate > 1:
+        b0 = w["batch"]
+        n0 = len(b0.pkts)
+        for _ in range(args.replicate - 1):
+            b0.pkts.extend(b0.pkts[:n0])
+            b0.src.extend(b0.src[:n0])
+            b0.kind.extend(b0.kind[:n0])
     packed = w["batch"].packed()
     t_prep0 = time.perf_counter()
     batch = eng.prepare(packed)

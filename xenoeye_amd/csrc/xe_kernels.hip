@@ -18,6 +18,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
 #include <stdio.h>
 #include <stdlib.h>
 #include "xe_kernels.h"
@@ -80,7 +81,7 @@ chain_answer(const uint32_t w[6], uint64_t hi, uint64_t lo, uint32_t depth)
 
 /* answers of all lists of a group for one address (left-aligned in hi:lo,
  * `bits` wide): bit l = list l.  iplist_match4/6, iplist.c:160-216 */
-__device__ uint32_t
+__device__ __forceinline__ uint32_t
 group_match(const uint32_t *T, uint32_t root, uint32_t nodes, uint32_t chains, uint64_t hi, uint64_t lo, uint32_t bits)
 {
 	if (!root) return 0;
@@ -168,7 +169,7 @@ __constant__ uint8_t c_fstr[XE_NFIELDS];
 /* value of a non-string field after all parsed occurrences were applied in
  * template order (a later, shorter occurrence overlays only its own bytes:
  * netflow.c:91 copies into the tail of the slot without clearing it) */
-__device__ fval
+__device__ __forceinline__ fval
 nf_get(const nf_rec &r, uint32_t f, uint32_t *size_out)
 {
 	fval out;
@@ -242,7 +243,7 @@ nf_val(const fval &f, uint32_t sizemax)
 }
 
 template <typename REC, fval (*GET)(const REC &, uint32_t, uint32_t *)>
-__device__ bool
+__device__ __forceinline__ bool
 term_match(const xe_kparams &kp, const REC &rec, const xe_term &t)
 {
 	const xe_dopnd *o = kp.opnds + t.opnd_base;
@@ -335,7 +336,7 @@ term_match(const xe_kparams &kp, const REC &rec, const xe_term &t)
 /* postfix program over a bit stack: bit 0 = top (filter.c:960-1012; depth
  * errors are resolved at compile time into constant programs) */
 template <typename REC, fval (*GET)(const REC &, uint32_t, uint32_t *)>
-__device__ bool
+__device__ __forceinline__ bool
 prog_match(const xe_kparams &kp, const REC &rec, const xe_prog &pr)
 {
 	if (pr.flags & XE_PROG_CONST) return pr.cval != 0;
@@ -378,7 +379,7 @@ wave_sum(unsigned long long v)
  * received it; parents always have a smaller index.  Returns false when the
  * record is dropped by skip-unmarked. */
 template <typename REC, fval (*GET)(const REC &, uint32_t, uint32_t *)>
-__device__ void
+__device__ __forceinline__ void
 classify(const xe_kparams &kp, REC &rec, int32_t device, uint32_t ridx, bool active,
 	unsigned long long bytes_x_rate, unsigned long long pkts_x_rate)
 {
@@ -1398,60 +1399,103 @@ xe_nf_fast_kernel(const xe_kparams kp)
  * quirks included: every copy is left-aligned in its field, the IPv6
  * destination is copied from the source address, VLAN fields keep the whole
  * TCI, and only parser states below NO_IP are skipped.
+ *
+ * The flow fields live in registers: field i = v[i], its bytes in memory
+ * order packed little-endian (byte k of the field at bits 8k); the two
+ * 16-byte fields keep bytes 8-15 in v6hi[].  Every field index below is a
+ * compile-time constant, so nothing is indexed dynamically.
  */
 #define SF_NFIELDS 23
-/* bit / slot order of the fields the sFlow decoder can set (same order as the
- * host uses when it re-creates struct flow_info) */
-__constant__ uint8_t c_sf_field[SF_NFIELDS] = {
-	XF_in_bytes, XF_in_pkts, XF_protocol, XF_src_tos, XF_dst_tos, XF_tcp_flags, XF_l4_src_port,
-	XF_ip4_src_addr, XF_input_snmp, XF_l4_dst_port, XF_ip4_dst_addr, XF_output_snmp, XF_ip6_src_addr,
-	XF_ip6_dst_addr, XF_icmp_type, XF_min_ttl, XF_max_ttl, XF_src_mac, XF_dst_mac, XF_src_vlan,
-	XF_dst_vlan, XF_src_dot1q_cvlan, XF_dst_dot1q_cvlan };
-/* byte offset of each of those fields in the per-thread flow image */
-__constant__ uint8_t c_sf_off[SF_NFIELDS + 1] = {
-	0, 8, 16, 17, 18, 19, 21, 23, 27, 31, 33, 37, 41, 57, 73, 75, 76, 77, 83, 89, 91, 93, 95, 97 };
+/* bit order of the fields the sFlow decoder can set (same order as the host
+ * uses when it re-creates struct flow_info) */
 enum { SFI_in_bytes, SFI_in_pkts, SFI_protocol, SFI_src_tos, SFI_dst_tos, SFI_tcp_flags, SFI_l4_src_port,
 	SFI_ip4_src, SFI_input_snmp, SFI_l4_dst_port, SFI_ip4_dst, SFI_output_snmp, SFI_ip6_src, SFI_ip6_dst,
 	SFI_icmp_type, SFI_min_ttl, SFI_max_ttl, SFI_src_mac, SFI_dst_mac, SFI_src_vlan, SFI_dst_vlan,
 	SFI_src_cvlan, SFI_dst_cvlan };
 
+__device__ constexpr int
+sf_field_of(int i)
+{
+	constexpr int t[SF_NFIELDS] = {
+		XF_in_bytes, XF_in_pkts, XF_protocol, XF_src_tos, XF_dst_tos, XF_tcp_flags, XF_l4_src_port,
+		XF_ip4_src_addr, XF_input_snmp, XF_l4_dst_port, XF_ip4_dst_addr, XF_output_snmp, XF_ip6_src_addr,
+		XF_ip6_dst_addr, XF_icmp_type, XF_min_ttl, XF_max_ttl, XF_src_mac, XF_dst_mac, XF_src_vlan,
+		XF_dst_vlan, XF_src_dot1q_cvlan, XF_dst_dot1q_cvlan };
+	return t[i];
+}
+
+/* maximum size of each of those fields in struct flow_info */
+__device__ constexpr int
+sf_size_of(int i)
+{
+	constexpr int t[SF_NFIELDS] = { 8, 8, 1, 1, 1, 2, 2, 4, 4, 2, 4, 4, 16, 16, 2, 1, 1, 6, 6, 2, 2, 2, 2 };
+	return t[i];
+}
+
 struct sf_rec
 {
-	uint8_t b[100];       /* field bytes as struct flow_info holds them */
+	uint64_t v[SF_NFIELDS];   /* field bytes 0-7 */
+	uint64_t v6hi[2];         /* bytes 8-15 of ip6_src / ip6_dst */
 	uint32_t has;
 	uint32_t mark;
 	const xe_sfrec *q;
-	pkt_src src;          /* the sampled header / IPv4 structure */
+	pkt_src src;              /* the sampled header / IPv4 structure */
 };
 
-__device__ void
-sf_copy(sf_rec &r, int fi, int32_t off, int n)
+/* N bytes of the sampled header at `off`, packed little-endian */
+template <int N>
+__device__ __forceinline__ uint64_t
+sf_bytes(const sf_rec &r, int32_t off)
 {
-	for (int i = 0; i < n; i++) r.b[c_sf_off[fi] + i] = (uint8_t)pkt_byte(r.src, off + i);
-	r.has |= 1u << fi;
+	uint64_t x = 0;
+#pragma unroll
+	for (int i = 0; i < N; i++) x |= (uint64_t)pkt_byte(r.src, off + i) << (8 * i);
+	return x;
 }
 
-__device__ void
+/* COPY_TO_FLOW of sflow.c:26-33: N bytes to the START of the field */
+template <int FI, int N>
+__device__ __forceinline__ void
+sf_copy(sf_rec &r, int32_t off)
+{
+	if (N <= 8) {
+		const uint64_t m = (N == 8) ? ~0ull : ((1ull << (8 * (N & 7))) - 1ull);
+		r.v[FI] = (r.v[FI] & ~m) | sf_bytes<N>(r, off);
+	} else {
+		r.v[FI] = sf_bytes<8>(r, off);
+		r.v6hi[FI - SFI_ip6_src] = sf_bytes<8>(r, off + 8);
+	}
+	r.has |= 1u << FI;
+}
+
+template <int FI>
+__device__ __forceinline__ void
+sf_set_byte0(sf_rec &r, uint32_t b)
+{
+	r.v[FI] = (r.v[FI] & ~0xFFull) | (b & 0xFF);
+	r.has |= 1u << FI;
+}
+
+__device__ __forceinline__ void
 sf_on_ip(sf_rec &r, int32_t iph)   /* sflow.c:47-54 */
 {
-	sf_copy(r, SFI_ip4_src, iph + 12, 4);
-	sf_copy(r, SFI_ip4_dst, iph + 16, 4);
-	sf_copy(r, SFI_src_tos, iph + 1, 1);
-	sf_copy(r, SFI_dst_tos, iph + 1, 1);
-	sf_copy(r, SFI_min_ttl, iph + 8, 1);
-	sf_copy(r, SFI_max_ttl, iph + 8, 1);
-	sf_copy(r, SFI_protocol, iph + 9, 1);
+	sf_copy<SFI_ip4_src, 4>(r, iph + 12);
+	sf_copy<SFI_ip4_dst, 4>(r, iph + 16);
+	sf_copy<SFI_src_tos, 1>(r, iph + 1);
+	sf_copy<SFI_dst_tos, 1>(r, iph + 1);
+	sf_copy<SFI_min_ttl, 1>(r, iph + 8);
+	sf_copy<SFI_max_ttl, 1>(r, iph + 8);
+	sf_copy<SFI_protocol, 1>(r, iph + 9);
 }
 
-__device__ void
+__device__ __forceinline__ void
 sf_on_ip6(sf_rec &r, int32_t ip6h, uint32_t nexthdr)   /* sflow.c:57-62 */
 {
-	sf_copy(r, SFI_ip6_src, ip6h + 8, 16);
-	sf_copy(r, SFI_ip6_dst, ip6h + 8, 16);
-	sf_copy(r, SFI_min_ttl, ip6h + 7, 1);
-	sf_copy(r, SFI_max_ttl, ip6h + 7, 1);
-	r.b[c_sf_off[SFI_protocol]] = (uint8_t)nexthdr;
-	r.has |= 1u << SFI_protocol;
+	sf_copy<SFI_ip6_src, 16>(r, ip6h + 8);
+	sf_copy<SFI_ip6_dst, 16>(r, ip6h + 8);
+	sf_copy<SFI_min_ttl, 1>(r, ip6h + 7);
+	sf_copy<SFI_max_ttl, 1>(r, ip6h + 7);
+	sf_set_byte0<SFI_protocol>(r, nexthdr);
 }
 
 __device__ __forceinline__ uint32_t
@@ -1461,7 +1505,7 @@ sf_be16(const sf_rec &r, int32_t off)
 }
 
 /* rawpacket_parse(), rawparse.h:89-281; returns the parser state 0..4 */
-__device__ int
+__device__ __forceinline__ int
 sf_rawparse(sf_rec &r, int32_t end, int type)
 {
 	int32_t ptr = 0;
@@ -1469,21 +1513,21 @@ sf_rawparse(sf_rec &r, int32_t end, int type)
 
 	if ((ptr + 14) >= end) return 0;
 	if (type == 0) {
-		sf_copy(r, SFI_dst_mac, 0, 6);
-		sf_copy(r, SFI_src_mac, 6, 6);
+		sf_copy<SFI_dst_mac, 6>(r, 0);
+		sf_copy<SFI_src_mac, 6>(r, 6);
 		h_proto = sf_be16(r, 12);
 		ptr = 14;
 		if ((h_proto == 0x8100) || (h_proto == 0x88a8)) {
 			if ((ptr + 4) >= end) return 1;
-			sf_copy(r, SFI_src_vlan, ptr, 2);
-			sf_copy(r, SFI_dst_vlan, ptr, 2);
+			sf_copy<SFI_src_vlan, 2>(r, ptr);
+			sf_copy<SFI_dst_vlan, 2>(r, ptr);
 			h_proto = sf_be16(r, ptr + 2);
 			ptr += 4;
 		}
 		if ((h_proto == 0x8100) || (h_proto == 0x88a8)) {
 			if ((ptr + 4) >= end) return 1;
-			sf_copy(r, SFI_src_cvlan, ptr, 2);
-			sf_copy(r, SFI_dst_cvlan, ptr, 2);
+			sf_copy<SFI_src_cvlan, 2>(r, ptr);
+			sf_copy<SFI_dst_cvlan, 2>(r, ptr);
 			h_proto = sf_be16(r, ptr + 2);
 			ptr += 4;
 		}
@@ -1536,51 +1580,81 @@ sf_rawparse(sf_rec &r, int32_t end, int type)
 
 	if (l4 == 6) {
 		if ((ptr + 20) >= end) return 3;
-		sf_copy(r, SFI_l4_src_port, ptr, 2);
-		sf_copy(r, SFI_l4_dst_port, ptr + 2, 2);
-		sf_copy(r, SFI_tcp_flags, ptr + 13, 1);
+		sf_copy<SFI_l4_src_port, 2>(r, ptr);
+		sf_copy<SFI_l4_dst_port, 2>(r, ptr + 2);
+		sf_copy<SFI_tcp_flags, 1>(r, ptr + 13);
 	} else if (l4 == 17) {
 		if ((ptr + 8) >= end) return 3;
-		sf_copy(r, SFI_l4_src_port, ptr, 2);
-		sf_copy(r, SFI_l4_dst_port, ptr + 2, 2);
+		sf_copy<SFI_l4_src_port, 2>(r, ptr);
+		sf_copy<SFI_l4_dst_port, 2>(r, ptr + 2);
 	} else {
 		if ((ptr + 8) >= end) return 3;
-		sf_copy(r, SFI_icmp_type, ptr, 1);
+		sf_copy<SFI_icmp_type, 1>(r, ptr);
 	}
 	return 4;
 }
 
 /* apply one element to the flow image; returns the parser state (4 for the
  * IPv4 structure element, which is always delivered) */
-__device__ int
+__device__ __forceinline__ int
 sf_apply(const xe_kparams &kp, sf_rec &r, const xe_sfrec *q)
 {
 	r.src.p = kp.pkt + q->hdr_off;
 	r.src.left = q->dgram_left;
 	r.src.checked = true;
-	/* sflow-impl.h:164-171 / :224-234 */
-	for (int i = 0; i < 4; i++) r.b[c_sf_off[SFI_in_bytes] + 4 + i] = ((const uint8_t *)&q->frame_len_be)[i];
-	r.b[c_sf_off[SFI_in_pkts] + 7] = 1;
+	/* sflow-impl.h:164-171 / :224-234: in_bytes[4..8] = frame length as on
+	 * the wire, in_pkts[7] = 1 */
+	r.v[SFI_in_bytes] = (r.v[SFI_in_bytes] & 0xFFFFFFFFull) | ((uint64_t)q->frame_len_be << 32);
+	r.v[SFI_in_pkts] = (r.v[SFI_in_pkts] & 0x00FFFFFFFFFFFFFFull) | (1ull << 56);
 	r.has |= (1u << SFI_in_bytes) | (1u << SFI_in_pkts);
 	if (q->kind == 1) return sf_rawparse(r, (int32_t)q->header_len, q->rp_type);
 
 	/* IPv4 structure, sflow-impl.h:236-260: seven 4-byte words */
-	r.b[c_sf_off[SFI_protocol]] = (uint8_t)pkt_byte(r.src, 3);
-	r.has |= 1u << SFI_protocol;
-	sf_copy(r, SFI_ip4_src, 4, 4);
-	sf_copy(r, SFI_ip4_dst, 8, 4);
-	sf_copy(r, SFI_l4_src_port, 14, 2);
-	sf_copy(r, SFI_l4_dst_port, 18, 2);
-	sf_copy(r, SFI_tcp_flags, 23, 1);
-	sf_copy(r, SFI_src_tos, 27, 1);
-	if (r.b[c_sf_off[SFI_protocol]] == 1) {
-		r.b[c_sf_off[SFI_icmp_type]] = (uint8_t)pkt_byte(r.src, 17);
-		r.has |= 1u << SFI_icmp_type;
-	}
+	sf_set_byte0<SFI_protocol>(r, pkt_byte(r.src, 3));
+	sf_copy<SFI_ip4_src, 4>(r, 4);
+	sf_copy<SFI_ip4_dst, 4>(r, 8);
+	sf_copy<SFI_l4_src_port, 2>(r, 14);
+	sf_copy<SFI_l4_dst_port, 2>(r, 18);
+	sf_copy<SFI_tcp_flags, 1>(r, 23);
+	sf_copy<SFI_src_tos, 1>(r, 27);
+	if ((r.v[SFI_protocol] & 0xFF) == 1) sf_set_byte0<SFI_icmp_type>(r, pkt_byte(r.src, 17));
 	return 4;
 }
 
-__device__ fval
+/* field FI as the filter terms see it: its maximum-size bytes read as one
+ * big-endian number */
+template <int FI>
+__device__ __forceinline__ void
+sf_number(const sf_rec &r, fval &out)
+{
+	constexpr int n = sf_size_of(FI);
+	out.has = ((r.has >> FI) & 1) != 0;
+	if (n <= 8) {
+		out.v.hi = 0;
+		out.v.lo = __builtin_bswap64(r.v[FI]) >> (64 - 8 * n);
+	} else {
+		out.v.hi = __builtin_bswap64(r.v[FI]);
+		out.v.lo = __builtin_bswap64(r.v6hi[FI - SFI_ip6_src]);
+	}
+}
+
+template <int FI>
+__device__ __forceinline__ bool
+sf_number_if(const sf_rec &r, uint32_t f, fval &out)
+{
+	if (f != (uint32_t)sf_field_of(FI)) return false;
+	sf_number<FI>(r, out);
+	return true;
+}
+
+template <int... FI>
+__device__ __forceinline__ void
+sf_number_any(const sf_rec &r, uint32_t f, fval &out, std::integer_sequence<int, FI...>)
+{
+	(void)(sf_number_if<FI>(r, f, out) || ...);
+}
+
+__device__ __forceinline__ fval
 sf_get(const sf_rec &r, uint32_t f, uint32_t *size_out)
 {
 	fval out;
@@ -1608,17 +1682,34 @@ sf_get(const sf_rec &r, uint32_t f, uint32_t *size_out)
 		out.v.lo = r.mark & 0x3FFFFFFFu;
 		return out;
 	}
-	for (int i = 0; i < SF_NFIELDS; i++) {
-		if (c_sf_field[i] != f) continue;
-		out.has = ((r.has >> i) & 1) != 0;
-		/* the field's maximum-size bytes read as one big-endian number */
-		for (int k = c_sf_off[i]; k < c_sf_off[i + 1]; k++) {
-			out.v.hi = (out.v.hi << 8) | (out.v.lo >> 56);
-			out.v.lo = (out.v.lo << 8) | r.b[k];
-		}
-		return out;
-	}
+	sf_number_any(r, f, out, std::make_integer_sequence<int, SF_NFIELDS>());
 	return out;
+}
+
+/* field FI to its column, if the record has it */
+template <int FI>
+__device__ __forceinline__ void
+sf_store(const xe_kparams &kp, const sf_rec &r, uint32_t ridx)
+{
+	constexpr int f = sf_field_of(FI), n = sf_size_of(FI);
+	constexpr int w = (n <= 1) ? 1 : (n <= 2) ? 2 : (n <= 4) ? 4 : (n <= 8) ? 8 : 16;
+	if (!((r.has >> FI) & 1)) return;
+	uint8_t *dst = kp.out_base + kp.col_off[f] + (size_t)ridx * w;
+	if (w == 1) *dst = (uint8_t)r.v[FI];
+	else if (w == 2) *(uint16_t *)dst = (uint16_t)r.v[FI];
+	else if (w == 4) *(uint32_t *)dst = (uint32_t)r.v[FI];
+	else if (w == 8) *(uint64_t *)dst = r.v[FI];
+	else {
+		((uint64_t *)dst)[0] = r.v[FI];
+		((uint64_t *)dst)[1] = r.v6hi[FI - SFI_ip6_src];
+	}
+}
+
+template <int... FI>
+__device__ __forceinline__ void
+sf_store_all(const xe_kparams &kp, const sf_rec &r, uint32_t ridx, std::integer_sequence<int, FI...>)
+{
+	(sf_store<FI>(kp, r, ridx), ...);
 }
 
 __global__ void __launch_bounds__(XE_BLOCK)
@@ -1632,6 +1723,9 @@ xe_sf_kernel(const xe_kparams kp)
 	int32_t device = -1;
 	bool deliver = false;
 
+#pragma unroll
+	for (int i = 0; i < SF_NFIELDS; i++) rec.v[i] = 0;
+	rec.v6hi[0] = rec.v6hi[1] = 0;
 	rec.has = 0;
 	rec.mark = 0;
 	rec.q = kp.sfrecs;
@@ -1639,26 +1733,17 @@ xe_sf_kernel(const xe_kparams kp)
 		/* elements of one sample share the flow: replay the earlier ones */
 		uint32_t first = g;
 		while ((first > 0) && kp.sfrecs[first].chained) first--;
-		for (int i = 0; i < 100; i++) rec.b[i] = 0;
 		rec.q = kp.sfrecs + g;
-		/* sf5_flow(), sflow-impl.h:106-143: interface indices */
-		for (int i = 0; i < 4; i++) {
-			rec.b[c_sf_off[SFI_input_snmp] + i] = ((const uint8_t *)&rec.q->in_if_be)[i];
-			rec.b[c_sf_off[SFI_output_snmp] + i] = ((const uint8_t *)&rec.q->out_if_be)[i];
-		}
+		/* sf5_flow(), sflow-impl.h:106-143: interface indices, bytes as stored */
+		rec.v[SFI_input_snmp] = rec.q->in_if_be;
+		rec.v[SFI_output_snmp] = rec.q->out_if_be;
 		rec.has |= (1u << SFI_input_snmp) | (1u << SFI_output_snmp);
 		int state = 4;
 		for (uint32_t k = first; k <= g; k++) state = sf_apply(kp, rec, kp.sfrecs + k);
 		deliver = state >= 2;   /* sflow.c:164-168 */
 		kp.nparsed[ridx] = (uint8_t)(state | (deliver ? 0 : XE_SF_SKIPPED));
 		kp.sf_has[g] = rec.has;
-		for (int i = 0; i < SF_NFIELDS; i++) {
-			if (!((rec.has >> i) & 1)) continue;
-			uint32_t f = c_sf_field[i], w = c_colw[f];
-			uint8_t *dst = kp.out_base + kp.col_off[f] + (size_t)ridx * w;
-			uint32_t n = c_sf_off[i + 1] - c_sf_off[i];
-			for (uint32_t k = 0; k < w; k++) dst[k] = (k < n) ? rec.b[c_sf_off[i] + k] : 0;
-		}
+		sf_store_all(kp, rec, ridx, std::make_integer_sequence<int, SF_NFIELDS>());
 		device = kp.exps[rec.q->exporter].device;
 		uint64_t rate = rec.q->sampling_rate;
 		bxr = sf_get(rec, XF_in_bytes, nullptr).v.lo * rate;
