@@ -423,7 +423,13 @@ struct xe_plan
 	uint64_t field_mask[2];    /* fields some template of the batch can set */
 	size_t soa_bytes_per_rec_sum; /* sum over records of stored widths (algorithmic bytes) */
 	size_t skipped_datagrams;  /* unknown version / aborted */
+	/* exporter (address, source id) -> index: open addressing, index + 1 */
+	uint32_t *ehash; size_t ehash_cap;
+	/* per device template slot, filled on first use in this batch: fields it
+	 * sets and the column bytes a complete record of it fills */
+	struct xe_blob tinfo;      /* struct xe_tinfo */
 };
+struct xe_tinfo { uint64_t mask[2]; uint32_t width; uint32_t known; };
 
 int xe_prepass(struct xe_host *hs, const uint8_t *data, const uint64_t *offs, const uint32_t *src,
 	const uint8_t *kinds, size_t n, struct xe_plan *plan);

@@ -99,6 +99,8 @@ xe_plan_free(struct xe_plan *p)
 	free(p->sets.p);
 	free(p->exporters.p);
 	free(p->sfrecs.p);
+	free(p->ehash);
+	free(p->tinfo.p);
 	memset(p, 0, sizeof(*p));
 }
 
@@ -127,18 +129,36 @@ device_find(const struct xe_host *hs, uint32_t ip, uint32_t id)
 static int
 exporter_get(struct xe_host *hs, struct xe_plan *plan, uint32_t ip, uint32_t id, uint32_t *out)
 {
-	struct xe_exporter *ex = plan->exporters.p;
+	struct xe_exporter *ex;
 	struct xe_exporter ne;
-	size_t i;
+	size_t i, m;
+	uint64_t hv = ((uint64_t)ip << 32 | id) * 0x9E3779B97F4A7C15ull;
 	int dev;
 
-	/* most recent first: consecutive datagrams usually share the exporter */
-	for (i = plan->exporters.n; i-- > 0;) {
-		if (!memcmp(ex[i].dev_ip, &ip, 4) && !memcmp(ex[i].dev_id, &id, 4)) {
-			*out = (uint32_t)i;
+	if ((plan->exporters.n + 1) * 2 > plan->ehash_cap) {
+		size_t ncap = plan->ehash_cap ? plan->ehash_cap * 2 : 256, j;
+		uint32_t *nh = calloc(ncap, sizeof(uint32_t));
+		if (!nh) return 0;
+		ex = plan->exporters.p;
+		for (j = 0; j < plan->exporters.n; j++) {
+			uint32_t eip, eid;
+			memcpy(&eip, ex[j].dev_ip, 4);
+			memcpy(&eid, ex[j].dev_id, 4);
+			for (i = ((((uint64_t)eip << 32 | eid) * 0x9E3779B97F4A7C15ull) >> 32) & (ncap - 1); nh[i]; i = (i + 1) & (ncap - 1)) {}
+			nh[i] = (uint32_t)j + 1;
+		}
+		free(plan->ehash);
+		plan->ehash = nh;
+		plan->ehash_cap = ncap;
+	}
+	ex = plan->exporters.p;
+	m = plan->ehash_cap - 1;
+	for (i = (hv >> 32) & m; plan->ehash[i]; i = (i + 1) & m) {
+		const struct xe_exporter *e = &ex[plan->ehash[i] - 1];
+		if (!memcmp(e->dev_ip, &ip, 4) && !memcmp(e->dev_id, &id, 4)) {
+			*out = plan->ehash[i] - 1;
 			return 1;
 		}
-		if (plan->exporters.n - i > 4096) break;   /* bound the scan; duplicates are harmless */
 	}
 	memset(&ne, 0, sizeof(ne));
 	memcpy(ne.dev_ip, &ip, 4);
@@ -147,6 +167,7 @@ exporter_get(struct xe_host *hs, struct xe_plan *plan, uint32_t ip, uint32_t id,
 	ne.device = dev;
 	ne.sampling_rate = (dev >= 0) ? (uint32_t)hs->devs[dev].sampling_rate : 1;
 	*out = (uint32_t)plan->exporters.n;
+	plan->ehash[i] = (uint32_t)plan->exporters.n + 1;
 	return xe_blob_push(&plan->exporters, &ne, sizeof(ne));
 }
 
@@ -363,14 +384,30 @@ emit_set(struct xe_plan *plan, const struct xe_host *hs, const struct dgram *d, 
 	 * may look at; past the datagram end the kernels must substitute zeros */
 	if ((extent < 0) || ((rel_off + extent) > d->len) || (rel_off < 0) || t->varlen) s.flags |= XE_SET_CHECKED;
 	plan->nrec += nrec;
-	for (i = 0; i < t->nfields; i++) {
-		if ((e[i].field != XE_F_NONE) && (e[i].flags & XE_TE_VALID)) {
-			int f = e[i].field;
-			plan->field_mask[f >> 6] |= 1ull << (f & 63);
-			if (!(e[i].flags & XE_TE_REPEAT)) w += xe_fields[f].col_width;
+	/* what the template's records fill: computed once per template and batch */
+	{
+		struct xe_tinfo *ti;
+		while (plan->tinfo.n <= tmpl) {
+			struct xe_tinfo z;
+			memset(&z, 0, sizeof(z));
+			if (!xe_blob_push(&plan->tinfo, &z, sizeof(z))) return 0;
 		}
+		ti = (struct xe_tinfo *)plan->tinfo.p + tmpl;
+		if (!ti->known) {
+			for (i = 0; i < t->nfields; i++) {
+				if ((e[i].field != XE_F_NONE) && (e[i].flags & XE_TE_VALID)) {
+					int f = e[i].field;
+					ti->mask[f >> 6] |= 1ull << (f & 63);
+					if (!(e[i].flags & XE_TE_REPEAT)) w += xe_fields[f].col_width;
+				}
+			}
+			ti->width = (uint32_t)w;
+			ti->known = 1;
+			plan->field_mask[0] |= ti->mask[0];
+			plan->field_mask[1] |= ti->mask[1];
+		}
+		plan->soa_bytes_per_rec_sum += (size_t)ti->width * nrec;
 	}
-	plan->soa_bytes_per_rec_sum += w * nrec;
 	return xe_blob_push(&plan->sets, &s, sizeof(s));
 }
 
@@ -810,6 +847,9 @@ xe_prepass(struct xe_host *hs, const uint8_t *data, const uint64_t *offs, const 
 		struct dgram d;
 		int rc = XE_OK;
 
+		/* only headers are read, one cache line per datagram, far apart: ask
+		 * for the lines of the datagrams to come */
+		if (i + 16 < n) __builtin_prefetch(data + offs[i + 16]);
 		memset(&d, 0, sizeof(d));
 		d.p = data + offs[i];
 		d.len = (long)(offs[i + 1] - offs[i]);
