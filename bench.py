@@ -3,7 +3,7 @@
 
 One step = one pass of the HIP path (counter reset + decode/classify kernels)
 over one batch of synthetic export packets that already sits in HBM.  The
-workload is BASELINE.json configs[1]: IPFIX from 64 exporters, 70 % IPv4
+workload is IPFIX from 64 exporters, 70 % IPv4
 records (46 B) / 30 % IPv6 records (62 B), 16 monitoring objects over 8 IP
 lists of 10 000 IPv4 + 10 000 IPv6 prefixes each.  With --gpus N every rank
 gets its own exporters (weak scaling, no data-path collective); rank 0 prints
@@ -54,7 +54,8 @@ def build_workload(name, nrec, rank, c4_prefixes=1000000):
     if name == "c1":
         return synth.workload_c1(nrec, seed=synth.SEED_C1 ^ (rank << 32)), \
             "C1 netflow-v9 1 exporter 21B records 1 object (src net mynet)"
-    w = synth.workload_c2(nrec, seed=synth.SEED_C2 ^ (rank << 32))
+    # every rank owns its own 64 exporters (10.255.0.x on rank 0, 10.254.0.x on rank 1 ...)
+    w = synth.workload_c2(nrec, seed=synth.SEED_C2 ^ (rank << 32), exporter_net=255 - rank)
     return w, "C2 ipfix 64 exporters 70% v4(46B)/30% v6(62B) 16 objects x 10k+10k-prefix lists"
 
 

@@ -309,8 +309,8 @@ def workload_c1(nrec, seed=SEED_C1, per_packet=64):
     return dict(batch=b, iplists=iplists, mos=mos, devices=[], nrec=nrec)
 
 
-def workload_c2(nrec, seed=SEED_C2, n_exporters=64, n_lists=8, prefixes=10000):
-    """IPFIX, 64 exporters 10.255.0.1-64 (observation domain = index), 70 % of
+def workload_c2(nrec, seed=SEED_C2, n_exporters=64, n_lists=8, prefixes=10000, exporter_net=255):
+    """IPFIX, 64 exporters 10.<exporter_net>.0.1-64 (observation domain = index), 70 % of
     the data sets use the IPv4 template 256 (46 B/record, 30 per datagram) and
     30 % the IPv6 template 257 (62 B/record, 22 per datagram).  16 objects:
     8 x `net listK` + 8 x `net6 listK`; every list holds `prefixes` IPv4
@@ -335,7 +335,7 @@ def workload_c2(nrec, seed=SEED_C2, n_exporters=64, n_lists=8, prefixes=10000):
     b = Batch()
     per_exp = []
     for e in range(n_exporters):
-        per_exp.append(bytes([10, 255, 0, e + 1]))
+        per_exp.append(bytes([10, exporter_net & 255, (e + 1) >> 8, (e + 1) & 255]))
         b.add(ipfix_template_packet(256, TMPL_IPFIX_V4, e + 1), per_exp[e])
         b.add(ipfix_template_packet(257, TMPL_IPFIX_V6, e + 1), per_exp[e])
 
