@@ -214,6 +214,27 @@ def test_devices_marks_and_sampling(eng, orc):
     assert b.dropped().sum() > 0
 
 
+def test_devices_sampling_rate_only(eng, orc):
+    """devices.conf entries that only set a sampling rate: records carry a
+    device mark of 0 and counters are scaled; exporters without an entry and
+    one with mark filters share the batch"""
+    w = synth.workload_c2(3000, prefixes=200)
+    w["devices"] = [dict(ip="10.255.0.1", sampling_rate=1000), dict(ip="10.255.0.2", dev_id=2, sampling_rate=64),
+                    dict(ip="10.255.0.3", sampling_rate=10, marks=("proto 6",)),
+                    dict(ip="10.255.0.4", sampling_rate=5, skip_unmarked=True)]
+    b = both(eng, orc, w)
+    fi = b.flow_info()
+    rates = np.unique(fi[:, 2304:2308].copy().view("<u4"))
+    assert set(rates.tolist()) >= {1, 10, 64, 1000}
+
+
+def test_devices_mark_read_by_an_object(eng, orc):
+    w = synth.workload_c2(2000, prefixes=100)
+    w["devices"] = [dict(ip="10.255.0.1", sampling_rate=1000), dict(ip="10.255.0.5", sampling_rate=2, marks=("proto 17",))]
+    w["mos"] = list(w["mos"]) + [("dev-mark 0", -1), ("dev-mark 1", -1), ("not dev-mark 0", -1)]
+    both(eng, orc, w)
+
+
 def test_devices_id_only_fallthrough(eng, orc):
     """an entry with ip and id whose ip does not match is still matched on the
     id alone (devices.c:224 is `if`, not `else if`)"""

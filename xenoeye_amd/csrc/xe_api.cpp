@@ -31,6 +31,7 @@ struct xe_gpu
 	uint32_t ntneed;           /* terms the fast kernel has to evaluate */
 	uint32_t ncjrows, ncjderived;
 	int fast_ok, want_dev;     /* want_dev: some object program reads dev_ip / dev_id */
+	int reads_mark;            /* some object program reads dev_mark */
 	char err[512];
 };
 
@@ -596,10 +597,12 @@ prog_to_cnf(const struct xe_prog *pg, const uint32_t *op, const struct xe_fterm 
 	return ok;
 }
 
-/* does some object program read the exporter's address or source id? */
+/* which per-exporter virtual fields some object program reads:
+ * bit 0 exporter address / source id, bit 1 the device mark */
 static int
 reads_device_fields(const struct xe_term *terms, size_t n)
 {
+	int r = 0;
 	for (size_t i = 0; i < n; i++) {
 		const struct xe_term *t = &terms[i];
 		uint8_t fl[2];
@@ -609,9 +612,12 @@ reads_device_fields(const struct xe_term *terms, size_t n)
 			if (t->dir & XE_DIR_SRC) fl[k++] = t->fsrc;
 			if (t->dir & XE_DIR_DST) fl[k++] = t->fdst;
 		}
-		for (int j = 0; j < k; j++) if ((fl[j] == XF_dev_ip) || (fl[j] == XF_dev_id)) return 1;
+		for (int j = 0; j < k; j++) {
+			if ((fl[j] == XF_dev_ip) || (fl[j] == XF_dev_id)) r |= 1;
+			if (fl[j] == XF_dev_mark) r |= 2;
+		}
 	}
-	return 0;
+	return r;
 }
 
 extern "C" int
@@ -632,7 +638,11 @@ xe_gpu_commit(xe_gpu *h)
 		 * terms used only by device mark filters follow them */
 		h->nterms = (uint32_t)terms.n;
 		h->fast_ok = 1;
-		h->want_dev = reads_device_fields((const struct xe_term *)terms.p, terms.n);
+		{
+			int rd = reads_device_fields((const struct xe_term *)terms.p, terms.n);
+			h->want_dev = rd & 1;
+			h->reads_mark = (rd & 2) != 0;
+		}
 		if (h->nterms > XE_MAX_FAST_TERMS) h->fast_ok = 0;
 		h->nlookups = (uint32_t)lookups.n;
 		if (h->nlookups > XE_MAX_PROBES) h->fast_ok = 0;
@@ -938,6 +948,7 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 	size_t nfast = 0, nslow = 0, ntiles = 0, work = 0, slowrec = 0;
 	/* the fast kernel addresses packet bytes with 32-bit offsets */
 	const int small = (total_bytes + 64) < 0xFFFF0000ull;
+	const int force_general = getenv("XE_FORCE_GENERAL") != NULL;   /* diagnostic: time the general kernel */
 	uint32_t maxchunk = 1, R, tilesz;
 	size_t cnt_bytes = (h->hs.nmos <= XE_MAX_LDS_COUNTER_MOS) ? h->hs.nmos * 24 : 0;
 	int rc = XE_ENOMEM;
@@ -959,8 +970,13 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 		tfast[i] = (uint8_t)ok;
 	}
 	for (i = 0; i < ns; i++) {
-		int ok = tfast[sets[i].tmpl] && !(sets[i].flags & (XE_SET_CHECKED | XE_SET_PARTIAL))
-			&& (ex[sets[i].exporter].device < 0);
+		/* an exporter with a devices.conf entry that only sets the sampling rate
+		 * (no mark filters, nothing dropped) needs no per-record rule check */
+		const int dev = ex[sets[i].exporter].device;
+		const int plain_dev = (dev < 0) || ((h->hs.devs[dev].nmarks == 0) && !h->hs.devs[dev].skip_unmarked
+			&& !h->reads_mark);
+		int ok = !force_general && tfast[sets[i].tmpl] && !(sets[i].flags & (XE_SET_CHECKED | XE_SET_PARTIAL))
+			&& plain_dev;
 		is_fast[i] = (uint8_t)ok;
 		if (ok) {
 			uint32_t nc = ((uint32_t)tm[sets[i].tmpl].stride + 15) / 16;
@@ -1003,7 +1019,8 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 				r->first_rec = sets[i].first_rec;
 				r->start = sets[i].tmpl;   /* template for now, position below */
 				r->nrec = sets[i].nrec;
-				r->stride = sets[i].stride;
+				/* bit 31: the exporter has a devices.conf entry (mark present, value 0) */
+				r->stride = sets[i].stride | ((e->device >= 0) ? 0x80000000u : 0u);
 				r->rate = e->sampling_rate;
 				r->dev_ip = ntohl(ipw);
 				r->dev_id = ntohl(idw);

@@ -1028,7 +1028,7 @@ template <int R>
 struct tile_lanes
 {
 	uint32_t voff[R], ridx[R], rate[R], dev_ip[R], dev_id[R];
-	bool live[R];
+	bool live[R], hasdev[R];  /* hasdev: the exporter has a devices.conf entry */
 	uint32_t tmpl, nchunk;    /* wave-uniform */
 };
 
@@ -1050,6 +1050,7 @@ tile_setup(const xe_kparams &kp, uint32_t tile, uint32_t lane, bool want_dev, ti
 #pragma unroll
 	for (int r = 0; r < R; r++) {
 		S.live[r] = false;
+		S.hasdev[r] = false;
 		S.voff[r] = S.ridx[r] = S.rate[r] = 0;
 		S.dev_ip[r] = S.dev_id[r] = 0;
 	}
@@ -1063,7 +1064,8 @@ tile_setup(const xe_kparams &kp, uint32_t tile, uint32_t lane, bool want_dev, ti
 			if ((start + nrec <= sub0) || (start >= sub0 + 64)) continue;
 			const uint32_t g = sub0 + lane, i = g - start;
 			const bool in = (g >= start) && (i < nrec);
-			S.voff[r] = in ? (RN[0] + i * RN[4]) : S.voff[r];
+			S.voff[r] = in ? (RN[0] + i * (RN[4] & 0x7FFFFFFFu)) : S.voff[r];
+			S.hasdev[r] = in ? ((RN[4] >> 31) != 0) : S.hasdev[r];
 			S.ridx[r] = in ? (RN[1] + i) : S.ridx[r];
 			S.rate[r] = in ? RN[5] : S.rate[r];
 			if (want_dev) {
@@ -1205,7 +1207,9 @@ xe_nf_fast_kernel(const xe_kparams kp)
 			uint64_t hi, b, p;
 			if (T.live[r]) {
 				((XE_GLOBAL uint8_t *)kp.nparsed)[ridx[r]] = (uint8_t)nparsed;
-				if (kp.marks) ((XE_GLOBAL uint32_t *)kp.marks)[ridx[r]] = 0;
+				/* device_rules_check() without mark filters (devices.c:286-314):
+				 * the mark is present, its value 0 */
+				if (kp.marks) ((XE_GLOBAL uint32_t *)kp.marks)[ridx[r]] = C.hasdev[r] ? XE_MARK_HAS : 0u;
 			}
 			/* what the counters add (monit-objects.c:995-1007, scale 1) */
 			fld_get<R>(T, XF_in_bytes, r, has, fmax, hi, b);
