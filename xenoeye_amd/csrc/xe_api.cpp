@@ -1082,6 +1082,16 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 		b->kp.cjcand = (const uint64_t *)h->d_cjcand;
 		b->kp.ncjrows = h->ncjrows;
 		b->kp.ncjderived = h->ncjderived;
+		{
+			uint64_t list = ~0ull;
+			uint32_t k = 0;
+			for (uint32_t pr = 0; (pr < h->nlookups) && (k < 8); pr++) {
+				if (!h->h_probes[pr].root_off) continue;
+				list = (list & ~(0xFFull << (8 * k))) | ((uint64_t)pr << (8 * k));
+				k++;
+			}
+			b->kp.all_probes = list;
+		}
 		b->kp.motab = (const uint64_t *)h->d_motab;
 		b->kp.motab_lds = ((size_t)h->mask_words * XE_MOTAB_ROWS * 8 <= 8192) ? 1u : 0u;
 		b->kp.probes = (const struct xe_probe *)h->d_lookups;

@@ -374,70 +374,6 @@ wave_sum(unsigned long long v)
 	return v;
 }
 
-/* device rules (devices.c:237-314), then the object walk (netflow.c:213-244):
- * object m receives the record iff its program matches and its parent
- * received it; parents always have a smaller index.  Returns false when the
- * record is dropped by skip-unmarked. */
-template <typename REC, fval (*GET)(const REC &, uint32_t, uint32_t *)>
-__device__ __forceinline__ void
-classify(const xe_kparams &kp, REC &rec, int32_t device, uint32_t ridx, bool active,
-	unsigned long long bytes_x_rate, unsigned long long pkts_x_rate)
-{
-	bool dropped = false;
-
-	if (active && kp.marks) {
-		uint32_t mk = 0;
-		if (device >= 0) {
-			const xe_devrule dr = kp.devrules[device];
-			uint32_t cnt = 0;
-			for (uint32_t i = 0; i < dr.nprogs; i++) {
-				cnt += prog_match<REC, GET>(kp, rec, kp.progs[dr.first_prog + i]) ? 1u : 0u;
-			}
-			if (dr.skip_unmarked && (cnt == 0)) {
-				dropped = true;
-				mk = XE_MARK_DROPPED;
-			} else {
-				mk = XE_MARK_HAS | (cnt & 0x3FFFFFFFu);
-			}
-		}
-		rec.mark = mk;
-		kp.marks[ridx] = mk;
-	}
-
-	for (uint32_t w = 0; w < kp.mask_words; w++) {
-		uint64_t bits = 0;
-		uint32_t m0 = w * 64, m1 = (m0 + 64 < kp.nmo) ? m0 + 64 : kp.nmo;
-		for (uint32_t m = m0; m < m1; m++) {
-			bool hit = false;
-			if (active && !dropped) {
-				const xe_prog pr = kp.progs[m];
-				bool parent_ok = true;
-				if (pr.parent >= 0) {
-					/* a parent in an earlier word was stored already */
-					parent_ok = ((uint32_t)pr.parent >= m0)
-						? ((bits >> ((uint32_t)pr.parent - m0)) & 1) != 0
-						: ((kp.masks[(size_t)ridx * kp.mask_words + ((uint32_t)pr.parent >> 6)]
-							>> ((uint32_t)pr.parent & 63)) & 1) != 0;
-				}
-				hit = parent_ok && prog_match<REC, GET>(kp, rec, pr);
-			}
-			if (hit) bits |= 1ull << (m - m0);
-			/* counters: wave-wide sums, one atomic per wave and counter */
-			unsigned long long ball = __ballot(hit);
-			if (ball) {
-				unsigned long long sb = wave_sum(hit ? bytes_x_rate : 0ull);
-				unsigned long long sp = wave_sum(hit ? pkts_x_rate : 0ull);
-				if ((threadIdx.x & 63) == 0) {
-					atomicAdd(&kp.counters[3 * m + 0], (unsigned long long)__popcll(ball));
-					atomicAdd(&kp.counters[3 * m + 1], sb);
-					atomicAdd(&kp.counters[3 * m + 2], sp);
-				}
-			}
-		}
-		if (active) kp.masks[(size_t)ridx * kp.mask_words + w] = bits;
-	}
-}
-
 /* store a non-string field value into its column in flow_info byte order */
 __device__ __forceinline__ void
 store_col(const xe_kparams &kp, uint32_t f, uint32_t ridx, const val128 &v)
@@ -454,120 +390,6 @@ store_col(const xe_kparams &kp, uint32_t f, uint32_t ridx, const val128 &v)
 			((uint64_t *)dst)[1] = __builtin_bswap64(v.lo);
 			break;
 	}
-}
-
-/* General kernel: any run the fast kernel does not take (reads that may pass
- * the datagram end, variable-length / repeated / string elements, exporters
- * with a devices.conf entry).  One thread per record, everything interpreted
- * per lane. */
-__global__ void __launch_bounds__(XE_BLOCK)
-xe_nf_general_kernel(const xe_kparams kp)
-{
-	uint32_t g = blockIdx.x * XE_BLOCK + threadIdx.x;
-	bool active = g < kp.nslowrec;
-	uint32_t ridx = 0;
-	nf_rec rec;
-	unsigned long long bxr = 0, pxr = 0;
-	int32_t device = -1;
-
-	rec.mark = 0;
-	rec.nparsed = 0;
-	if (active) {
-		/* the run whose work range holds this thread */
-		uint32_t lo = 0, hi = kp.nssets - 1;
-		while (lo < hi) {
-			uint32_t mid = (lo + hi + 1) >> 1;
-			if (kp.swstart[mid] <= g) lo = mid; else hi = mid - 1;
-		}
-		const xe_set s = kp.ssets[lo];
-		uint32_t i = g - kp.swstart[lo];
-		ridx = s.first_rec + i;
-		int64_t roff = (int64_t)i * s.stride;
-		int32_t avail = s.avail - (int32_t)roff;
-
-		rec.src.p = kp.pkt + s.data_off + roff;
-		rec.src.left = s.dgram_left - (int32_t)roff;
-		rec.src.checked = (s.flags & XE_SET_CHECKED) != 0;
-		rec.t = kp.tmpls + s.tmpl;
-		rec.e = kp.tents + rec.t->ent_base;
-		rec.ex = kp.exps + s.exporter;
-		device = rec.ex->device;
-
-		/* how many template fields the reference parses for this record */
-		uint32_t nf = rec.t->nfields, np = 0;
-		int32_t pos = 0;
-		if (rec.t->mode == XE_MODE_V9) {
-			for (; np < nf; np++) {
-				if ((pos + (int32_t)rec.e[np].len) > avail) break;
-				pos += rec.e[np].len;
-			}
-		} else {
-			for (; np < nf;) {
-				int32_t off;
-				uint32_t len;
-				if (rec.t->varlen) {
-					rec.locate(np, &off, &len);
-					pos = off + (int32_t)len;
-				} else {
-					pos += rec.e[np].len;
-				}
-				np++;
-				if (pos >= avail) break;
-			}
-		}
-		rec.nparsed = np;
-		kp.nparsed[ridx] = (uint8_t)np;
-
-		/* decode into the columns */
-		for (uint32_t j = 0; j < np; j++) {
-			uint32_t f = rec.e[j].field;
-			if (f == XE_F_NONE) continue;
-			bool special = rec.t->varlen || (rec.e[j].flags & XE_TE_REPEAT)
-				|| (rec.e[j].next_same != 0xFF) || c_fstr[f];
-			if (!special) {
-				bool ok = (rec.e[j].flags & XE_TE_VALID) != 0;
-				if (ok) store_col(kp, f, ridx, pkt_be(rec.src, rec.e[j].off, rec.e[j].len));
-				if (kp.vsize_off[f] != ~0ull) {
-					((uint16_t *)(kp.out_base + kp.vsize_off[f]))[ridx] = ok ? rec.e[j].len : (uint16_t)0xFFFF;
-				}
-				continue;
-			}
-			int32_t off;
-			uint32_t len;
-			rec.locate(j, &off, &len);
-			bool ok = rec.valid(j, len, c_fmin, c_fmax);
-			if (c_fstr[f]) {
-				/* left-aligned copy; the first occurrence also clears the
-				 * rest of the slot (the record starts zeroed, netflow.c:275) */
-				uint32_t w = c_colw[f];
-				uint8_t *dst = kp.out_base + kp.col_off[f] + (size_t)ridx * w;
-				bool first = !(rec.e[j].flags & XE_TE_REPEAT);
-				if (first) {
-					for (uint32_t b = 0; b < w; b++) dst[b] = (ok && (b < len)) ? (uint8_t)pkt_byte(rec.src, off + (int32_t)b) : 0;
-				} else if (ok) {
-					for (uint32_t b = 0; b < len; b++) dst[b] = (uint8_t)pkt_byte(rec.src, off + (int32_t)b);
-				}
-				if (kp.vsize_off[f] != ~0ull) {
-					uint16_t *vs = (uint16_t *)(kp.out_base + kp.vsize_off[f]) + ridx;
-					if (ok) *vs = (uint16_t)len;
-					else if (first) *vs = 0xFFFF;
-				}
-			} else {
-				uint32_t sz = 0;
-				fval fv = nf_get(rec, f, &sz);
-				if (fv.has) store_col(kp, f, ridx, fv.v);
-				if (kp.vsize_off[f] != ~0ull) {
-					((uint16_t *)(kp.out_base + kp.vsize_off[f]))[ridx] = fv.has ? (uint16_t)sz : 0xFFFF;
-				}
-			}
-		}
-
-		/* what the counters add: get_nf_val(8 bytes) * sampling_rate, wrapping */
-		uint64_t rate = rec.ex->sampling_rate;
-		bxr = nf_get(rec, XF_in_bytes, nullptr).v.lo * rate;
-		pxr = nf_get(rec, XF_in_pkts, nullptr).v.lo * rate;
-	}
-	classify<nf_rec, nf_get>(kp, rec, device, ridx, active, bxr, pxr);
 }
 
 /* ------------------------------------------------------------------ fast kernel */
@@ -701,6 +523,38 @@ fld_get(const fast_tile<R> &T, uint32_t field, uint32_t r, bool &has, uint32_t &
 	wire_number(a, len, hi, lo);
 }
 
+/* field access of the classification code: from the staged record of a fast
+ * tile, or through the field getter of the per-lane kernels */
+template <int R>
+__device__ __forceinline__ void
+tile_get(const fast_tile<R> &T, uint32_t field, uint32_t r, bool &has, uint32_t &fmax, uint64_t &hi, uint64_t &lo)
+{
+	fld_get<R>(T, field, r, has, fmax, hi, lo);
+}
+
+template <typename REC, fval (*GET)(const REC &, uint32_t, uint32_t *)>
+struct lane_tile
+{
+	const REC *rec;
+	bool live[1];
+};
+
+template <typename REC, fval (*GET)(const REC &, uint32_t, uint32_t *)>
+__device__ __forceinline__ void
+tile_get(const lane_tile<REC, GET> &T, uint32_t field, uint32_t r, bool &has, uint32_t &fmax, uint64_t &hi, uint64_t &lo)
+{
+	(void)r;
+	/* the record of a lane that is not live may be unset: never read it */
+	fval v;
+	v.has = false;
+	v.v.hi = v.v.lo = 0;
+	if (T.live[0]) v = GET(*T.rec, field, nullptr);
+	has = v.has;
+	fmax = c_fmax[field];
+	hi = v.has ? v.v.hi : 0;
+	lo = v.has ? v.v.lo : 0;
+}
+
 /*
  * All IP-list membership tests of a tile.  Per probe (one field against one
  * group of up to 8 lists) ONE walk of the group's merged tables per record: a
@@ -712,9 +566,9 @@ fld_get(const fast_tile<R> &T, uint32_t field, uint32_t r, bool &has, uint32_t &
  * the probes whose field the template carries (byte i = probe index, 0xFF =
  * end).  Bit (8 * probe + l) of lk[r] = list l of the probe's group matched.
  */
-template <int R>
+template <int R, typename TT>
 __device__ void
-fast_lookups(const xe_kparams &kp, const fast_tile<R> &T, uint64_t plist, uint64_t lk[R])
+fast_lookups(const xe_kparams &kp, const TT &T, uint64_t plist, uint64_t lk[R])
 {
 	constexpr int PC = 2;
 	typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -749,14 +603,14 @@ fast_lookups(const xe_kparams &kp, const fast_tile<R> &T, uint64_t plist, uint64
 				e[c][r] = XE_TRIE_TERM;
 				hi[c][r] = lo[c][r] = 0;
 				if (!act[c]) continue;
-				fld_get<R>(T, (w1 >> 8) & 0xFF, r, has, fmax, hi[c][r], lo[c][r]);
+				tile_get(T, (w1 >> 8) & 0xFF, r, has, fmax, hi[c][r], lo[c][r]);
 				if (bits[c] == 32) {
 					/* IPv4: the field's 4 bytes, or the first 4 of a 16-byte field */
 					const uint32_t a4 = ((w1 >> 16) & 1) ? (uint32_t)(hi[c][r] >> 32) : (uint32_t)lo[c][r];
 					hi[c][r] = (uint64_t)a4 << 32;
 					lo[c][r] = 0;
 				}
-				if (T.live[r]) e[c][r] = ((const XE_CONST uint32_t *)(kp.trie + root))[(uint32_t)(hi[c][r] >> 48)];
+				if (T.live[r] && has) e[c][r] = ((const XE_CONST uint32_t *)(kp.trie + root))[(uint32_t)(hi[c][r] >> 48)];
 			}
 		}
 		for (uint32_t depth = 16; depth < maxbits; depth += 8) {
@@ -824,9 +678,9 @@ fast_lookups(const xe_kparams &kp, const fast_tile<R> &T, uint64_t plist, uint64
 
 /* one term for record r of all lanes; same semantics as term_match(), with the
  * list memberships taken from fast_lookups() */
-template <int R>
+template <int R, typename TT>
 __device__ bool
-fast_term(const xe_kparams &kp, const fast_tile<R> &T, const term_s &t, uint32_t r, uint64_t lkbits)
+fast_term(const xe_kparams &kp, const TT &T, const term_s &t, uint32_t r, uint64_t lkbits)
 {
 	const xe_dopnd *o = t.o;
 	bool has;
@@ -834,9 +688,9 @@ fast_term(const xe_kparams &kp, const fast_tile<R> &T, const term_s &t, uint32_t
 	uint64_t hi, lo;
 
 	if (t.func != XE_FN_NONE) {
-		fld_get<R>(T, t.fa, r, has, fmax, hi, lo);
+		tile_get(T, t.fa, r, has, fmax, hi, lo);
 		uint64_t a = ((fmax == 1) || (fmax == 2) || (fmax == 4) || (fmax == 8)) ? lo : 0;
-		fld_get<R>(T, t.fb, r, has, fmax, hi, lo);
+		tile_get(T, t.fb, r, has, fmax, hi, lo);
 		uint64_t b = ((fmax == 1) || (fmax == 2) || (fmax == 4) || (fmax == 8)) ? lo : 0;
 		if (t.func == XE_FN_MIN) return in_ranges_u(o, t.nopnd, (int64_t)((a < b) ? a : b));
 		int32_t q = 0;
@@ -852,7 +706,7 @@ fast_term(const xe_kparams &kp, const fast_tile<R> &T, const term_s &t, uint32_t
 	for (uint32_t side = XE_DIR_SRC; side <= XE_DIR_DST; side <<= 1) {
 		if (!(t.dir & side)) continue;
 		uint32_t f = (side == XE_DIR_SRC) ? t.fsrc : t.fdst;
-		fld_get<R>(T, f, r, has, fmax, hi, lo);
+		tile_get(T, f, r, has, fmax, hi, lo);
 		if (((t.type == XE_BT_ADDR4) || (t.type == XE_BT_ADDR6)) && !has) continue;
 		switch (t.type) {
 			case XE_BT_ADDR4: {
@@ -1097,6 +951,170 @@ tile_issue(const xe_kparams &kp, const tile_lanes<R> &S, u32x4 (&q)[4][R])
 	}
 }
 
+/* every IP-list membership (lookup bits), then every term some program needs
+ * (term bits), once per record */
+template <int R, typename TT>
+__device__ __forceinline__ void
+classify_atoms(const xe_kparams &kp, const TT &T, uint64_t plist, uint64_t (&lk)[R], uint64_t (&tb)[R][4])
+{
+		if (kp.pad2 & 1) {
+#pragma unroll
+			for (int r = 0; r < R; r++) lk[r] = 0;
+		} else {
+			fast_lookups<R, TT>(kp, T, plist, lk);
+		}
+#pragma unroll
+		for (int r = 0; r < R; r++) tb[r][0] = tb[r][1] = tb[r][2] = tb[r][3] = 0;
+		for (uint32_t ti = 0; (ti < kp.ntneed) && !(kp.pad2 & 2); ti++) {
+			const uint32_t t = ((cu32)kp.tneed)[ti];
+			cu64 fq = (cu64)(kp.fterms + t);
+			const uint64_t fkind = fq[0];
+			const term_s tm = ld_term(kp, t);
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				bool res;
+				/* all operands IP lists: a mask over the lookup bits */
+				if (fkind & 1) res = (lk[r] & fq[1]) != 0;
+				else res = fast_term<R, TT>(kp, T, tm, r, lk[r]);
+				const uint64_t bit = (uint64_t)(T.live[r] && res) << (t & 63);
+				switch (t >> 6) {
+					case 0: tb[r][0] |= bit; break;
+					case 1: tb[r][1] |= bit; break;
+					case 2: tb[r][2] |= bit; break;
+					default: tb[r][3] |= bit; break;
+				}
+			}
+		}
+
+}
+
+/* from lookup and term bits to the match masks and counters of a record:
+ * the atom table, the conjunctive objects (need / forbid rows), the listed
+ * objects; lcnt / lmt = the block's LDS counters and atom-table copy */
+template <int R>
+__device__ __forceinline__ void
+classify_objects(const xe_kparams &kp, const bool (&live)[R], const uint64_t (&lk)[R], const uint64_t (&tb)[R][4],
+	const uint32_t (&ridx)[R], const unsigned long long (&bxr)[R], const unsigned long long (&pxr)[R],
+	unsigned long long *lcnt, const uint64_t *lmt)
+{
+		/* derived atoms: the multi-literal clauses of the conjunctive objects */
+		uint64_t dbits[R];
+#pragma unroll
+		for (int r = 0; r < R; r++) dbits[r] = 0;
+		for (uint32_t j = 0; (j < kp.ncjderived) && !(kp.pad2 & 8); j++) {
+			cu64 dq = (cu64)(kp.cjderived + j);
+			const uint64_t pl = dq[0], pt = dq[1], nl = dq[2], nt = dq[3];
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				const bool d = (((lk[r] & pl) | (tb[r][0] & pt) | (~lk[r] & nl) | (~tb[r][0] & nt)) != 0);
+				dbits[r] |= (uint64_t)d << j;
+			}
+		}
+
+		/* object programs: the atom table first, then the conjunctive objects
+		 * (need / forbid rows), then the listed objects */
+		uint32_t bi = 0, ci = 0;
+		for (uint32_t w = 0; (w < kp.mask_words) && !(kp.pad2 & 8); w++) {
+			uint64_t bits[R];
+			const uint32_t m0 = w * 64, m1 = (m0 + 64 < kp.nmo) ? m0 + 64 : kp.nmo;
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				uint64_t acc = 0;
+				if (live[r]) {
+					uint64_t x = lk[r];
+					while (x) {
+						const uint32_t a = (uint32_t)__builtin_ctzll(x);
+						x &= x - 1;
+						acc |= kp.motab_lds ? lmt[w * XE_MOTAB_ROWS + a] : kp.motab[w * XE_MOTAB_ROWS + a];
+					}
+					x = tb[r][0];
+					while (x) {
+						const uint32_t a = 64 + (uint32_t)__builtin_ctzll(x);
+						x &= x - 1;
+						acc |= kp.motab_lds ? lmt[w * XE_MOTAB_ROWS + a] : kp.motab[w * XE_MOTAB_ROWS + a];
+					}
+				}
+				bits[r] = acc;
+			}
+			if (kp.ncjrows) {
+				uint64_t fail[R];
+#pragma unroll
+				for (int r = 0; r < R; r++) fail[r] = 0;
+				while (ci < kp.ncjrows) {
+					cu32 rq = (cu32)(kp.cjrows + ci);
+					const uint32_t a = rq[0];
+					if (rq[1] != w) break;
+					const uint64_t need = (uint64_t)rq[2] | ((uint64_t)rq[3] << 32);
+					const uint64_t forbid = (uint64_t)rq[4] | ((uint64_t)rq[5] << 32);
+					ci++;
+#pragma unroll
+					for (int r = 0; r < R; r++) {
+						bool val;
+						if (a < XE_ATOM_TERM0) {
+							val = ((lk[r] >> a) & 1) != 0;
+						} else if (a < XE_ATOM_DERIVED0) {
+							const uint32_t t = a - XE_ATOM_TERM0, wsel = t >> 6;
+							const uint64_t word = (wsel == 0) ? tb[r][0] : (wsel == 1) ? tb[r][1] : (wsel == 2) ? tb[r][2] : tb[r][3];
+							val = ((word >> (t & 63)) & 1) != 0;
+						} else {
+							val = ((dbits[r] >> (a - XE_ATOM_DERIVED0)) & 1) != 0;
+						}
+						fail[r] |= val ? forbid : need;
+					}
+				}
+				const uint64_t cand = ((cu64)kp.cjcand)[w];
+#pragma unroll
+				for (int r = 0; r < R; r++) {
+					if (live[r]) bits[r] |= cand & ~fail[r];
+				}
+			}
+			while (bi < kp.nfprogs) {
+				typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+				const XE_CONST u32x4v *fq = (const XE_CONST u32x4v *)(kp.fprogs + bi);
+				const u32x4v f0 = fq[0], f1 = fq[1], f2 = fq[2];
+				const uint32_t FP[12] = { f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w };
+				const uint32_t m = FP[8];
+				const int32_t parent = (int32_t)FP[6];
+				if (m >= m1) break;
+				bi++;
+#pragma unroll
+				for (int r = 0; r < R; r++) {
+					bool h;
+					if (FP[2] == XE_FPROG_GATE) h = ((bits[r] >> (m - m0)) & 1) != 0;   /* matched above */
+					else h = prog_eval<R>(kp, FP, lk[r], tb[r]) && live[r];
+					if (parent >= 0) {
+						const uint32_t par = (uint32_t)parent;
+						bool pok;
+						if (par >= m0) pok = ((bits[r] >> (par - m0)) & 1) != 0;
+						else pok = live[r] && (((kp.masks[(size_t)ridx[r] * kp.mask_words + (par >> 6)] >> (par & 63)) & 1) != 0);
+						h = h && pok;
+					}
+					bits[r] = (bits[r] & ~(1ull << (m - m0))) | ((uint64_t)h << (m - m0));
+				}
+			}
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				if (!live[r]) continue;
+				((XE_GLOBAL uint64_t *)kp.masks)[(size_t)ridx[r] * kp.mask_words + w] = bits[r];
+				/* counters: every lane adds for each object it matched */
+				uint64_t x = (kp.pad2 & 4) ? 0 : bits[r];
+				while (x) {
+					const uint32_t m = m0 + (uint32_t)__builtin_ctzll(x);
+					x &= x - 1;
+					if (kp.lds_counters) {
+						atomicAdd(lcnt + 3 * m + 0, 1ull);
+						atomicAdd(lcnt + 3 * m + 1, bxr[r]);
+						atomicAdd(lcnt + 3 * m + 2, pxr[r]);
+					} else {
+						atomicAdd(kp.counters + 3 * m + 0, 1ull);
+						atomicAdd(kp.counters + 3 * m + 1, bxr[r]);
+						atomicAdd(kp.counters + 3 * m + 2, pxr[r]);
+					}
+				}
+			}
+		}
+}
+
 /* diagnostic phase timing (XE_ABLATE bit 6): wave-clock cycles per phase, summed
  * over the waves' tiles into xe_fast_phase_cycles[] */
 __device__ unsigned long long xe_fast_phase_cycles[8];
@@ -1219,38 +1237,9 @@ xe_nf_fast_kernel(const xe_kparams kp)
 		}
 
 		/* every IP-list membership, then every term some program needs, once */
-		uint64_t lk[R];
-		if (kp.pad2 & 1) {
-#pragma unroll
-			for (int r = 0; r < R; r++) lk[r] = 0;
-		} else {
-			fast_lookups<R>(kp, T, plist, lk);
-		}
+		uint64_t lk[R], tb[R][4];
+		classify_atoms<R>(kp, T, plist, lk, tb);
 		XE_PHASE(2);
-		uint64_t tb[R][4];
-#pragma unroll
-		for (int r = 0; r < R; r++) tb[r][0] = tb[r][1] = tb[r][2] = tb[r][3] = 0;
-		for (uint32_t ti = 0; (ti < kp.ntneed) && !(kp.pad2 & 2); ti++) {
-			const uint32_t t = ((cu32)kp.tneed)[ti];
-			cu64 fq = (cu64)(kp.fterms + t);
-			const uint64_t fkind = fq[0];
-			const term_s tm = ld_term(kp, t);
-#pragma unroll
-			for (int r = 0; r < R; r++) {
-				bool res;
-				/* all operands IP lists: a mask over the lookup bits */
-				if (fkind & 1) res = (lk[r] & fq[1]) != 0;
-				else res = fast_term<R>(kp, T, tm, r, lk[r]);
-				const uint64_t bit = (uint64_t)(T.live[r] && res) << (t & 63);
-				switch (t >> 6) {
-					case 0: tb[r][0] |= bit; break;
-					case 1: tb[r][1] |= bit; break;
-					case 2: tb[r][2] |= bit; break;
-					default: tb[r][3] |= bit; break;
-				}
-			}
-		}
-
 		XE_PHASE(3);
 		/* decode: the template's micro-ops, sorted by kind.  The stores come
 		 * after the list walks so that no gather waits behind them (the vector
@@ -1265,122 +1254,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 			if (PL[6]) general_ops<R>(kp, stg, j, PL[6], ridx, T.live);
 		}
 		XE_PHASE(4);
-		/* derived atoms: the multi-literal clauses of the conjunctive objects */
-		uint64_t dbits[R];
-#pragma unroll
-		for (int r = 0; r < R; r++) dbits[r] = 0;
-		for (uint32_t j = 0; (j < kp.ncjderived) && !(kp.pad2 & 8); j++) {
-			cu64 dq = (cu64)(kp.cjderived + j);
-			const uint64_t pl = dq[0], pt = dq[1], nl = dq[2], nt = dq[3];
-#pragma unroll
-			for (int r = 0; r < R; r++) {
-				const bool d = (((lk[r] & pl) | (tb[r][0] & pt) | (~lk[r] & nl) | (~tb[r][0] & nt)) != 0);
-				dbits[r] |= (uint64_t)d << j;
-			}
-		}
-
-		/* object programs: the atom table first, then the conjunctive objects
-		 * (need / forbid rows), then the listed objects */
-		uint32_t bi = 0, ci = 0;
-		for (uint32_t w = 0; (w < kp.mask_words) && !(kp.pad2 & 8); w++) {
-			uint64_t bits[R];
-			const uint32_t m0 = w * 64, m1 = (m0 + 64 < kp.nmo) ? m0 + 64 : kp.nmo;
-#pragma unroll
-			for (int r = 0; r < R; r++) {
-				uint64_t acc = 0;
-				if (T.live[r]) {
-					uint64_t x = lk[r];
-					while (x) {
-						const uint32_t a = (uint32_t)__builtin_ctzll(x);
-						x &= x - 1;
-						acc |= kp.motab_lds ? lmt[w * XE_MOTAB_ROWS + a] : kp.motab[w * XE_MOTAB_ROWS + a];
-					}
-					x = tb[r][0];
-					while (x) {
-						const uint32_t a = 64 + (uint32_t)__builtin_ctzll(x);
-						x &= x - 1;
-						acc |= kp.motab_lds ? lmt[w * XE_MOTAB_ROWS + a] : kp.motab[w * XE_MOTAB_ROWS + a];
-					}
-				}
-				bits[r] = acc;
-			}
-			if (kp.ncjrows) {
-				uint64_t fail[R];
-#pragma unroll
-				for (int r = 0; r < R; r++) fail[r] = 0;
-				while (ci < kp.ncjrows) {
-					cu32 rq = (cu32)(kp.cjrows + ci);
-					const uint32_t a = rq[0];
-					if (rq[1] != w) break;
-					const uint64_t need = (uint64_t)rq[2] | ((uint64_t)rq[3] << 32);
-					const uint64_t forbid = (uint64_t)rq[4] | ((uint64_t)rq[5] << 32);
-					ci++;
-#pragma unroll
-					for (int r = 0; r < R; r++) {
-						bool val;
-						if (a < XE_ATOM_TERM0) {
-							val = ((lk[r] >> a) & 1) != 0;
-						} else if (a < XE_ATOM_DERIVED0) {
-							const uint32_t t = a - XE_ATOM_TERM0, wsel = t >> 6;
-							const uint64_t word = (wsel == 0) ? tb[r][0] : (wsel == 1) ? tb[r][1] : (wsel == 2) ? tb[r][2] : tb[r][3];
-							val = ((word >> (t & 63)) & 1) != 0;
-						} else {
-							val = ((dbits[r] >> (a - XE_ATOM_DERIVED0)) & 1) != 0;
-						}
-						fail[r] |= val ? forbid : need;
-					}
-				}
-				const uint64_t cand = ((cu64)kp.cjcand)[w];
-#pragma unroll
-				for (int r = 0; r < R; r++) {
-					if (T.live[r]) bits[r] |= cand & ~fail[r];
-				}
-			}
-			while (bi < kp.nfprogs) {
-				typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
-				const XE_CONST u32x4v *fq = (const XE_CONST u32x4v *)(kp.fprogs + bi);
-				const u32x4v f0 = fq[0], f1 = fq[1], f2 = fq[2];
-				const uint32_t FP[12] = { f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w };
-				const uint32_t m = FP[8];
-				const int32_t parent = (int32_t)FP[6];
-				if (m >= m1) break;
-				bi++;
-#pragma unroll
-				for (int r = 0; r < R; r++) {
-					bool h;
-					if (FP[2] == XE_FPROG_GATE) h = ((bits[r] >> (m - m0)) & 1) != 0;   /* matched above */
-					else h = prog_eval<R>(kp, FP, lk[r], tb[r]) && T.live[r];
-					if (parent >= 0) {
-						const uint32_t par = (uint32_t)parent;
-						bool pok;
-						if (par >= m0) pok = ((bits[r] >> (par - m0)) & 1) != 0;
-						else pok = T.live[r] && (((kp.masks[(size_t)ridx[r] * kp.mask_words + (par >> 6)] >> (par & 63)) & 1) != 0);
-						h = h && pok;
-					}
-					bits[r] = (bits[r] & ~(1ull << (m - m0))) | ((uint64_t)h << (m - m0));
-				}
-			}
-#pragma unroll
-			for (int r = 0; r < R; r++) {
-				if (!T.live[r]) continue;
-				((XE_GLOBAL uint64_t *)kp.masks)[(size_t)ridx[r] * kp.mask_words + w] = bits[r];
-				/* counters: every lane adds for each object it matched */
-				uint64_t x = (kp.pad2 & 4) ? 0 : bits[r];
-				while (x) {
-					const uint32_t m = m0 + (uint32_t)__builtin_ctzll(x);
-					x &= x - 1;
-					if (kp.lds_counters) {
-						atomicAdd(lcnt + 3 * m + 0, 1ull);
-						atomicAdd(lcnt + 3 * m + 1, bxr[r]);
-						atomicAdd(lcnt + 3 * m + 2, pxr[r]);
-					} else {
-						atomicAdd(kp.counters + 3 * m + 0, 1ull);
-						atomicAdd(kp.counters + 3 * m + 1, bxr[r]);
-						atomicAdd(kp.counters + 3 * m + 2, pxr[r]);
-					}
-				}
-			}
-		}
+		classify_objects<R>(kp, T.live, lk, tb, ridx, bxr, pxr, lcnt, lmt);
 		XE_PHASE(5);
 		C = N;
 	}
@@ -1392,6 +1266,196 @@ xe_nf_fast_kernel(const xe_kparams kp)
 			if (v) atomicAdd(kp.counters + i, v);
 		}
 	}
+}
+
+/* ------------------------------------------------------------------ general kernel */
+/* device rules (devices.c:237-314), then the object walk (netflow.c:213-244)
+ * through the classification code shared with the fast kernel: object m
+ * receives the record iff its program matches and its parent received it.
+ * plist = all probes (kp.all_probes): presence is per lane here. */
+template <typename REC, fval (*GET)(const REC &, uint32_t, uint32_t *)>
+__device__ __forceinline__ void
+classify(const xe_kparams &kp, REC &rec, int32_t device, uint32_t ridx, bool active,
+	unsigned long long bytes_x_rate, unsigned long long pkts_x_rate, unsigned long long *lcnt, const uint64_t *lmt)
+{
+	bool dropped = false;
+
+	if (active && kp.marks) {
+		uint32_t mk = 0;
+		if (device >= 0) {
+			const xe_devrule dr = kp.devrules[device];
+			uint32_t cnt = 0;
+			for (uint32_t i = 0; i < dr.nprogs; i++) {
+				cnt += prog_match<REC, GET>(kp, rec, kp.progs[dr.first_prog + i]) ? 1u : 0u;
+			}
+			if (dr.skip_unmarked && (cnt == 0)) {
+				dropped = true;
+				mk = XE_MARK_DROPPED;
+			} else {
+				mk = XE_MARK_HAS | (cnt & 0x3FFFFFFFu);
+			}
+		}
+		rec.mark = mk;
+		kp.marks[ridx] = mk;
+	}
+
+	lane_tile<REC, GET> T;
+	uint64_t lk[1], tb[1][4];
+	const uint32_t ri[1] = { ridx };
+	const unsigned long long bx[1] = { bytes_x_rate }, px[1] = { pkts_x_rate };
+	T.rec = &rec;
+	T.live[0] = active && !dropped;
+	classify_atoms<1>(kp, T, kp.all_probes, lk, tb);
+	classify_objects<1>(kp, T.live, lk, tb, ri, bx, px, lcnt, lmt);
+	/* a dropped record still owns its mask words */
+	if (active && dropped) {
+		for (uint32_t w = 0; w < kp.mask_words; w++) kp.masks[(size_t)ridx * kp.mask_words + w] = 0;
+	}
+}
+
+/* the block's LDS counters and atom-table copy of the per-lane kernels */
+__device__ __forceinline__ void
+lane_kernel_lds(const xe_kparams &kp, uint64_t *lds, unsigned long long *&lcnt, uint64_t *&lmt)
+{
+	lcnt = (unsigned long long *)lds;
+	lmt = lds + (kp.lds_counters ? (size_t)kp.nmo * 3 : 0);
+	if (kp.lds_counters) {
+		for (uint32_t i = threadIdx.x; i < kp.nmo * 3; i += XE_BLOCK) lcnt[i] = 0;
+	}
+	if (kp.motab_lds) {
+		for (uint32_t i = threadIdx.x; i < kp.mask_words * XE_MOTAB_ROWS; i += XE_BLOCK) lmt[i] = kp.motab[i];
+	}
+	__syncthreads();
+}
+
+__device__ __forceinline__ void
+lane_kernel_flush(const xe_kparams &kp, const unsigned long long *lcnt)
+{
+	if (!kp.lds_counters) return;
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < kp.nmo * 3; i += XE_BLOCK) {
+		unsigned long long v = lcnt[i];
+		if (v) atomicAdd(kp.counters + i, v);
+	}
+}
+
+/* General kernel: any run the fast kernel does not take (reads that may pass
+ * the datagram end, variable-length / repeated / string elements, exporters
+ * with a devices.conf entry).  One thread per record, everything interpreted
+ * per lane. */
+__global__ void __launch_bounds__(XE_BLOCK)
+xe_nf_general_kernel(const xe_kparams kp)
+{
+	extern __shared__ uint64_t lane_lds[];
+	unsigned long long *lcnt;
+	uint64_t *lmt;
+	lane_kernel_lds(kp, lane_lds, lcnt, lmt);
+	uint32_t g = blockIdx.x * XE_BLOCK + threadIdx.x;
+	bool active = g < kp.nslowrec;
+	uint32_t ridx = 0;
+	nf_rec rec;
+	unsigned long long bxr = 0, pxr = 0;
+	int32_t device = -1;
+
+	rec.mark = 0;
+	rec.nparsed = 0;
+	if (active) {
+		/* the run whose work range holds this thread */
+		uint32_t lo = 0, hi = kp.nssets - 1;
+		while (lo < hi) {
+			uint32_t mid = (lo + hi + 1) >> 1;
+			if (kp.swstart[mid] <= g) lo = mid; else hi = mid - 1;
+		}
+		const xe_set s = kp.ssets[lo];
+		uint32_t i = g - kp.swstart[lo];
+		ridx = s.first_rec + i;
+		int64_t roff = (int64_t)i * s.stride;
+		int32_t avail = s.avail - (int32_t)roff;
+
+		rec.src.p = kp.pkt + s.data_off + roff;
+		rec.src.left = s.dgram_left - (int32_t)roff;
+		rec.src.checked = (s.flags & XE_SET_CHECKED) != 0;
+		rec.t = kp.tmpls + s.tmpl;
+		rec.e = kp.tents + rec.t->ent_base;
+		rec.ex = kp.exps + s.exporter;
+		device = rec.ex->device;
+
+		/* how many template fields the reference parses for this record */
+		uint32_t nf = rec.t->nfields, np = 0;
+		int32_t pos = 0;
+		if (rec.t->mode == XE_MODE_V9) {
+			for (; np < nf; np++) {
+				if ((pos + (int32_t)rec.e[np].len) > avail) break;
+				pos += rec.e[np].len;
+			}
+		} else {
+			for (; np < nf;) {
+				int32_t off;
+				uint32_t len;
+				if (rec.t->varlen) {
+					rec.locate(np, &off, &len);
+					pos = off + (int32_t)len;
+				} else {
+					pos += rec.e[np].len;
+				}
+				np++;
+				if (pos >= avail) break;
+			}
+		}
+		rec.nparsed = np;
+		kp.nparsed[ridx] = (uint8_t)np;
+
+		/* decode into the columns */
+		for (uint32_t j = 0; j < np; j++) {
+			uint32_t f = rec.e[j].field;
+			if (f == XE_F_NONE) continue;
+			bool special = rec.t->varlen || (rec.e[j].flags & XE_TE_REPEAT)
+				|| (rec.e[j].next_same != 0xFF) || c_fstr[f];
+			if (!special) {
+				bool ok = (rec.e[j].flags & XE_TE_VALID) != 0;
+				if (ok) store_col(kp, f, ridx, pkt_be(rec.src, rec.e[j].off, rec.e[j].len));
+				if (kp.vsize_off[f] != ~0ull) {
+					((uint16_t *)(kp.out_base + kp.vsize_off[f]))[ridx] = ok ? rec.e[j].len : (uint16_t)0xFFFF;
+				}
+				continue;
+			}
+			int32_t off;
+			uint32_t len;
+			rec.locate(j, &off, &len);
+			bool ok = rec.valid(j, len, c_fmin, c_fmax);
+			if (c_fstr[f]) {
+				/* left-aligned copy; the first occurrence also clears the
+				 * rest of the slot (the record starts zeroed, netflow.c:275) */
+				uint32_t w = c_colw[f];
+				uint8_t *dst = kp.out_base + kp.col_off[f] + (size_t)ridx * w;
+				bool first = !(rec.e[j].flags & XE_TE_REPEAT);
+				if (first) {
+					for (uint32_t b = 0; b < w; b++) dst[b] = (ok && (b < len)) ? (uint8_t)pkt_byte(rec.src, off + (int32_t)b) : 0;
+				} else if (ok) {
+					for (uint32_t b = 0; b < len; b++) dst[b] = (uint8_t)pkt_byte(rec.src, off + (int32_t)b);
+				}
+				if (kp.vsize_off[f] != ~0ull) {
+					uint16_t *vs = (uint16_t *)(kp.out_base + kp.vsize_off[f]) + ridx;
+					if (ok) *vs = (uint16_t)len;
+					else if (first) *vs = 0xFFFF;
+				}
+			} else {
+				uint32_t sz = 0;
+				fval fv = nf_get(rec, f, &sz);
+				if (fv.has) store_col(kp, f, ridx, fv.v);
+				if (kp.vsize_off[f] != ~0ull) {
+					((uint16_t *)(kp.out_base + kp.vsize_off[f]))[ridx] = fv.has ? (uint16_t)sz : 0xFFFF;
+				}
+			}
+		}
+
+		/* what the counters add: get_nf_val(8 bytes) * sampling_rate, wrapping */
+		uint64_t rate = rec.ex->sampling_rate;
+		bxr = nf_get(rec, XF_in_bytes, nullptr).v.lo * rate;
+		pxr = nf_get(rec, XF_in_pkts, nullptr).v.lo * rate;
+	}
+	classify<nf_rec, nf_get>(kp, rec, device, ridx, active, bxr, pxr, lcnt, lmt);
+	lane_kernel_flush(kp, lcnt);
 }
 
 /* ------------------------------------------------------------------ sFlow v5 */
@@ -1719,6 +1783,10 @@ sf_store_all(const xe_kparams &kp, const sf_rec &r, uint32_t ridx, std::integer_
 __global__ void __launch_bounds__(XE_BLOCK)
 xe_sf_kernel(const xe_kparams kp)
 {
+	extern __shared__ uint64_t lane_lds[];
+	unsigned long long *lcnt;
+	uint64_t *lmt;
+	lane_kernel_lds(kp, lane_lds, lcnt, lmt);
 	uint32_t g = blockIdx.x * XE_BLOCK + threadIdx.x;
 	bool active = g < kp.nsf;
 	uint32_t ridx = kp.nrec + g;
@@ -1754,10 +1822,11 @@ xe_sf_kernel(const xe_kparams kp)
 		pxr = sf_get(rec, XF_in_pkts, nullptr).v.lo * rate;
 		if (!deliver && kp.marks) kp.marks[ridx] = 0;
 	}
-	classify<sf_rec, sf_get>(kp, rec, device, ridx, active && deliver, bxr, pxr);
+	classify<sf_rec, sf_get>(kp, rec, device, ridx, active && deliver, bxr, pxr, lcnt, lmt);
 	if (active && !deliver) {
 		for (uint32_t w = 0; w < kp.mask_words; w++) kp.masks[(size_t)ridx * kp.mask_words + w] = 0;
 	}
+	lane_kernel_flush(kp, lcnt);
 }
 
 /* ------------------------------------------------------------------ list probe */
@@ -1862,17 +1931,19 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 				(double)pc[3] / kp->ntiles, (double)pc[4] / kp->ntiles, (double)pc[5] / kp->ntiles);
 		}
 	}
+	const size_t lane_lds = (kp->lds_counters ? (size_t)kp->nmo * 24 : 0)
+		+ (kp->motab_lds ? (size_t)kp->mask_words * XE_MOTAB_ROWS * 8 : 0) + 16;
 	if (kp->nslowrec) {
 		uint32_t blocks = (kp->nslowrec + XE_BLOCK - 1) / XE_BLOCK;
 		if (ev) (void)hipEventRecord(ev[2], st);
-		hipLaunchKernelGGL(xe_nf_general_kernel, dim3(blocks), dim3(XE_BLOCK), 0, st, *kp);
+		hipLaunchKernelGGL(xe_nf_general_kernel, dim3(blocks), dim3(XE_BLOCK), lane_lds, st, *kp);
 		if (ev) (void)hipEventRecord(ev[3], st);
 		if (hipGetLastError() != hipSuccess) return XE_EHIP;
 	}
 	if (kp->nsf) {
 		uint32_t blocks = (kp->nsf + XE_BLOCK - 1) / XE_BLOCK;
 		if (ev) (void)hipEventRecord(ev[4], st);
-		hipLaunchKernelGGL(xe_sf_kernel, dim3(blocks), dim3(XE_BLOCK), 0, st, *kp);
+		hipLaunchKernelGGL(xe_sf_kernel, dim3(blocks), dim3(XE_BLOCK), lane_lds, st, *kp);
 		if (ev) (void)hipEventRecord(ev[5], st);
 		if (hipGetLastError() != hipSuccess) return XE_EHIP;
 	}
