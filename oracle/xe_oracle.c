@@ -808,7 +808,7 @@ read_token(struct finput *q)
 /* ------------------------------------------------------------------ */
 enum { DIR_NONE = 0, DIR_SRC = 1, DIR_DST = 2, DIR_BOTH = 3 };
 enum { OP_BASIC, OP_NOT, OP_AND, OP_OR };
-enum { FN_NONE, FN_DIV, FN_DIV_R, FN_DIV_L, FN_MIN };
+enum { FN_NONE, FN_DIV, FN_DIV_R, FN_DIV_L, FN_MIN, FN_TFSTR };
 
 struct bdata  /* filter.h:109-119 */
 {
@@ -1149,9 +1149,29 @@ function_min(struct finput *in, struct fexpr *e)
 	return id(in, e, BT_RANGE);
 }
 
-/* filter-parser.c:107-156.  mfreq / tfstr / portstr / ppstr / geoip / asn /
- * asd rules are outside the restated path: the oracle reports them as
- * errors instead of building stateful or database-backed terms. */
+/* filter-parser-funcs.c:526-580 */
+static int
+function_tfstr(struct finput *in, struct fexpr *e)
+{
+	struct basic tmp, *fb;
+
+	memset(&tmp, 0, sizeof(tmp));
+	if (!accept_(in, TK_TFSTR)) return 0;
+	if (!accept_(in, TK_LPAREN)) { mkerror(in, "Expected '(' after 'tfstr'"); return 0; }
+	if (!nonaggr_field(in, &tmp.a_off, &tmp.a_size)) {
+		mkerror(in, "Incorrect field name"); return 0;
+	}
+	if (!accept_(in, TK_RPAREN)) { mkerror(in, "Expected ')'"); return 0; }
+	if (!add_basic(e, BT_STRING, -1, DIR_NONE)) return 0;
+	fb = e->ops[e->n - 1].arg;
+	fb->func = FN_TFSTR;
+	fb->a_off = tmp.a_off; fb->a_size = tmp.a_size;
+	return id(in, e, BT_STRING);
+}
+
+/* filter-parser.c:107-156.  mfreq / portstr / ppstr / geoip / asn / asd
+ * rules are outside the restated path: the oracle reports them as errors
+ * instead of building stateful or database-backed terms. */
 static int
 rule(struct finput *q, struct fexpr *e)
 {
@@ -1159,7 +1179,8 @@ rule(struct finput *q, struct fexpr *e)
 
 	if (function_div(q, e)) return 1;
 	if (function_min(q, e)) return 1;
-	if ((t == TK_MFREQ) || (t == TK_TFSTR) || (t == TK_PORTSTR) || (t == TK_PPSTR)
+	if (function_tfstr(q, e)) return 1;
+	if ((t == TK_MFREQ) || (t == TK_PORTSTR) || (t == TK_PPSTR)
 		|| (t == TK_GEOIP) || (t == TK_ASN) || (t == TK_ASD)) {
 		mkerror(q, "function not restated by the oracle");
 		return 0;
@@ -1395,9 +1416,44 @@ xdiv(uint64_t dividend, uint64_t divisor, int is_log, int k)  /* filter.h:396-41
 	return quotient;
 }
 
+/* the text of a TCP flags byte: the names of the set bits, most significant
+ * first, joined with '+' (table utils-data.inc:4-261, reached through
+ * tcp_flags_to_str(), utils.c:22-26) */
+void
+xo_tcp_flags_str(uint8_t tf, char out[40])
+{
+	static const char *const names[8] = { "CWR", "ECE", "URG", "ACK", "PSH", "RST", "SYN", "FIN" };
+	int b;
+
+	out[0] = '\0';
+	for (b = 0; b < 8; b++) {
+		if (!(tf & (0x80 >> b))) continue;
+		if (out[0]) strcat(out, "+");
+		strcat(out, names[b]);
+	}
+}
+
+static int
+match_tfstr(struct basic *fb, struct xo_flow *flow)  /* filter.c:836-858 */
+{
+	const uint8_t *p = (const uint8_t *)flow + fb->a_off;
+	uint8_t tf = (fb->a_size == 2) ? p[1] : p[0];
+	char flg[40];
+	size_t i;
+
+	xo_tcp_flags_str(tf, flg);
+	for (i = 0; i < fb->n; i++) {
+		/* an operand that is not a quoted string has no text in the
+		 * reference (uninitialised pointer): it never matches here */
+		if (fb->data[i].str && (strcasecmp(fb->data[i].str, flg) == 0)) return 1;
+	}
+	return 0;
+}
+
 static int
 basic_match(struct basic *fb, struct xo_flow *flow)  /* filter.c:907-958 */
 {
+	if (fb->func == FN_TFSTR) return match_tfstr(fb, flow);
 	if (fb->func == FN_MIN) {  /* filter.c:685-709 */
 		uint64_t a = get_nf_val((uint8_t *)flow + fb->a_off, fb->a_size);
 		uint64_t b = get_nf_val((uint8_t *)flow + fb->b_off, fb->b_size);
@@ -1478,6 +1534,10 @@ filter_dump(struct fexpr *e, FILE *f)
 			fprintf(f, "DIV_L ([offset %d]/[offset %d]/k %d)", (int)fb->a_off, (int)fb->b_off, fb->k);
 		} else if (fb->func == FN_MIN) {
 			fprintf(f, "MIN ([offset %d]/[offset %d])", (int)fb->a_off, (int)fb->b_off);
+		} else if (fb->func == FN_TFSTR) {
+			/* no case for it in filter.c:1113-1172: the default branch prints
+			 * the enum value (filter.h:130-151: 36 fields, then the functions) */
+			fprintf(f, "<Unknown name %d> ", 1 + N_FFIELDS + 5 + 8 + 2);
 		} else {
 			/* fprintf(f, #STR" ") stringifies the quoted keyword (filter.c:1117) */
 			fprintf(f, "\"%s\" ", ffields[fb->ffield].kw);

@@ -95,6 +95,8 @@ void xo_log_clear(void);
 
 /* helpers restated from utils.c */
 int xo_mac_addr_read(const char *s, uint8_t mac[6]);
+/* text of a TCP flags byte, as tcp_flags_to_str() (utils.c:22-26) gives it */
+void xo_tcp_flags_str(uint8_t tf, char out[40]);
 
 #ifdef __cplusplus
 }

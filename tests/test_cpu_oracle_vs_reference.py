@@ -114,6 +114,58 @@ def test_mac_addr_read_matches_reference(orc):
             assert a.raw == b.raw, s
 
 
+def _oracle_flags_text(orc, v):
+    import ctypes as C
+    out = C.create_string_buffer(40)
+    orc.L.xo_tcp_flags_str.argtypes = [C.c_uint8, C.c_char_p]
+    orc.L.xo_tcp_flags_str.restype = None
+    orc.L.xo_tcp_flags_str(v, out)
+    return out.value.decode()
+
+
+@needs_ref_utils
+def test_tcp_flags_text_matches_reference(orc):
+    """the rule the oracle states for tfstr() against the reference's 256-entry table"""
+    import ctypes as C
+    ref = RefUtils()
+    ref.L.tcp_flags_to_str.argtypes = [C.c_uint8]
+    ref.L.tcp_flags_to_str.restype = C.c_char_p
+    for v in range(256):
+        assert _oracle_flags_text(orc, v) == ref.L.tcp_flags_to_str(v).decode(), v
+
+
+def test_tcp_flags_text_known_answers(orc):
+    # filter.c:836-858 compares these texts; values as the reference's table holds them
+    for v, want in {0: "", 1: "FIN", 2: "SYN", 0x12: "ACK+SYN", 0x18: "ACK+PSH", 0x20: "URG", 0x40: "ECE",
+                    0x80: "CWR", 0xFF: "CWR+ECE+URG+ACK+PSH+RST+SYN+FIN"}.items():
+        assert _oracle_flags_text(orc, v) == want
+
+
+def test_tfstr_match_reads_the_reference_byte(orc):
+    """filter.c:842-847: byte 1 of a 2-byte field, byte 0 otherwise; no presence test"""
+    fields = {f["name"]: f for f in orc.fields()}
+    flow = bytearray(FLOW_INFO_SIZE)
+    h_syn = orc.filter_parse("tfstr(tcp-flags) 'syn' or 'ACK+SYN'")
+    h_none = orc.filter_parse("not tfstr(tcp-flags) 'FIN' or 'SYN' or 'ACK+SYN' or 'RST'")   # '' is not a token
+    h_proto = orc.filter_parse("tfstr(proto) 'RST+SYN'")
+    h_port = orc.filter_parse("tfstr(dst port) 'FIN'")
+    assert not orc.filter_match(h_syn, bytes(flow)) and orc.filter_match(h_none, bytes(flow))
+    off = fields["tcp_flags"]["off"]
+    flow[off + 1] = 0x02
+    assert orc.filter_match(h_syn, bytes(flow)) and not orc.filter_match(h_none, bytes(flow))
+    flow[off + 1] = 0x12
+    assert orc.filter_match(h_syn, bytes(flow))
+    flow[off], flow[off + 1] = 0x02, 0x00           # the sFlow placement of the flags byte
+    assert not orc.filter_match(h_syn, bytes(flow)) and orc.filter_match(h_none, bytes(flow))
+    flow[fields["protocol"]["off"]] = 0x06
+    assert orc.filter_match(h_proto, bytes(flow))
+    po = fields["l4_dst_port"]["off"]
+    flow[po], flow[po + 1] = 0x01, 0x00
+    assert not orc.filter_match(h_port, bytes(flow))
+    flow[po], flow[po + 1] = 0x00, 0x01
+    assert orc.filter_match(h_port, bytes(flow))
+
+
 def _flow_sets(flows, fields):
     """per record: {field: (size, bytes)} of the fields that are set"""
     out = []

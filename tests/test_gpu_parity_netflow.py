@@ -205,6 +205,28 @@ def test_nested_objects_and_quirky_filters(eng, orc):
     both(eng, orc, w)
 
 
+def test_tfstr_objects(eng, orc):
+    """tfstr() lowered to a set of byte values: the shipped sample tree's
+    `tfstr(tcp-flags) 'SYN'`, case-insensitive texts, other fields, and the
+    same terms inside device mark filters (per-lane kernel)"""
+    w = synth.workload_c2(4000, prefixes=100)
+    w["mos"] = [("proto 6", -1), ("tfstr(tcp-flags) 'SYN'", 0), ("tfstr(tcp-flags) 'ack+syn' or 'ACK' or 'bogus'", 0),
+                ("not tfstr(tcp-flags) 'ACK+PSH'", -1), ("tfstr(proto) 'RST+SYN'", -1),
+                ("tfstr(dst port) 'FIN' or 'SYN' or 'SYN+FIN'", -1), ("tfstr(src host) 'ACK+PSH+SYN'", -1),
+                ("tfstr(src host6) 'URG'", -1)]
+    b = both(eng, orc, w)
+    c = b.counters()
+    assert c[4, 0] > 0, "proto 6 reads as RST+SYN"
+
+
+def test_tfstr_in_device_marks(eng, orc):
+    w2 = synth.workload_c1(3000)
+    w2["mos"] = [("proto 6", -1), ("tfstr(tcp-flags) 'SYN'", 0), ("not tfstr(proto) 'RST+SYN'", -1)]
+    w2["devices"] = [dict(ip="192.0.2.1", sampling_rate=10, marks=("tfstr(proto) 'RST+SYN'", "tfstr(dst port) 'SYN'"))]
+    w2["mos"] = list(w2["mos"]) + [("dev-mark 1", -1), ("dev-mark 2", -1)]
+    both(eng, orc, w2)
+
+
 def test_devices_marks_and_sampling(eng, orc):
     w = synth.workload_c1(2000)
     w["devices"] = [dict(ip="192.0.2.1", dev_id=77, sampling_rate=100, skip_unmarked=True,

@@ -56,6 +56,17 @@ def test_vlan_tcp_syn_is_left_aligned(eng, orc):
     assert bytes(fi[0:8]) == (1500).to_bytes(8, "big")
 
 
+def test_tfstr_reads_byte_one_of_the_flags_field(eng, orc):
+    """sFlow puts the flags byte at byte 0 of the field, tfstr() reads byte 1
+    (filter.c:842-847): the text is always empty, so no name ever matches"""
+    w = synth.workload_c3(500)
+    w["mos"] = [("tfstr(tcp-flags) 'SYN'", -1), ("not tfstr(tcp-flags) 'SYN' or 'ACK' or 'ACK+PSH' or 'ACK+SYN'", -1),
+                ("tfstr(proto) 'RST+SYN'", -1), ("tfstr(src vlan) 'SYN' or 'FIN' or 'ACK'", -1)]
+    b = both(eng, orc, w)
+    c = b.counters()
+    assert c[0, 0] == 0 and c[1, 0] == (b.dropped() == 0).sum() and c[2, 0] > 0
+
+
 def test_ipv6_destination_is_the_source(eng, orc):
     rng = synth.Rng(22)
     src6 = bytes.fromhex("20010db80000000000000000000000aa")

@@ -332,6 +332,21 @@ upload(xe_gpu *h, void **dst, const void *src, size_t bytes)
 }
 
 /* device form of one operand */
+/* the text of a TCP flags byte: the names of the set bits, most significant
+ * first, joined with '+' (the reference's table utils-data.inc:4-261) */
+static void
+tcp_flags_text(unsigned tf, char out[40])
+{
+	static const char *const names[8] = { "CWR", "ECE", "URG", "ACK", "PSH", "RST", "SYN", "FIN" };
+
+	out[0] = '\0';
+	for (int b = 0; b < 8; b++) {
+		if (!(tf & (0x80u >> b))) continue;
+		if (out[0]) strcat(out, "+");
+		strcat(out, names[b]);
+	}
+}
+
 static struct xe_dopnd
 make_dopnd(const struct xe_term *t, const struct xe_opnd *o)
 {
@@ -340,6 +355,18 @@ make_dopnd(const struct xe_term *t, const struct xe_opnd *o)
 
 	memset(&d, 0, sizeof(d));
 	d.is_list = o->is_list;
+	if (t->func == XE_FN_TFSTR) {
+		/* strcasecmp() against the text of the flags byte (filter.c:849-855)
+		 * is a set of byte values: 256 bits in net_hi, net_lo, mask_hi, mask_lo */
+		uint64_t set[4] = { 0, 0, 0, 0 };
+		for (unsigned v = 0; v < 256; v++) {
+			char txt[40];
+			tcp_flags_text(v, txt);
+			if (strcasecmp((const char *)b, txt) == 0) set[v >> 6] |= 1ull << (v & 63);
+		}
+		d.net_hi = set[0]; d.net_lo = set[1]; d.mask_hi = set[2]; d.mask_lo = set[3];
+		return d;
+	}
 	switch (t->type) {
 		case XE_BT_ADDR4:
 			if (o->is_list) d.list = o->w[0];

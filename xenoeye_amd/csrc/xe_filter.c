@@ -30,7 +30,7 @@ enum tok
 {
 	T_ID, T_RANGE, T_MAC, T_STR, T_LP, T_RP, T_COMMA,
 	T_OR, T_AND, T_NOT, T_SRC, T_DST, T_ASC, T_DESC,
-	T_DIV, T_DIV_R, T_DIV_L, T_MIN, T_OTHERFUNC,
+	T_DIV, T_DIV_R, T_DIV_L, T_MIN, T_TFSTR, T_OTHERFUNC,
 	T_FIELD,     /* val = index into kfields */
 	T_AGGR       /* val = index into kaggr */
 };
@@ -90,7 +90,7 @@ static const struct { const char *kw; enum tok t; } kwords[] = {
 	{ "or", T_OR }, { "and", T_AND }, { "not", T_NOT }, { "asc", T_ASC }, { "desc", T_DESC },
 	{ "div", T_DIV }, { "div_r", T_DIV_R }, { "div_l", T_DIV_L }, { "min", T_MIN },
 	/* recognised so that they cannot be list names, but not compiled */
-	{ "mfreq", T_OTHERFUNC }, { "tfstr", T_OTHERFUNC }, { "portstr", T_OTHERFUNC },
+	{ "mfreq", T_OTHERFUNC }, { "tfstr", T_TFSTR }, { "portstr", T_OTHERFUNC },
 	{ "ppstr", T_OTHERFUNC }, { "continent", T_OTHERFUNC }, { "country_code", T_OTHERFUNC },
 	{ "country", T_OTHERFUNC }, { "state", T_OTHERFUNC }, { "city", T_OTHERFUNC },
 	{ "zip", T_OTHERFUNC }, { "lat", T_OTHERFUNC }, { "long", T_OTHERFUNC },
@@ -426,7 +426,12 @@ add_operand(struct pctx *p, int type)
 			memcpy(&o.w[0], p->lx.mac, 6);
 			break;
 		case T_STR:
-			not_on_device(p, "string operand");
+			if (((struct xe_term *)p->terms.p)[p->terms.n - 1].func == XE_FN_TFSTR) {
+				/* the text itself; turned into a set of flag bytes at commit */
+				snprintf((char *)&o.w[0], sizeof(o.w), "%s", p->lx.text);
+			} else {
+				not_on_device(p, "string operand");
+			}
 			break;
 		default:
 			return;
@@ -518,6 +523,27 @@ field_arg(struct pctx *p, uint8_t *field)
 	return *field < XE_NTABLE_FIELDS;   /* virtual fields have no table entry */
 }
 
+/* tfstr(field) 'FLAGS' ... (filter-parser-funcs.c:526-580): the byte that
+ * the reference reads (filter.c:842-847) against the text of each operand */
+static int
+tfstr_rule(struct pctx *p)
+{
+	struct xe_term t;
+
+	if (p->lx.t != T_TFSTR) return 0;
+	if (!take(p, T_TFSTR)) return 0;
+	memset(&t, 0, sizeof(t));
+	t.type = XE_BT_STRING;
+	t.dir = XE_DIR_NONE;
+	t.func = XE_FN_TFSTR;
+	if (!take(p, T_LP)) { fail(&p->lx, "Expected '(' after 'tfstr'"); return 0; }
+	if (!field_arg(p, &t.fa)) { fail(&p->lx, "Incorrect field name"); return 0; }
+	if (!take(p, T_RP)) { fail(&p->lx, "Expected ')'"); return 0; }
+	if (xe_fields[t.fa].type == XE_T_STR) not_on_device(p, "tfstr() over a string field");
+	emit_term(p, &t);
+	return value_list(p, XE_BT_STRING);
+}
+
 /* div / div_r / div_l / min (filter-parser-funcs.c:83-282) */
 static int
 func_rule(struct pctx *p)
@@ -560,6 +586,7 @@ static int
 parse_rule(struct pctx *p)
 {
 	if (func_rule(p)) return 1;
+	if (tfstr_rule(p)) return 1;
 	if (p->lx.t == T_OTHERFUNC) {
 		p->other_func = 1;
 		fail(&p->lx, "function is not compiled");
@@ -662,7 +689,7 @@ xe_filter_compile(const struct xe_iplists *reg, const char *text, struct xe_filt
 		if (p.other_func) {
 			/* valid in the reference (filter-parser-funcs.c:285-560), but
 			 * these need its geoip / string tables */
-			if (err && errlen) snprintf(err, errlen, "mfreq/tfstr/portstr/ppstr/geoip/asn/asd "
+			if (err && errlen) snprintf(err, errlen, "mfreq/portstr/ppstr/geoip/asn/asd "
 				"functions are not supported by this library");
 			return XE_EUNSUPPORTED;
 		}
@@ -728,6 +755,11 @@ xe_filter_dump_text(const struct xe_iplists *reg, const struct xe_filter *f, cha
 			case XE_FN_MIN:
 				PUT("MIN ([offset %d]/[offset %d])", xe_fields[t->fa].off, xe_fields[t->fb].off);
 				break;
+			case XE_FN_TFSTR:
+				/* filter.c:1113-1172 has no case for it: the default branch
+				 * prints the enum value (filter.h:130-151) */
+				PUT("<Unknown name %d> ", 1 + NKFIELDS + 5 + 8 + 2);
+				break;
 			default:
 				PUT("\"%s\" ", kfields[t->pad].kw);
 				break;
@@ -750,6 +782,8 @@ xe_filter_dump_text(const struct xe_iplists *reg, const struct xe_filter *f, cha
 				PUT(" %d-%d", (int32_t)o->w[0], (int32_t)o->w[1]);
 			} else if (t->type == XE_BT_MAC) {
 				PUT(" %02x:%02x:%02x:%02x:%02x:%02x", b[0], b[1], b[2], b[3], b[4], b[5]);
+			} else if (t->func == XE_FN_TFSTR) {
+				PUT(" %s", (const char *)b);
 			}
 		}
 		PUT("\n");

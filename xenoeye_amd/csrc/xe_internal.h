@@ -140,7 +140,7 @@ struct xe_sfrec
 /* flat filter programs */
 enum { XE_OP_BASIC = 0, XE_OP_NOT = 1, XE_OP_AND = 2, XE_OP_OR = 3 };
 enum { XE_BT_ADDR4 = 0, XE_BT_ADDR6 = 1, XE_BT_RANGE = 2, XE_BT_MAC = 3, XE_BT_STRING = 4 };
-enum { XE_FN_NONE = 0, XE_FN_DIV = 1, XE_FN_DIV_R = 2, XE_FN_DIV_L = 3, XE_FN_MIN = 4 };
+enum { XE_FN_NONE = 0, XE_FN_DIV = 1, XE_FN_DIV_R = 2, XE_FN_DIV_L = 3, XE_FN_MIN = 4, XE_FN_TFSTR = 5 };
 enum { XE_DIR_NONE = 0, XE_DIR_SRC = 1, XE_DIR_DST = 2, XE_DIR_BOTH = 3 };
 
 struct xe_term
@@ -159,7 +159,9 @@ struct xe_opnd
 	uint32_t w[XE_OPND_WORDS - 1];
 	/* range: w[0]=low w[1]=high (int32)   addr4: w[0]=addr w[1]=mask (bytes as stored)
 	 * list:  w[0]=list index              addr6: w[0..3]=addr w[4..7]=mask
-	 * mac:   w[0..1] = 6 bytes */
+	 * mac:   w[0..1] = 6 bytes
+	 * tfstr: w[0..8] = the operand's text, NUL-terminated (cut at 35 characters;
+	 *        the longest TCP flags text has 31) */
 };
 
 #define XE_PROG_CONST 1      /* result is `cval` whatever the record */

@@ -242,12 +242,33 @@ nf_val(const fval &f, uint32_t sizemax)
 	return ((sizemax == 1) || (sizemax == 2) || (sizemax == 4) || (sizemax == 8)) ? f.v.lo : 0;
 }
 
+/* tfstr(): the byte the reference reads from the field's storage (byte 1 of
+ * a 2-byte field, else byte 0; filter.c:842-847) out of the right-aligned
+ * value; absent fields read as 0 */
+__device__ __forceinline__ uint32_t
+tfstr_byte(uint64_t hi, uint64_t lo, uint32_t fmax)
+{
+	if (fmax == 2) return (uint32_t)lo & 0xFF;
+	if (fmax > 8) return (uint32_t)(hi >> ((fmax - 9) * 8)) & 0xFF;
+	return (uint32_t)(lo >> ((fmax - 1) * 8)) & 0xFF;
+}
+
 template <typename REC, fval (*GET)(const REC &, uint32_t, uint32_t *)>
 __device__ __forceinline__ bool
 term_match(const xe_kparams &kp, const REC &rec, const xe_term &t)
 {
 	const xe_dopnd *o = kp.opnds + t.opnd_base;
 
+	if (t.func == XE_FN_TFSTR) {
+		const fval v = GET(rec, t.fa, nullptr);
+		const uint32_t by = tfstr_byte(v.v.hi, v.v.lo, c_fmax[t.fa]);
+		bool res = false;
+		for (uint32_t i = 0; i < t.nopnd; i++) {
+			const uint64_t w = (by < 64) ? o[i].net_hi : (by < 128) ? o[i].net_lo : (by < 192) ? o[i].mask_hi : o[i].mask_lo;
+			res |= ((w >> (by & 63)) & 1) != 0;
+		}
+		return res;
+	}
 	if (t.func != XE_FN_NONE) {
 		uint64_t a = nf_val(GET(rec, t.fa, nullptr), c_fmax[t.fa]);
 		uint64_t b = nf_val(GET(rec, t.fb, nullptr), c_fmax[t.fb]);
@@ -687,6 +708,17 @@ fast_term(const xe_kparams &kp, const TT &T, const term_s &t, uint32_t r, uint64
 	uint32_t fmax;
 	uint64_t hi, lo;
 
+	if (t.func == XE_FN_TFSTR) {
+		tile_get(T, t.fa, r, has, fmax, hi, lo);
+		const uint32_t by = tfstr_byte(hi, lo, fmax);
+		bool res = false;
+		for (uint32_t i = 0; i < t.nopnd; i++) {
+			cu64 w = (cu64)(o + i);
+			const uint64_t set = (by < 64) ? w[2] : (by < 128) ? w[3] : (by < 192) ? w[4] : w[5];
+			res |= ((set >> (by & 63)) & 1) != 0;
+		}
+		return res;
+	}
 	if (t.func != XE_FN_NONE) {
 		tile_get(T, t.fa, r, has, fmax, hi, lo);
 		uint64_t a = ((fmax == 1) || (fmax == 2) || (fmax == 4) || (fmax == 8)) ? lo : 0;
