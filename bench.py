@@ -34,7 +34,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--records", type=int, default=1 << 22, help="records per GPU per step")
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4"])
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
     ap.add_argument("--c4-prefixes", type=int, default=1000000, help="prefixes per list of the c4 workload")
     ap.add_argument("--cpu-sample", type=int, default=12000000, help="records timed on the CPU oracle (0 = skip)")
     ap.add_argument("--replicate", type=int, default=1, help="repeat the generated datagrams this many times")
@@ -43,8 +43,12 @@ def parse_args():
     return ap.parse_args()
 
 
-def build_workload(name, nrec, rank, c4_prefixes=1000000):
+def build_workload(name, nrec, rank, c4_prefixes=1000000, world=1):
     from xenoeye_amd import synth
+    if name == "c5":
+        # one replay of 512 exporters cut by exporter hash: this rank generates its share only
+        return synth.workload_c5(nrec * world, rank=rank, world=world), \
+            "C5 sharded replay, 512 exporters (256 netflow-v9 21B + 256 ipfix 46B records), 17 objects, %d ranks" % world
     if name == "c4":
         return synth.workload_c4(nrec, seed=synth.SEED_C4 ^ (rank << 32), prefixes=c4_prefixes), \
             "C4 netflow-v9 29B records, 256 objects = 8 lists x %d prefixes x 32 variants (net + port/AS/proto)" % c4_prefixes
@@ -121,7 +125,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import xenoeye_amd
-    w, wl_name = build_workload(args.workload, args.records, rank, args.c4_prefixes)
+    w, wl_name = build_workload(args.workload, args.records, rank, args.c4_prefixes, world)
     eng = xenoeye_amd.Engine(device=local_rank)
     for name, text in w["iplists"].items():
         eng.add_iplist(name, text)
@@ -210,6 +214,8 @@ def main():
                        "sharding": "exporters per rank, no data-path collective"},
             "payload_GBps": pay * args.steps / dt_all / 1e9,
             "merged_counters_object0": [int(x) for x in ctr[0]] if len(ctr) else [],
+            "merged_records_per_object": [int(x) for x in ctr[:, 0]] if len(ctr) else [],
+            "records_all_steps": int(tot) * args.steps,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": args.traffic if args.traffic is not None else measured_traffic(args.workload, nrec),
                          "kernel": kernel_name, "kernel_ms": kernel_ms, "step_ms_events": step_ms,

@@ -75,6 +75,31 @@ def test_select_partitions_exporters():
     assert one[0] is not None and len(one[1]) == len(offs)
 
 
+def test_c5_generated_per_rank_equals_cut_from_the_whole():
+    """the 512-exporter replay: a rank that generates only its exporters gets
+    the datagrams that select() cuts out of the whole batch, and the oracle's
+    counters over the shards add up to its counters over the whole"""
+    world = 3
+    w = synth.workload_c5(60000, prefixes=100)
+    full = w["batch"].packed()
+    nrec, ctr, _ = _oracle_run(w, full)
+    assert nrec == w["nrec"]
+    total = np.zeros_like(ctr)
+    seen = 0
+    for r in range(world):
+        part = synth.workload_c5(60000, prefixes=100, rank=r, world=world)
+        mine = part["batch"].packed()
+        cut = shard.select(full, r, world)
+        assert sorted(mine[2].tolist()) == sorted(cut[2].tolist())
+        n_r, c_r, _ = _oracle_run(part, mine)
+        n_c, c_c, _ = _oracle_run(w, cut)
+        assert n_r == n_c == part["nrec"] and np.array_equal(c_r, c_c)
+        total = total + c_r
+        seen += n_r
+    assert seen == nrec and np.array_equal(total, ctr)
+    assert (ctr[:, 0] > 0).sum() >= 9
+
+
 def test_wrapping_merge_without_process_group():
     c = np.array([[2**64 - 1, 5, 7]], dtype=np.uint64)
     assert np.array_equal(shard.merge_counters(c), c)

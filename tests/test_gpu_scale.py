@@ -114,3 +114,43 @@ def test_random_boolean_structures(eng, orc):
     compare(b, orc, flows=False)
     c = b.counters()
     assert 20 < (c[:, 0] > 0).sum() < 190
+
+
+def test_c5_shards_sum_to_the_whole(eng, orc):
+    """512 exporters (half Netflow v9, half IPFIX), 17 objects: the per-object
+    counters of 8 exporter shards, each generated and processed on its own,
+    add up (wrapping u64) to the counters of the unsharded batch, and a prefix
+    of the unsharded batch equals the oracle record for record."""
+    from xenoeye_amd import shard
+    world = 8
+    w = synth.workload_c5(600000, prefixes=2000)
+    configure(eng, orc, w["iplists"], w["mos"])
+    b = eng.prepare(w["batch"])
+    b.run()
+    assert b.records == w["nrec"]
+    whole = b.counters().copy()
+    assert (whole[:, 0] > 0).sum() >= 9      # the v4 objects and `mynet` all see traffic
+    total = np.zeros_like(whole)
+    nrec = 0
+    for r in range(world):
+        part = synth.workload_c5(600000, prefixes=2000, rank=r, world=world)
+        pb = eng.prepare(part["batch"])
+        pb.run()
+        nrec += pb.records
+        total = total + pb.counters()        # uint64: wraps like the reference's adds
+        # the same shard cut out of the whole batch gives the same counters
+        cut = eng.prepare(shard.select(w["batch"].packed(), r, world))
+        cut.run()
+        assert np.array_equal(cut.counters(), pb.counters()), r
+        pb.free()
+        cut.free()
+    assert nrec == w["nrec"]
+    assert np.array_equal(total, whole)
+    nd = 512 + 3000
+    sub = synth.Batch()
+    for p, a in zip(w["batch"].pkts[:nd], w["batch"].src[:nd]):
+        sub.add(p, a)
+    run_oracle(orc, sub, keep_flows=False)
+    n = orc.nrecords()
+    assert n > 100000
+    assert np.array_equal(b.masks()[:n], orc.masks())

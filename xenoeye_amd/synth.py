@@ -436,6 +436,68 @@ def workload_c4(nrec, seed=SEED_C4, n_lists=8, prefixes=1000000, variants=32, pe
     return dict(batch=b, iplists=iplists, mos=mos, devices=[], nrec=nrec)
 
 
+def workload_c5(nrec, seed=SEED_C5, n_exporters=512, prefixes=10000, n_lists=8, rank=0, world=1, owner=None):
+    """Sharded replay: `n_exporters` exporters 10.5.x.y, the first half Netflow v9
+    with the 21-byte template of workload_c1 (source id = index), the second
+    half IPFIX with the IPv4 template of workload_c2 (observation domain =
+    index); the 16 objects of workload_c2 (same lists) plus `src net mynet`.
+    Every exporter's records come from its own stream (seed ^ index), so a
+    rank can generate just its share: with `world` > 1 only the exporters with
+    owner(address array, world) == rank are produced (default owner:
+    shard.exporter_rank).  Datagrams of the exporters are interleaved round
+    robin, templates first."""
+    from . import shard
+    if owner is None:
+        owner = shard.exporter_rank
+    lists4, iplists = [], {}
+    for k in range(n_lists):
+        lr = Rng(SEED_C2 ^ (0x1000 + k))
+        v4 = prefix_list_v4(lr, prefixes, np.arange(12, 29), nested_frac=0.1)
+        v6 = prefix_list_v6(lr, prefixes)
+        lists4.append(v4)
+        iplists["list%d" % k] = iplist_text(v4, v6)
+    iplists["mynet"] = "\n".join(MYNET_C1) + "\n"
+    all4 = (np.concatenate([a for a, _ in lists4]), np.concatenate([l for _, l in lists4]))
+    mynets, mylens = _parse_v4_prefixes(MYNET_C1)
+
+    addrs = [bytes([10, 5, (e + 1) >> 8, (e + 1) & 255]) for e in range(n_exporters)]
+    own = owner(np.frombuffer(b"".join(addrs), dtype="<u4"), world) if world > 1 else np.zeros(n_exporters, dtype=np.int64)
+    per_exp = max(1, nrec // n_exporters)
+    streams, head, total = [], Batch(), 0
+    for e in range(n_exporters):
+        if own[e] != rank:
+            continue
+        rng = Rng(seed ^ (e + 1))
+        if e < n_exporters // 2:
+            n = max(64, per_exp // 64 * 64)
+            inside = addrs_in_prefixes_v4(rng, n, mynets, mylens)
+            rnd = (rng.u64(n) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+            rec = flow_columns(rng, n, TMPL_V9_C1, src4=np.where(rng.below(n, 2) == 0, inside, rnd))
+            head.add(v9_template_packet(256, TMPL_V9_C1, e + 1), addrs[e])
+            pk = v9_data_packets(256, rec, 64, e + 1)
+        else:
+            n = max(30, per_exp // 30 * 30)
+
+            def mix4(m):
+                inside = addrs_in_prefixes_v4(rng, m, *all4)
+                rnd = (rng.u64(m) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+                return np.where(rng.below(m, 6) == 0, inside, rnd)
+            rec = flow_columns(rng, n, TMPL_IPFIX_V4, src4=mix4(n), dst4=mix4(n))
+            head.add(ipfix_template_packet(256, TMPL_IPFIX_V4, e + 1), addrs[e])
+            pk = ipfix_data_packets(256, rec, 30, e + 1)
+        total += n
+        streams.append((addrs[e], pk))
+    b = head
+    depth = max((len(pk) for _, pk in streams), default=0)
+    for j in range(depth):
+        for a, pk in streams:
+            if j < len(pk):
+                b.add(pk[j], a)
+    mos = [("net list%d" % k, -1) for k in range(n_lists)] + [("net6 list%d" % k, -1) for k in range(n_lists)]
+    mos.append(("src net mynet", -1))
+    return dict(batch=b, iplists=iplists, mos=mos, devices=[], nrec=total)
+
+
 # ------------------------------------------------------------------ sflow v5
 def _eth(rng, ethertype, vlan=None, qinq=None):
     h = rng.bytes(12).tobytes()
