@@ -31,6 +31,50 @@ def test_c4_shape_256_objects(eng, orc):
     assert (c[:, 0] > 0).sum() > 200     # nearly every object sees traffic
 
 
+@pytest.mark.timeout(600)
+def test_c4_full_scale_lists(eng, orc):
+    """8 lists of 1 000 000 prefixes each (routing-table like lengths), 256
+    objects: tables of several hundred MB, every walk depth in use"""
+    w = synth.workload_c4(30000, prefixes=1000000)
+    configure(eng, orc, w["iplists"], w["mos"])
+    b = eng.prepare(w["batch"])
+    b.run()
+    run_oracle(orc, w["batch"], keep_flows=False)
+    compare(b, orc, flows=False)
+    assert (b.counters()[:, 0] > 0).sum() > 200
+
+
+def test_more_terms_and_lookups_than_the_shared_classification_holds(eng, orc):
+    """over 256 distinct terms, and lists in more than 8 (group, field) pairs:
+    every object program is then run on its own, same results"""
+    w = synth.workload_c1(3000)
+    w["mos"] = [("src net mynet", -1)] + [("dst port %d-%d" % (200 * i, 200 * i + 150), 0 if i % 7 == 0 else -1)
+                                          for i in range(300)]
+    configure(eng, orc, w["iplists"], w["mos"])
+    b = eng.prepare(w["batch"])
+    b.run()
+    run_oracle(orc, w["batch"], keep_flows=True)
+    compare(b, orc)
+    assert (b.counters()[:, 0] > 0).sum() > 250
+
+
+def test_seventy_lists(eng, orc):
+    w = synth.workload_c1(3000)
+    rng = synth.Rng(404)
+    lists = dict(w["iplists"])
+    mos = [("src net mynet", -1)]
+    for k in range(70):
+        v4 = synth.prefix_list_v4(rng, 40, np.arange(4, 20), nested_frac=0.2)
+        lists["l%02d" % k] = synth.iplist_text(v4, None)
+        mos.append(("%s net l%02d" % (["src", "dst", ""][k % 3], k), -1))
+    configure(eng, orc, lists, mos)
+    b = eng.prepare(w["batch"])
+    b.run()
+    run_oracle(orc, w["batch"], keep_flows=False)
+    compare(b, orc, flows=False)
+    assert (b.counters()[:, 0] > 0).sum() > 60
+
+
 def test_c4_nested_objects(eng, orc):
     """children under table-resolved and listed parents, across mask words"""
     w = synth.workload_c4(6000, prefixes=5000, n_lists=4, variants=4)

@@ -858,6 +858,10 @@ xe_gpu_commit(xe_gpu *h)
 			}
 			h->ncjrows = (uint32_t)nrows;
 			h->ncjderived = (uint32_t)nder;
+			if (getenv("XE_DEBUG")) {
+				fprintf(stderr, "xe_gpu_commit: %zu objects, %u terms, %u lookups, %zu listed programs, "
+					"%zu need/forbid rows, %zu derived atoms\n", h->hs.nmos, h->nterms, h->nlookups, nb, nrows, nder);
+			}
 			if (rc == XE_OK) rc = upload(h, &h->d_motab, mt, words * XE_MOTAB_ROWS * sizeof(uint64_t));
 			if (rc == XE_OK) rc = upload(h, &h->d_fprogs, fp, nb * sizeof(*fp));
 			if (rc == XE_OK) rc = upload(h, &h->d_cjrows, rows, nrows * sizeof(*rows));
@@ -875,6 +879,7 @@ xe_gpu_commit(xe_gpu *h)
 			if (!need) rc = XE_ENOMEM;
 			for (uint32_t t = 0; (rc == XE_OK) && (t < h->nterms); t++) if (ft[t].kind & 2) need[n++] = t;
 			h->ntneed = n;
+			if (getenv("XE_DEBUG")) fprintf(stderr, "xe_gpu_commit: %u terms evaluated per record\n", n);
 			if (rc == XE_OK) rc = upload(h, &h->d_tneed, need, (size_t)n * sizeof(uint32_t));
 			free(need);
 		}
@@ -1118,6 +1123,7 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 				k++;
 			}
 			b->kp.all_probes = list;
+			b->kp.per_object = h->fast_ok ? 0u : 1u;
 		}
 		b->kp.motab = (const uint64_t *)h->d_motab;
 		b->kp.motab_lds = ((size_t)h->mask_words * XE_MOTAB_ROWS * 8 <= 8192) ? 1u : 0u;

@@ -77,6 +77,7 @@ struct xe_kparams
 	const uint64_t *cjcand;      /* per mask word: the objects matched through cjrows */
 	uint32_t ncjrows, ncjderived;
 	uint64_t all_probes;         /* byte i = i-th probe with non-empty tables, 0xFF = end */
+	uint32_t per_object, pad_po;   /* per_object: run every object's program on its own (limits exceeded) */
 	const uint32_t *fflds;       /* [template slot][XE_NFIELDS] XE_FFLD_* words */
 	uint32_t nfruns, ntiles;
 	uint32_t fast_r;             /* records per lane and tile: 1, 2 or 4 */

@@ -1331,6 +1331,45 @@ classify(const xe_kparams &kp, REC &rec, int32_t device, uint32_t ridx, bool act
 		kp.marks[ridx] = mk;
 	}
 
+	if (kp.per_object) {
+		/* configurations beyond the limits of the shared classification (more
+		 * distinct terms or lookups than its bit sets hold): every object's
+		 * program is run on its own, parents always have a smaller index */
+		for (uint32_t w = 0; w < kp.mask_words; w++) {
+			uint64_t bits = 0;
+			uint32_t m0 = w * 64, m1 = (m0 + 64 < kp.nmo) ? m0 + 64 : kp.nmo;
+			for (uint32_t m = m0; m < m1; m++) {
+				bool hit = false;
+				if (active && !dropped) {
+					const xe_prog pr = kp.progs[m];
+					bool parent_ok = true;
+					if (pr.parent >= 0) {
+						/* a parent in an earlier word was stored already */
+						parent_ok = ((uint32_t)pr.parent >= m0)
+							? ((bits >> ((uint32_t)pr.parent - m0)) & 1) != 0
+							: ((kp.masks[(size_t)ridx * kp.mask_words + ((uint32_t)pr.parent >> 6)]
+								>> ((uint32_t)pr.parent & 63)) & 1) != 0;
+					}
+					hit = parent_ok && prog_match<REC, GET>(kp, rec, pr);
+				}
+				if (hit) bits |= 1ull << (m - m0);
+				/* counters: wave-wide sums, one atomic per wave and counter */
+				unsigned long long ball = __ballot(hit);
+				if (ball) {
+					unsigned long long sb = wave_sum(hit ? bytes_x_rate : 0ull);
+					unsigned long long sp = wave_sum(hit ? pkts_x_rate : 0ull);
+					if ((threadIdx.x & 63) == 0) {
+						atomicAdd(&kp.counters[3 * m + 0], (unsigned long long)__popcll(ball));
+						atomicAdd(&kp.counters[3 * m + 1], sb);
+						atomicAdd(&kp.counters[3 * m + 2], sp);
+					}
+				}
+			}
+			if (active) kp.masks[(size_t)ridx * kp.mask_words + w] = bits;
+		}
+		return;
+	}
+
 	lane_tile<REC, GET> T;
 	uint64_t lk[1], tb[1][4];
 	const uint32_t ri[1] = { ridx };
