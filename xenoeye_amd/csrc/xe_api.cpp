@@ -20,7 +20,7 @@ struct xe_gpu
 	int device;
 	struct xe_host hs;
 	int committed;
-	void *d_progs, *d_ops, *d_terms, *d_opnds, *d_trie, *d_lists, *d_devrules, *d_lookups, *d_fterms, *d_fprogs, *d_motab, *d_tneed, *d_cjrows, *d_cjderived, *d_cjcand;
+	void *d_progs, *d_ops, *d_terms, *d_opnds, *d_trie, *d_lists, *d_devrules, *d_lookups, *d_fterms, *d_fprogs, *d_motab, *d_tneed, *d_cjgb, *d_cjtab, *d_cjderived, *d_cjcand, *d_rgroups, *d_rgdata;
 	uint32_t nmo, mask_words, nprogs_total, nlookups;
 	struct xe_list_dev *h_lists;
 	struct xe_probe *h_probes;   /* host copy of the probe table (nlookups entries) */
@@ -29,7 +29,7 @@ struct xe_gpu
 	uint32_t nterms;           /* distinct terms of the object programs */
 	uint32_t nfprogs;          /* objects the fast kernel evaluates one by one */
 	uint32_t ntneed;           /* terms the fast kernel has to evaluate */
-	uint32_t ncjrows, ncjderived;
+	uint32_t ncjgroups, ncjderived, nrgroups;
 	int fast_ok, want_dev;     /* want_dev: some object program reads dev_ip / dev_id */
 	int reads_mark;            /* some object program reads dev_mark */
 	char err[512];
@@ -116,7 +116,7 @@ free_config_dev(xe_gpu *h)
 {
 	void **p[] = { &h->d_progs, &h->d_ops, &h->d_terms, &h->d_opnds, &h->d_trie, &h->d_lists, &h->d_devrules,
 		&h->d_lookups, &h->d_fterms, &h->d_fprogs, &h->d_motab, &h->d_tneed,
-		&h->d_cjrows, &h->d_cjderived, &h->d_cjcand };
+		&h->d_cjgb, &h->d_cjtab, &h->d_cjderived, &h->d_cjcand, &h->d_rgroups, &h->d_rgdata };
 	for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); i++) {
 		if (*p[i]) (void)hipFree(*p[i]);
 		*p[i] = NULL;
@@ -856,21 +856,167 @@ xe_gpu_commit(xe_gpu *h)
 				while (j && (rows[j - 1].word > x.word)) { rows[j] = rows[j - 1]; j--; }
 				rows[j] = x;
 			}
-			h->ncjrows = (uint32_t)nrows;
 			h->ncjderived = (uint32_t)nder;
+			{
+				/* fold the rows into tables indexed by 8 atoms at once */
+				uint8_t gof[XE_CJ_MAX_GROUPS];
+				uint32_t gb[XE_CJ_MAX_GROUPS + 4], ng = 0;
+				uint64_t *tab = NULL;
+				memset(gof, 0xFF, sizeof(gof));
+				for (size_t j = 0; j < nrows; j++) {
+					uint32_t a = rows[j].atom;
+					uint32_t k = (a < XE_ATOM_TERM0) ? (a >> 3) : (a < XE_ATOM_DERIVED0) ? 8 + ((a - XE_ATOM_TERM0) >> 3)
+						: 40 + ((a - XE_ATOM_DERIVED0) >> 3);
+					gof[k] = 0;
+				}
+				for (uint32_t k = 0; k < XE_CJ_MAX_GROUPS; k++) if (gof[k] == 0) { gof[k] = (uint8_t)ng; gb[ng++] = k; }
+				if (ng) {
+					tab = (uint64_t *)calloc((size_t)ng * 256 * words, sizeof(uint64_t));
+					if (!tab) rc = XE_ENOMEM;
+				}
+				for (size_t j = 0; (rc == XE_OK) && (j < nrows); j++) {
+					uint32_t a = rows[j].atom;
+					uint32_t k = (a < XE_ATOM_TERM0) ? (a >> 3) : (a < XE_ATOM_DERIVED0) ? 8 + ((a - XE_ATOM_TERM0) >> 3)
+						: 40 + ((a - XE_ATOM_DERIVED0) >> 3);
+					uint64_t *t0 = tab + (size_t)gof[k] * 256 * words + rows[j].word;
+					for (uint32_t v = 0; v < 256; v++) {
+						t0[(size_t)v * words] |= ((v >> (a & 7)) & 1) ? rows[j].forbid : rows[j].need;
+					}
+				}
+				/* the kernel takes 4 groups per step: repeating a group is harmless (OR) */
+				h->ncjgroups = ng;
+				while (ng & 3) { gb[ng] = gb[0]; ng++; }
+				if ((rc == XE_OK) && h->ncjgroups) {
+					/* a repeated group must also find its table: copies share group 0's
+					 * index, so the list holds (byte, table index) pairs */
+					uint32_t pairs[2 * (XE_CJ_MAX_GROUPS + 4)];
+					for (uint32_t g = 0; g < ng; g++) {
+						pairs[2 * g] = gb[g];
+						pairs[2 * g + 1] = (g < h->ncjgroups) ? g : 0;
+					}
+					rc = upload(h, &h->d_cjgb, pairs, (size_t)ng * 8);
+					if (rc == XE_OK) rc = upload(h, &h->d_cjtab, tab, (size_t)h->ncjgroups * 256 * words * sizeof(uint64_t));
+				}
+				free(tab);
+			}
 			if (getenv("XE_DEBUG")) {
 				fprintf(stderr, "xe_gpu_commit: %zu objects, %u terms, %u lookups, %zu listed programs, "
-					"%zu need/forbid rows, %zu derived atoms\n", h->hs.nmos, h->nterms, h->nlookups, nb, nrows, nder);
+					"%zu need/forbid rows in %u byte tables, %zu derived atoms\n", h->hs.nmos, h->nterms, h->nlookups, nb, nrows, h->ncjgroups, nder);
 			}
 			if (rc == XE_OK) rc = upload(h, &h->d_motab, mt, words * XE_MOTAB_ROWS * sizeof(uint64_t));
 			if (rc == XE_OK) rc = upload(h, &h->d_fprogs, fp, nb * sizeof(*fp));
-			if (rc == XE_OK) rc = upload(h, &h->d_cjrows, rows, nrows * sizeof(*rows));
 			if (rc == XE_OK) rc = upload(h, &h->d_cjderived, der, nder * sizeof(*der));
 			if (rc == XE_OK) rc = upload(h, &h->d_cjcand, cand, words * sizeof(uint64_t));
 			free(mt);
 			free(cand);
 			free(der);
 			free(rows);
+		}
+		h->nrgroups = 0;
+		if (rc == XE_OK) {
+			/* needed range terms, grouped by the field they read */
+			uint8_t chosen[XE_NFIELDS];
+			struct xe_rgroup rg[XE_MAX_RGROUPS + 4];
+			struct xe_blob rgd = {0};
+			uint32_t nrg = 0, nchosen = 0;
+			memset(chosen, 0, sizeof(chosen));
+#define XE_RTERM(T) ((ft[T].kind & 2) && (tt[T].type == XE_BT_RANGE) && (tt[T].func == XE_FN_NONE) && (tt[T].dir != XE_DIR_NONE))
+			for (uint32_t t = 0; t < h->nterms; t++) {
+				if (!XE_RTERM(t)) continue;
+				for (int side = 0; side < 2; side++) {
+					uint32_t f = side ? tt[t].fdst : tt[t].fsrc;
+					if (!(tt[t].dir & (side ? XE_DIR_DST : XE_DIR_SRC)) || chosen[f]) continue;
+					if (nchosen < XE_MAX_RGROUPS) { chosen[f] = 1; nchosen++; }
+				}
+			}
+			for (uint32_t f = 0; (rc == XE_OK) && (f < XE_NFIELDS); f++) {
+				int64_t *bp;
+				size_t nb = 0, cap = 0;
+				if (!chosen[f]) continue;
+				/* a term is taken out of the one-by-one list only when all the
+				 * fields it reads have a group */
+				for (uint32_t t = 0; t < h->nterms; t++) {
+					if (!XE_RTERM(t)) continue;
+					if ((tt[t].dir & XE_DIR_SRC) && !chosen[tt[t].fsrc]) continue;
+					if ((tt[t].dir & XE_DIR_DST) && !chosen[tt[t].fdst]) continue;
+					if (!(((tt[t].dir & XE_DIR_SRC) && (tt[t].fsrc == f)) || ((tt[t].dir & XE_DIR_DST) && (tt[t].fdst == f)))) continue;
+					cap += 2 * (size_t)tt[t].nopnd;
+				}
+				bp = (int64_t *)malloc((cap ? cap : 1) * sizeof(int64_t));
+				if (!bp) { rc = XE_ENOMEM; break; }
+				for (uint32_t t = 0; t < h->nterms; t++) {
+					if (!XE_RTERM(t)) continue;
+					if ((tt[t].dir & XE_DIR_SRC) && !chosen[tt[t].fsrc]) continue;
+					if ((tt[t].dir & XE_DIR_DST) && !chosen[tt[t].fdst]) continue;
+					if (!(((tt[t].dir & XE_DIR_SRC) && (tt[t].fsrc == f)) || ((tt[t].dir & XE_DIR_DST) && (tt[t].fdst == f)))) continue;
+					for (uint32_t j = 0; j < tt[t].nopnd; j++) {
+						const struct xe_dopnd *o = &oo[tt[t].opnd_base + j];
+						if (o->low > o->high) continue;
+						bp[nb++] = o->low;
+						if (o->high < INT32_MAX) bp[nb++] = (int64_t)o->high + 1;
+					}
+				}
+				if (nb) {
+					/* sort, unique */
+					for (size_t i = 1; i < nb; i++) {
+						int64_t x = bp[i];
+						size_t j = i;
+						while (j && (bp[j - 1] > x)) { bp[j] = bp[j - 1]; j--; }
+						bp[j] = x;
+					}
+					size_t u = 1;
+					for (size_t i = 1; i < nb; i++) if (bp[i] != bp[u - 1]) bp[u++] = bp[i];
+					nb = u;
+					struct xe_rgroup g;
+					g.field = f;
+					g.n = (uint32_t)nb;
+					g.bp_off = (uint32_t)rgd.n;
+					for (size_t i = 0; i < nb; i++) {
+						int32_t v = (int32_t)bp[i];
+						if (!xe_blob_push(&rgd, &v, 4)) rc = XE_ENOMEM;
+					}
+					while ((rc == XE_OK) && (rgd.n & 3)) { uint32_t z = 0; if (!xe_blob_push(&rgd, &z, 4)) rc = XE_ENOMEM; }
+					g.tab_off = (uint32_t)rgd.n;
+					for (size_t i = 0; (rc == XE_OK) && (i <= nb); i++) {
+						/* a value inside interval i: below the first breakpoint, or the
+						 * breakpoint that opens it */
+						int64_t rep = i ? bp[i - 1] : bp[0] - 1;
+						uint64_t e[4] = { 0, 0, 0, 0 };
+						for (uint32_t t = 0; t < h->nterms; t++) {
+							if (!XE_RTERM(t)) continue;
+							if ((tt[t].dir & XE_DIR_SRC) && !chosen[tt[t].fsrc]) continue;
+							if ((tt[t].dir & XE_DIR_DST) && !chosen[tt[t].fdst]) continue;
+							if (!(((tt[t].dir & XE_DIR_SRC) && (tt[t].fsrc == f)) || ((tt[t].dir & XE_DIR_DST) && (tt[t].fdst == f)))) continue;
+							for (uint32_t j = 0; j < tt[t].nopnd; j++) {
+								const struct xe_dopnd *o = &oo[tt[t].opnd_base + j];
+								if ((rep >= o->low) && (rep <= o->high)) { e[(t >> 6) & 3] |= 1ull << (t & 63); break; }
+							}
+						}
+						for (int k = 0; (k < 4) && (rc == XE_OK); k++) {
+							uint32_t lo32 = (uint32_t)e[k], hi32 = (uint32_t)(e[k] >> 32);
+							if (!xe_blob_push(&rgd, &lo32, 4) || !xe_blob_push(&rgd, &hi32, 4)) rc = XE_ENOMEM;
+						}
+					}
+					if (rc == XE_OK) rg[nrg++] = g;
+				}
+				free(bp);
+			}
+			/* grouped terms leave the one-by-one list (also those whose ranges are all empty) */
+			for (uint32_t t = 0; (rc == XE_OK) && (t < h->nterms); t++) {
+				if (!XE_RTERM(t)) continue;
+				if ((tt[t].dir & XE_DIR_SRC) && !chosen[tt[t].fsrc]) continue;
+				if ((tt[t].dir & XE_DIR_DST) && !chosen[tt[t].fdst]) continue;
+				ft[t].kind = (ft[t].kind & ~2u) | 4u;
+			}
+#undef XE_RTERM
+			h->nrgroups = nrg;
+			while (nrg & 3) { rg[nrg] = rg[0]; nrg++; }   /* taken 4 at a time; a repeat is harmless (OR) */
+			if ((rc == XE_OK) && h->nrgroups) {
+				rc = upload(h, &h->d_rgroups, rg, (size_t)nrg * sizeof(rg[0]));
+				if (rc == XE_OK) rc = upload(h, &h->d_rgdata, rgd.p, rgd.n * 4);
+			}
+			if (getenv("XE_DEBUG")) fprintf(stderr, "xe_gpu_commit: %u range groups, %zu table bytes\n", h->nrgroups, rgd.n * 4);
+			free(rgd.p);
 		}
 		if (rc == XE_OK) rc = upload(h, &h->d_fterms, ft, (size_t)h->nterms * sizeof(*ft));
 		if (rc == XE_OK) {
@@ -1109,10 +1255,14 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 		b->kp.ntneed = h->ntneed;
 		b->kp.fprogs = (const struct xe_fprog *)h->d_fprogs;
 		b->kp.nfprogs = h->nfprogs;
-		b->kp.cjrows = (const struct xe_cjrow *)h->d_cjrows;
+		b->kp.cjgb = (const uint32_t *)h->d_cjgb;
+		b->kp.cjtab = (const uint64_t *)h->d_cjtab;
+		b->kp.ncjgroups = (h->ncjgroups + 3) & ~3u;
+		b->kp.rgroups = (const struct xe_rgroup *)h->d_rgroups;
+		b->kp.rgdata = (const uint32_t *)h->d_rgdata;
+		b->kp.nrgroups = (h->nrgroups + 3) & ~3u;
 		b->kp.cjderived = (const struct xe_cjderived *)h->d_cjderived;
 		b->kp.cjcand = (const uint64_t *)h->d_cjcand;
-		b->kp.ncjrows = h->ncjrows;
 		b->kp.ncjderived = h->ncjderived;
 		{
 			uint64_t list = ~0ull;

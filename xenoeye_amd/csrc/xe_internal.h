@@ -321,6 +321,20 @@ struct xe_cjrow
  * false; literals are lookup bits and terms 0-63 */
 struct xe_cjderived { uint64_t pos_lk, pos_tb, neg_lk, neg_tb; };
 
+/* Range terms grouped by the field they read.  Per group: `n` sorted
+ * breakpoints over the field's value (int32, as the reference compares it)
+ * and n + 1 table entries, one per interval between breakpoints: the set of
+ * terms (4 x u64 = term bits 0..255) with a range that covers the interval.
+ * Offsets count 32-bit words of the group blob. */
+#define XE_MAX_RGROUPS 16
+struct xe_rgroup { uint32_t field, n, bp_off, tab_off; };
+
+/* Need / forbid rows folded into tables indexed by 8 atoms at once: per group
+ * (one byte of the lookup bits, term bits or derived bits that some row
+ * reads) 256 entries of `mask_words` u64: the objects that fail when the byte
+ * has that value.  Byte k: 0..7 lookup bits, 8..39 term bits, 40..47 derived. */
+#define XE_CJ_MAX_GROUPS 48
+
 
 struct xe_list_dev
 {

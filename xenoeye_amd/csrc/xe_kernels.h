@@ -72,10 +72,14 @@ struct xe_kparams
 	const struct xe_fprog *fprogs;  /* objects not resolved through motab, in index order */
 	const uint64_t *motab;       /* [mask word][XE_MOTAB_ROWS] */
 	uint32_t nfprogs, motab_lds; /* motab_lds: the table is small enough to be copied to LDS */
-	const struct xe_cjrow *cjrows;       /* sorted by mask word */
+	const uint32_t *cjgb;        /* byte index of every fail-table group (count padded to a multiple of 4) */
+	const uint64_t *cjtab;       /* [group][byte value][mask word] */
 	const struct xe_cjderived *cjderived;
+	const struct xe_rgroup *rgroups;     /* range-term groups (count padded to a multiple of 4) */
+	const uint32_t *rgdata;      /* their breakpoints and tables */
+	uint32_t nrgroups, ncjgroups;
 	const uint64_t *cjcand;      /* per mask word: the objects matched through cjrows */
-	uint32_t ncjrows, ncjderived;
+	uint32_t pad_cj, ncjderived;
 	uint64_t all_probes;         /* byte i = i-th probe with non-empty tables, 0xFF = end */
 	uint32_t per_object, pad_po;   /* per_object: run every object's program on its own (limits exceeded) */
 	const uint32_t *fflds;       /* [template slot][XE_NFIELDS] XE_FFLD_* words */

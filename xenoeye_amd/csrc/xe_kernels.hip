@@ -985,6 +985,91 @@ tile_issue(const xe_kparams &kp, const tile_lanes<R> &S, u32x4 (&q)[4][R])
 
 /* every IP-list membership (lookup bits), then every term some program needs
  * (term bits), once per record */
+#ifndef XE_RG_STEP
+#define XE_RG_STEP 2     /* range groups / fail-table groups advanced together (the host pads to 4) */
+#endif
+#ifndef XE_CJ_STEP
+#define XE_CJ_STEP 2
+#endif
+
+/* Range terms by field: one search of the field's value among the group's
+ * breakpoints answers every range term that reads the field (a table entry
+ * per interval holds the terms' bits).  Four groups advance together so their
+ * dependent loads overlap. */
+template <int R, typename TT>
+__device__ __forceinline__ void
+range_groups(const xe_kparams &kp, const TT &T, uint64_t (&tb)[R][4])
+{
+	constexpr int GC = XE_RG_STEP;
+	typedef uint32_t u32x4r __attribute__((ext_vector_type(4)));
+
+	for (uint32_t g0 = 0; g0 < kp.nrgroups; g0 += GC) {
+		uint32_t n[GC], bpo[GC], tbo[GC], pos[GC][R], maxn = 1;
+		int32_t v[GC][R];
+#pragma unroll
+		for (int c = 0; c < GC; c++) {
+			cu32 q = (cu32)(kp.rgroups + g0 + c);
+			const uint32_t field = q[0];
+			n[c] = q[1];
+			bpo[c] = q[2];
+			tbo[c] = q[3];
+			if (n[c] > maxn) maxn = n[c];
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				bool has;
+				uint32_t fmax;
+				uint64_t hi, lo;
+				tile_get(T, field, r, has, fmax, hi, lo);
+				/* absent fields compare as 0; only 1/2/4-byte fields carry a value */
+				v[c][r] = (fmax <= 4) ? (int32_t)(uint32_t)lo : 0;
+				pos[c][r] = 0;
+			}
+		}
+		/* pos = number of breakpoints <= v */
+		for (uint32_t step = 1u << (31 - __builtin_clz(maxn)); step; step >>= 1) {
+			int32_t b[GC][R];
+#pragma unroll
+			for (int c = 0; c < GC; c++) {
+#pragma unroll
+				for (int r = 0; r < R; r++) {
+					const uint32_t cand = pos[c][r] + step;
+					const uint32_t idx = ((cand < n[c]) ? cand : n[c]) - 1;
+					b[c][r] = ((const XE_CONST int32_t *)kp.rgdata)[bpo[c] + idx];
+				}
+			}
+#pragma unroll
+			for (int c = 0; c < GC; c++) {
+#pragma unroll
+				for (int r = 0; r < R; r++) {
+					const uint32_t cand = pos[c][r] + step;
+					if ((cand <= n[c]) && (b[c][r] <= v[c][r])) pos[c][r] = cand;
+				}
+			}
+		}
+		u32x4r ea[GC][R], eb[GC][R];
+#pragma unroll
+		for (int c = 0; c < GC; c++) {
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				const XE_CONST u32x4r *e = (const XE_CONST u32x4r *)(kp.rgdata + tbo[c] + (size_t)pos[c][r] * 8);
+				ea[c][r] = e[0];
+				eb[c][r] = e[1];
+			}
+		}
+#pragma unroll
+		for (int c = 0; c < GC; c++) {
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				if (!T.live[r]) continue;
+				tb[r][0] |= (uint64_t)ea[c][r].x | ((uint64_t)ea[c][r].y << 32);
+				tb[r][1] |= (uint64_t)ea[c][r].z | ((uint64_t)ea[c][r].w << 32);
+				tb[r][2] |= (uint64_t)eb[c][r].x | ((uint64_t)eb[c][r].y << 32);
+				tb[r][3] |= (uint64_t)eb[c][r].z | ((uint64_t)eb[c][r].w << 32);
+			}
+		}
+	}
+}
+
 template <int R, typename TT>
 __device__ __forceinline__ void
 classify_atoms(const xe_kparams &kp, const TT &T, uint64_t plist, uint64_t (&lk)[R], uint64_t (&tb)[R][4])
@@ -997,6 +1082,7 @@ classify_atoms(const xe_kparams &kp, const TT &T, uint64_t plist, uint64_t (&lk)
 		}
 #pragma unroll
 		for (int r = 0; r < R; r++) tb[r][0] = tb[r][1] = tb[r][2] = tb[r][3] = 0;
+		if (!(kp.pad2 & 2)) range_groups<R, TT>(kp, T, tb);
 		for (uint32_t ti = 0; (ti < kp.ntneed) && !(kp.pad2 & 2); ti++) {
 			const uint32_t t = ((cu32)kp.tneed)[ti];
 			cu64 fq = (cu64)(kp.fterms + t);
@@ -1045,7 +1131,7 @@ classify_objects(const xe_kparams &kp, const bool (&live)[R], const uint64_t (&l
 
 		/* object programs: the atom table first, then the conjunctive objects
 		 * (need / forbid rows), then the listed objects */
-		uint32_t bi = 0, ci = 0;
+		uint32_t bi = 0;
 		for (uint32_t w = 0; (w < kp.mask_words) && !(kp.pad2 & 8); w++) {
 			uint64_t bits[R];
 			const uint32_t m0 = w * 64, m1 = (m0 + 64 < kp.nmo) ? m0 + 64 : kp.nmo;
@@ -1068,30 +1154,36 @@ classify_objects(const xe_kparams &kp, const bool (&live)[R], const uint64_t (&l
 				}
 				bits[r] = acc;
 			}
-			if (kp.ncjrows) {
+			if (kp.ncjgroups) {
+				/* the conjunctive objects: an object fails when one of its needed
+				 * atoms is false or a forbidden one true; tables indexed by 8
+				 * atoms at once give the failing objects, 4 groups per step */
 				uint64_t fail[R];
 #pragma unroll
 				for (int r = 0; r < R; r++) fail[r] = 0;
-				while (ci < kp.ncjrows) {
-					cu32 rq = (cu32)(kp.cjrows + ci);
-					const uint32_t a = rq[0];
-					if (rq[1] != w) break;
-					const uint64_t need = (uint64_t)rq[2] | ((uint64_t)rq[3] << 32);
-					const uint64_t forbid = (uint64_t)rq[4] | ((uint64_t)rq[5] << 32);
-					ci++;
+				for (uint32_t g0 = 0; g0 < kp.ncjgroups; g0 += XE_CJ_STEP) {
+					uint64_t e[XE_CJ_STEP][R];
 #pragma unroll
-					for (int r = 0; r < R; r++) {
-						bool val;
-						if (a < XE_ATOM_TERM0) {
-							val = ((lk[r] >> a) & 1) != 0;
-						} else if (a < XE_ATOM_DERIVED0) {
-							const uint32_t t = a - XE_ATOM_TERM0, wsel = t >> 6;
-							const uint64_t word = (wsel == 0) ? tb[r][0] : (wsel == 1) ? tb[r][1] : (wsel == 2) ? tb[r][2] : tb[r][3];
-							val = ((word >> (t & 63)) & 1) != 0;
-						} else {
-							val = ((dbits[r] >> (a - XE_ATOM_DERIVED0)) & 1) != 0;
+					for (int c = 0; c < XE_CJ_STEP; c++) {
+						cu32 gq = (cu32)(kp.cjgb + 2 * (g0 + c));
+						const uint32_t k = gq[0], ti = gq[1];
+#pragma unroll
+						for (int r = 0; r < R; r++) {
+							uint64_t src;
+							if (k < 8) src = lk[r];
+							else if (k < 16) src = tb[r][0];
+							else if (k < 24) src = tb[r][1];
+							else if (k < 32) src = tb[r][2];
+							else if (k < 40) src = tb[r][3];
+							else src = dbits[r];
+							const uint32_t by = (uint32_t)(src >> ((k & 7) * 8)) & 0xFF;
+							e[c][r] = ((const XE_CONST uint64_t *)kp.cjtab)[((size_t)ti * 256 + by) * kp.mask_words + w];
 						}
-						fail[r] |= val ? forbid : need;
+					}
+#pragma unroll
+					for (int c = 0; c < XE_CJ_STEP; c++) {
+#pragma unroll
+						for (int r = 0; r < R; r++) fail[r] |= e[c][r];
 					}
 				}
 				const uint64_t cand = ((cu64)kp.cjcand)[w];
