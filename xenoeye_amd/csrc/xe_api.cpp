@@ -726,7 +726,8 @@ xe_gpu_commit(xe_gpu *h)
 		{
 			/* objects resolved through the atom table, the rest listed */
 			size_t words = h->hs.nmos ? (h->hs.nmos + 63) / 64 : 1, nb = 0;
-			uint64_t *mt = (uint64_t *)calloc(words * XE_MOTAB_ROWS, sizeof(uint64_t));
+			/* + per word: which lookup atoms / term atoms have a row that is not empty */
+			uint64_t *mt = (uint64_t *)calloc(words * (XE_MOTAB_ROWS + 2), sizeof(uint64_t));
 			uint64_t *cand = (uint64_t *)calloc(words, sizeof(uint64_t));
 			struct xe_cjderived *der = (struct xe_cjderived *)calloc(XE_MAX_DERIVED, sizeof(struct xe_cjderived));
 			struct xe_cjrow *rows = NULL;
@@ -903,7 +904,12 @@ xe_gpu_commit(xe_gpu *h)
 				fprintf(stderr, "xe_gpu_commit: %zu objects, %u terms, %u lookups, %zu listed programs, "
 					"%zu need/forbid rows in %u byte tables, %zu derived atoms\n", h->hs.nmos, h->nterms, h->nlookups, nb, nrows, h->ncjgroups, nder);
 			}
-			if (rc == XE_OK) rc = upload(h, &h->d_motab, mt, words * XE_MOTAB_ROWS * sizeof(uint64_t));
+			for (size_t w = 0; mt && (w < words); w++) {
+				for (int a = 0; a < XE_MOTAB_ROWS; a++) {
+					if (mt[w * XE_MOTAB_ROWS + a]) mt[words * XE_MOTAB_ROWS + 2 * w + (a >> 6)] |= 1ull << (a & 63);
+				}
+			}
+			if (rc == XE_OK) rc = upload(h, &h->d_motab, mt, words * (XE_MOTAB_ROWS + 2) * sizeof(uint64_t));
 			if (rc == XE_OK) rc = upload(h, &h->d_fprogs, fp, nb * sizeof(*fp));
 			if (rc == XE_OK) rc = upload(h, &h->d_cjderived, der, nder * sizeof(*der));
 			if (rc == XE_OK) rc = upload(h, &h->d_cjcand, cand, words * sizeof(uint64_t));

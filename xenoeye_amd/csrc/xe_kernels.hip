@@ -1070,7 +1070,10 @@ range_groups(const xe_kparams &kp, const TT &T, uint64_t (&tb)[R][4])
 	}
 }
 
-template <int R, typename TT>
+/* LEAN = the configuration has no range groups, conjunctive or listed objects
+ * (objects with a single condition and no parent only): those parts are
+ * compiled out, which keeps the common simple case small */
+template <int R, bool LEAN, typename TT>
 __device__ __forceinline__ void
 classify_atoms(const xe_kparams &kp, const TT &T, uint64_t plist, uint64_t (&lk)[R], uint64_t (&tb)[R][4])
 {
@@ -1082,7 +1085,7 @@ classify_atoms(const xe_kparams &kp, const TT &T, uint64_t plist, uint64_t (&lk)
 		}
 #pragma unroll
 		for (int r = 0; r < R; r++) tb[r][0] = tb[r][1] = tb[r][2] = tb[r][3] = 0;
-		if (!(kp.pad2 & 2)) range_groups<R, TT>(kp, T, tb);
+		if (!LEAN && !(kp.pad2 & 2)) range_groups<R, TT>(kp, T, tb);
 		for (uint32_t ti = 0; (ti < kp.ntneed) && !(kp.pad2 & 2); ti++) {
 			const uint32_t t = ((cu32)kp.tneed)[ti];
 			cu64 fq = (cu64)(kp.fterms + t);
@@ -1109,7 +1112,7 @@ classify_atoms(const xe_kparams &kp, const TT &T, uint64_t plist, uint64_t (&lk)
 /* from lookup and term bits to the match masks and counters of a record:
  * the atom table, the conjunctive objects (need / forbid rows), the listed
  * objects; lcnt / lmt = the block's LDS counters and atom-table copy */
-template <int R>
+template <int R, bool LEAN>
 __device__ __forceinline__ void
 classify_objects(const xe_kparams &kp, const bool (&live)[R], const uint64_t (&lk)[R], const uint64_t (&tb)[R][4],
 	const uint32_t (&ridx)[R], const unsigned long long (&bxr)[R], const unsigned long long (&pxr)[R],
@@ -1119,7 +1122,7 @@ classify_objects(const xe_kparams &kp, const bool (&live)[R], const uint64_t (&l
 		uint64_t dbits[R];
 #pragma unroll
 		for (int r = 0; r < R; r++) dbits[r] = 0;
-		for (uint32_t j = 0; (j < kp.ncjderived) && !(kp.pad2 & 8); j++) {
+		for (uint32_t j = 0; !LEAN && (j < kp.ncjderived) && !(kp.pad2 & 8); j++) {
 			cu64 dq = (cu64)(kp.cjderived + j);
 			const uint64_t pl = dq[0], pt = dq[1], nl = dq[2], nt = dq[3];
 #pragma unroll
@@ -1135,17 +1138,21 @@ classify_objects(const xe_kparams &kp, const bool (&live)[R], const uint64_t (&l
 		for (uint32_t w = 0; (w < kp.mask_words) && !(kp.pad2 & 8); w++) {
 			uint64_t bits[R];
 			const uint32_t m0 = w * 64, m1 = (m0 + 64 < kp.nmo) ? m0 + 64 : kp.nmo;
+			/* atoms whose row for this word is not empty */
+			const size_t any_at = (size_t)kp.mask_words * XE_MOTAB_ROWS + 2 * w;
+			const uint64_t any_lk = kp.motab_lds ? lmt[any_at] : ((cu64)kp.motab)[any_at];
+			const uint64_t any_tb = kp.motab_lds ? lmt[any_at + 1] : ((cu64)kp.motab)[any_at + 1];
 #pragma unroll
 			for (int r = 0; r < R; r++) {
 				uint64_t acc = 0;
 				if (live[r]) {
-					uint64_t x = lk[r];
+					uint64_t x = lk[r] & any_lk;
 					while (x) {
 						const uint32_t a = (uint32_t)__builtin_ctzll(x);
 						x &= x - 1;
 						acc |= kp.motab_lds ? lmt[w * XE_MOTAB_ROWS + a] : kp.motab[w * XE_MOTAB_ROWS + a];
 					}
-					x = tb[r][0];
+					x = tb[r][0] & any_tb;
 					while (x) {
 						const uint32_t a = 64 + (uint32_t)__builtin_ctzll(x);
 						x &= x - 1;
@@ -1154,7 +1161,7 @@ classify_objects(const xe_kparams &kp, const bool (&live)[R], const uint64_t (&l
 				}
 				bits[r] = acc;
 			}
-			if (kp.ncjgroups) {
+			if (!LEAN && kp.ncjgroups) {
 				/* the conjunctive objects: an object fails when one of its needed
 				 * atoms is false or a forbidden one true; tables indexed by 8
 				 * atoms at once give the failing objects, 4 groups per step */
@@ -1192,7 +1199,7 @@ classify_objects(const xe_kparams &kp, const bool (&live)[R], const uint64_t (&l
 					if (live[r]) bits[r] |= cand & ~fail[r];
 				}
 			}
-			while (bi < kp.nfprogs) {
+			while (!LEAN && (bi < kp.nfprogs)) {
 				typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 				const XE_CONST u32x4v *fq = (const XE_CONST u32x4v *)(kp.fprogs + bi);
 				const u32x4v f0 = fq[0], f1 = fq[1], f2 = fq[2];
@@ -1245,7 +1252,7 @@ __device__ unsigned long long xe_fast_phase_cycles[8];
 #define XE_PHASE(N) do { if (kp.pad2 & 64) { const uint64_t now_ = __builtin_readcyclecounter(); \
 	if (lane == 0) atomicAdd(&xe_fast_phase_cycles[N], (unsigned long long)(now_ - tprev)); tprev = now_; } } while (0)
 
-template <int R>
+template <int R, bool LEAN>
 __global__ void __launch_bounds__(XE_BLOCK)
 xe_nf_fast_kernel(const xe_kparams kp)
 {
@@ -1264,7 +1271,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 		for (uint32_t i = threadIdx.x; i < kp.nmo * 3; i += XE_BLOCK) lcnt[i] = 0;
 	}
 	if (kp.motab_lds) {
-		for (uint32_t i = threadIdx.x; i < kp.mask_words * XE_MOTAB_ROWS; i += XE_BLOCK) lmt[i] = kp.motab[i];
+		for (uint32_t i = threadIdx.x; i < kp.mask_words * (XE_MOTAB_ROWS + 2); i += XE_BLOCK) lmt[i] = kp.motab[i];
 	}
 	__syncthreads();
 
@@ -1362,7 +1369,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 
 		/* every IP-list membership, then every term some program needs, once */
 		uint64_t lk[R], tb[R][4];
-		classify_atoms<R>(kp, T, plist, lk, tb);
+		classify_atoms<R, LEAN>(kp, T, plist, lk, tb);
 		XE_PHASE(2);
 		XE_PHASE(3);
 		/* decode: the template's micro-ops, sorted by kind.  The stores come
@@ -1378,7 +1385,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 			if (PL[6]) general_ops<R>(kp, stg, j, PL[6], ridx, T.live);
 		}
 		XE_PHASE(4);
-		classify_objects<R>(kp, T.live, lk, tb, ridx, bxr, pxr, lcnt, lmt);
+		classify_objects<R, LEAN>(kp, T.live, lk, tb, ridx, bxr, pxr, lcnt, lmt);
 		XE_PHASE(5);
 		C = N;
 	}
@@ -1468,8 +1475,8 @@ classify(const xe_kparams &kp, REC &rec, int32_t device, uint32_t ridx, bool act
 	const unsigned long long bx[1] = { bytes_x_rate }, px[1] = { pkts_x_rate };
 	T.rec = &rec;
 	T.live[0] = active && !dropped;
-	classify_atoms<1>(kp, T, kp.all_probes, lk, tb);
-	classify_objects<1>(kp, T.live, lk, tb, ri, bx, px, lcnt, lmt);
+	classify_atoms<1, false>(kp, T, kp.all_probes, lk, tb);
+	classify_objects<1, false>(kp, T.live, lk, tb, ri, bx, px, lcnt, lmt);
 	/* a dropped record still owns its mask words */
 	if (active && dropped) {
 		for (uint32_t w = 0; w < kp.mask_words; w++) kp.masks[(size_t)ridx * kp.mask_words + w] = 0;
@@ -1486,7 +1493,7 @@ lane_kernel_lds(const xe_kparams &kp, uint64_t *lds, unsigned long long *&lcnt, 
 		for (uint32_t i = threadIdx.x; i < kp.nmo * 3; i += XE_BLOCK) lcnt[i] = 0;
 	}
 	if (kp.motab_lds) {
-		for (uint32_t i = threadIdx.x; i < kp.mask_words * XE_MOTAB_ROWS; i += XE_BLOCK) lmt[i] = kp.motab[i];
+		for (uint32_t i = threadIdx.x; i < kp.mask_words * (XE_MOTAB_ROWS + 2); i += XE_BLOCK) lmt[i] = kp.motab[i];
 	}
 	__syncthreads();
 }
@@ -2072,15 +2079,17 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 		uint32_t blocks = (kp->ntiles + per_block - 1) / per_block;
 		size_t shmem = (size_t)per_block * kp->fast_dwords * kp->fast_r * 64 * 4
 			+ (kp->lds_counters ? (size_t)kp->nmo * 24 : 0)
-			+ (kp->motab_lds ? (size_t)kp->mask_words * XE_MOTAB_ROWS * 8 : 0);
+			+ (kp->motab_lds ? (size_t)kp->mask_words * (XE_MOTAB_ROWS + 2) * 8 : 0);
 		if (blocks > 4096) blocks = 4096;
 		/* the kernel deals the tile list to 8 groups of blocks (blockIdx % 8):
 		 * every group needs at least one block */
 		if (blocks < 8) blocks = 8;
 		if (ev) (void)hipEventRecord(ev[0], st);
-		if (kp->fast_r == 4) hipLaunchKernelGGL(xe_nf_fast_kernel<4>, dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
-		else if (kp->fast_r == 2) hipLaunchKernelGGL(xe_nf_fast_kernel<2>, dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
-		else hipLaunchKernelGGL(xe_nf_fast_kernel<1>, dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
+		const bool lean = !kp->nrgroups && !kp->ncjgroups && !kp->ncjderived && !kp->nfprogs;
+		if (kp->fast_r == 4) hipLaunchKernelGGL((xe_nf_fast_kernel<4, false>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
+		else if (kp->fast_r == 2) hipLaunchKernelGGL((xe_nf_fast_kernel<2, false>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
+		else if (lean) hipLaunchKernelGGL((xe_nf_fast_kernel<1, true>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
+		else hipLaunchKernelGGL((xe_nf_fast_kernel<1, false>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
 		if (ev) (void)hipEventRecord(ev[1], st);
 		if (hipGetLastError() != hipSuccess) return XE_EHIP;
 		if (kp->pad2 & 64) {
@@ -2095,7 +2104,7 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 		}
 	}
 	const size_t lane_lds = (kp->lds_counters ? (size_t)kp->nmo * 24 : 0)
-		+ (kp->motab_lds ? (size_t)kp->mask_words * XE_MOTAB_ROWS * 8 : 0) + 16;
+		+ (kp->motab_lds ? (size_t)kp->mask_words * (XE_MOTAB_ROWS + 2) * 8 : 0) + 16;
 	if (kp->nslowrec) {
 		uint32_t blocks = (kp->nslowrec + XE_BLOCK - 1) / XE_BLOCK;
 		if (ev) (void)hipEventRecord(ev[2], st);
