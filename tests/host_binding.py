@@ -25,7 +25,6 @@ class Exporter(C.Structure):
 
 
 TERM = 0x80000000
-NODE_WORDS = 256
 
 
 class Host:
@@ -122,10 +121,13 @@ CHAIN = 0x40000000
 CHAIN_WORDS = 8
 
 
+NODE_BITS = int(xenoeye_amd.load_library().xe_ht_node_bits())
+
+
 def walk_flat(words, root, nodes, addr_bytes, bit=0, chains=0):
     """Reference walker of the flattened list format (tests only): the
-    group's root table over the first 16 bits, then one directly indexed
-    256-entry node per address byte, or a chain record that settles the rest
+    group's root table over the first 16 bits, then one directly indexed node
+    per NODE_BITS address bits, or a chain record that settles the rest
     of the walk with one comparison; `bit` selects the list inside the group's
     answer bits."""
     if not root:
@@ -144,6 +146,6 @@ def walk_flat(words, root, nodes, addr_bytes, bit=0, chains=0):
             m = ((rest ^ pat) >> (128 - ln)) == 0
             e = TERM | (meta & 0xFF) | (int(m) << lst)
         else:
-            e = int(words[nodes + e * NODE_WORDS + ((addr >> (nbits - depth - 8)) & 0xFF)])
-        depth += 8
+            e = int(words[nodes + e * (1 << NODE_BITS) + ((addr >> (nbits - depth - NODE_BITS)) & ((1 << NODE_BITS) - 1))])
+        depth += NODE_BITS
     return ((e >> bit) & 1) if (e & TERM) else 0

@@ -102,6 +102,9 @@ xe_ht_prepass(struct xe_host *hs, const uint8_t *data, const uint64_t *offs, con
 }
 
 void xe_ht_plan_free(struct xe_plan *p) { if (p) { xe_plan_free(p); free(p); } }
+/* stride of the flattened list nodes, for the tests' own walk */
+int xe_ht_node_bits(void) { return XE_NODE_BITS; }
+
 size_t xe_ht_plan_nrec(const struct xe_plan *p) { return p->nrec; }
 size_t xe_ht_plan_nsf(const struct xe_plan *p) { return p->nsf; }
 size_t xe_ht_plan_nsets(const struct xe_plan *p) { return p->sets.n; }

@@ -175,11 +175,13 @@ struct xe_prog
 
 /* Flattened IP lists.  Lists are merged in groups of XE_LIST_GROUP (registry
  * order); per group and address family: a 65536-entry root over the first 16
- * address bits, then 8-bit-stride nodes of 256 entries, one per chunk value.
+ * address bits, then nodes of 2^XE_NODE_BITS entries, one per value of the next
+ * XE_NODE_BITS address bits.  8 bits per node measured faster on MI355X than 4
+ * (tables a quarter of the size, but one more dependent load per walk).
  * An entry (root and node alike): bit 31 set = the walk ends here and bits
  * 0..7 are the answers of the group's lists (bit l = list l); bit 30 set =
  * index of a chain record; else the index of the node for the next address
- * byte.  A visit is one 4-byte load.
+ * bits.  A visit is one 4-byte load.
  * Chain record (XE_CHAIN_WORDS words): only list `l` can still go deeper, along
  * one path of `len` bits that ends in a prefix:
  *   word 0      answers of the other lists (bits 0-7) | l << 8 | len << 11
@@ -189,7 +191,10 @@ struct xe_prog
 #define XE_TRIE_CHAIN 0x40000000u
 #define XE_CHAIN_WORDS 8
 #define XE_LIST_GROUP 8
-#define XE_NODE_WORDS 256
+#ifndef XE_NODE_BITS
+#define XE_NODE_BITS 8
+#endif
+#define XE_NODE_WORDS (1u << XE_NODE_BITS)
 /* one distinct (list, address family, field) membership test; the fast kernel
  * resolves all of them for a tile in batches before any term is evaluated */
 struct xe_lookup

@@ -419,7 +419,7 @@ flatten_group(const struct xe_bnode *const *bt, struct xe_blob *words,
 		uint32_t k;
 
 		c.node = nw;
-		if (!gexpand(bt, &st, 8, 0, gnode_cb, &c)) goto out;
+		if (!gexpand(bt, &st, XE_NODE_BITS, 0, gnode_cb, &c)) goto out;
 		for (k = 0; k < XE_NODE_WORDS; k++) {
 			if (!xe_blob_push(words, &nw[k], 4)) goto out;
 		}

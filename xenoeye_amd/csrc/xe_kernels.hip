@@ -55,12 +55,13 @@ pkt_be(const pkt_src &s, int32_t off, uint32_t len)
 }
 
 /* ------------------------------------------------------------------ flattened IP list */
-/* address byte that starts `depth` bits into the left-aligned 128-bit address
- * (depth is a multiple of 8) */
+/* the XE_NODE_BITS address bits that start `depth` bits into the left-aligned
+ * 128-bit address (depth is a multiple of XE_NODE_BITS, which divides 16) */
 __device__ __forceinline__ uint32_t
 addr_byte(uint64_t hi, uint64_t lo, uint32_t depth)
 {
-	return (depth < 64) ? (uint32_t)((hi << depth) >> 56) : (uint32_t)((lo << (depth - 64)) >> 56);
+	return (depth < 64) ? (uint32_t)((hi << depth) >> (64 - XE_NODE_BITS))
+		: (uint32_t)((lo << (depth - 64)) >> (64 - XE_NODE_BITS));
 }
 
 /* chain record: the answers of the group's lists when the rest of the walk is
@@ -86,7 +87,7 @@ group_match(const uint32_t *T, uint32_t root, uint32_t nodes, uint32_t chains, u
 {
 	if (!root) return 0;
 	uint32_t e = T[root + (uint32_t)(hi >> 48)];
-	for (uint32_t depth = 16; !(e & XE_TRIE_TERM) && (depth < bits); depth += 8) {
+	for (uint32_t depth = 16; !(e & XE_TRIE_TERM) && (depth < bits); depth += XE_NODE_BITS) {
 		if (e & XE_TRIE_CHAIN) {
 			const uint32_t *c = T + chains + (size_t)(e & ~XE_TRIE_CHAIN) * XE_CHAIN_WORDS;
 			const uint32_t w[6] = { c[0], c[1], c[2], c[3], c[4], c[5] };
@@ -634,7 +635,7 @@ fast_lookups(const xe_kparams &kp, const TT &T, uint64_t plist, uint64_t lk[R])
 				if (T.live[r] && has) e[c][r] = ((const XE_CONST uint32_t *)(kp.trie + root))[(uint32_t)(hi[c][r] >> 48)];
 			}
 		}
-		for (uint32_t depth = 16; depth < maxbits; depth += 8) {
+		for (uint32_t depth = 16; depth < maxbits; depth += XE_NODE_BITS) {
 			bool walk[PC][R], any = false;
 			uint32_t nx[PC][R];
 			u32x4 ca[PC][R];
@@ -660,11 +661,11 @@ fast_lookups(const xe_kparams &kp, const TT &T, uint64_t plist, uint64_t lk[R])
 					if (walk[c][r]) {
 						if (e[c][r] & XE_TRIE_CHAIN) {
 							const XE_CONST uint32_t *cp = (const XE_CONST uint32_t *)(kp.trie + chains[c])
-								+ (size_t)(e[c][r] & ~XE_TRIE_CHAIN) * XE_CHAIN_WORDS;
+								+ (size_t)((e[c][r] & ~XE_TRIE_CHAIN) & ((kp.pad2 & 128) ? 63u : ~0u)) * XE_CHAIN_WORDS;
 							ca[c][r] = *(const XE_CONST u32x4 *)cp;
 							cb[c][r] = *(const XE_CONST u32x2 *)(cp + 4);
 						} else {
-							nx[c][r] = ((const XE_CONST uint32_t *)(kp.trie + nodes[c]))[(size_t)e[c][r] * XE_NODE_WORDS
+							nx[c][r] = ((const XE_CONST uint32_t *)(kp.trie + nodes[c]))[(size_t)(e[c][r] & ((kp.pad2 & 128) ? 15u : ~0u)) * XE_NODE_WORDS
 								+ addr_byte(hi[c][r], lo[c][r], depth)];
 						}
 					}
