@@ -1678,8 +1678,25 @@ struct sf_rec
 	uint32_t has;
 	uint32_t mark;
 	const xe_sfrec *q;
-	pkt_src src;              /* the sampled header / IPv4 structure */
+	/* the sampled header / IPv4 structure: its first SF_STAGE_BYTES bytes staged
+	 * in LDS (dword d of this thread at stg[d * XE_BLOCK]), the rest, if a
+	 * header ever reaches that far, read from the datagram at p */
+	const uint32_t *stg;
+	const uint8_t *p;
+	int32_t left;             /* bytes from p to the end of the datagram */
 };
+
+#define SF_STAGE_DWORDS 40
+#define SF_STAGE_BYTES (4 * SF_STAGE_DWORDS)
+
+/* byte `off` of the element; zero beyond the end of the datagram */
+__device__ __forceinline__ uint32_t
+sf_byte(const sf_rec &r, int32_t off)
+{
+	if (off >= r.left) return 0;
+	if (off < SF_STAGE_BYTES) return (r.stg[(off >> 2) * XE_BLOCK] >> ((off & 3) * 8)) & 0xFF;
+	return r.p[off];
+}
 
 /* N bytes of the sampled header at `off`, packed little-endian */
 template <int N>
@@ -1688,7 +1705,7 @@ sf_bytes(const sf_rec &r, int32_t off)
 {
 	uint64_t x = 0;
 #pragma unroll
-	for (int i = 0; i < N; i++) x |= (uint64_t)pkt_byte(r.src, off + i) << (8 * i);
+	for (int i = 0; i < N; i++) x |= (uint64_t)sf_byte(r, off + i) << (8 * i);
 	return x;
 }
 
@@ -1740,7 +1757,7 @@ sf_on_ip6(sf_rec &r, int32_t ip6h, uint32_t nexthdr)   /* sflow.c:57-62 */
 __device__ __forceinline__ uint32_t
 sf_be16(const sf_rec &r, int32_t off)
 {
-	return (pkt_byte(r.src, off) << 8) | pkt_byte(r.src, off + 1);
+	return (sf_byte(r, off) << 8) | sf_byte(r, off + 1);
 }
 
 /* rawpacket_parse(), rawparse.h:89-281; returns the parser state 0..4 */
@@ -1782,31 +1799,31 @@ sf_rawparse(sf_rec &r, int32_t end, int type)
 			sf_on_ip(r, iph);
 			return 3;
 		}
-		ptr += (int32_t)(pkt_byte(r.src, iph) & 0x0f) * 4;
-		if (pkt_byte(r.src, iph + 9) == 4) {
+		ptr += (int32_t)(sf_byte(r, iph) & 0x0f) * 4;
+		if (sf_byte(r, iph + 9) == 4) {
 			if ((ptr + 20) >= end) return 2;
 			iph = ptr;
-			ptr += (int32_t)(pkt_byte(r.src, iph) & 0x0f) * 4;
+			ptr += (int32_t)(sf_byte(r, iph) & 0x0f) * 4;
 		}
 		sf_on_ip(r, iph);
-		l4 = pkt_byte(r.src, iph + 9);
+		l4 = sf_byte(r, iph + 9);
 		if ((l4 != 6) && (l4 != 17) && (l4 != 1)) return 3;
 	} else if (h_proto == 0x86dd) {
 		if ((ptr + 40) >= end) return 2;
 		int32_t ip6h = ptr;
 		ptr += 40;
-		l4 = pkt_byte(r.src, ip6h + 6);
+		l4 = sf_byte(r, ip6h + 6);
 		if (l4 == 4) {
 			if ((ptr + 20) >= end) return 2;
 			int32_t iph = ptr;
-			l4 = pkt_byte(r.src, iph + 9);
-			ptr += (int32_t)(pkt_byte(r.src, iph) & 0x0f) * 4;
+			l4 = sf_byte(r, iph + 9);
+			ptr += (int32_t)(sf_byte(r, iph) & 0x0f) * 4;
 			sf_on_ip(r, iph);
 		} else if (l4 == 41) {
 			if ((ptr + 40) >= end) return 2;
 			ip6h = ptr;
 			ptr += 40;
-			l4 = pkt_byte(r.src, ip6h + 6);
+			l4 = sf_byte(r, ip6h + 6);
 			sf_on_ip6(r, ip6h, l4);
 		} else {
 			sf_on_ip6(r, ip6h, l4);
@@ -1838,9 +1855,23 @@ sf_rawparse(sf_rec &r, int32_t end, int type)
 __device__ __forceinline__ int
 sf_apply(const xe_kparams &kp, sf_rec &r, const xe_sfrec *q)
 {
-	r.src.p = kp.pkt + q->hdr_off;
-	r.src.left = q->dgram_left;
-	r.src.checked = true;
+	r.p = kp.pkt + q->hdr_off;
+	r.left = q->dgram_left;
+	{
+		/* wide loads of the element into this thread's LDS column; a piece that
+		 * starts inside the datagram may run past its end (the batch buffer is
+		 * padded), those bytes are never used */
+		uint32_t *d = const_cast<uint32_t *>(r.stg);
+#pragma unroll
+		for (int i = 0; i < SF_STAGE_DWORDS / 4; i++) {
+			u32x4 v = (u32x4){0, 0, 0, 0};
+			if (16 * i < r.left) __builtin_memcpy(&v, r.p + 16 * i, 16);
+			d[(4 * i + 0) * XE_BLOCK] = v.x;
+			d[(4 * i + 1) * XE_BLOCK] = v.y;
+			d[(4 * i + 2) * XE_BLOCK] = v.z;
+			d[(4 * i + 3) * XE_BLOCK] = v.w;
+		}
+	}
 	/* sflow-impl.h:164-171 / :224-234: in_bytes[4..8] = frame length as on
 	 * the wire, in_pkts[7] = 1 */
 	r.v[SFI_in_bytes] = (r.v[SFI_in_bytes] & 0xFFFFFFFFull) | ((uint64_t)q->frame_len_be << 32);
@@ -1849,14 +1880,14 @@ sf_apply(const xe_kparams &kp, sf_rec &r, const xe_sfrec *q)
 	if (q->kind == 1) return sf_rawparse(r, (int32_t)q->header_len, q->rp_type);
 
 	/* IPv4 structure, sflow-impl.h:236-260: seven 4-byte words */
-	sf_set_byte0<SFI_protocol>(r, pkt_byte(r.src, 3));
+	sf_set_byte0<SFI_protocol>(r, sf_byte(r, 3));
 	sf_copy<SFI_ip4_src, 4>(r, 4);
 	sf_copy<SFI_ip4_dst, 4>(r, 8);
 	sf_copy<SFI_l4_src_port, 2>(r, 14);
 	sf_copy<SFI_l4_dst_port, 2>(r, 18);
 	sf_copy<SFI_tcp_flags, 1>(r, 23);
 	sf_copy<SFI_src_tos, 1>(r, 27);
-	if ((r.v[SFI_protocol] & 0xFF) == 1) sf_set_byte0<SFI_icmp_type>(r, pkt_byte(r.src, 17));
+	if ((r.v[SFI_protocol] & 0xFF) == 1) sf_set_byte0<SFI_icmp_type>(r, sf_byte(r, 17));
 	return 4;
 }
 
@@ -1972,6 +2003,11 @@ xe_sf_kernel(const xe_kparams kp)
 	rec.has = 0;
 	rec.mark = 0;
 	rec.q = kp.sfrecs;
+	/* the staging columns follow the counters and the atom-table copy */
+	rec.stg = (const uint32_t *)(lane_lds + (kp.lds_counters ? (size_t)kp.nmo * 3 : 0)
+		+ (kp.motab_lds ? (size_t)kp.mask_words * (XE_MOTAB_ROWS + 2) : 0)) + threadIdx.x;
+	rec.p = kp.pkt;
+	rec.left = 0;
 	if (active) {
 		/* elements of one sample share the flow: replay the earlier ones */
 		uint32_t first = g;
@@ -2115,8 +2151,18 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 	}
 	if (kp->nsf) {
 		uint32_t blocks = (kp->nsf + XE_BLOCK - 1) / XE_BLOCK;
+		size_t sf_lds = lane_lds + (size_t)XE_BLOCK * SF_STAGE_BYTES;
+		xe_kparams ksf;
+		if (sf_lds > 64 * 1024) {
+			/* many objects: their counters go to memory directly, the staging
+			 * columns keep the LDS */
+			ksf = *kp;
+			ksf.lds_counters = 0;
+			kp = &ksf;
+			sf_lds -= (size_t)kp->nmo * 24;
+		}
 		if (ev) (void)hipEventRecord(ev[4], st);
-		hipLaunchKernelGGL(xe_sf_kernel, dim3(blocks), dim3(XE_BLOCK), lane_lds, st, *kp);
+		hipLaunchKernelGGL(xe_sf_kernel, dim3(blocks), dim3(XE_BLOCK), sf_lds, st, *kp);
 		if (ev) (void)hipEventRecord(ev[5], st);
 		if (hipGetLastError() != hipSuccess) return XE_EHIP;
 	}
