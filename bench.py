@@ -184,6 +184,17 @@ def main():
     t_e2e = time.perf_counter() - t1
     b2.free()
     del m
+    # the same from a page-locked datagram buffer (xe_gpu_host_alloc), as a capture thread would fill it
+    pinned = (eng.pinned(packed[0]),) + tuple(packed[1:])
+    t1 = time.perf_counter()
+    b3 = eng.prepare(pinned)
+    b3.run(stream)
+    m = b3.masks()
+    c3 = b3.counters()
+    t_e2e_pinned = time.perf_counter() - t1
+    assert (c3 == c).all()
+    b3.free()
+    del m
 
     from xenoeye_amd import shard
     dev = torch.device("cuda", local_rank)
@@ -222,7 +233,9 @@ def main():
                          "algorithmic_bytes_per_launch": alg,
                          "algorithmic_bytes_per_record": alg / max(nrec, 1)},
             "host_inclusive": {"prepare_s": t_prep, "prepare_run_fetch_s": t_e2e,
-                               "records_per_s": nrec / t_e2e},
+                               "records_per_s": nrec / t_e2e,
+                               "page_locked_input_s": t_e2e_pinned,
+                               "page_locked_input_records_per_s": nrec / t_e2e_pinned},
         }
         if args.cpu_sample > 0:
             rps, n_cpu, nd, secs = cpu_baseline(w, args.cpu_sample)

@@ -91,6 +91,22 @@ int xe_gpu_load_devices(xe_gpu *h, const char *path);
  * batch and after any configuration change */
 int xe_gpu_commit(xe_gpu *h);
 
+/* Host threads xe_gpu_batch_prepare() walks datagram headers with (default 8,
+ * or the environment's XE_PREPASS_THREADS; 1 = the calling thread only).
+ * Datagrams of one exporter stay on one thread, in arrival order, the way the
+ * reference pins exporters to capture threads (xenoeye.c:584-625); the result
+ * does not depend on the number of threads. */
+int xe_gpu_set_prepass_threads(xe_gpu *h, int nthreads);
+
+/* Page-locked host memory for the datagram buffer handed to
+ * xe_gpu_batch_prepare() and for result buffers: copies to and from such
+ * memory run at the full speed of the link (the capture threads of the
+ * reference fill a 64 KiB stack buffer per datagram, scapture.c:25-61; a
+ * batching caller appends the datagrams to a buffer from here instead).
+ * Ordinary memory works too, only slower.  NULL on failure. */
+void *xe_gpu_host_alloc(xe_gpu *h, size_t bytes);
+void xe_gpu_host_free(xe_gpu *h, void *p);
+
 /* ---- data path ---- */
 /* replaces the per-datagram entry points netflow_process() (netflow.h:157,
  * netflow.c:788) and sflow_process() (sflow.h:17, sflow-impl.h:293) for a

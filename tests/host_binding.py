@@ -45,6 +45,8 @@ class Host:
                                     C.POINTER(C.c_int)]
         L.xe_ht_prepass.restype = C.c_void_p
         L.xe_ht_plan_free.argtypes = [C.c_void_p]
+        L.xe_ht_set_prepass_threads.argtypes = [C.c_void_p, C.c_int]
+        L.xe_ht_set_prepass_threads.restype = None
         for f in ("nrec", "nsf", "nsets", "nexporters", "skipped"):
             fn = getattr(L, "xe_ht_plan_" + f)
             fn.argtypes = [C.c_void_p]
@@ -87,7 +89,9 @@ class Host:
         self.L.xe_ht_release(words)
         return arr, [(d.root4, d.root6, d.nodes4, d.nodes6, d.bit, d.chains4, d.chains6) for d in dev[:n]]
 
-    def prepass(self, batch):
+    def prepass(self, batch, threads=None):
+        if threads is not None:
+            self.L.xe_ht_set_prepass_threads(self.h, int(threads))
         data, offs, src, kinds = batch.packed()
         rc = C.c_int()
         p = self.L.xe_ht_prepass(self.h, data.ctypes.data, offs.ctypes.data, src.ctypes.data, kinds.ctypes.data,
@@ -98,7 +102,8 @@ class Host:
         sets = [L.xe_ht_plan_sets(p)[i] for i in range(ns)]
         out = dict(nrec=L.xe_ht_plan_nrec(p), nsf=L.xe_ht_plan_nsf(p), skipped=L.xe_ht_plan_skipped(p),
                    sets=[dict(first_rec=s.first_rec, nrec=s.nrec, avail=s.avail, stride=s.stride, tmpl=s.tmpl,
-                              flags=s.flags, data_off=s.data_off, exporter=s.exporter) for s in sets],
+                              flags=s.flags, data_off=s.data_off, exporter=s.exporter, dgram_left=s.dgram_left)
+                         for s in sets],
                    exporters=[dict(dev_ip=bytes(e.dev_ip), dev_id=bytes(e.dev_id), rate=e.sampling_rate,
                                    device=e.device)
                               for e in (L.xe_ht_plan_exporters(p)[i] for i in range(L.xe_ht_plan_nexporters(p)))])

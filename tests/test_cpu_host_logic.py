@@ -260,6 +260,37 @@ def test_prepass_counts_on_mutated_datagrams(orc):
         assert plan["nrec"] == orc.nrecords(), trial
 
 
+def test_prepass_with_threads_equals_single_thread():
+    """the pre-pass sharded over threads by exporter gives the same plan as
+    the single-threaded walk: set order, record indices, exporter table"""
+    w5 = synth.workload_c5(300000, prefixes=50)
+    w2 = synth.workload_c2(150000, prefixes=50)
+    # templates that change in mid-stream, and v5 datagrams in between
+    b = synth.Batch()
+    for i, (p, s, k) in enumerate(zip(w2["batch"].pkts, w2["batch"].src, w2["batch"].kind)):
+        b.add(p, s, k)
+        if i % 997 == 500:
+            e = (i // 997) % 64
+            b.add(synth.ipfix_template_packet(256, synth.TMPL_IPFIX_V6 if (i // 997) % 2 else synth.TMPL_IPFIX_V4, e + 1),
+                  bytes([10, 255, 0, e + 1]))
+        if i % 1501 == 7:
+            b.add(synth.v5_packet(synth.Rng(i), 9), bytes([10, 77, 0, i % 5]))
+    for batch in (w5["batch"], b):
+        assert len(batch) >= 4096
+        plans = []
+        for T in (1, 2, 7, 16):
+            h = Host()
+            plans.append(h.prepass(batch, threads=T))
+            h.close()
+        for p in plans[1:]:
+            assert p["nrec"] == plans[0]["nrec"] and p["skipped"] == plans[0]["skipped"]
+            assert p["exporters"] == plans[0]["exporters"]
+            assert len(p["sets"]) == len(plans[0]["sets"])
+            for a, c in zip(p["sets"], plans[0]["sets"]):
+                # device template slots may be numbered in another order
+                assert {k: v for k, v in a.items() if k != "tmpl"} == {k: v for k, v in c.items() if k != "tmpl"}
+
+
 def test_prepass_exporters_and_device_lookup(host):
     # id-only fallthrough of devices.c:224: entry 0 has ip+id, ip differs, id equals -> still found
     host.L.xe_ht_add_device(host.h, 1, int.from_bytes(bytes([10, 9, 9, 9]), "little"), 1,

@@ -53,6 +53,9 @@ def load_library(path=LIB_PATH):
         "xe_gpu_add_device": (i32, [vp, i32, u32, i32, u32, i32, i32, C.POINTER(cp), i32]),
         "xe_gpu_load_devices": (i32, [vp, cp]),
         "xe_gpu_commit": (i32, [vp]),
+        "xe_gpu_set_prepass_threads": (i32, [vp, i32]),
+        "xe_gpu_host_alloc": (vp, [vp, C.c_size_t]),
+        "xe_gpu_host_free": (None, [vp, vp]),
         "xe_gpu_batch_prepare": (i32, [vp, vp, vp, vp, vp, sz, C.POINTER(vp)]),
         "xe_gpu_batch_free": (None, [vp]),
         "xe_gpu_batch_run": (i32, [vp, vp]),
@@ -115,6 +118,7 @@ class Engine:
                           (device, self.L.xe_gpu_strerror(rc).decode()))
         self._h = h
         self._batches = weakref.WeakSet()
+        self._pinned = []
 
     def close(self):
         """Destroys the handle; batches made from it are freed first (a batch
@@ -122,6 +126,9 @@ class Engine:
         if self._h:
             for b in list(self._batches):
                 b.free()
+            for p in self._pinned:
+                self.L.xe_gpu_host_free(self._h, p)
+            self._pinned = []
             self.L.xe_gpu_destroy(self._h)
             self._h = None
 
@@ -175,6 +182,10 @@ class Engine:
         self._chk(self.L.xe_gpu_add_device(self._h, int(ip is not None), ipn, int(dev_id is not None),
                                            dev_id or 0, sampling_rate, int(skip_unmarked), arr, len(marks)))
 
+    def set_prepass_threads(self, n):
+        """host threads that walk datagram headers in prepare() (1 = calling thread only)"""
+        self._chk(self.L.xe_gpu_set_prepass_threads(self._h, int(n)))
+
     def commit(self):
         self._chk(self.L.xe_gpu_commit(self._h))
 
@@ -183,6 +194,18 @@ class Engine:
         n = a.size // (4 if family == 4 else 16)
         out = np.zeros(n, dtype=np.uint8)
         self._chk(self.L.xe_gpu_iplist_match(self._h, name.encode(), family, a.ctypes.data, n, out.ctypes.data))
+        return out
+
+    def pinned(self, data):
+        """a copy of the byte array `data` in page-locked memory (freed with the engine)"""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        n = max(int(data.size), 1)
+        p = self.L.xe_gpu_host_alloc(self._h, n)
+        if not p:
+            raise XeError(-2, "xe_gpu_host_alloc(%d) failed" % n)
+        self._pinned.append(p)
+        out = np.ctypeslib.as_array((C.c_uint8 * n).from_address(p))[:data.size]
+        out[:] = data
         return out
 
     def prepare(self, batch):

@@ -8,6 +8,7 @@
  */
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 #include <arpa/inet.h>
@@ -645,6 +646,35 @@ reads_device_fields(const struct xe_term *terms, size_t n)
 		}
 	}
 	return r;
+}
+
+extern "C" void *
+xe_gpu_host_alloc(xe_gpu *h, size_t bytes)
+{
+	void *p = NULL;
+	if (!h || !bytes) return NULL;
+	if (hipSetDevice(h->device) != hipSuccess) return NULL;
+	if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+		(void)hipGetLastError();
+		snprintf(h->err, sizeof(h->err), "hipHostMalloc(%zu) failed", bytes);
+		return NULL;
+	}
+	return p;
+}
+
+extern "C" void
+xe_gpu_host_free(xe_gpu *h, void *p)
+{
+	(void)h;
+	if (p) (void)hipHostFree(p);
+}
+
+extern "C" int
+xe_gpu_set_prepass_threads(xe_gpu *h, int nthreads)
+{
+	if (!h || (nthreads < 0) || (nthreads > 64)) return XE_EINVAL;
+	h->hs.prepass_threads = nthreads;
+	return XE_OK;
 }
 
 extern "C" int
@@ -1300,6 +1330,11 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 	xe_batch *b;
 	int rc;
 	size_t total, off, f;
+	const int dbg = getenv("XE_DEBUG") != NULL;
+	double tm_[8];
+	int ntm_ = 0;
+#define XE_TICK() do { if (dbg && (ntm_ < 8)) { struct timespec ts_; clock_gettime(CLOCK_MONOTONIC, &ts_); \
+	tm_[ntm_++] = ts_.tv_sec * 1e3 + ts_.tv_nsec * 1e-6; } } while (0)
 
 	if (!h || !out || (n && (!data || !offsets || !src_ip4))) return XE_EINVAL;
 	*out = NULL;
@@ -1311,7 +1346,9 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 	b = (xe_batch *)calloc(1, sizeof(*b));
 	if (!b) return XE_ENOMEM;
 	b->h = h;
+	XE_TICK();
 	rc = xe_prepass(&h->hs, data, offsets, src_ip4, kinds, n, &b->plan);
+	XE_TICK();
 	if (rc != XE_OK) {
 		snprintf(h->err, sizeof(h->err), "pre-pass failed: %s", xe_gpu_strerror(rc));
 		free(b);
@@ -1336,14 +1373,17 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 		hipError_t e = hipMemset((uint8_t *)b->d_pkt + total, 0, 64);
 		if (e != hipSuccess) { xe_gpu_batch_free(b); return hip_fail(h, e, "hipMemset(pad)"); }
 	}
+	XE_TICK();
 	rc = upload(h, &b->d_sets, b->plan.sets.p, b->plan.sets.n * sizeof(struct xe_set));
 	if (rc == XE_OK) rc = upload(h, &b->d_exps, b->plan.exporters.p, b->plan.exporters.n * sizeof(struct xe_exporter));
 	if (rc == XE_OK) rc = upload(h, &b->d_sfrecs, b->plan.sfrecs.p, b->plan.sfrecs.n * sizeof(struct xe_sfrec));
 	if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
 
 	memset(&b->kp, 0, sizeof(b->kp));
+	XE_TICK();
 	rc = build_work_lists(h, b, total);
 	if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
+	XE_TICK();
 
 	/* output layout */
 	off = 0;
@@ -1401,6 +1441,7 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 		if (e != hipSuccess) { xe_gpu_batch_free(b); return hip_fail(h, e, "hipMemset(outputs)"); }
 	}
 
+	XE_TICK();
 	/* decode plans of the fast kernel: per template the micro-ops of its
 	 * known, valid fields with this batch's column addresses, and the
 	 * location of every field for the filter terms */
@@ -1495,6 +1536,13 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 	b->kp.marks = h->hs.ndevs ? (uint32_t *)((uint8_t *)b->d_out + b->marks_off) : NULL;
 	b->kp.counters = (unsigned long long *)((uint8_t *)b->d_out + b->counters_off);
 	b->kp.sf_has = (uint32_t *)((uint8_t *)b->d_out + b->sfhas_off);
+	XE_TICK();
+	if (dbg && (ntm_ == 7)) {
+		fprintf(stderr, "prepare: pre-pass %.2f, packets to device %.2f, plan tables %.2f, work lists %.2f, "
+			"outputs %.2f, decode plans %.2f ms\n", tm_[1] - tm_[0], tm_[2] - tm_[1], tm_[3] - tm_[2],
+			tm_[4] - tm_[3], tm_[5] - tm_[4], tm_[6] - tm_[5]);
+	}
+#undef XE_TICK
 	*out = b;
 	return XE_OK;
 }

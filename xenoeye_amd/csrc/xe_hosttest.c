@@ -102,6 +102,8 @@ xe_ht_prepass(struct xe_host *hs, const uint8_t *data, const uint64_t *offs, con
 }
 
 void xe_ht_plan_free(struct xe_plan *p) { if (p) { xe_plan_free(p); free(p); } }
+void xe_ht_set_prepass_threads(struct xe_host *hs, int n) { hs->prepass_threads = n; }
+
 /* stride of the flattened list nodes, for the tests' own walk */
 int xe_ht_node_bits(void) { return XE_NODE_BITS; }
 

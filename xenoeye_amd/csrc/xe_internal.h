@@ -10,6 +10,8 @@
 #include <stdint.h>
 #include "../../include/xe_gpu.h"
 
+#include <pthread.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -427,6 +429,11 @@ struct xe_host
 	struct xe_blob dev_tmpls;   /* struct xe_tmpl */
 	struct xe_blob dev_tents;   /* struct xe_tent */
 	uint32_t v5_slot_plus1;     /* device template of the fixed v5 record, 0 = not built */
+	/* the pre-pass may walk a batch with several threads (one exporter always
+	 * on one thread): the template store is then guarded by tlock */
+	pthread_rwlock_t tlock;
+	int mt;                     /* 1 while several threads are walking */
+	int prepass_threads;        /* 0 = default */
 	char err[512];
 };
 

@@ -23,6 +23,8 @@
  *     64 KiB buffer; zero is what a fresh buffer holds).
  */
 #include <stdlib.h>
+#include <stdio.h>
+#include <time.h>
 #include <string.h>
 #include <arpa/inet.h>
 #include "xe_internal.h"
@@ -70,7 +72,34 @@ gcopy(const struct dgram *d, long off, uint8_t *dst, long n)
 void
 xe_host_init(struct xe_host *hs)
 {
+	pthread_rwlockattr_t a;
+
 	memset(hs, 0, sizeof(*hs));
+	pthread_rwlockattr_init(&a);
+	/* a waiting writer (a new template) goes before readers that come back */
+	pthread_rwlockattr_setkind_np(&a, PTHREAD_RWLOCK_PREFER_WRITER_NONRECURSIVE_NP);
+	pthread_rwlock_init(&hs->tlock, &a);
+	pthread_rwlockattr_destroy(&a);
+}
+
+/* Template store access while several threads walk datagrams: every walking
+ * thread holds the read side all the time (it lets go for a moment every few
+ * hundred datagrams), and trades it for the write side while it stores a new
+ * or changed template.  Nothing to do when one thread walks alone. */
+static inline void
+tl_write(struct xe_host *hs)
+{
+	if (!hs->mt) return;
+	pthread_rwlock_unlock(&hs->tlock);
+	pthread_rwlock_wrlock(&hs->tlock);
+}
+
+static inline void
+tl_write_done(struct xe_host *hs)
+{
+	if (!hs->mt) return;
+	pthread_rwlock_unlock(&hs->tlock);
+	pthread_rwlock_rdlock(&hs->tlock);
 }
 
 void
@@ -90,6 +119,7 @@ xe_host_free(struct xe_host *hs)
 	free(hs->thash);
 	free(hs->dev_tmpls.p);
 	free(hs->dev_tents.p);
+	pthread_rwlock_destroy(&hs->tlock);
 	memset(hs, 0, sizeof(*hs));
 }
 
@@ -358,6 +388,21 @@ tmpl_put(struct xe_host *hs, const struct xe_tkey *k, const uint8_t *raw, size_t
 	return XE_OK;
 }
 
+/* tmpl_put() for the walkers: a template that is already stored unchanged
+ * (the usual periodic re-send) only takes the read side of the lock */
+static int
+tmpl_store(struct xe_host *hs, const struct xe_tkey *k, const uint8_t *raw, size_t raw_len)
+{
+	struct xe_tslot *s = tmpl_find(hs, k);
+	int rc;
+
+	if (s && (s->raw_len == raw_len) && !memcmp(s->raw, raw, raw_len)) return XE_OK;
+	tl_write(hs);
+	rc = tmpl_put(hs, k, raw, raw_len);
+	tl_write_done(hs);
+	return rc;
+}
+
 /* ------------------------------------------------------------------ set emission */
 static int
 emit_set(struct xe_plan *plan, const struct xe_host *hs, const struct dgram *d, long rel_off,
@@ -496,7 +541,7 @@ walk_v9(struct xe_host *hs, struct xe_plan *plan, struct dgram *d)
 			if (!raw) return XE_ENOMEM;
 			gcopy(d, ptr, raw, tsize);
 			memcpy(&k.tid, raw, 2);
-			rc = tmpl_put(hs, &k, raw, (size_t)tsize);
+			rc = tmpl_store(hs, &k, raw, (size_t)tsize);
 			free(raw);
 			if (rc != XE_OK) return rc;
 			ptr += tsize;
@@ -544,7 +589,7 @@ ipfix_template(struct xe_host *hs, struct dgram *d, long ptr, long length, int *
 		}
 	}
 	memcpy(&k.tid, raw, 2);
-	rc = tmpl_put(hs, &k, raw, 4 + 8 * (size_t)fc);
+	rc = tmpl_store(hs, &k, raw, 4 + 8 * (size_t)fc);
 	free(raw);
 	if (rc == XE_OK) *ok = 1;
 	return rc;
@@ -673,15 +718,19 @@ walk_v5(struct xe_host *hs, struct xe_plan *plan, struct dgram *d)
 	if ((24 + 48 * n) != d->len) { plan->skipped_datagrams++; return XE_OK; }
 	d->source_id = g8(d, 21);   /* engine_id widened to a host-order word */
 	if (!exporter_get(hs, plan, d->src_ip, d->source_id, &d->exporter)) return XE_ENOMEM;
-	if (hs->v5_slot_plus1) {
-		slot = hs->v5_slot_plus1 - 1;
-	} else {
-		rc = v5_template(hs, &slot);
+	slot = hs->v5_slot_plus1;
+	if (!slot) {
+		tl_write(hs);
+		if (!hs->v5_slot_plus1) {
+			rc = v5_template(hs, &slot);
+			if (rc == XE_OK) hs->v5_slot_plus1 = slot + 1;
+		}
+		slot = hs->v5_slot_plus1;
+		tl_write_done(hs);
 		if (rc != XE_OK) return rc;
-		hs->v5_slot_plus1 = slot + 1;
 	}
-	if (!emit_set(plan, hs, d, 24, (uint32_t)n, 48 * n, 48, slot, 48 * n, 0)) return XE_ENOMEM;
-	return XE_OK;
+	slot--;
+	return emit_set(plan, hs, d, 24, (uint32_t)n, 48 * n, 48, slot, 48 * n, 0) ? XE_OK : XE_ENOMEM;
 }
 
 /* ------------------------------------------------------------------ sFlow v5 */
@@ -836,37 +885,312 @@ walk_sflow(struct xe_host *hs, struct xe_plan *plan, struct dgram *d)
 }
 
 /* ------------------------------------------------------------------ entry */
+/* one datagram: netflow_process(), netflow.c:804-819 / sflow_process() */
+static int
+walk_one(struct xe_host *hs, struct xe_plan *plan, const uint8_t *data, const uint64_t *offs,
+	const uint32_t *src, const uint8_t *kinds, size_t i)
+{
+	struct dgram d;
+
+	memset(&d, 0, sizeof(d));
+	d.p = data + offs[i];
+	d.len = (long)(offs[i + 1] - offs[i]);
+	if (d.len > 65536) d.len = 65536;
+	d.base = offs[i];
+	d.src_ip = src[i];
+	if (kinds && (kinds[i] == XE_KIND_SFLOW)) return walk_sflow(hs, plan, &d);
+	switch (g16(&d, 0)) {
+		case 5: return walk_v5(hs, plan, &d);
+		case 9: return walk_v9(hs, plan, &d);
+		case 10: return walk_ipfix(hs, plan, &d);
+		default: plan->skipped_datagrams++; break;
+	}
+	return XE_OK;
+}
+
+/*
+ * Several threads: all state of the walk is keyed by exporter (templates,
+ * sampling rate), so thread t takes the datagrams of the exporter addresses
+ * that hash to t, in arrival order, into a plan of its own.  Per datagram the
+ * owner notes how many sets, records and sFlow elements it produced; prefix
+ * sums over the datagrams then give every set its place and every record its
+ * index exactly as the single-threaded walk assigns them, and the threads copy
+ * their pieces there.
+ */
+struct pp_ent          /* one datagram of a thread */
+{
+	uint32_t nsets, nrec, nsf, pad;        /* what its walk produced */
+	uint64_t base_sets, base_rec, base_sf; /* where that goes in the merged plan */
+};
+
+struct pp_shared
+{
+	struct xe_host *hs;
+	const uint8_t *data;
+	const uint64_t *offs;
+	const uint32_t *src;
+	const uint8_t *kinds;
+	size_t n;
+	int T;
+	uint8_t *own;                              /* thread of every datagram */
+	struct xe_set *sets;                       /* final arrays */
+	struct xe_sfrec *sfrecs;
+	struct pp_thread *th;
+};
+
+struct pp_thread
+{
+	struct pp_shared *sh;
+	int t, rc;
+	pthread_t tid;
+	struct xe_plan plan;
+	struct xe_blob ents;        /* struct pp_ent, one per datagram of this thread, in order */
+	struct xe_blob efirst;      /* size_t: datagram that introduced each local exporter */
+	uint32_t *eremap;           /* local exporter index -> index in the merged table */
+} __attribute__((aligned(128)));   /* no cache line shared between two threads' state */
+
+static inline int
+pp_owner(uint32_t ip, int T)
+{
+	/* the high half of a 64-bit product mixes every address bit */
+	return (int)((uint32_t)(((uint64_t)ip * 0x9E3779B97F4A7C15ull) >> 40) % (uint32_t)T);
+}
+
+struct pp_efirst { size_t first; int t; uint32_t local; };
+
+static int
+pp_efirst_cmp(const void *a, const void *b)
+{
+	const struct pp_efirst *x = a, *y = b;
+	return (x->first > y->first) - (x->first < y->first);
+}
+
+/* between the two phases, on one thread: places of sets and records, the
+ * merged exporter table (in order of first appearance), the final arrays */
+static int
+pp_merge(struct pp_shared *sh, struct xe_plan *out)
+{
+	size_t i, ne = 0, k = 0, ns = 0, nr = 0, nf = 0;
+	size_t cur[64];
+	struct pp_efirst *ef;
+	int t;
+
+	memset(cur, 0, sizeof(cur));
+	for (i = 0; i < sh->n; i++) {
+		struct pp_ent *e;
+		t = sh->own[i];
+		e = (struct pp_ent *)sh->th[t].ents.p + cur[t]++;
+		e->base_sets = ns; ns += e->nsets;
+		e->base_rec = nr;  nr += e->nrec;
+		e->base_sf = nf;   nf += e->nsf;
+	}
+	if (nr > 0xFFFFFFF0u) return XE_EUNSUPPORTED;
+	for (t = 0; t < sh->T; t++) ne += sh->th[t].plan.exporters.n;
+	ef = malloc((ne ? ne : 1) * sizeof(*ef));
+	if (!ef) return XE_ENOMEM;
+	for (t = 0; t < sh->T; t++) {
+		for (i = 0; i < sh->th[t].plan.exporters.n; i++) {
+			ef[k].first = ((size_t *)sh->th[t].efirst.p)[i];
+			ef[k].t = t;
+			ef[k].local = (uint32_t)i;
+			k++;
+		}
+		sh->th[t].eremap = malloc((sh->th[t].plan.exporters.n ? sh->th[t].plan.exporters.n : 1) * sizeof(uint32_t));
+		if (!sh->th[t].eremap) { free(ef); return XE_ENOMEM; }
+	}
+	qsort(ef, ne, sizeof(*ef), pp_efirst_cmp);
+	for (k = 0; k < ne; k++) {
+		const struct xe_exporter *e = (const struct xe_exporter *)sh->th[ef[k].t].plan.exporters.p + ef[k].local;
+		sh->th[ef[k].t].eremap[ef[k].local] = (uint32_t)k;
+		if (!xe_blob_push(&out->exporters, e, sizeof(*e))) { free(ef); return XE_ENOMEM; }
+	}
+	free(ef);
+	out->sets.p = malloc((ns ? ns : 1) * sizeof(struct xe_set));
+	out->sfrecs.p = malloc((nf ? nf : 1) * sizeof(struct xe_sfrec));
+	if (!out->sets.p || !out->sfrecs.p) return XE_ENOMEM;
+	out->sets.n = ns;   out->sets.cap = (ns ? ns : 1) * sizeof(struct xe_set);
+	out->sfrecs.n = nf; out->sfrecs.cap = (nf ? nf : 1) * sizeof(struct xe_sfrec);
+	out->nrec = nr;
+	out->nsf = nf;
+	for (t = 0; t < sh->T; t++) {
+		const struct xe_plan *p = &sh->th[t].plan;
+		const struct xe_tinfo *ti = p->tinfo.p;
+		out->field_mask[0] |= p->field_mask[0];
+		out->field_mask[1] |= p->field_mask[1];
+		out->soa_bytes_per_rec_sum += p->soa_bytes_per_rec_sum;
+		out->skipped_datagrams += p->skipped_datagrams;
+		for (i = 0; i < p->tinfo.n; i++) {
+			while (out->tinfo.n <= i) {
+				struct xe_tinfo z;
+				memset(&z, 0, sizeof(z));
+				if (!xe_blob_push(&out->tinfo, &z, sizeof(z))) return XE_ENOMEM;
+			}
+			if (ti[i].known) ((struct xe_tinfo *)out->tinfo.p)[i] = ti[i];
+		}
+	}
+	return XE_OK;
+}
+
+/* phase 1: walk this thread's datagrams */
+static void *
+pp_walk(void *arg)
+{
+	struct pp_thread *me = arg;
+	struct pp_shared *sh = me->sh;
+	struct xe_plan *plan = &me->plan;
+	size_t i, since = 0;
+
+	pthread_rwlock_rdlock(&sh->hs->tlock);
+	for (i = 0; (i < sh->n) && (me->rc == XE_OK); i++) {
+		struct pp_ent e;
+		size_t s0, r0, f0, e0;
+		if (sh->own[i] != me->t) continue;
+		if ((i + 32 < sh->n) && (sh->own[i + 32] == me->t)) __builtin_prefetch(sh->data + sh->offs[i + 32]);
+		if (++since == 512) {
+			/* a thread that waits to store a template gets its turn */
+			pthread_rwlock_unlock(&sh->hs->tlock);
+			pthread_rwlock_rdlock(&sh->hs->tlock);
+			since = 0;
+		}
+		s0 = plan->sets.n; r0 = plan->nrec; f0 = plan->nsf; e0 = plan->exporters.n;
+		me->rc = walk_one(sh->hs, plan, sh->data, sh->offs, sh->src, sh->kinds, i);
+		memset(&e, 0, sizeof(e));
+		e.nsets = (uint32_t)(plan->sets.n - s0);
+		e.nrec = (uint32_t)(plan->nrec - r0);
+		e.nsf = (uint32_t)(plan->nsf - f0);
+		if (!xe_blob_push(&me->ents, &e, sizeof(e))) me->rc = XE_ENOMEM;
+		for (; e0 < plan->exporters.n; e0++) {
+			if (!xe_blob_push(&me->efirst, &i, sizeof(i))) me->rc = XE_ENOMEM;
+		}
+	}
+	pthread_rwlock_unlock(&sh->hs->tlock);
+	return NULL;
+}
+
+/* phase 2: this thread's pieces to their places */
+static void *
+pp_place(void *arg)
+{
+	struct pp_thread *me = arg;
+	struct pp_shared *sh = me->sh;
+	const struct xe_set *ls = me->plan.sets.p;
+	const struct xe_sfrec *lf = me->plan.sfrecs.p;
+	const struct pp_ent *en = me->ents.p;
+	size_t cs = 0, cr = 0, cf = 0, i;
+
+	for (i = 0; i < me->ents.n; i++) {
+		const struct pp_ent *e = &en[i];
+		uint32_t k;
+		for (k = 0; k < e->nsets; k++) {
+			struct xe_set s = ls[cs + k];
+			s.first_rec = (uint32_t)(e->base_rec + (s.first_rec - cr));
+			s.exporter = me->eremap[s.exporter];
+			sh->sets[e->base_sets + k] = s;
+		}
+		for (k = 0; k < e->nsf; k++) {
+			struct xe_sfrec r = lf[cf + k];
+			r.exporter = me->eremap[r.exporter];
+			sh->sfrecs[e->base_sf + k] = r;
+		}
+		cs += e->nsets;
+		cr += e->nrec;
+		cf += e->nsf;
+	}
+	return NULL;
+}
+
+/* fn on every thread's share; the caller is thread 0, and takes over the share
+ * of any thread that could not be started */
+static void
+pp_all(struct pp_shared *sh, void *(*fn)(void *))
+{
+	int t;
+	char started[64];
+
+	memset(started, 0, sizeof(started));
+	for (t = 1; t < sh->T; t++) {
+		if (pthread_create(&sh->th[t].tid, NULL, fn, &sh->th[t]) == 0) started[t] = 1;
+	}
+	fn(&sh->th[0]);
+	for (t = 1; t < sh->T; t++) {
+		if (started[t]) pthread_join(sh->th[t].tid, NULL);
+		else fn(&sh->th[t]);
+	}
+}
+
+static int
+prepass_threads(struct xe_host *hs, const uint8_t *data, const uint64_t *offs, const uint32_t *src,
+	const uint8_t *kinds, size_t n, struct xe_plan *plan, int T)
+{
+	struct pp_shared sh;
+	struct pp_thread *th;
+	int t, rc = XE_OK;
+
+	memset(&sh, 0, sizeof(sh));
+	if (posix_memalign((void **)&th, 128, (size_t)T * sizeof(*th)) != 0) return XE_ENOMEM;
+	memset(th, 0, (size_t)T * sizeof(*th));
+	sh.hs = hs; sh.data = data; sh.offs = offs; sh.src = src; sh.kinds = kinds; sh.n = n; sh.T = T; sh.th = th;
+	for (t = 0; t < T; t++) { th[t].sh = &sh; th[t].t = t; }
+	sh.own = malloc(n ? n : 1);
+	if (!sh.own) { free(th); return XE_ENOMEM; }
+	{
+		size_t i;
+		for (i = 0; i < n; i++) sh.own[i] = (uint8_t)pp_owner(src[i], T);
+	}
+
+	struct timespec t0_, t1_, t2_, t3_;
+	clock_gettime(CLOCK_MONOTONIC, &t0_);
+	hs->mt = 1;
+	pp_all(&sh, pp_walk);
+	hs->mt = 0;
+	clock_gettime(CLOCK_MONOTONIC, &t1_);
+	for (t = 0; t < T; t++) if ((rc == XE_OK) && (th[t].rc != XE_OK)) rc = th[t].rc;
+	if (rc == XE_OK) rc = pp_merge(&sh, plan);
+	clock_gettime(CLOCK_MONOTONIC, &t2_);
+	if (rc == XE_OK) {
+		sh.sets = plan->sets.p;
+		sh.sfrecs = plan->sfrecs.p;
+		pp_all(&sh, pp_place);
+	}
+	clock_gettime(CLOCK_MONOTONIC, &t3_);
+	if (getenv("XE_DEBUG")) fprintf(stderr, "prepass T=%d walk %.2f merge %.2f place %.2f ms\n", T,
+		((t1_.tv_sec - t0_.tv_sec) * 1e3 + (t1_.tv_nsec - t0_.tv_nsec) * 1e-6),
+		((t2_.tv_sec - t1_.tv_sec) * 1e3 + (t2_.tv_nsec - t1_.tv_nsec) * 1e-6),
+		((t3_.tv_sec - t2_.tv_sec) * 1e3 + (t3_.tv_nsec - t2_.tv_nsec) * 1e-6));
+	for (t = 0; t < T; t++) {
+		xe_plan_free(&th[t].plan);
+		free(th[t].ents.p);
+		free(th[t].efirst.p);
+		free(th[t].eremap);
+	}
+	free(th);
+	free(sh.own);
+	if (rc != XE_OK) xe_plan_free(plan);
+	return rc;
+}
+
 int
 xe_prepass(struct xe_host *hs, const uint8_t *data, const uint64_t *offs, const uint32_t *src,
 	const uint8_t *kinds, size_t n, struct xe_plan *plan)
 {
 	size_t i;
+	int T = hs->prepass_threads;
 
 	memset(plan, 0, sizeof(*plan));
+	if (T <= 0) {
+		const char *e = getenv("XE_PREPASS_THREADS");
+		T = e ? atoi(e) : 8;
+	}
+	if (T > 64) T = 64;
+	/* small batches are not worth the thread start */
+	if ((T > 1) && (n >= 4096)) return prepass_threads(hs, data, offs, src, kinds, n, plan, T);
 	for (i = 0; i < n; i++) {
-		struct dgram d;
-		int rc = XE_OK;
+		int rc;
 
 		/* only headers are read, one cache line per datagram, far apart: ask
 		 * for the lines of the datagrams to come */
 		if (i + 16 < n) __builtin_prefetch(data + offs[i + 16]);
-		memset(&d, 0, sizeof(d));
-		d.p = data + offs[i];
-		d.len = (long)(offs[i + 1] - offs[i]);
-		if (d.len > 65536) d.len = 65536;
-		d.base = offs[i];
-		d.src_ip = src[i];
-		if (kinds && (kinds[i] == XE_KIND_SFLOW)) {
-			rc = walk_sflow(hs, plan, &d);
-		} else {
-			/* netflow_process(), netflow.c:804-819 */
-			switch (g16(&d, 0)) {
-				case 5: rc = walk_v5(hs, plan, &d); break;
-				case 9: rc = walk_v9(hs, plan, &d); break;
-				case 10: rc = walk_ipfix(hs, plan, &d); break;
-				default: plan->skipped_datagrams++; break;
-			}
-		}
+		rc = walk_one(hs, plan, data, offs, src, kinds, i);
 		if (rc != XE_OK) {
 			xe_plan_free(plan);
 			return rc;
