@@ -291,6 +291,25 @@ def test_prepass_with_threads_equals_single_thread():
                 assert {k: v for k, v in a.items() if k != "tmpl"} == {k: v for k, v in c.items() if k != "tmpl"}
 
 
+def test_prepass_threads_under_thread_sanitizer(tmp_path):
+    """the sharded pre-pass built with -fsanitize=thread (host code only): no
+    data race reported, and templates that change in mid-stream give the same
+    plan as the one-thread walk"""
+    import subprocess
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "prepass_threads_driver.c")
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xenoeye_amd", "csrc")
+    exe = str(tmp_path / "pp_tsan")
+    cmd = ["gcc", "-std=gnu11", "-O1", "-g", "-w", "-fsanitize=thread", "-pthread", "-I", csrc, src] + \
+          [os.path.join(csrc, f) for f in ("xe_prepass.c", "xe_fields.c", "xe_filter.c", "xe_iplist.c", "xe_conf.c")] + ["-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and "tsan" in (r.stderr or "").lower():
+        pytest.skip("no ThreadSanitizer runtime")
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "same plans" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
+
+
 def test_prepass_exporters_and_device_lookup(host):
     # id-only fallthrough of devices.c:224: entry 0 has ip+id, ip differs, id equals -> still found
     host.L.xe_ht_add_device(host.h, 1, int.from_bytes(bytes([10, 9, 9, 9]), "little"), 1,
