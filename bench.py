@@ -38,6 +38,9 @@ def parse_args():
     ap.add_argument("--c4-prefixes", type=int, default=1000000, help="prefixes per list of the c4 workload")
     ap.add_argument("--cpu-sample", type=int, default=12000000, help="records timed on the CPU oracle (0 = skip)")
     ap.add_argument("--replicate", type=int, default=1, help="repeat the generated datagrams this many times")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for --gpus > 1 (gloo: rehearsal of the multi-rank path on one GPU)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch from a rocprofv3 --pmc pass (reported as roofline.traffic)")
     return ap.parse_args()
@@ -120,9 +123,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the flow path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
 
     import xenoeye_amd
     w, wl_name = build_workload(args.workload, args.records, rank, args.c4_prefixes, world)
@@ -197,7 +205,7 @@ def main():
     del m
 
     from xenoeye_amd import shard
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank) if args.backend == "nccl" else None
     dt_all, tot, pay = shard.reduce_scalars([dt, nrec, batch.payload_bytes], ["max", "sum", "sum"],
                                             dist if world > 1 else None, dev)
     # per-object counters of the shards merge by wrapping u64 addition
