@@ -120,6 +120,26 @@ def test_v9_odd_templates(eng, orc):
                                        ("div(octets, packets) 0-100000", -1), ("ifidx 1-48", -1)]))
 
 
+def test_v9_long_records(eng, orc):
+    """records of 200-256 bytes (many elements the field table does not know):
+    staged whole while the block's LDS holds them, decoded per lane beyond"""
+    rng = synth.Rng(5)
+    for pad_fields in (44, 52, 57, 58, 70):
+        tmpl = [(8, 4), (12, 4), (7, 2), (11, 2), (4, 1)] + [(30000 + i, 4) for i in range(pad_fields)] + [(1, 4), (2, 4)]
+        rl = sum(l for _, l in tmpl)
+        nrec = 5 * (1400 // rl) + 3
+        rec = rng.bytes(nrec * rl).reshape(nrec, rl)
+        b = synth.Batch()
+        b.add(synth.v9_template_packet(300, tmpl, 9), EXP)
+        b.extend(synth.v9_data_packets(300, rec, 1400 // rl, 9), EXP)
+        e = xenoeye_amd.Engine(device=0)
+        orc.reset()
+        w = dict(batch=b, mos=[("proto 6", -1), ("src net 10.0.0.0/8 or dst port 0-1023", -1), ("", -1)] +
+                 [("dst port %d" % i, -1) for i in range(40)])
+        both(e, orc, w)
+        e.close()
+
+
 def test_v9_two_templates_in_one_flowset(eng, orc):
     """only the first template of a template flowset is registered; the second
     one's header is then read as a flowset header"""

@@ -1173,8 +1173,14 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 	gpos = (uint64_t *)calloc(nt + 1, sizeof(uint64_t));
 	if (!tfast || !is_fast || !gcount || !gpos) goto out;
 	for (i = 0; i < nt; i++) {
+		/* a block stages 4 tiles of 64 records in LDS, beside the counters and
+		 * the atom-table copy: long records only while all of it fits */
+		const size_t motab_bytes = ((size_t)h->mask_words * XE_MOTAB_ROWS * 8 <= 8192)
+			? (size_t)h->mask_words * (XE_MOTAB_ROWS + 2) * 8 : 0;
+		const size_t stage_bytes = (size_t)4 * 64 * 4 * (4 * (((size_t)tm[i].stride + 15) / 16) + 1);
 		int ok = h->fast_ok && small && !tm[i].varlen && !tm[i].repeats
-			&& (tm[i].stride > 0) && (tm[i].stride <= XE_FAST_MAX_STRIDE);
+			&& (tm[i].stride > 0) && (tm[i].stride <= XE_FAST_MAX_STRIDE)
+			&& (stage_bytes + cnt_bytes + motab_bytes <= XE_FAST_LDS_BUDGET);
 		for (uint32_t j = 0; ok && (j < tm[i].nfields); j++) {
 			if ((te[tm[i].ent_base + j].field != XE_F_NONE) && (te[tm[i].ent_base + j].flags & XE_TE_STR)) ok = 0;
 			if (((te[tm[i].ent_base + j].len > 16) || (te[tm[i].ent_base + j].len == 0))
