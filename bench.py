@@ -36,6 +36,7 @@ def parse_args():
     ap.add_argument("--records", type=int, default=1 << 22, help="records per GPU per step")
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
     ap.add_argument("--c4-prefixes", type=int, default=1000000, help="prefixes per list of the c4 workload")
+    ap.add_argument("--c4-lists", type=int, default=8, help="distinct lists of the c4 workload (objects = 256)")
     ap.add_argument("--cpu-sample", type=int, default=12000000, help="records timed on the CPU oracle (0 = skip)")
     ap.add_argument("--replicate", type=int, default=1, help="repeat the generated datagrams this many times")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -46,15 +47,17 @@ def parse_args():
     return ap.parse_args()
 
 
-def build_workload(name, nrec, rank, c4_prefixes=1000000, world=1):
+def build_workload(name, nrec, rank, c4_prefixes=1000000, world=1, c4_lists=8):
     from xenoeye_amd import synth
     if name == "c5":
         # one replay of 512 exporters cut by exporter hash: this rank generates its share only
         return synth.workload_c5(nrec * world, rank=rank, world=world), \
             "C5 sharded replay, 512 exporters (256 netflow-v9 21B + 256 ipfix 46B records), 17 objects, %d ranks" % world
     if name == "c4":
-        return synth.workload_c4(nrec, seed=synth.SEED_C4 ^ (rank << 32), prefixes=c4_prefixes), \
-            "C4 netflow-v9 29B records, 256 objects = 8 lists x %d prefixes x 32 variants (net + port/AS/proto)" % c4_prefixes
+        return synth.workload_c4(nrec, seed=synth.SEED_C4 ^ (rank << 32), prefixes=c4_prefixes,
+                                 n_lists=c4_lists, variants=256 // c4_lists), \
+            "C4 netflow-v9 29B records, 256 objects = %d lists x %d prefixes x %d variants (net + port/AS/proto)" % (
+                c4_lists, c4_prefixes, 256 // c4_lists)
     if name == "c3":
         return synth.workload_c3(nrec, seed=synth.SEED_C3 ^ (rank << 32)), \
             "C3 sflow-v5 32 agents 7 samples/datagram 128B raw headers 8 objects"
@@ -133,7 +136,7 @@ def main():
             dist.init_process_group(backend="gloo")
 
     import xenoeye_amd
-    w, wl_name = build_workload(args.workload, args.records, rank, args.c4_prefixes, world)
+    w, wl_name = build_workload(args.workload, args.records, rank, args.c4_prefixes, world, args.c4_lists)
     eng = xenoeye_amd.Engine(device=local_rank)
     for name, text in w["iplists"].items():
         eng.add_iplist(name, text)

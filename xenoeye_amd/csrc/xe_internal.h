@@ -434,6 +434,12 @@ struct xe_host
 	pthread_rwlock_t tlock;
 	int mt;                     /* 1 while several threads are walking */
 	int prepass_threads;        /* 0 = default */
+	/* memory kept between batches (fresh memory costs a page fault per 4 KiB,
+	 * which dominates the pre-pass of large sFlow batches): the walking threads'
+	 * state with its grown arrays, and a few big buffers of freed plans */
+	void *walkers; int nwalkers;
+	pthread_mutex_t pool_mu;
+	void *pool_p[8]; size_t pool_cap[8];
 	char err[512];
 };
 
@@ -456,6 +462,7 @@ struct xe_plan
 	/* per device template slot, filled on first use in this batch: fields it
 	 * sets and the column bytes a complete record of it fills */
 	struct xe_blob tinfo;      /* struct xe_tinfo */
+	struct xe_host *pool;      /* not NULL: sets / sfrecs go back to this host's buffer pool */
 };
 struct xe_tinfo { uint64_t mask[2]; uint32_t width; uint32_t known; };
 

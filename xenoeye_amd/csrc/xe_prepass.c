@@ -80,7 +80,62 @@ xe_host_init(struct xe_host *hs)
 	pthread_rwlockattr_setkind_np(&a, PTHREAD_RWLOCK_PREFER_WRITER_NONRECURSIVE_NP);
 	pthread_rwlock_init(&hs->tlock, &a);
 	pthread_rwlockattr_destroy(&a);
+	pthread_mutex_init(&hs->pool_mu, NULL);
 }
+
+/* a buffer of at least `bytes` from the host's pool of kept buffers */
+static void *
+pool_get(struct xe_host *hs, size_t bytes, size_t *cap)
+{
+	int i, best = -1;
+	void *p = NULL;
+
+	if (!bytes) bytes = 1;
+	pthread_mutex_lock(&hs->pool_mu);
+	for (i = 0; i < 8; i++) {
+		if (hs->pool_p[i] && (hs->pool_cap[i] >= bytes) && ((best < 0) || (hs->pool_cap[i] < hs->pool_cap[best]))) best = i;
+	}
+	if ((best >= 0) && (hs->pool_cap[best] <= 4 * bytes + (1u << 20))) {
+		p = hs->pool_p[best];
+		*cap = hs->pool_cap[best];
+		hs->pool_p[best] = NULL;
+	}
+	pthread_mutex_unlock(&hs->pool_mu);
+	if (p) return p;
+	*cap = bytes + bytes / 4;
+	return malloc(*cap);
+}
+
+static void
+pool_put(struct xe_host *hs, void *p, size_t cap)
+{
+	int i, slot = -1;
+
+	if (!p) return;
+	pthread_mutex_lock(&hs->pool_mu);
+	for (i = 0; i < 8; i++) {
+		if (!hs->pool_p[i]) { slot = i; break; }
+	}
+	if (slot < 0) {
+		/* full: the smallest kept buffer makes room if this one is bigger */
+		int small = 0;
+		for (i = 1; i < 8; i++) if (hs->pool_cap[i] < hs->pool_cap[small]) small = i;
+		if (hs->pool_cap[small] < cap) {
+			void *old = hs->pool_p[small];
+			hs->pool_p[small] = p;
+			hs->pool_cap[small] = cap;
+			p = old;
+		}
+	} else {
+		hs->pool_p[slot] = p;
+		hs->pool_cap[slot] = cap;
+		p = NULL;
+	}
+	pthread_mutex_unlock(&hs->pool_mu);
+	free(p);
+}
+
+static void walkers_free(struct xe_host *hs);
 
 /* Template store access while several threads walk datagrams: every walking
  * thread holds the read side all the time (it lets go for a moment every few
@@ -119,6 +174,9 @@ xe_host_free(struct xe_host *hs)
 	free(hs->thash);
 	free(hs->dev_tmpls.p);
 	free(hs->dev_tents.p);
+	walkers_free(hs);
+	for (i = 0; i < 8; i++) free(hs->pool_p[i]);
+	pthread_mutex_destroy(&hs->pool_mu);
 	pthread_rwlock_destroy(&hs->tlock);
 	memset(hs, 0, sizeof(*hs));
 }
@@ -126,9 +184,14 @@ xe_host_free(struct xe_host *hs)
 void
 xe_plan_free(struct xe_plan *p)
 {
-	free(p->sets.p);
+	if (p->pool) {
+		pool_put(p->pool, p->sets.p, p->sets.cap);
+		pool_put(p->pool, p->sfrecs.p, p->sfrecs.cap);
+	} else {
+		free(p->sets.p);
+		free(p->sfrecs.p);
+	}
 	free(p->exporters.p);
-	free(p->sfrecs.p);
 	free(p->ehash);
 	free(p->tinfo.p);
 	memset(p, 0, sizeof(*p));
@@ -1005,11 +1068,12 @@ pp_merge(struct pp_shared *sh, struct xe_plan *out)
 		if (!xe_blob_push(&out->exporters, e, sizeof(*e))) { free(ef); return XE_ENOMEM; }
 	}
 	free(ef);
-	out->sets.p = malloc((ns ? ns : 1) * sizeof(struct xe_set));
-	out->sfrecs.p = malloc((nf ? nf : 1) * sizeof(struct xe_sfrec));
+	out->pool = sh->hs;
+	out->sets.p = pool_get(sh->hs, ns * sizeof(struct xe_set), &out->sets.cap);
+	out->sfrecs.p = pool_get(sh->hs, nf * sizeof(struct xe_sfrec), &out->sfrecs.cap);
 	if (!out->sets.p || !out->sfrecs.p) return XE_ENOMEM;
-	out->sets.n = ns;   out->sets.cap = (ns ? ns : 1) * sizeof(struct xe_set);
-	out->sfrecs.n = nf; out->sfrecs.cap = (nf ? nf : 1) * sizeof(struct xe_sfrec);
+	out->sets.n = ns;
+	out->sfrecs.n = nf;
 	out->nrec = nr;
 	out->nsf = nf;
 	for (t = 0; t < sh->T; t++) {
@@ -1118,6 +1182,41 @@ pp_all(struct pp_shared *sh, void *(*fn)(void *))
 	}
 }
 
+static void
+walkers_free(struct xe_host *hs)
+{
+	struct pp_thread *th = hs->walkers;
+	int t;
+
+	for (t = 0; t < hs->nwalkers; t++) {
+		xe_plan_free(&th[t].plan);
+		free(th[t].ents.p);
+		free(th[t].efirst.p);
+		free(th[t].eremap);
+	}
+	free(th);
+	hs->walkers = NULL;
+	hs->nwalkers = 0;
+}
+
+/* a walker's state for the next batch: empty, arrays kept at their size */
+static void
+walker_reset(struct pp_thread *w)
+{
+	struct xe_plan *p = &w->plan;
+
+	p->sets.n = p->exporters.n = p->sfrecs.n = p->tinfo.n = 0;
+	p->nrec = p->nsf = 0;
+	p->field_mask[0] = p->field_mask[1] = 0;
+	p->soa_bytes_per_rec_sum = 0;
+	p->skipped_datagrams = 0;
+	if (p->ehash) memset(p->ehash, 0, p->ehash_cap * sizeof(uint32_t));
+	w->ents.n = w->efirst.n = 0;
+	free(w->eremap);
+	w->eremap = NULL;
+	w->rc = XE_OK;
+}
+
 static int
 prepass_threads(struct xe_host *hs, const uint8_t *data, const uint64_t *offs, const uint32_t *src,
 	const uint8_t *kinds, size_t n, struct xe_plan *plan, int T)
@@ -1127,12 +1226,19 @@ prepass_threads(struct xe_host *hs, const uint8_t *data, const uint64_t *offs, c
 	int t, rc = XE_OK;
 
 	memset(&sh, 0, sizeof(sh));
-	if (posix_memalign((void **)&th, 128, (size_t)T * sizeof(*th)) != 0) return XE_ENOMEM;
-	memset(th, 0, (size_t)T * sizeof(*th));
+	if (hs->nwalkers != T) {
+		walkers_free(hs);
+		if (posix_memalign((void **)&th, 128, (size_t)T * sizeof(*th)) != 0) return XE_ENOMEM;
+		memset(th, 0, (size_t)T * sizeof(*th));
+		hs->walkers = th;
+		hs->nwalkers = T;
+	}
+	th = hs->walkers;
+	for (t = 0; t < T; t++) walker_reset(&th[t]);
 	sh.hs = hs; sh.data = data; sh.offs = offs; sh.src = src; sh.kinds = kinds; sh.n = n; sh.T = T; sh.th = th;
 	for (t = 0; t < T; t++) { th[t].sh = &sh; th[t].t = t; }
 	sh.own = malloc(n ? n : 1);
-	if (!sh.own) { free(th); return XE_ENOMEM; }
+	if (!sh.own) return XE_ENOMEM;
 	{
 		size_t i;
 		for (i = 0; i < n; i++) sh.own[i] = (uint8_t)pp_owner(src[i], T);
@@ -1157,13 +1263,6 @@ prepass_threads(struct xe_host *hs, const uint8_t *data, const uint64_t *offs, c
 		((t1_.tv_sec - t0_.tv_sec) * 1e3 + (t1_.tv_nsec - t0_.tv_nsec) * 1e-6),
 		((t2_.tv_sec - t1_.tv_sec) * 1e3 + (t2_.tv_nsec - t1_.tv_nsec) * 1e-6),
 		((t3_.tv_sec - t2_.tv_sec) * 1e3 + (t3_.tv_nsec - t2_.tv_nsec) * 1e-6));
-	for (t = 0; t < T; t++) {
-		xe_plan_free(&th[t].plan);
-		free(th[t].ents.p);
-		free(th[t].efirst.p);
-		free(th[t].eremap);
-	}
-	free(th);
 	free(sh.own);
 	if (rc != XE_OK) xe_plan_free(plan);
 	return rc;
