@@ -99,6 +99,29 @@ group_match(const uint32_t *T, uint32_t root, uint32_t nodes, uint32_t chains, u
 	return (e & XE_TRIE_TERM) ? (e & 0xFF) : 0;
 }
 
+/* the last group walk of a lane: objects that test the lists of one group on
+ * the same address (the usual `net listK` families) share one walk */
+struct walk_cache
+{
+	uint32_t root;      /* 0 = empty */
+	uint64_t hi, lo;
+	uint32_t ans;
+};
+
+__device__ __forceinline__ uint32_t
+group_match_cached(walk_cache &wc, const uint32_t *T, uint32_t root, uint32_t nodes, uint32_t chains,
+	uint64_t hi, uint64_t lo, uint32_t bits)
+{
+	if (!root) return 0;
+	if ((wc.root != root) || (wc.hi != hi) || (wc.lo != lo)) {
+		wc.ans = group_match(T, root, nodes, chains, hi, lo, bits);
+		wc.root = root;
+		wc.hi = hi;
+		wc.lo = lo;
+	}
+	return wc.ans;
+}
+
 __device__ __forceinline__ uint32_t
 trie_match4(const uint32_t *T, const xe_list_dev &L, uint32_t a)
 {
@@ -256,7 +279,7 @@ tfstr_byte(uint64_t hi, uint64_t lo, uint32_t fmax)
 
 template <typename REC, fval (*GET)(const REC &, uint32_t, uint32_t *)>
 __device__ __forceinline__ bool
-term_match(const xe_kparams &kp, const REC &rec, const xe_term &t)
+term_match(const xe_kparams &kp, const REC &rec, const xe_term &t, walk_cache &wc)
 {
 	const xe_dopnd *o = kp.opnds + t.opnd_base;
 
@@ -308,13 +331,15 @@ term_match(const xe_kparams &kp, const REC &rec, const xe_term &t)
 					if (t.type == XE_BT_ADDR4) {
 						uint32_t a = wide4 ? (uint32_t)(c[k].v.hi >> 32) : (uint32_t)c[k].v.lo;
 						if (o[i].is_list) {
-							if (trie_match4(kp.trie, kp.lists[o[i].list], a)) return true;
+							const xe_list_dev &L = kp.lists[o[i].list];
+							if ((group_match_cached(wc, kp.trie, L.root4, L.nodes4, L.chains4, (uint64_t)a << 32, 0, 32) >> L.bit) & 1) return true;
 						} else if ((a & (uint32_t)o[i].mask_lo) == (uint32_t)o[i].net_lo) {
 							return true;
 						}
 					} else {
 						if (o[i].is_list) {
-							if (trie_match6(kp.trie, kp.lists[o[i].list], c[k].v.hi, c[k].v.lo)) return true;
+							const xe_list_dev &L = kp.lists[o[i].list];
+							if ((group_match_cached(wc, kp.trie, L.root6, L.nodes6, L.chains6, c[k].v.hi, c[k].v.lo, 128) >> L.bit) & 1) return true;
 						} else if (((c[k].v.hi & o[i].mask_hi) == o[i].net_hi)
 							&& ((c[k].v.lo & o[i].mask_lo) == o[i].net_lo)) {
 							return true;
@@ -359,7 +384,7 @@ term_match(const xe_kparams &kp, const REC &rec, const xe_term &t)
  * errors are resolved at compile time into constant programs) */
 template <typename REC, fval (*GET)(const REC &, uint32_t, uint32_t *)>
 __device__ __forceinline__ bool
-prog_match(const xe_kparams &kp, const REC &rec, const xe_prog &pr)
+prog_match(const xe_kparams &kp, const REC &rec, const xe_prog &pr, walk_cache &wc)
 {
 	if (pr.flags & XE_PROG_CONST) return pr.cval != 0;
 	uint64_t st = 0;
@@ -367,7 +392,7 @@ prog_match(const xe_kparams &kp, const REC &rec, const xe_prog &pr)
 		uint32_t w = kp.ops[pr.op_base + i];
 		switch (w & 3) {
 			case XE_OP_BASIC:
-				st = (st << 1) | (uint64_t)term_match<REC, GET>(kp, rec, kp.terms[w >> 2]);
+				st = (st << 1) | (uint64_t)term_match<REC, GET>(kp, rec, kp.terms[w >> 2], wc);
 				break;
 			case XE_OP_NOT:
 				st ^= 1;
@@ -1411,6 +1436,10 @@ classify(const xe_kparams &kp, REC &rec, int32_t device, uint32_t ridx, bool act
 	unsigned long long bytes_x_rate, unsigned long long pkts_x_rate, unsigned long long *lcnt, const uint64_t *lmt)
 {
 	bool dropped = false;
+	walk_cache wc;
+	wc.root = 0;
+	wc.hi = wc.lo = 0;
+	wc.ans = 0;
 
 	if (active && kp.marks) {
 		uint32_t mk = 0;
@@ -1418,7 +1447,7 @@ classify(const xe_kparams &kp, REC &rec, int32_t device, uint32_t ridx, bool act
 			const xe_devrule dr = kp.devrules[device];
 			uint32_t cnt = 0;
 			for (uint32_t i = 0; i < dr.nprogs; i++) {
-				cnt += prog_match<REC, GET>(kp, rec, kp.progs[dr.first_prog + i]) ? 1u : 0u;
+				cnt += prog_match<REC, GET>(kp, rec, kp.progs[dr.first_prog + i], wc) ? 1u : 0u;
 			}
 			if (dr.skip_unmarked && (cnt == 0)) {
 				dropped = true;
@@ -1450,7 +1479,7 @@ classify(const xe_kparams &kp, REC &rec, int32_t device, uint32_t ridx, bool act
 							: ((kp.masks[(size_t)ridx * kp.mask_words + ((uint32_t)pr.parent >> 6)]
 								>> ((uint32_t)pr.parent & 63)) & 1) != 0;
 					}
-					hit = parent_ok && prog_match<REC, GET>(kp, rec, pr);
+					hit = parent_ok && prog_match<REC, GET>(kp, rec, pr, wc);
 				}
 				if (hit) bits |= 1ull << (m - m0);
 				/* counters: wave-wide sums, one atomic per wave and counter */
