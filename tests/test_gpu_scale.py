@@ -75,6 +75,20 @@ def test_seventy_lists(eng, orc):
     assert (b.counters()[:, 0] > 0).sum() > 60
 
 
+def test_c4_256_distinct_lists(eng, orc):
+    """every object tests a list of its own: 32 lookups (four words of lookup
+    bits per record), 256 list-only terms numbered behind the others"""
+    w = synth.workload_c4(12000, prefixes=1500, n_lists=256, variants=1)
+    mos = list(w["mos"])
+    mos += [("dst net big%d" % k, -1) for k in (3, 77, 200)] + [("proto 6", 3), ("net big9 or big250", 5)]
+    configure(eng, orc, w["iplists"], mos)
+    b = eng.prepare(w["batch"])
+    b.run()
+    run_oracle(orc, w["batch"], keep_flows=False)
+    compare(b, orc, flows=False)
+    assert (b.counters()[:, 0] > 0).sum() > 100
+
+
 def test_c4_nested_objects(eng, orc):
     """children under table-resolved and listed parents, across mask words"""
     w = synth.workload_c4(6000, prefixes=5000, n_lists=4, variants=4)

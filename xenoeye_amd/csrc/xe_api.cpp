@@ -31,6 +31,9 @@ struct xe_gpu
 	uint32_t nfprogs;          /* objects the fast kernel evaluates one by one */
 	uint32_t ntneed;           /* terms the fast kernel has to evaluate */
 	uint32_t ncjgroups, ncjderived, nrgroups;
+	uint32_t lw;               /* 64-bit words of lookup bits per record: 1 or XE_LK_WORDS */
+	uint32_t nplain_terms;     /* object terms [0, nplain_terms) have operands other than IP lists */
+	size_t motab_words;        /* u64 words of the atom table and its non-empty-row masks */
 	int fast_ok, want_dev;     /* want_dev: some object program reads dev_ip / dev_id */
 	int reads_mark;            /* some object program reads dev_mark */
 	char err[512];
@@ -594,8 +597,8 @@ prog_to_cnf(const struct xe_prog *pg, const uint32_t *op, const struct xe_fterm 
 			c->n = 1;
 			if (ft[t].kind & 1) {
 				/* all operands are lists: an OR of lookup bits */
-				for (int b = 0; b < 64; b++) {
-					if (!((ft[t].mask >> b) & 1)) continue;
+				for (int b = 0; b < 64 * XE_LK_WORDS; b++) {
+					if (!((ft[t].mask[b >> 6] >> (b & 63)) & 1)) continue;
 					if (c->c[0].n >= CNF_MAXL) { c->ok = 0; break; }
 					c->c[0].l[c->c[0].n].atom = (uint16_t)b;
 					c->c[0].l[c->c[0].n].neg = 0;
@@ -700,9 +703,44 @@ xe_gpu_commit(xe_gpu *h)
 			h->want_dev = rd & 1;
 			h->reads_mark = (rd & 2) != 0;
 		}
-		if (h->nterms > XE_MAX_FAST_TERMS) h->fast_ok = 0;
+		{
+			/* Terms whose operands are all IP lists are answered from the lookup
+			 * bits and need no term bit of their own unless a listed program
+			 * reads them: they are numbered after the others, so that only
+			 * the others count against the 256 term bits of a record. */
+			struct xe_term *tt = (struct xe_term *)terms.p;
+			const struct xe_dopnd *oo = (const struct xe_dopnd *)opnds.p;
+			uint32_t *op = (uint32_t *)ops.p;
+			size_t n = terms.n, k = 0;
+			uint32_t *newid = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+			struct xe_term *copy = (struct xe_term *)malloc((n ? n : 1) * sizeof(*copy));
+			if (!newid || !copy) {
+				rc = XE_ENOMEM;
+			} else {
+				for (int pass = 0; pass < 2; pass++) {
+					for (size_t t = 0; t < n; t++) {
+						int all_lists = (tt[t].func == XE_FN_NONE) && (tt[t].nopnd > 0)
+							&& ((tt[t].type == XE_BT_ADDR4) || (tt[t].type == XE_BT_ADDR6));
+						for (uint32_t j = 0; all_lists && (j < tt[t].nopnd); j++) {
+							if (!oo[tt[t].opnd_base + j].is_list) all_lists = 0;
+						}
+						if (all_lists == pass) newid[t] = (uint32_t)k++;
+					}
+					if (pass == 0) h->nplain_terms = (uint32_t)k;
+				}
+				memcpy(copy, tt, n * sizeof(*copy));
+				for (size_t t = 0; t < n; t++) tt[newid[t]] = copy[t];
+				for (size_t i = 0; i < ops.n; i++) {
+					if ((op[i] & 3) == XE_OP_BASIC) op[i] = XE_OP_BASIC | (newid[op[i] >> 2] << 2);
+				}
+			}
+			free(newid);
+			free(copy);
+		}
+		if (h->nplain_terms > XE_MAX_FAST_TERMS) h->fast_ok = 0;
 		h->nlookups = (uint32_t)lookups.n;
 		if (h->nlookups > XE_MAX_PROBES) h->fast_ok = 0;
+		h->lw = (h->nlookups <= 8) ? 1u : (uint32_t)XE_LK_WORDS;
 	}
 	for (size_t d = 0; (d < h->hs.ndevs) && (rc == XE_OK); d++) {
 		struct xe_devrule r;
@@ -743,21 +781,23 @@ xe_gpu_commit(xe_gpu *h)
 		for (uint32_t t = 0; (rc == XE_OK) && (t < h->nterms); t++) {
 			int all_lists = (tt[t].func == XE_FN_NONE) && (tt[t].nopnd > 0)
 				&& ((tt[t].type == XE_BT_ADDR4) || (tt[t].type == XE_BT_ADDR6));
-			uint64_t m = 0;
+			uint64_t m[XE_LK_WORDS];
+			memset(m, 0, sizeof(m));
 			for (uint32_t j = 0; all_lists && (j < tt[t].nopnd); j++) {
 				const struct xe_dopnd *o = &oo[tt[t].opnd_base + j];
 				if (!o->is_list) { all_lists = 0; break; }
-				if ((o->low >= 0) && (o->low < 64)) m |= 1ull << o->low;
-				if ((o->high >= 0) && (o->high < 64)) m |= 1ull << o->high;
+				if ((o->low >= 0) && (o->low < 64 * XE_LK_WORDS)) m[o->low >> 6] |= 1ull << (o->low & 63);
+				if ((o->high >= 0) && (o->high < 64 * XE_LK_WORDS)) m[o->high >> 6] |= 1ull << (o->high & 63);
 			}
 			ft[t].kind = all_lists ? 1 : 0;
-			ft[t].mask = all_lists ? m : 0;
+			for (int k = 0; k < XE_LK_WORDS; k++) ft[t].mask[k] = all_lists ? m[k] : 0;
 		}
 		{
 			/* objects resolved through the atom table, the rest listed */
 			size_t words = h->hs.nmos ? (h->hs.nmos + 63) / 64 : 1, nb = 0;
 			/* + per word: which lookup atoms / term atoms have a row that is not empty */
-			uint64_t *mt = (uint64_t *)calloc(words * (XE_MOTAB_ROWS + 2), sizeof(uint64_t));
+			const size_t mrows = XE_MOTAB_ROWS(h->lw);
+			uint64_t *mt = (uint64_t *)calloc(words * (mrows + h->lw + 1), sizeof(uint64_t));
 			uint64_t *cand = (uint64_t *)calloc(words, sizeof(uint64_t));
 			struct xe_cjderived *der = (struct xe_cjderived *)calloc(XE_MAX_DERIVED, sizeof(struct xe_cjderived));
 			struct xe_cjrow *rows = NULL;
@@ -776,9 +816,15 @@ xe_gpu_commit(xe_gpu *h)
 					q.kind = XE_FPROG_CONST;
 				} else if ((pg[m].nops == 1) && ((op[pg[m].op_base] & 3) == XE_OP_BASIC)) {
 					uint32_t t = op[pg[m].op_base] >> 2;
-					if (ft[t].kind & 1) {
+					if ((ft[t].kind & 1) && (h->lw == 1)) {
 						q.kind = XE_FPROG_MASK;
-						q.mask = ft[t].mask;
+						q.mask = ft[t].mask[0];
+					} else if ((ft[t].kind & 1) && (pg[m].parent < 0)) {
+						/* lookup bits in several words: straight to the atom table */
+						for (int bit = 0; bit < 64 * XE_LK_WORDS; bit++) {
+							if ((ft[t].mask[bit >> 6] >> (bit & 63)) & 1) mt[(m / 64) * mrows + bit] |= 1ull << (m % 64);
+						}
+						continue;
 					} else {
 						q.kind = XE_FPROG_TERM;
 						q.term = t;
@@ -788,12 +834,12 @@ xe_gpu_commit(xe_gpu *h)
 				}
 				if ((q.parent < 0) && (q.kind == XE_FPROG_MASK)) {
 					for (int bit = 0; bit < 64; bit++) {
-						if ((q.mask >> bit) & 1) mt[(m / 64) * XE_MOTAB_ROWS + bit] |= 1ull << (m % 64);
+						if ((q.mask >> bit) & 1) mt[(m / 64) * mrows + bit] |= 1ull << (m % 64);
 					}
 					continue;
 				}
 				if ((q.parent < 0) && (q.kind == XE_FPROG_TERM) && (q.term < 64)) {
-					mt[(m / 64) * XE_MOTAB_ROWS + 64 + q.term] |= 1ull << (m % 64);
+					mt[(m / 64) * mrows + 64 * h->lw + q.term] |= 1ull << (m % 64);
 					ft[q.term].kind |= 2;
 					continue;
 				}
@@ -816,9 +862,15 @@ xe_gpu_commit(xe_gpu *h)
 							memset(&d, 0, sizeof(d));
 							for (int li = 0; li < c->n; li++) {
 								uint32_t a = c->l[li].atom;
-								if (a < 64) { if (c->l[li].neg) d.neg_lk |= 1ull << a; else d.pos_lk |= 1ull << a; }
-								else if (a < 128) { if (c->l[li].neg) d.neg_tb |= 1ull << (a - 64); else d.pos_tb |= 1ull << (a - 64); }
-								else fits = 0;
+								if (a < XE_ATOM_TERM0) {
+									if (c->l[li].neg) d.neg_lk[a >> 6] |= 1ull << (a & 63);
+									else d.pos_lk[a >> 6] |= 1ull << (a & 63);
+								} else if (a < XE_ATOM_TERM0 + 64) {
+									if (c->l[li].neg) d.neg_tb |= 1ull << (a - XE_ATOM_TERM0);
+									else d.pos_tb |= 1ull << (a - XE_ATOM_TERM0);
+								} else {
+									fits = 0;
+								}
 							}
 							if (!fits) break;
 							for (j = 0; j < nder; j++) if (!memcmp(&der[j], &d, sizeof(d))) break;
@@ -896,8 +948,8 @@ xe_gpu_commit(xe_gpu *h)
 				memset(gof, 0xFF, sizeof(gof));
 				for (size_t j = 0; j < nrows; j++) {
 					uint32_t a = rows[j].atom;
-					uint32_t k = (a < XE_ATOM_TERM0) ? (a >> 3) : (a < XE_ATOM_DERIVED0) ? 8 + ((a - XE_ATOM_TERM0) >> 3)
-						: 40 + ((a - XE_ATOM_DERIVED0) >> 3);
+					uint32_t k = (a < XE_ATOM_TERM0) ? (a >> 3) : (a < XE_ATOM_DERIVED0) ? 32 + ((a - XE_ATOM_TERM0) >> 3)
+						: 64 + ((a - XE_ATOM_DERIVED0) >> 3);
 					gof[k] = 0;
 				}
 				for (uint32_t k = 0; k < XE_CJ_MAX_GROUPS; k++) if (gof[k] == 0) { gof[k] = (uint8_t)ng; gb[ng++] = k; }
@@ -907,8 +959,8 @@ xe_gpu_commit(xe_gpu *h)
 				}
 				for (size_t j = 0; (rc == XE_OK) && (j < nrows); j++) {
 					uint32_t a = rows[j].atom;
-					uint32_t k = (a < XE_ATOM_TERM0) ? (a >> 3) : (a < XE_ATOM_DERIVED0) ? 8 + ((a - XE_ATOM_TERM0) >> 3)
-						: 40 + ((a - XE_ATOM_DERIVED0) >> 3);
+					uint32_t k = (a < XE_ATOM_TERM0) ? (a >> 3) : (a < XE_ATOM_DERIVED0) ? 32 + ((a - XE_ATOM_TERM0) >> 3)
+						: 64 + ((a - XE_ATOM_DERIVED0) >> 3);
 					uint64_t *t0 = tab + (size_t)gof[k] * 256 * words + rows[j].word;
 					for (uint32_t v = 0; v < 256; v++) {
 						t0[(size_t)v * words] |= ((v >> (a & 7)) & 1) ? rows[j].forbid : rows[j].need;
@@ -935,11 +987,12 @@ xe_gpu_commit(xe_gpu *h)
 					"%zu need/forbid rows in %u byte tables, %zu derived atoms\n", h->hs.nmos, h->nterms, h->nlookups, nb, nrows, h->ncjgroups, nder);
 			}
 			for (size_t w = 0; mt && (w < words); w++) {
-				for (int a = 0; a < XE_MOTAB_ROWS; a++) {
-					if (mt[w * XE_MOTAB_ROWS + a]) mt[words * XE_MOTAB_ROWS + 2 * w + (a >> 6)] |= 1ull << (a & 63);
+				for (size_t a = 0; a < mrows; a++) {
+					if (mt[w * mrows + a]) mt[words * mrows + (h->lw + 1) * w + (a >> 6)] |= 1ull << (a & 63);
 				}
 			}
-			if (rc == XE_OK) rc = upload(h, &h->d_motab, mt, words * (XE_MOTAB_ROWS + 2) * sizeof(uint64_t));
+			h->motab_words = words * (mrows + h->lw + 1);
+			if (rc == XE_OK) rc = upload(h, &h->d_motab, mt, h->motab_words * sizeof(uint64_t));
 			if (rc == XE_OK) rc = upload(h, &h->d_fprogs, fp, nb * sizeof(*fp));
 			if (rc == XE_OK) rc = upload(h, &h->d_cjderived, der, nder * sizeof(*der));
 			if (rc == XE_OK) rc = upload(h, &h->d_cjcand, cand, words * sizeof(uint64_t));
@@ -1059,7 +1112,12 @@ xe_gpu_commit(xe_gpu *h)
 			uint32_t *need = (uint32_t *)calloc(h->nterms ? h->nterms : 1, sizeof(uint32_t));
 			uint32_t n = 0;
 			if (!need) rc = XE_ENOMEM;
-			for (uint32_t t = 0; (rc == XE_OK) && (t < h->nterms); t++) if (ft[t].kind & 2) need[n++] = t;
+			for (uint32_t t = 0; (rc == XE_OK) && (t < h->nterms); t++) {
+				if (!(ft[t].kind & 2)) continue;
+				need[n++] = t;
+				/* a list-only term beyond the term bits that a listed program reads */
+				if (t >= XE_MAX_FAST_TERMS) h->fast_ok = 0;
+			}
 			h->ntneed = n;
 			if (getenv("XE_DEBUG")) fprintf(stderr, "xe_gpu_commit: %u terms evaluated per record\n", n);
 			if (rc == XE_OK) rc = upload(h, &h->d_tneed, need, (size_t)n * sizeof(uint32_t));
@@ -1175,8 +1233,7 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 	for (i = 0; i < nt; i++) {
 		/* a block stages 4 tiles of 64 records in LDS, beside the counters and
 		 * the atom-table copy: long records only while all of it fits */
-		const size_t motab_bytes = ((size_t)h->mask_words * XE_MOTAB_ROWS * 8 <= 8192)
-			? (size_t)h->mask_words * (XE_MOTAB_ROWS + 2) * 8 : 0;
+		const size_t motab_bytes = (h->motab_words * 8 <= 8192 + 64) ? h->motab_words * 8 : 0;
 		const size_t stage_bytes = (size_t)4 * 64 * 4 * (4 * (((size_t)tm[i].stride + 15) / 16) + 1);
 		int ok = h->fast_ok && small && !tm[i].varlen && !tm[i].repeats
 			&& (tm[i].stride > 0) && (tm[i].stride <= XE_FAST_MAX_STRIDE)
@@ -1307,18 +1364,20 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 		b->kp.cjcand = (const uint64_t *)h->d_cjcand;
 		b->kp.ncjderived = h->ncjderived;
 		{
-			uint64_t list = ~0ull;
 			uint32_t k = 0;
-			for (uint32_t pr = 0; (pr < h->nlookups) && (k < 8); pr++) {
+			for (int w = 0; w < XE_LK_WORDS; w++) b->kp.all_probes[w] = ~0ull;
+			for (uint32_t pr = 0; (pr < h->nlookups) && (k < XE_MAX_PROBES); pr++) {
 				if (!h->h_probes[pr].root_off) continue;
-				list = (list & ~(0xFFull << (8 * k))) | ((uint64_t)pr << (8 * k));
+				b->kp.all_probes[k >> 3] = (b->kp.all_probes[k >> 3] & ~(0xFFull << (8 * (k & 7))))
+					| ((uint64_t)pr << (8 * (k & 7)));
 				k++;
 			}
-			b->kp.all_probes = list;
 			b->kp.per_object = h->fast_ok ? 0u : 1u;
+			b->kp.lw = h->lw;
 		}
 		b->kp.motab = (const uint64_t *)h->d_motab;
-		b->kp.motab_lds = ((size_t)h->mask_words * XE_MOTAB_ROWS * 8 <= 8192) ? 1u : 0u;
+		b->kp.motab_words = (uint32_t)h->motab_words;
+		b->kp.motab_lds = (h->motab_words * 8 <= 8192 + 64) ? 1u : 0u;
 		b->kp.probes = (const struct xe_probe *)h->d_lookups;
 		b->kp.nprobes = h->nlookups;
 		b->kp.lds_counters = (h->hs.nmos <= XE_MAX_LDS_COUNTER_MOS) ? 1u : 0u;
@@ -1493,16 +1552,16 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 			}
 			/* probes that can match at all: the field is there, the tables are not empty */
 			{
-				uint64_t list = ~0ull;
 				uint32_t k = 0;
-				for (uint32_t pr = 0; (pr < h->nlookups) && (k < 8); pr++) {
+				for (int w = 0; w < XE_LK_WORDS; w++) pl[t].probes[w] = ~0ull;
+				for (uint32_t pr = 0; (pr < h->nlookups) && (k < XE_MAX_PROBES); pr++) {
 					const struct xe_probe *q = &h->h_probes[pr];
 					if (q->root_off && (fld[q->field] & XE_FFLD_PRESENT)) {
-						list = (list & ~(0xFFull << (8 * k))) | ((uint64_t)pr << (8 * k));
+						pl[t].probes[k >> 3] = (pl[t].probes[k >> 3] & ~(0xFFull << (8 * (k & 7))))
+							| ((uint64_t)pr << (8 * (k & 7)));
 						k++;
 					}
 				}
-				pl[t].probes = list;
 			}
 		}
 		rc = upload(h, &b->d_fplans, pl, nt * sizeof(*pl));

@@ -23,6 +23,10 @@ enum { XE_T_ADDR = 0, XE_T_INT = 1, XE_T_MAC = 2, XE_T_STR = 3 };
 #define XE_NTABLE_FIELDS 63
 #define XE_F_NONE 0xFF
 
+/* lookup bits (list memberships) of a record: configurations with up to 8
+ * (list group, family, field) lookups use one 64-bit word, up to 32 use four */
+#define XE_LK_WORDS 4
+
 struct xe_field
 {
 	const char *name;
@@ -270,7 +274,7 @@ struct xe_fplan
 	uint32_t nparsed;    /* fields a complete record parses (all of the template's) */
 	uint32_t nchunk;     /* 16-byte pieces that cover one record */
 	uint32_t pad;
-	uint64_t probes;     /* byte i = i-th probe whose field the template carries, 0xFF = end */
+	uint64_t probes[XE_LK_WORDS]; /* byte i = i-th probe whose field the template carries, 0xFF = end */
 };
 
 /* per template and field (XE_NFIELDS words per template): where the field's
@@ -285,7 +289,7 @@ struct xe_fterm
 {
 	uint64_t kind;       /* bit 0: every operand is an IP list -> result = lookup bits & mask;
 	                        bit 1: some program needs the term's bit */
-	uint64_t mask;
+	uint64_t mask[XE_LK_WORDS];
 };
 
 /* Fast-kernel view of the object programs.
@@ -293,9 +297,9 @@ struct xe_fterm
  * Objects without a parent whose program is a single term are resolved through
  * a table: "atom" a (0-63: lookup bit a; 64-127: term a - 64) -> the set of
  * such objects that match when the atom is true; a record's match bits are the
- * OR of the rows of its true atoms (xe_kparams.motab[word][128]).
+ * OR of the rows of its true atoms (xe_kparams.motab[word][XE_MOTAB_ROWS(lw)]).
  * All other objects are listed, in index order, as xe_fprog entries. */
-#define XE_MOTAB_ROWS 128
+#define XE_MOTAB_ROWS(LW) (64 * (LW) + 64)   /* lookup atoms of LW words, then the first 64 terms */
 struct xe_fprog
 {
 	uint64_t mask;       /* XE_FPROG_MASK: lookup bits that make it match */
@@ -313,10 +317,10 @@ enum { XE_FPROG_GENERAL = 0, XE_FPROG_CONST = 1, XE_FPROG_MASK = 2, XE_FPROG_TER
 /* Objects whose program is a conjunction of clauses (each an OR of possibly
  * negated atoms) are matched all at once: an object fails when one of the
  * atoms it needs is false or one it forbids is true.
- * Atoms: 0-63 lookup bits, 64-319 terms, 320-383 derived (multi-literal clauses).
+ * Atoms: 0-255 lookup bits, 256-511 terms, 512-575 derived (multi-literal clauses).
  * One xe_cjrow per (atom, mask word) with objects that care about the atom. */
-#define XE_ATOM_TERM0 64
-#define XE_ATOM_DERIVED0 320
+#define XE_ATOM_TERM0 (64 * XE_LK_WORDS)
+#define XE_ATOM_DERIVED0 (XE_ATOM_TERM0 + 256)
 #define XE_MAX_DERIVED 64
 struct xe_cjrow
 {
@@ -326,7 +330,7 @@ struct xe_cjrow
 };
 /* derived atom: true iff some positive literal is true or some negative one
  * false; literals are lookup bits and terms 0-63 */
-struct xe_cjderived { uint64_t pos_lk, pos_tb, neg_lk, neg_tb; };
+struct xe_cjderived { uint64_t pos_lk[XE_LK_WORDS], neg_lk[XE_LK_WORDS], pos_tb, neg_tb; };
 
 /* Range terms grouped by the field they read.  Per group: `n` sorted
  * breakpoints over the field's value (int32, as the reference compares it)
@@ -339,8 +343,8 @@ struct xe_rgroup { uint32_t field, n, bp_off, tab_off; };
 /* Need / forbid rows folded into tables indexed by 8 atoms at once: per group
  * (one byte of the lookup bits, term bits or derived bits that some row
  * reads) 256 entries of `mask_words` u64: the objects that fail when the byte
- * has that value.  Byte k: 0..7 lookup bits, 8..39 term bits, 40..47 derived. */
-#define XE_CJ_MAX_GROUPS 48
+ * has that value.  Byte k: 0..31 lookup bits, 32..63 term bits, 64..71 derived. */
+#define XE_CJ_MAX_GROUPS (8 * XE_LK_WORDS + 32 + 8)
 
 
 struct xe_list_dev

@@ -80,7 +80,9 @@ struct xe_kparams
 	uint32_t nrgroups, ncjgroups;
 	const uint64_t *cjcand;      /* per mask word: the objects matched through cjrows */
 	uint32_t pad_cj, ncjderived;
-	uint64_t all_probes;         /* byte i = i-th probe with non-empty tables, 0xFF = end */
+	uint64_t all_probes[XE_LK_WORDS]; /* byte i = i-th probe with non-empty tables, 0xFF = end */
+	uint32_t lw;                 /* 64-bit words of lookup bits per record: 1, or XE_LK_WORDS */
+	uint32_t motab_words;        /* u64 words of the atom table with its non-empty-row masks */
 	uint32_t per_object, pad_po;   /* per_object: run every object's program on its own (limits exceeded) */
 	const uint32_t *fflds;       /* [template slot][XE_NFIELDS] XE_FFLD_* words */
 	uint32_t nfruns, ntiles;
@@ -103,7 +105,7 @@ struct xe_kparams
 #define XE_MAX_FAST_TERMS 256
 #define XE_FAST_MAX_STRIDE 256       /* longest record the fast kernel stages in LDS */
 #define XE_FAST_LDS_BUDGET (64 * 1024) /* LDS bytes per 256-thread block (2 blocks per CU) */
-#define XE_MAX_PROBES 8
+#define XE_MAX_PROBES (8 * XE_LK_WORDS)
 #define XE_MAX_LDS_COUNTER_MOS 1024
 
 #ifdef __cplusplus

@@ -613,16 +613,25 @@ tile_get(const lane_tile<REC, GET> &T, uint32_t field, uint32_t r, bool &has, ui
  * the probes whose field the template carries (byte i = probe index, 0xFF =
  * end).  Bit (8 * probe + l) of lk[r] = list l of the probe's group matched.
  */
-template <int R, typename TT>
+template <int R, int LW, typename TT>
 __device__ void
-fast_lookups(const xe_kparams &kp, const TT &T, uint64_t plist, uint64_t lk[R])
+fast_lookups(const xe_kparams &kp, const TT &T, const uint64_t (&plists)[LW], uint64_t (&lk)[R][LW])
 {
 	constexpr int PC = 2;
 	typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 #pragma unroll
-	for (int r = 0; r < R; r++) lk[r] = 0;
+	for (int r = 0; r < R; r++) {
+#pragma unroll
+		for (int w = 0; w < LW; w++) lk[r][w] = 0;
+	}
 
+	/* LW words of 8 probe indices each, filled from the front */
+#pragma unroll 1
+	for (int pw = 0; pw < LW; pw++) {
+	uint64_t plist = plists[0];
+#pragma unroll
+	for (int k = 1; k < LW; k++) plist = (pw == k) ? plists[k] : plist;
 	while ((plist & 0xFF) != 0xFF) {
 		uint32_t nodes[PC], chains[PC], used[PC], pidx[PC], bits[PC];
 		bool act[PC];
@@ -715,19 +724,37 @@ fast_lookups(const xe_kparams &kp, const TT &T, uint64_t plist, uint64_t lk[R])
 			if (!act[c]) continue;
 #pragma unroll
 			for (int r = 0; r < R; r++) {
-				lk[r] |= (uint64_t)(((e[c][r] & XE_TRIE_TERM) ? e[c][r] : 0u) & used[c] & 0xFFu)
-					<< (pidx[c] * XE_LIST_GROUP);
+				const uint64_t bits8 = (uint64_t)(((e[c][r] & XE_TRIE_TERM) ? e[c][r] : 0u) & used[c] & 0xFFu)
+					<< ((pidx[c] & 7) * XE_LIST_GROUP);
+				if (LW == 1) {
+					lk[r][0] |= bits8;
+				} else {
+#pragma unroll
+					for (int w = 0; w < LW; w++) lk[r][w] |= ((pidx[c] >> 3) == (uint32_t)w) ? bits8 : 0;
+				}
 			}
 		}
 		plist = (PC >= 8) ? ~0ull : ((plist >> (8 * PC)) | (~0ull << (64 - 8 * PC)));
+	}
 	}
 }
 
 /* one term for record r of all lanes; same semantics as term_match(), with the
  * list memberships taken from fast_lookups() */
-template <int R, typename TT>
+/* lookup bit `id` (8 * probe + list) of a record */
+template <int LW>
+__device__ __forceinline__ bool
+lk_bit(const uint64_t (&lk)[LW], uint32_t id)
+{
+	uint64_t w = lk[0];
+#pragma unroll
+	for (int k = 1; k < LW; k++) w = ((id >> 6) == (uint32_t)k) ? lk[k] : w;
+	return ((w >> (id & 63)) & 1) != 0;
+}
+
+template <int R, int LW, typename TT>
 __device__ bool
-fast_term(const xe_kparams &kp, const TT &T, const term_s &t, uint32_t r, uint64_t lkbits)
+fast_term(const xe_kparams &kp, const TT &T, const term_s &t, uint32_t r, const uint64_t (&lkbits)[LW])
 {
 	const xe_dopnd *o = t.o;
 	bool has;
@@ -773,7 +800,7 @@ fast_term(const xe_kparams &kp, const TT &T, const term_s &t, uint32_t r, uint64
 					cu32 q = (cu32)(o + i);
 					cu64 w = (cu64)(o + i);
 					bool m;
-					if (q[0]) m = ((lkbits >> q[(side == XE_DIR_SRC) ? 2 : 3]) & 1) != 0;
+					if (q[0]) m = lk_bit<LW>(lkbits, q[(side == XE_DIR_SRC) ? 2 : 3]);
 					else m = (a & (uint32_t)w[5]) == (uint32_t)w[3];
 					res |= m;
 				}
@@ -784,7 +811,7 @@ fast_term(const xe_kparams &kp, const TT &T, const term_s &t, uint32_t r, uint64
 					cu32 q = (cu32)(o + i);
 					cu64 w = (cu64)(o + i);
 					bool m;
-					if (q[0]) m = ((lkbits >> q[(side == XE_DIR_SRC) ? 2 : 3]) & 1) != 0;
+					if (q[0]) m = lk_bit<LW>(lkbits, q[(side == XE_DIR_SRC) ? 2 : 3]);
 					else m = ((hi & w[4]) == w[2]) && ((lo & w[5]) == w[3]);
 					res |= m;
 				}
@@ -1099,15 +1126,18 @@ range_groups(const xe_kparams &kp, const TT &T, uint64_t (&tb)[R][4])
 /* LEAN = the configuration has no range groups, conjunctive or listed objects
  * (objects with a single condition and no parent only): those parts are
  * compiled out, which keeps the common simple case small */
-template <int R, bool LEAN, typename TT>
+template <int R, bool LEAN, int LW, typename TT>
 __device__ __forceinline__ void
-classify_atoms(const xe_kparams &kp, const TT &T, uint64_t plist, uint64_t (&lk)[R], uint64_t (&tb)[R][4])
+classify_atoms(const xe_kparams &kp, const TT &T, const uint64_t (&plist)[LW], uint64_t (&lk)[R][LW], uint64_t (&tb)[R][4])
 {
 		if (kp.pad2 & 1) {
 #pragma unroll
-			for (int r = 0; r < R; r++) lk[r] = 0;
+			for (int r = 0; r < R; r++) {
+#pragma unroll
+				for (int w = 0; w < LW; w++) lk[r][w] = 0;
+			}
 		} else {
-			fast_lookups<R, TT>(kp, T, plist, lk);
+			fast_lookups<R, LW, TT>(kp, T, plist, lk);
 		}
 #pragma unroll
 		for (int r = 0; r < R; r++) tb[r][0] = tb[r][1] = tb[r][2] = tb[r][3] = 0;
@@ -1121,8 +1151,14 @@ classify_atoms(const xe_kparams &kp, const TT &T, uint64_t plist, uint64_t (&lk)
 			for (int r = 0; r < R; r++) {
 				bool res;
 				/* all operands IP lists: a mask over the lookup bits */
-				if (fkind & 1) res = (lk[r] & fq[1]) != 0;
-				else res = fast_term<R, TT>(kp, T, tm, r, lk[r]);
+				if (fkind & 1) {
+					uint64_t any = 0;
+#pragma unroll
+					for (int w = 0; w < LW; w++) any |= lk[r][w] & fq[1 + w];
+					res = any != 0;
+				} else {
+					res = fast_term<R, LW, TT>(kp, T, tm, r, lk[r]);
+				}
 				const uint64_t bit = (uint64_t)(T.live[r] && res) << (t & 63);
 				switch (t >> 6) {
 					case 0: tb[r][0] |= bit; break;
@@ -1138,9 +1174,9 @@ classify_atoms(const xe_kparams &kp, const TT &T, uint64_t plist, uint64_t (&lk)
 /* from lookup and term bits to the match masks and counters of a record:
  * the atom table, the conjunctive objects (need / forbid rows), the listed
  * objects; lcnt / lmt = the block's LDS counters and atom-table copy */
-template <int R, bool LEAN>
+template <int R, bool LEAN, int LW>
 __device__ __forceinline__ void
-classify_objects(const xe_kparams &kp, const bool (&live)[R], const uint64_t (&lk)[R], const uint64_t (&tb)[R][4],
+classify_objects(const xe_kparams &kp, const bool (&live)[R], const uint64_t (&lk)[R][LW], const uint64_t (&tb)[R][4],
 	const uint32_t (&ridx)[R], const unsigned long long (&bxr)[R], const unsigned long long (&pxr)[R],
 	unsigned long long *lcnt, const uint64_t *lmt)
 {
@@ -1149,12 +1185,15 @@ classify_objects(const xe_kparams &kp, const bool (&live)[R], const uint64_t (&l
 #pragma unroll
 		for (int r = 0; r < R; r++) dbits[r] = 0;
 		for (uint32_t j = 0; !LEAN && (j < kp.ncjderived) && !(kp.pad2 & 8); j++) {
+			/* xe_cjderived: pos_lk[4], neg_lk[4], pos_tb, neg_tb */
 			cu64 dq = (cu64)(kp.cjderived + j);
-			const uint64_t pl = dq[0], pt = dq[1], nl = dq[2], nt = dq[3];
+			const uint64_t pt = dq[8], nt = dq[9];
 #pragma unroll
 			for (int r = 0; r < R; r++) {
-				const bool d = (((lk[r] & pl) | (tb[r][0] & pt) | (~lk[r] & nl) | (~tb[r][0] & nt)) != 0);
-				dbits[r] |= (uint64_t)d << j;
+				uint64_t any = (tb[r][0] & pt) | (~tb[r][0] & nt);
+#pragma unroll
+				for (int w = 0; w < LW; w++) any |= (lk[r][w] & dq[w]) | (~lk[r][w] & dq[4 + w]);
+				dbits[r] |= (uint64_t)(any != 0) << j;
 			}
 		}
 
@@ -1165,24 +1204,33 @@ classify_objects(const xe_kparams &kp, const bool (&live)[R], const uint64_t (&l
 			uint64_t bits[R];
 			const uint32_t m0 = w * 64, m1 = (m0 + 64 < kp.nmo) ? m0 + 64 : kp.nmo;
 			/* atoms whose row for this word is not empty */
-			const size_t any_at = (size_t)kp.mask_words * XE_MOTAB_ROWS + 2 * w;
-			const uint64_t any_lk = kp.motab_lds ? lmt[any_at] : ((cu64)kp.motab)[any_at];
-			const uint64_t any_tb = kp.motab_lds ? lmt[any_at + 1] : ((cu64)kp.motab)[any_at + 1];
+			/* table of this mask word: 64 * LW lookup rows, 64 term rows; behind
+			 * all tables per mask word LW + 1 words: the rows that are not empty */
+			const uint32_t mrows = 64 * LW + 64;
+			const size_t any_at = (size_t)kp.mask_words * mrows + (size_t)(LW + 1) * w;
+			uint64_t any_lk[LW];
+#pragma unroll
+			for (int k = 0; k < LW; k++) any_lk[k] = kp.motab_lds ? lmt[any_at + k] : ((cu64)kp.motab)[any_at + k];
+			const uint64_t any_tb = kp.motab_lds ? lmt[any_at + LW] : ((cu64)kp.motab)[any_at + LW];
 #pragma unroll
 			for (int r = 0; r < R; r++) {
 				uint64_t acc = 0;
 				if (live[r]) {
-					uint64_t x = lk[r] & any_lk;
-					while (x) {
-						const uint32_t a = (uint32_t)__builtin_ctzll(x);
-						x &= x - 1;
-						acc |= kp.motab_lds ? lmt[w * XE_MOTAB_ROWS + a] : kp.motab[w * XE_MOTAB_ROWS + a];
+					uint64_t x;
+#pragma unroll
+					for (int k = 0; k < LW; k++) {
+						x = lk[r][k] & any_lk[k];
+						while (x) {
+							const uint32_t a = 64 * k + (uint32_t)__builtin_ctzll(x);
+							x &= x - 1;
+							acc |= kp.motab_lds ? lmt[w * mrows + a] : kp.motab[w * mrows + a];
+						}
 					}
 					x = tb[r][0] & any_tb;
 					while (x) {
-						const uint32_t a = 64 + (uint32_t)__builtin_ctzll(x);
+						const uint32_t a = 64 * LW + (uint32_t)__builtin_ctzll(x);
 						x &= x - 1;
-						acc |= kp.motab_lds ? lmt[w * XE_MOTAB_ROWS + a] : kp.motab[w * XE_MOTAB_ROWS + a];
+						acc |= kp.motab_lds ? lmt[w * mrows + a] : kp.motab[w * mrows + a];
 					}
 				}
 				bits[r] = acc;
@@ -1202,13 +1250,15 @@ classify_objects(const xe_kparams &kp, const bool (&live)[R], const uint64_t (&l
 						const uint32_t k = gq[0], ti = gq[1];
 #pragma unroll
 						for (int r = 0; r < R; r++) {
-							uint64_t src;
-							if (k < 8) src = lk[r];
-							else if (k < 16) src = tb[r][0];
-							else if (k < 24) src = tb[r][1];
-							else if (k < 32) src = tb[r][2];
-							else if (k < 40) src = tb[r][3];
-							else src = dbits[r];
+							/* byte k: 0-31 lookup bits, 32-63 term bits, 64-71 derived */
+							uint64_t src = lk[r][0];
+#pragma unroll
+							for (int q = 1; q < LW; q++) src = ((k >> 3) == (uint32_t)q) ? lk[r][q] : src;
+							if (k >= 32) src = tb[r][0];
+							if (k >= 40) src = tb[r][1];
+							if (k >= 48) src = tb[r][2];
+							if (k >= 56) src = tb[r][3];
+							if (k >= 64) src = dbits[r];
 							const uint32_t by = (uint32_t)(src >> ((k & 7) * 8)) & 0xFF;
 							e[c][r] = ((const XE_CONST uint64_t *)kp.cjtab)[((size_t)ti * 256 + by) * kp.mask_words + w];
 						}
@@ -1238,7 +1288,7 @@ classify_objects(const xe_kparams &kp, const bool (&live)[R], const uint64_t (&l
 				for (int r = 0; r < R; r++) {
 					bool h;
 					if (FP[2] == XE_FPROG_GATE) h = ((bits[r] >> (m - m0)) & 1) != 0;   /* matched above */
-					else h = prog_eval<R>(kp, FP, lk[r], tb[r]) && live[r];
+					else h = prog_eval<R>(kp, FP, lk[r][0], tb[r]) && live[r];
 					if (parent >= 0) {
 						const uint32_t par = (uint32_t)parent;
 						bool pok;
@@ -1278,7 +1328,7 @@ __device__ unsigned long long xe_fast_phase_cycles[8];
 #define XE_PHASE(N) do { if (kp.pad2 & 64) { const uint64_t now_ = __builtin_readcyclecounter(); \
 	if (lane == 0) atomicAdd(&xe_fast_phase_cycles[N], (unsigned long long)(now_ - tprev)); tprev = now_; } } while (0)
 
-template <int R, bool LEAN>
+template <int R, bool LEAN, int LW>
 __global__ void __launch_bounds__(XE_BLOCK)
 xe_nf_fast_kernel(const xe_kparams kp)
 {
@@ -1297,7 +1347,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 		for (uint32_t i = threadIdx.x; i < kp.nmo * 3; i += XE_BLOCK) lcnt[i] = 0;
 	}
 	if (kp.motab_lds) {
-		for (uint32_t i = threadIdx.x; i < kp.mask_words * (XE_MOTAB_ROWS + 2); i += XE_BLOCK) lmt[i] = kp.motab[i];
+		for (uint32_t i = threadIdx.x; i < kp.motab_words; i += XE_BLOCK) lmt[i] = kp.motab[i];
 	}
 	__syncthreads();
 
@@ -1326,7 +1376,10 @@ xe_nf_fast_kernel(const xe_kparams kp)
 		const uint32_t tmpl = C.tmpl, nchunk = C.nchunk;
 		cu32 PL = (cu32)(kp.fplans + tmpl);
 		const uint32_t op_base = PL[0], nparsed = PL[7];
-		const uint64_t plist = ((cu64)PL)[5];
+		/* xe_fplan: the probe lists are its 64-bit words 5..8 */
+		uint64_t plist[LW];
+#pragma unroll
+		for (int k = 0; k < LW; k++) plist[k] = ((cu64)PL)[5 + k];
 		fast_tile<R> T;
 		uint32_t ridx[R], rate[R];
 
@@ -1394,8 +1447,8 @@ xe_nf_fast_kernel(const xe_kparams kp)
 		}
 
 		/* every IP-list membership, then every term some program needs, once */
-		uint64_t lk[R], tb[R][4];
-		classify_atoms<R, LEAN>(kp, T, plist, lk, tb);
+		uint64_t lk[R][LW], tb[R][4];
+		classify_atoms<R, LEAN, LW>(kp, T, plist, lk, tb);
 		XE_PHASE(2);
 		XE_PHASE(3);
 		/* decode: the template's micro-ops, sorted by kind.  The stores come
@@ -1411,7 +1464,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 			if (PL[6]) general_ops<R>(kp, stg, j, PL[6], ridx, T.live);
 		}
 		XE_PHASE(4);
-		classify_objects<R, LEAN>(kp, T.live, lk, tb, ridx, bxr, pxr, lcnt, lmt);
+		classify_objects<R, LEAN, LW>(kp, T.live, lk, tb, ridx, bxr, pxr, lcnt, lmt);
 		XE_PHASE(5);
 		C = N;
 	}
@@ -1500,13 +1553,23 @@ classify(const xe_kparams &kp, REC &rec, int32_t device, uint32_t ridx, bool act
 	}
 
 	lane_tile<REC, GET> T;
-	uint64_t lk[1], tb[1][4];
+	uint64_t tb[1][4];
 	const uint32_t ri[1] = { ridx };
 	const unsigned long long bx[1] = { bytes_x_rate }, px[1] = { pkts_x_rate };
 	T.rec = &rec;
 	T.live[0] = active && !dropped;
-	classify_atoms<1, false>(kp, T, kp.all_probes, lk, tb);
-	classify_objects<1, false>(kp, T.live, lk, tb, ri, bx, px, lcnt, lmt);
+	if (kp.lw == 1) {
+		uint64_t lk[1][1];
+		const uint64_t pl[1] = { kp.all_probes[0] };
+		classify_atoms<1, false, 1>(kp, T, pl, lk, tb);
+		classify_objects<1, false, 1>(kp, T.live, lk, tb, ri, bx, px, lcnt, lmt);
+	} else {
+		uint64_t lk[1][XE_LK_WORDS];
+		uint64_t pl[XE_LK_WORDS];
+		for (int k = 0; k < XE_LK_WORDS; k++) pl[k] = kp.all_probes[k];
+		classify_atoms<1, false, XE_LK_WORDS>(kp, T, pl, lk, tb);
+		classify_objects<1, false, XE_LK_WORDS>(kp, T.live, lk, tb, ri, bx, px, lcnt, lmt);
+	}
 	/* a dropped record still owns its mask words */
 	if (active && dropped) {
 		for (uint32_t w = 0; w < kp.mask_words; w++) kp.masks[(size_t)ridx * kp.mask_words + w] = 0;
@@ -1523,7 +1586,7 @@ lane_kernel_lds(const xe_kparams &kp, uint64_t *lds, unsigned long long *&lcnt, 
 		for (uint32_t i = threadIdx.x; i < kp.nmo * 3; i += XE_BLOCK) lcnt[i] = 0;
 	}
 	if (kp.motab_lds) {
-		for (uint32_t i = threadIdx.x; i < kp.mask_words * (XE_MOTAB_ROWS + 2); i += XE_BLOCK) lmt[i] = kp.motab[i];
+		for (uint32_t i = threadIdx.x; i < kp.motab_words; i += XE_BLOCK) lmt[i] = kp.motab[i];
 	}
 	__syncthreads();
 }
@@ -2034,7 +2097,7 @@ xe_sf_kernel(const xe_kparams kp)
 	rec.q = kp.sfrecs;
 	/* the staging columns follow the counters and the atom-table copy */
 	rec.stg = (const uint32_t *)(lane_lds + (kp.lds_counters ? (size_t)kp.nmo * 3 : 0)
-		+ (kp.motab_lds ? (size_t)kp.mask_words * (XE_MOTAB_ROWS + 2) : 0)) + threadIdx.x;
+		+ (kp.motab_lds ? (size_t)kp.motab_words : 0)) + threadIdx.x;
 	rec.p = kp.pkt;
 	rec.left = 0;
 	if (active) {
@@ -2145,17 +2208,18 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 		uint32_t blocks = (kp->ntiles + per_block - 1) / per_block;
 		size_t shmem = (size_t)per_block * kp->fast_dwords * kp->fast_r * 64 * 4
 			+ (kp->lds_counters ? (size_t)kp->nmo * 24 : 0)
-			+ (kp->motab_lds ? (size_t)kp->mask_words * (XE_MOTAB_ROWS + 2) * 8 : 0);
+			+ (kp->motab_lds ? (size_t)kp->motab_words * 8 : 0);
 		if (blocks > 4096) blocks = 4096;
 		/* the kernel deals the tile list to 8 groups of blocks (blockIdx % 8):
 		 * every group needs at least one block */
 		if (blocks < 8) blocks = 8;
 		if (ev) (void)hipEventRecord(ev[0], st);
-		const bool lean = !kp->nrgroups && !kp->ncjgroups && !kp->ncjderived && !kp->nfprogs;
-		if (kp->fast_r == 4) hipLaunchKernelGGL((xe_nf_fast_kernel<4, false>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
-		else if (kp->fast_r == 2) hipLaunchKernelGGL((xe_nf_fast_kernel<2, false>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
-		else if (lean) hipLaunchKernelGGL((xe_nf_fast_kernel<1, true>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
-		else hipLaunchKernelGGL((xe_nf_fast_kernel<1, false>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
+		const bool lean = !kp->nrgroups && !kp->ncjgroups && !kp->ncjderived && !kp->nfprogs && (kp->lw == 1);
+		if (kp->lw != 1) hipLaunchKernelGGL((xe_nf_fast_kernel<1, false, XE_LK_WORDS>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
+		else if (kp->fast_r == 4) hipLaunchKernelGGL((xe_nf_fast_kernel<4, false, 1>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
+		else if (kp->fast_r == 2) hipLaunchKernelGGL((xe_nf_fast_kernel<2, false, 1>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
+		else if (lean) hipLaunchKernelGGL((xe_nf_fast_kernel<1, true, 1>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
+		else hipLaunchKernelGGL((xe_nf_fast_kernel<1, false, 1>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
 		if (ev) (void)hipEventRecord(ev[1], st);
 		if (hipGetLastError() != hipSuccess) return XE_EHIP;
 		if (kp->pad2 & 64) {
@@ -2170,7 +2234,7 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 		}
 	}
 	const size_t lane_lds = (kp->lds_counters ? (size_t)kp->nmo * 24 : 0)
-		+ (kp->motab_lds ? (size_t)kp->mask_words * (XE_MOTAB_ROWS + 2) * 8 : 0) + 16;
+		+ (kp->motab_lds ? (size_t)kp->motab_words * 8 : 0) + 16;
 	if (kp->nslowrec) {
 		uint32_t blocks = (kp->nslowrec + XE_BLOCK - 1) / XE_BLOCK;
 		if (ev) (void)hipEventRecord(ev[2], st);
