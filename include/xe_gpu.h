@@ -138,6 +138,11 @@ int xe_gpu_batch_sync(xe_batch *b);
 int xe_gpu_batch_timing(xe_batch *b, int enable);
 int xe_gpu_batch_kernel_ms(xe_batch *b, float ms[3]);
 
+/* data sets left out because their template has more elements than this
+ * library's device form of a template holds (254 within the first 64 KiB of a
+ * record; the reference has no such limit): 0 in any sane stream */
+size_t xe_gpu_batch_unsupported_sets(const xe_batch *b);
+
 /* sizes */
 size_t xe_gpu_batch_records(const xe_batch *b);      /* records reaching classification */
 size_t xe_gpu_batch_mask_words(const xe_batch *b);   /* 64-bit words per record */

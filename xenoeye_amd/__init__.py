@@ -54,6 +54,7 @@ def load_library(path=LIB_PATH):
         "xe_gpu_load_devices": (i32, [vp, cp]),
         "xe_gpu_commit": (i32, [vp]),
         "xe_gpu_set_prepass_threads": (i32, [vp, i32]),
+        "xe_gpu_batch_unsupported_sets": (C.c_size_t, [vp]),
         "xe_gpu_host_alloc": (vp, [vp, C.c_size_t]),
         "xe_gpu_host_free": (None, [vp, vp]),
         "xe_gpu_batch_prepare": (i32, [vp, vp, vp, vp, vp, sz, C.POINTER(vp)]),
@@ -233,6 +234,7 @@ class PreparedBatch:
         self.L = eng.L
         self._b = handle
         self.records = self.L.xe_gpu_batch_records(handle)
+        self.unsupported_sets = self.L.xe_gpu_batch_unsupported_sets(handle)
         self.mask_words = self.L.xe_gpu_batch_mask_words(handle)
         self.payload_bytes = self.L.xe_gpu_batch_payload_bytes(handle)
         self.algorithmic_bytes = self.L.xe_gpu_batch_algorithmic_bytes(handle)

@@ -651,6 +651,12 @@ reads_device_fields(const struct xe_term *terms, size_t n)
 	return r;
 }
 
+extern "C" size_t
+xe_gpu_batch_unsupported_sets(const xe_batch *b)
+{
+	return b ? b->plan.unsupported_sets : 0;
+}
+
 extern "C" void *
 xe_gpu_host_alloc(xe_gpu *h, size_t bytes)
 {

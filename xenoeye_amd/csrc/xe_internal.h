@@ -82,6 +82,7 @@ struct xe_tent
 #define XE_TE_REPEAT 4   /* an earlier entry of this template has the same destination */
 
 #define XE_TMPL_MAXF 254
+#define XE_TMPL_UNSUPPORTED 0xFFFFFFFFu   /* template slot: too many elements for the device form */
 #define XE_MODE_V9 0     /* field admitted while pos + len <= avail (netflow.c:284) */
 #define XE_MODE_IPFIX 1  /* field parsed, then stop when pos >= avail (netflow.c:596) */
 
@@ -461,6 +462,7 @@ struct xe_plan
 	uint64_t field_mask[2];    /* fields some template of the batch can set */
 	size_t soa_bytes_per_rec_sum; /* sum over records of stored widths (algorithmic bytes) */
 	size_t skipped_datagrams;  /* unknown version / aborted */
+	size_t unsupported_sets;   /* data sets of templates with more than XE_TMPL_MAXF reachable elements */
 	/* exporter (address, source id) -> index: open addressing, index + 1 */
 	uint32_t *ehash; size_t ehash_cap;
 	/* per device template slot, filled on first use in this batch: fields it

@@ -426,6 +426,9 @@ tmpl_put(struct xe_host *hs, const struct xe_tkey *k, const uint8_t *raw, size_t
 	}
 	rc = dev_template(hs, mode, types, lens, n, &slot);
 	free(types);
+	/* more elements than a device template holds: the template is remembered
+	 * as such and its data sets are left out (and counted) */
+	if (rc == XE_EUNSUPPORTED) { slot = XE_TMPL_UNSUPPORTED; rc = XE_OK; }
 	if (rc != XE_OK) return rc;
 
 	if (!s) {
@@ -532,6 +535,7 @@ v9_data_set(struct xe_host *hs, struct xe_plan *plan, struct dgram *d, long *ptr
 	long S, nfull, done, start;
 
 	if (!ts) return 0;
+	if (ts->dev_slot == XE_TMPL_UNSUPPORTED) { plan->unsupported_sets++; return 0; }
 	t = (const struct xe_tmpl *)hs->dev_tmpls.p + ts->dev_slot;
 	e = (const struct xe_tent *)hs->dev_tents.p + t->ent_base;
 	S = (t->varlen == 2) ? 0x10000 : t->stride;
@@ -670,6 +674,7 @@ ipfix_data_set(struct xe_host *hs, struct xe_plan *plan, struct dgram *d, long p
 	long fc, S;
 
 	if (!ts) return 0;
+	if (ts->dev_slot == XE_TMPL_UNSUPPORTED) { plan->unsupported_sets++; return 0; }
 	t = (const struct xe_tmpl *)hs->dev_tmpls.p + ts->dev_slot;
 	e = (const struct xe_tent *)hs->dev_tents.p + t->ent_base;
 	fc = ((long)ts->raw[2] << 8) | ts->raw[3];   /* the loop test uses the full field count */
@@ -1083,6 +1088,7 @@ pp_merge(struct pp_shared *sh, struct xe_plan *out)
 		out->field_mask[1] |= p->field_mask[1];
 		out->soa_bytes_per_rec_sum += p->soa_bytes_per_rec_sum;
 		out->skipped_datagrams += p->skipped_datagrams;
+		out->unsupported_sets += p->unsupported_sets;
 		for (i = 0; i < p->tinfo.n; i++) {
 			while (out->tinfo.n <= i) {
 				struct xe_tinfo z;
@@ -1210,6 +1216,7 @@ walker_reset(struct pp_thread *w)
 	p->field_mask[0] = p->field_mask[1] = 0;
 	p->soa_bytes_per_rec_sum = 0;
 	p->skipped_datagrams = 0;
+	p->unsupported_sets = 0;
 	if (p->ehash) memset(p->ehash, 0, p->ehash_cap * sizeof(uint32_t));
 	w->ents.n = w->efirst.n = 0;
 	free(w->eremap);
