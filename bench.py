@@ -39,6 +39,9 @@ def parse_args():
     ap.add_argument("--c4-lists", type=int, default=8, help="distinct lists of the c4 workload (objects = 256)")
     ap.add_argument("--cpu-sample", type=int, default=12000000, help="records timed on the CPU oracle (0 = skip)")
     ap.add_argument("--replicate", type=int, default=1, help="repeat the generated datagrams this many times")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="capture threads (one handle each) of the sustained host-inclusive measurement, 0/1 = skip")
+    ap.add_argument("--pipeline-rounds", type=int, default=6)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus > 1 (gloo: rehearsal of the multi-rank path on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -207,6 +210,52 @@ def main():
     b3.free()
     del m
 
+    # sustained host-inclusive rate: `args.pipeline` capture threads, each with a handle of its own
+    # (as INTEGRATION.md describes), take turns on this GPU: while one walks headers on the host,
+    # another copies or runs.  Every thread owns a share of the exporters and a page-locked buffer.
+    piped = None
+    if args.pipeline > 1 and world == 1:
+        import threading
+        from xenoeye_amd import shard as _sh
+        nthr, rounds = args.pipeline, args.pipeline_rounds
+        engines, inputs = [], []
+        for t in range(nthr):
+            e = xenoeye_amd.Engine(device=local_rank)
+            for name, text in w["iplists"].items():
+                e.add_iplist(name, text)
+            for filt, parent in w["mos"]:
+                e.add_mo("mo", filt, parent)
+            e.set_prepass_threads(max(1, 8 // nthr))
+            e.commit()
+            part = _sh.select(packed, t, nthr)
+            inputs.append((e.pinned(part[0]),) + tuple(part[1:]))
+            engines.append(e)
+        done = [0] * nthr
+
+        def worker(t):
+            st = torch.cuda.Stream(device=local_rank)
+            for _ in range(rounds):
+                bb = engines[t].prepare(inputs[t])
+                bb.run(st.cuda_stream)
+                bb.masks()
+                bb.counters()
+                done[t] += bb.records
+                bb.free()
+
+        for t in range(nthr):          # first batch of every handle untimed (templates, buffers)
+            bb = engines[t].prepare(inputs[t]); bb.run(stream); bb.counters(); bb.free()
+        ths = [threading.Thread(target=worker, args=(t,)) for t in range(nthr)]
+        t1 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        dt_p = time.perf_counter() - t1
+        piped = {"threads": nthr, "rounds": rounds, "records": int(sum(done)), "seconds": dt_p,
+                 "records_per_s": sum(done) / dt_p}
+        for e in engines:
+            e.close()
+
     from xenoeye_amd import shard
     dev = torch.device("cuda", local_rank) if args.backend == "nccl" else None
     dt_all, tot, pay = shard.reduce_scalars([dt, nrec, batch.payload_bytes], ["max", "sum", "sum"],
@@ -246,7 +295,8 @@ def main():
             "host_inclusive": {"prepare_s": t_prep, "prepare_run_fetch_s": t_e2e,
                                "records_per_s": nrec / t_e2e,
                                "page_locked_input_s": t_e2e_pinned,
-                               "page_locked_input_records_per_s": nrec / t_e2e_pinned},
+                               "page_locked_input_records_per_s": nrec / t_e2e_pinned,
+                               "pipelined": piped},
         }
         if args.cpu_sample > 0:
             rps, n_cpu, nd, secs = cpu_baseline(w, args.cpu_sample)

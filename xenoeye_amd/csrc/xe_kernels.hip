@@ -1328,8 +1328,14 @@ __device__ unsigned long long xe_fast_phase_cycles[8];
 #define XE_PHASE(N) do { if (kp.pad2 & 64) { const uint64_t now_ = __builtin_readcyclecounter(); \
 	if (lane == 0) atomicAdd(&xe_fast_phase_cycles[N], (unsigned long long)(now_ - tprev)); tprev = now_; } } while (0)
 
+#ifndef XE_FAST_WAVES
+#define XE_FAST_WAVES 0
+#endif
 template <int R, bool LEAN, int LW>
 __global__ void __launch_bounds__(XE_BLOCK)
+#if XE_FAST_WAVES
+__attribute__((amdgpu_waves_per_eu(XE_FAST_WAVES, XE_FAST_WAVES)))
+#endif
 xe_nf_fast_kernel(const xe_kparams kp)
 {
 	uint64_t tprev = __builtin_readcyclecounter();
