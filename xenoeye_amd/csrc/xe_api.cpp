@@ -1335,8 +1335,36 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 			/* sort key: batch index of the tile's first record */
 			ft[t].pad = fr[sidx].first_rec + (uint32_t)(g0 - fr[sidx].start);
 		}
-		/* groups are in arrival order already; merge them by that key */
-		qsort(ft, ntiles, sizeof(*ft), ftile_cmp);
+		/* every template's tiles are in arrival order already: merge the
+		 * groups by that key (a few templates: pick the smallest head; many:
+		 * sort) */
+		{
+			size_t gstart[17], gend[17], ng = 0, t;
+			for (t = 0; t < ntiles; t++) {
+				if (!t || (ft[t].tmpl != ft[t - 1].tmpl)) {
+					if (ng == 16) { ng = 17; break; }
+					if (ng) gend[ng - 1] = t;
+					gstart[ng++] = t;
+				}
+			}
+			if (ng && (ng <= 16)) gend[ng - 1] = ntiles;
+			if (ng > 16) {
+				qsort(ft, ntiles, sizeof(*ft), ftile_cmp);
+			} else if (ng > 1) {
+				struct xe_ftile *m = (struct xe_ftile *)malloc((ntiles + 1) * sizeof(*m));
+				if (!m) goto out;
+				for (t = 0; t < ntiles; t++) {
+					size_t best = 17, g;
+					for (g = 0; g < ng; g++) {
+						if (gstart[g] == gend[g]) continue;
+						if ((best == 17) || (ft[gstart[g]].pad < ft[gstart[best]].pad)) best = g;
+					}
+					m[t] = ft[gstart[best]++];
+				}
+				free(ft);
+				ft = m;
+			}
+		}
 	}
 	rc = upload(h, &b->d_fruns, fr, nfast * sizeof(*fr));
 	if (rc == XE_OK) rc = upload(h, &b->d_ftiles, ft, ntiles * sizeof(*ft));
