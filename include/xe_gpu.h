@@ -91,6 +91,27 @@ int xe_gpu_load_devices(xe_gpu *h, const char *path);
  * batch and after any configuration change */
 int xe_gpu_commit(xe_gpu *h);
 
+/* ---- fixed-window tables ----
+ * The per-record part of monit_object_process_nf() (monit-objects.h:288,
+ * monit-objects.c:923-1023) for one "fwm" entry of an object's mo.conf: per
+ * distinct key (the bytes of the key fields as struct flow_info holds them,
+ * one after the other) the wrapping u64 sums of value * scale * sampling rate
+ * of the aggregable fields.  `fields` are the strings of the entry's "fields"
+ * array (`[src|dst] name [asc|desc]`, `octets`, `bits`, `packets` ...,
+ * filter-parser.c:396-484; the function forms answer XE_EUNSUPPORTED).  The
+ * table lives on the device as long as the handle; every xe_gpu_batch_run()
+ * adds the batch's records to it.  Returns the table's index.  max_keys = the
+ * distinct keys to make room for (0: 65536); records whose key finds no room
+ * are counted in `dropped` (the reference drops them on TKVDB_ENOMEM). */
+int xe_gpu_add_fwm(xe_gpu *h, int mo, const char *const *fields, int nfields, size_t max_keys);
+int xe_gpu_fwm_info(const xe_gpu *h, int fwm, size_t *key_bytes, int *nvals, size_t *slots);
+/* rows in no particular order (the reference sorts when it exports a window,
+ * monit-objects-fwm.c:497-691): keys[row][key_bytes], vals[row][nvals].
+ * Returns the number of rows the table holds (copies at most max_rows). */
+long xe_gpu_fwm_read(xe_gpu *h, int fwm, uint8_t *keys, uint64_t *vals, size_t max_rows, uint64_t *dropped);
+/* end of a window: empties the table */
+int xe_gpu_fwm_clear(xe_gpu *h, int fwm);
+
 /* Host threads xe_gpu_batch_prepare() walks datagram headers with (default 8,
  * or the environment's XE_PREPASS_THREADS; 1 = the calling thread only).
  * Datagrams of one exporter stay on one thread, in arrival order, the way the
@@ -137,6 +158,7 @@ int xe_gpu_batch_sync(xe_batch *b);
  * kernel in milliseconds (-1 for a kernel the batch does not need) */
 int xe_gpu_batch_timing(xe_batch *b, int enable);
 int xe_gpu_batch_kernel_ms(xe_batch *b, float ms[3]);
+int xe_gpu_batch_fwm_ms(xe_batch *b, float *ms);   /* the fixed-window kernel, -1 without tables */
 
 /* data sets left out because their template has more elements than this
  * library's device form of a template holds (254 within the first 64 KiB of a

@@ -1826,6 +1826,208 @@ xo_counters(void)
 	return counters;
 }
 
+/* ------------------------------------------------------------------ */
+/* fixed-window tables (monit-objects.c:923-1023, filter-parser.c:348-484) */
+/* ------------------------------------------------------------------ */
+struct ofield   /* struct field, monit-objects.h; plain and aggregable fields only */
+{
+	int aggr, descending;
+	size_t off, size;
+	int scale;
+};
+
+struct ofwm
+{
+	int mo;
+	struct ofield naggr[16], aggr[8];
+	size_t n_naggr, n_aggr, keysize;
+	/* keyed sums: open addressing over `cap` rows of keysize bytes + n_aggr u64 */
+	uint8_t *keys;
+	uint64_t *vals;
+	uint8_t *used;
+	size_t cap, n;
+};
+
+static struct ofwm *fwms = NULL;
+static size_t n_fwms = 0;
+
+/* parse_field(), filter-parser.c:396-484, without the function forms */
+static int
+parse_field(const char *text, struct ofield *fld, char *err, size_t errlen)
+{
+	struct finput in;
+	int i, dir = DIR_BOTH, found = 0;
+
+	memset(&in, 0, sizeof(in));
+	memset(fld, 0, sizeof(*fld));
+	in.s = text;
+	read_token(&in);
+	if (in.error) { snprintf(err, errlen, "%s", in.errmsg); return 0; }
+	if (in.end) { snprintf(err, errlen, "Empty field not allowed"); return 0; }
+	switch (in.tok.id) {
+		case TK_DIV: case TK_DIV_R: case TK_DIV_L: case TK_MIN: case TK_MFREQ: case TK_GEOIP:
+		case TK_ASN: case TK_ASD: case TK_TFSTR: case TK_PORTSTR: case TK_PPSTR:
+			snprintf(err, errlen, "function fields are not restated by the oracle");
+			return 0;
+		default:
+			break;
+	}
+	for (i = 0; i < N_AGFIELDS; i++) {
+		if (accept_(&in, TK_AGFIELD0 + i)) {
+			fld->aggr = 1;
+			fld->size = 8;
+			fld->off = fields[agfields[i].field].off;
+			fld->scale = agfields[i].scale;
+			found = 1;
+			break;
+		}
+	}
+	if (!found) {
+		if (accept_(&in, TK_SRC)) dir = DIR_SRC;
+		else if (accept_(&in, TK_DST)) dir = DIR_DST;
+		for (i = 0; i < N_FFIELDS; i++) {
+			if (accept_(&in, TK_FIELD0 + i)) {
+				int fi;
+				if (dir == DIR_BOTH) {
+					if (ffields[i].src != ffields[i].dst) {
+						snprintf(err, errlen, "This field requires direction");
+						return 0;
+					}
+					fi = ffields[i].src;
+				} else {
+					fi = (dir == DIR_SRC) ? ffields[i].src : ffields[i].dst;
+				}
+				/* field_map_flow_info() knows the netflow.def fields only */
+				if (fi >= F_dev_ip6) { snprintf(err, errlen, "Unknown field"); return 0; }
+				fld->off = fields[fi].off;
+				fld->size = fields[fi].mx;
+				found = 1;
+				break;
+			}
+		}
+		if (!found) { snprintf(err, errlen, "Unknown field '%s'", in.tok.str); return 0; }
+	}
+	if (in.error) { snprintf(err, errlen, "%s", in.errmsg); return 0; }
+	if (accept_(&in, TK_DESC)) fld->descending = 1;
+	else (void)accept_(&in, TK_ASC);
+	if (in.error) { snprintf(err, errlen, "%s", in.errmsg); return 0; }
+	if (!in.end) { snprintf(err, errlen, "Extra symbols after field name"); return 0; }
+	return 1;
+}
+
+/* describes a field text: returns 1 and {aggr, offset, size, scale, descending} or 0 + err */
+int
+xo_field_parse(const char *text, int out[5], char *err, size_t errlen)
+{
+	struct ofield f;
+	if (!parse_field(text, &f, err, errlen)) return 0;
+	out[0] = f.aggr; out[1] = (int)f.off; out[2] = (int)f.size; out[3] = f.scale; out[4] = f.descending;
+	return 1;
+}
+
+/* one "fwm" entry of an object (fwm_fields_init(), monit-objects-fwm.c:28-100):
+ * the fields in the order given, split into key fields and aggregable ones */
+int
+xo_fwm_add(int mo, const char *const *field_texts, int n, char *err, size_t errlen)
+{
+	struct ofwm w, *tmp;
+	int i;
+
+	memset(&w, 0, sizeof(w));
+	w.mo = mo;
+	for (i = 0; i < n; i++) {
+		struct ofield f;
+		if (!parse_field(field_texts[i], &f, err, errlen)) return -1;
+		if (f.aggr) {
+			if (w.n_aggr == 8) { snprintf(err, errlen, "too many fields"); return -1; }
+			w.aggr[w.n_aggr++] = f;
+		} else {
+			if (w.n_naggr == 16) { snprintf(err, errlen, "too many fields"); return -1; }
+			w.naggr[w.n_naggr++] = f;
+			w.keysize += f.size;
+		}
+	}
+	tmp = realloc(fwms, (n_fwms + 1) * sizeof(*tmp));
+	if (!tmp) return -1;
+	fwms = tmp;
+	fwms[n_fwms] = w;
+	return (int)n_fwms++;
+}
+
+static void
+fwm_grow(struct ofwm *w)
+{
+	size_t ncap = w->cap ? w->cap * 2 : 1024, i, ks = w->keysize ? w->keysize : 1, na = w->n_aggr ? w->n_aggr : 1;
+	uint8_t *nk = calloc(ncap, ks), *nu = calloc(ncap, 1);
+	uint64_t *nv = calloc(ncap * na, sizeof(uint64_t));
+	for (i = 0; i < w->cap; i++) {
+		size_t h = 1469598103934665603ull, j, k;
+		if (!w->used[i]) continue;
+		for (k = 0; k < w->keysize; k++) h = (h ^ w->keys[i * ks + k]) * 1099511628211ull;
+		for (j = h & (ncap - 1); nu[j]; j = (j + 1) & (ncap - 1)) {}
+		nu[j] = 1;
+		memcpy(nk + j * ks, w->keys + i * ks, ks);
+		memcpy(nv + j * na, w->vals + i * na, na * sizeof(uint64_t));
+	}
+	free(w->keys); free(w->vals); free(w->used);
+	w->keys = nk; w->vals = nv; w->used = nu; w->cap = ncap;
+}
+
+/* the fixed-window part of monit_object_process_nf(), monit-objects.c:927-1023 */
+static void
+fwm_update(struct ofwm *w, struct xo_flow *flow)
+{
+	uint8_t key[16 * 64];
+	size_t pos = 0, f, j, h = 1469598103934665603ull, ks = w->keysize ? w->keysize : 1, na = w->n_aggr ? w->n_aggr : 1;
+
+	for (f = 0; f < w->n_naggr; f++) {
+		memcpy(key + pos, (uint8_t *)flow + w->naggr[f].off, w->naggr[f].size);
+		pos += w->naggr[f].size;
+	}
+	if ((w->n + 1) * 2 > w->cap) fwm_grow(w);
+	for (j = 0; j < w->keysize; j++) h = (h ^ key[j]) * 1099511628211ull;
+	for (j = h & (w->cap - 1); w->used[j]; j = (j + 1) & (w->cap - 1)) {
+		if (!memcmp(w->keys + j * ks, key, w->keysize)) break;
+	}
+	if (!w->used[j]) {
+		w->used[j] = 1;
+		memcpy(w->keys + j * ks, key, w->keysize);
+		w->n++;
+	}
+	for (f = 0; f < w->n_aggr; f++) {
+		uint64_t val = get_nf_val((uint8_t *)flow + w->aggr[f].off, 8);
+		w->vals[j * na + f] += val * (uint64_t)w->aggr[f].scale * flow->sampling_rate;
+	}
+}
+
+size_t xo_fwm_rows(int fwm) { return fwms[fwm].n; }
+size_t xo_fwm_keysize(int fwm) { return fwms[fwm].keysize; }
+size_t xo_fwm_nvals(int fwm) { return fwms[fwm].n_aggr; }
+
+/* rows of a table in no particular order: keys[row][keysize], vals[row][nvals] */
+void
+xo_fwm_dump(int fwm, uint8_t *keys, uint64_t *vals)
+{
+	struct ofwm *w = &fwms[fwm];
+	size_t i, r = 0, ks = w->keysize ? w->keysize : 1, na = w->n_aggr ? w->n_aggr : 1;
+	for (i = 0; i < w->cap; i++) {
+		if (!w->used[i]) continue;
+		memcpy(keys + r * w->keysize, w->keys + i * ks, w->keysize);
+		memcpy(vals + r * w->n_aggr, w->vals + i * na, w->n_aggr * sizeof(uint64_t));
+		r++;
+	}
+}
+
+static void
+fwms_free(void)
+{
+	size_t i;
+	for (i = 0; i < n_fwms; i++) { free(fwms[i].keys); free(fwms[i].vals); free(fwms[i].used); }
+	free(fwms);
+	fwms = NULL;
+	n_fwms = 0;
+}
+
 /* what monit_object_process_nf() sees (monit-objects.h:288); the oracle's
  * consumer adds {1, in_bytes*rate, in_pkts*rate} like the aggregable-field
  * arithmetic of monit-objects.c:995-1007 with scale 1 */
@@ -1839,6 +2041,10 @@ deliver(int mo_idx, struct xo_flow *flow, uint64_t *mask)
 	c[0] += 1;
 	c[1] += get_nf_val(flow->in_bytes, 8) * flow->sampling_rate;
 	c[2] += get_nf_val(flow->in_pkts, 8) * flow->sampling_rate;
+	{
+		size_t i;
+		for (i = 0; i < n_fwms; i++) if (fwms[i].mo == mo_idx) fwm_update(&fwms[i], flow);
+	}
 }
 
 /* netflow.c:213-244 / sflow.c:84-129: pre-order, children only if the
@@ -2616,6 +2822,7 @@ xo_reset(void)
 	}
 	free(mos); mos = NULL; n_mos = 0;
 	free(top_mos); top_mos = NULL; n_top = 0;
+	fwms_free();
 	for (i = 0; i < n_devices; i++) {
 		for (j = 0; j < devices[i].n_exprs; j++) fexpr_free(devices[i].exprs[j]);
 		free(devices[i].exprs);

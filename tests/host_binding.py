@@ -45,6 +45,7 @@ class Host:
                                     C.POINTER(C.c_int)]
         L.xe_ht_prepass.restype = C.c_void_p
         L.xe_ht_plan_free.argtypes = [C.c_void_p]
+        L.xe_ht_field_parse.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
         L.xe_ht_set_prepass_threads.argtypes = [C.c_void_p, C.c_int]
         L.xe_ht_set_prepass_threads.restype = None
         for f in ("nrec", "nsf", "nsets", "nexporters", "skipped"):
@@ -88,6 +89,12 @@ class Host:
         arr = np.ctypeslib.as_array(words, shape=(max(nw.value, 1),)).copy() if nw.value else np.zeros(1, np.uint32)
         self.L.xe_ht_release(words)
         return arr, [(d.root4, d.root6, d.nodes4, d.nodes6, d.bit, d.chains4, d.chains6) for d in dev[:n]]
+
+    def field_parse(self, text):
+        out = (C.c_int * 5)()
+        err = C.create_string_buffer(1100)
+        rc = self.L.xe_ht_field_parse(text.encode(), out, err, len(err))
+        return rc, tuple(out), err.value.decode(errors="replace")
 
     def prepass(self, batch, threads=None):
         if threads is not None:

@@ -31,6 +31,13 @@ class Oracle:
         L.xo_filter_dump.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
         L.xo_filter_match.argtypes = [C.c_int, C.c_void_p]
         L.xo_mo_add.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_size_t]
+        L.xo_field_parse.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
+        L.xo_fwm_add.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_char_p, C.c_size_t]
+        for f in ("xo_fwm_rows", "xo_fwm_keysize", "xo_fwm_nvals"):
+            getattr(L, f).argtypes = [C.c_int]
+            getattr(L, f).restype = C.c_size_t
+        L.xo_fwm_dump.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.xo_fwm_dump.restype = None
         L.xo_device_add.argtypes = [C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int,
                                     C.POINTER(C.c_char_p), C.c_int, C.c_char_p, C.c_size_t]
         L.xo_netflow_process.argtypes = [C.c_char_p, C.c_int, C.c_uint32]
@@ -88,6 +95,32 @@ class Oracle:
     def filter_match(self, h, flow_bytes):
         b = C.create_string_buffer(bytes(flow_bytes), FLOW_INFO_SIZE)
         return self.L.xo_filter_match(h, C.cast(b, C.c_void_p))
+
+    def field_parse(self, text):
+        """(aggr, offset, size, scale, descending) of a fixed-window field text"""
+        out = (C.c_int * 5)()
+        err = C.create_string_buffer(1100)
+        if not self.L.xo_field_parse(text.encode(), out, err, len(err)):
+            raise ValueError(err.value.decode(errors="replace"))
+        return tuple(out)
+
+    def fwm_add(self, mo, fields):
+        err = C.create_string_buffer(1100)
+        arr = (C.c_char_p * len(fields))(*[f.encode() for f in fields])
+        i = self.L.xo_fwm_add(mo, arr, len(fields), err, len(err))
+        if i < 0:
+            raise ValueError(err.value.decode(errors="replace"))
+        return i
+
+    def fwm_read(self, fwm):
+        """{key bytes: tuple of sums}"""
+        import numpy as np
+        n, ks, nv = self.L.xo_fwm_rows(fwm), self.L.xo_fwm_keysize(fwm), self.L.xo_fwm_nvals(fwm)
+        keys = np.zeros((max(n, 1), max(ks, 1)), dtype=np.uint8)
+        vals = np.zeros((max(n, 1), max(nv, 1)), dtype=np.uint64)
+        if n:
+            self.L.xo_fwm_dump(fwm, keys.ctypes.data, vals.ctypes.data)
+        return {bytes(keys[i, :ks]): tuple(int(x) for x in vals[i, :nv]) for i in range(n)}
 
     def mo_add(self, filt, parent=-1):
         err = C.create_string_buffer(1100)

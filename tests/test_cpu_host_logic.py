@@ -260,6 +260,28 @@ def test_prepass_counts_on_mutated_datagrams(orc):
         assert plan["nrec"] == orc.nrecords(), trial
 
 
+def test_fixed_window_field_parser_matches_oracle(host, orc):
+    """`fields` strings of an mo.conf "fwm" entry (parse_field(), filter-parser.c:396-484)"""
+    good = ["src host", "dst host desc", "proto", "octets", "bits desc", "packets asc", "src port", "dst port",
+            "src host6", "dst mac", "src as", "tcp-flags", "src tos", "src ifidx", "dst vlan", "SRC HOST DESC", "dev-ip",
+            "ioctets", "rpackets", "src net", "dst net6 asc"]
+    for f in good:
+        rc, got, err = host.field_parse(f)
+        assert rc == 0, (f, err)
+        assert got == orc.field_parse(f), f
+    assert host.field_parse("bits")[1][3] == 8 and host.field_parse("src host6")[1][2] == 16
+    for f in ["", "host", "port", "tos", "src", "src nothing", "octets extra", "src host desc desc", "dev-id", "dev-mark",
+              "src host asc desc", "proto 6", "(proto)"]:
+        rc, got, err = host.field_parse(f)
+        assert rc == -4, (f, rc, got)
+        with pytest.raises(ValueError):
+            orc.field_parse(f)
+    for f in ["div(octets, packets)", "min(src port, dst port)", "tfstr(tcp-flags)", "portstr(src port)",
+              "country(src host)", "vashost", "sni"]:
+        rc, got, err = host.field_parse(f)
+        assert rc == -5 and err, (f, rc)
+
+
 def test_prepass_with_threads_equals_single_thread():
     """the pre-pass sharded over threads by exporter gives the same plan as
     the single-threaded walk: set order, record indices, exporter table"""

@@ -1,0 +1,140 @@
+"""GPU parity of the fixed-window tables (the per-record part of
+monit_object_process_nf(), monit-objects.c:923-1023): for every table the set
+of rows {key bytes -> sums} equals the oracle's, whatever the order of
+records, across batches and across window ends."""
+import numpy as np
+import pytest
+
+import xenoeye_amd
+from xenoeye_amd import synth
+from helpers import configure, run_oracle, compare
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def eng():
+    e = xenoeye_amd.Engine(device=0)
+    yield e
+    e.close()
+
+
+def setup(eng, orc, w, tables, max_keys=0):
+    """tables: [(object index, [field strings])]"""
+    for name, text in (w.get("iplists") or {}).items():
+        eng.add_iplist(name, text)
+        orc.iplist_add(name, text)
+    for d in w.get("devices", ()):
+        eng.add_device(**d)
+        orc.device_add(**d)
+    for filt, parent in w["mos"]:
+        eng.add_mo("mo", filt, parent)
+        orc.mo_add(filt, parent)
+    ids = []
+    for mo, fields in tables:
+        g = eng.add_fwm(mo, fields, max_keys)
+        o = orc.fwm_add(mo, fields)
+        assert g == o
+        ids.append(g)
+    eng.commit()
+    return ids
+
+
+def same_tables(eng, orc, ids):
+    for t in ids:
+        got, dropped = eng.fwm_read(t)
+        want = orc.fwm_read(t)
+        assert dropped == 0
+        assert len(got) == len(want), (t, len(got), len(want))
+        assert got == want, t
+
+
+def test_c2_tables(eng, orc):
+    w = synth.workload_c2(30000, prefixes=300)
+    w["mos"] = list(w["mos"]) + [("", -1), ("proto 6", 16)]
+    tables = [(16, ["proto", "octets", "packets"]),                    # every record, tiny key
+              (16, ["src host", "dst host", "bits desc", "packets"]),   # absent for IPv6 records: zeros
+              (0, ["dst port", "proto", "octets"]),
+              (8, ["src host6", "packets", "bits"]),
+              (17, ["src port", "dst port", "tcp-flags", "src as", "octets desc"]),
+              (3, ["packets"]),                                         # no key field: one row
+              (5, ["dst host6", "src host", "dst ifidx", "src tos", "proto", "octets"])]
+    ids = setup(eng, orc, w, tables)
+    b = eng.prepare(w["batch"])
+    b.run()
+    run_oracle(orc, w["batch"], keep_flows=False)
+    compare(b, orc, flows=False)
+    same_tables(eng, orc, ids)
+    rows, _ = eng.fwm_read(ids[0])
+    assert len(rows) == 3 and sum(v[1] for v in rows.values()) > 30000
+    # a second batch adds to the same window
+    w2 = synth.workload_c2(12000, prefixes=300, seed=99)
+    b2 = eng.prepare(w2["batch"])
+    b2.run()
+    run_oracle(orc, w2["batch"], keep_flows=False)
+    same_tables(eng, orc, ids)
+    # window end
+    eng.fwm_clear(ids[1])
+    assert eng.fwm_read(ids[1])[0] == {}
+    assert len(eng.fwm_read(ids[2])[0]) > 0
+
+
+def test_devices_sampling_rate_scales_the_sums(eng, orc):
+    w = synth.workload_c1(5000)
+    w["devices"] = [dict(ip="192.0.2.1", sampling_rate=1000)]
+    ids = setup(eng, orc, w, [(0, ["dst port", "octets", "bits", "packets"]), (0, ["dev-ip", "packets"])])
+    b = eng.prepare(w["batch"])
+    b.run()
+    run_oracle(orc, w["batch"], keep_flows=False)
+    same_tables(eng, orc, ids)
+    rows, _ = eng.fwm_read(ids[1])
+    assert list(rows) == [bytes([192, 0, 2, 1])]
+    assert rows[bytes([192, 0, 2, 1])][0] % 1000 == 0
+
+
+def test_sflow_and_general_path_records(eng, orc):
+    """sFlow samples (left-aligned fields, per-sample rate), cut-short v9
+    records and mark-dropped ones: the tables see what the reference's
+    consumer sees"""
+    # record indices: Netflow records first, then sFlow ones; the batch is built in that order
+    w = synth.workload_c1(3000, per_packet=24)
+    w["mos"] = [("", -1), ("proto 6", 0)]
+    c3 = synth.workload_c3(1500)
+    for p, a, k in zip(c3["batch"].pkts, c3["batch"].src, c3["batch"].kind):
+        w["batch"].add(p, a, k)
+    w["devices"] = [dict(ip="192.0.2.1", sampling_rate=7, skip_unmarked=True, marks=("proto 17",))]
+    ids = setup(eng, orc, w, [(0, ["src mac", "src vlan", "proto", "octets", "packets"]),
+                              (1, ["src host", "tcp-flags", "bits"]),
+                              (0, ["src host6", "dst host6", "packets"]),
+                              (0, ["src ifidx", "dst ifidx", "octets"])])
+    b = eng.prepare(w["batch"])
+    b.run()
+    run_oracle(orc, w["batch"], keep_flows=False)
+    compare(b, orc, flows=False)
+    assert b.dropped().sum() > 0
+    same_tables(eng, orc, ids)
+
+
+def test_table_that_is_too_small_counts_what_it_drops(eng, orc):
+    w = synth.workload_c1(20000)
+    ids = setup(eng, orc, w, [(0, ["src host", "src port", "packets"])], max_keys=256)
+    b = eng.prepare(w["batch"])
+    b.run()
+    run_oracle(orc, w["batch"], keep_flows=False)
+    got, dropped = eng.fwm_read(ids[0])
+    want = orc.fwm_read(ids[0])
+    assert len(got) == 1024 and dropped > 0          # 256 keys asked for: 1024 slots
+    # a table never frees a slot within a window, so a key is either complete or absent
+    assert all(want[k] == v for k, v in got.items())
+    assert len(want) > len(got)
+
+
+def test_unsupported_fields_are_reported(eng):
+    eng.add_mo("mo", "", -1)
+    for f in (["div(octets, packets)", "octets"], ["sni", "packets"], ["tfstr(tcp-flags)", "packets"]):
+        with pytest.raises(xenoeye_amd.XeError) as e:
+            eng.add_fwm(0, f)
+        assert e.value.code == -5
+    with pytest.raises(xenoeye_amd.XeError) as e:
+        eng.add_fwm(0, ["host", "packets"])
+    assert e.value.code == -4

@@ -55,6 +55,11 @@ def load_library(path=LIB_PATH):
         "xe_gpu_commit": (i32, [vp]),
         "xe_gpu_set_prepass_threads": (i32, [vp, i32]),
         "xe_gpu_batch_unsupported_sets": (C.c_size_t, [vp]),
+        "xe_gpu_add_fwm": (i32, [vp, i32, C.POINTER(C.c_char_p), i32, C.c_size_t]),
+        "xe_gpu_fwm_info": (i32, [vp, i32, C.POINTER(C.c_size_t), C.POINTER(i32), C.POINTER(C.c_size_t)]),
+        "xe_gpu_fwm_read": (C.c_long, [vp, i32, vp, vp, C.c_size_t, C.POINTER(C.c_uint64)]),
+        "xe_gpu_fwm_clear": (i32, [vp, i32]),
+        "xe_gpu_batch_fwm_ms": (i32, [vp, C.POINTER(C.c_float)]),
         "xe_gpu_host_alloc": (vp, [vp, C.c_size_t]),
         "xe_gpu_host_free": (None, [vp, vp]),
         "xe_gpu_batch_prepare": (i32, [vp, vp, vp, vp, vp, sz, C.POINTER(vp)]),
@@ -183,6 +188,27 @@ class Engine:
         self._chk(self.L.xe_gpu_add_device(self._h, int(ip is not None), ipn, int(dev_id is not None),
                                            dev_id or 0, sampling_rate, int(skip_unmarked), arr, len(marks)))
 
+    def add_fwm(self, mo, fields, max_keys=0):
+        """fixed-window table of object `mo` over the given field strings; returns its index"""
+        arr = (C.c_char_p * len(fields))(*[f.encode() for f in fields])
+        return self._chk(self.L.xe_gpu_add_fwm(self._h, int(mo), arr, len(fields), int(max_keys)))
+
+    def fwm_read(self, fwm):
+        """{key bytes: tuple of sums}, and the number of records that found no room"""
+        kb, nv, sl = C.c_size_t(), C.c_int(), C.c_size_t()
+        self._chk(self.L.xe_gpu_fwm_info(self._h, fwm, C.byref(kb), C.byref(nv), C.byref(sl)))
+        n = self._chk(self.L.xe_gpu_fwm_read(self._h, fwm, None, None, 0, None))
+        keys = np.zeros((max(n, 1), max(kb.value, 1)), dtype=np.uint8)
+        vals = np.zeros((max(n, 1), max(nv.value, 1)), dtype=np.uint64)
+        dropped = C.c_uint64()
+        n2 = self._chk(self.L.xe_gpu_fwm_read(self._h, fwm, keys.ctypes.data, vals.ctypes.data, n, C.byref(dropped)))
+        assert n2 == n
+        return ({bytes(keys[i, :kb.value]): tuple(int(x) for x in vals[i, :nv.value]) for i in range(n)},
+                int(dropped.value))
+
+    def fwm_clear(self, fwm):
+        self._chk(self.L.xe_gpu_fwm_clear(self._h, fwm))
+
     def set_prepass_threads(self, n):
         """host threads that walk datagram headers in prepare() (1 = calling thread only)"""
         self._chk(self.L.xe_gpu_set_prepass_threads(self._h, int(n)))
@@ -258,6 +284,11 @@ class PreparedBatch:
 
     def timing(self, enable=True):
         self.eng._chk(self.L.xe_gpu_batch_timing(self._b, int(enable)))
+
+    def fwm_ms(self):
+        ms = C.c_float()
+        self.eng._chk(self.L.xe_gpu_batch_fwm_ms(self._b, C.byref(ms)))
+        return float(ms.value)
 
     def kernel_ms(self):
         """(fast netflow, general netflow, sflow) kernel time of the last run, -1 = not launched"""

@@ -31,12 +31,23 @@ struct xe_gpu
 	uint32_t nfprogs;          /* objects the fast kernel evaluates one by one */
 	uint32_t ntneed;           /* terms the fast kernel has to evaluate */
 	uint32_t ncjgroups, ncjderived, nrgroups;
+	/* fixed-window tables: they live as long as the handle, batches add to them */
+	struct fwm_host *fwms; size_t nfwm;
+	void *d_fwmdesc;
+	int fwm_devip;             /* some table is keyed by dev-ip: the kernels note it per record */
 	uint32_t lw;               /* 64-bit words of lookup bits per record: 1 or XE_LK_WORDS */
 	uint32_t nplain_terms;     /* object terms [0, nplain_terms) have operands other than IP lists */
 	size_t motab_words;        /* u64 words of the atom table and its non-empty-row masks */
 	int fast_ok, want_dev;     /* want_dev: some object program reads dev_ip / dev_id */
 	int reads_mark;            /* some object program reads dev_mark */
 	char err[512];
+};
+
+struct fwm_host
+{
+	struct xe_fwm_dev dev;     /* with the device pointers */
+	size_t slots, max_keys;
+	uint32_t keybytes;
 };
 
 struct xe_batch
@@ -46,12 +57,13 @@ struct xe_batch
 	size_t ntot, payload_bytes;
 	void *d_pkt, *d_sets, *d_exps, *d_sfrecs, *d_out;
 	void *d_fruns, *d_ftiles, *d_ssets, *d_swstart, *d_fplans, *d_fops, *d_fflds;
-	size_t out_bytes, masks_off, nparsed_off, marks_off, counters_off, sfhas_off;
+	size_t out_bytes, masks_off, nparsed_off, marks_off, counters_off, sfhas_off, rates_off, devips_off;
 	struct xe_kparams kp;
 	hipStream_t last_stream;
 	int ran;
 	int timing;              /* record events around each kernel launch */
 	hipEvent_t ev[6];
+	hipEvent_t ev_fwm[2];      /* around the fixed-window kernel */
 };
 
 #define ALIGN_UP(x, a) (((x) + (a) - 1) / (a) * (a))
@@ -139,6 +151,14 @@ xe_gpu_destroy(xe_gpu *h)
 	free_config_dev(h);
 	if (h->d_tmpls) (void)hipFree(h->d_tmpls);
 	if (h->d_tents) (void)hipFree(h->d_tents);
+	for (size_t i = 0; i < h->nfwm; i++) {
+		if (h->fwms[i].dev.state) (void)hipFree(h->fwms[i].dev.state);
+		if (h->fwms[i].dev.keys) (void)hipFree(h->fwms[i].dev.keys);
+		if (h->fwms[i].dev.vals) (void)hipFree(h->fwms[i].dev.vals);
+		if (h->fwms[i].dev.dropped) (void)hipFree(h->fwms[i].dev.dropped);
+	}
+	free(h->fwms);
+	if (h->d_fwmdesc) (void)hipFree(h->d_fwmdesc);
 	xe_host_free(&h->hs);
 	free(h);
 }
@@ -651,6 +671,134 @@ reads_device_fields(const struct xe_term *terms, size_t n)
 	return r;
 }
 
+/* ------------------------------------------------------------------ fixed-window tables */
+extern "C" int
+xe_gpu_add_fwm(xe_gpu *h, int mo, const char *const *fields, int nfields, size_t max_keys)
+{
+	struct fwm_host w, *tmp;
+	uint32_t pos = 0;
+
+	if (!h || !fields || (nfields < 1) || (mo < 0) || ((size_t)mo >= h->hs.nmos)) return XE_EINVAL;
+	memset(&w, 0, sizeof(w));
+	w.dev.mo = (uint32_t)mo;
+	for (int i = 0; i < nfields; i++) {
+		struct xe_agfield f;
+		char err[400];
+		int rc = xe_field_parse(fields[i], &f, err, sizeof(err));
+		if (rc != XE_OK) {
+			snprintf(h->err, sizeof(h->err), "field '%.100s': %s", fields[i], err);
+			return rc;
+		}
+		if (f.aggr) {
+			if (w.dev.nval == XE_FWM_MAX_VALS) {
+				snprintf(h->err, sizeof(h->err), "more than %d aggregable fields", XE_FWM_MAX_VALS);
+				return XE_EUNSUPPORTED;
+			}
+			w.dev.vfield[w.dev.nval] = f.field;
+			w.dev.vscale[w.dev.nval] = f.scale;
+			w.dev.nval++;
+		} else {
+			if ((w.dev.nkey == XE_FWM_MAX_KEY_FIELDS) || (pos + f.size > 8 * XE_FWM_MAX_KWORDS)) {
+				snprintf(h->err, sizeof(h->err), "key of more than %d fields or %d bytes",
+					XE_FWM_MAX_KEY_FIELDS, 8 * XE_FWM_MAX_KWORDS);
+				return XE_EUNSUPPORTED;
+			}
+			if (f.field == XF_dev_ip) h->fwm_devip = 1;
+			w.dev.kfield[w.dev.nkey] = f.field;
+			w.dev.ksize[w.dev.nkey] = (uint8_t)f.size;
+			w.dev.nkey++;
+			pos += f.size;
+		}
+	}
+	w.keybytes = pos;
+	w.dev.kwords = (pos + 7) / 8;
+	if (!w.dev.kwords) w.dev.kwords = 1;     /* no key field: one row for everything */
+	w.max_keys = max_keys ? max_keys : 65536;
+	w.slots = 1024;
+	while (w.slots < 2 * w.max_keys) w.slots <<= 1;
+	if (w.slots > 0x40000000u) return XE_EINVAL;
+	w.dev.cap_mask = (uint32_t)(w.slots - 1);
+
+	HIPCHK(h, hipSetDevice(h->device));
+	HIPCHK(h, hipMalloc((void **)&w.dev.state, w.slots * 4));
+	HIPCHK(h, hipMalloc((void **)&w.dev.keys, w.slots * w.dev.kwords * 8));
+	HIPCHK(h, hipMalloc((void **)&w.dev.vals, w.slots * (w.dev.nval ? w.dev.nval : 1) * 8));
+	HIPCHK(h, hipMalloc((void **)&w.dev.dropped, 8));
+	HIPCHK(h, hipMemset(w.dev.state, 0, w.slots * 4));
+	HIPCHK(h, hipMemset(w.dev.vals, 0, w.slots * (w.dev.nval ? w.dev.nval : 1) * 8));
+	HIPCHK(h, hipMemset(w.dev.dropped, 0, 8));
+
+	tmp = (struct fwm_host *)realloc(h->fwms, (h->nfwm + 1) * sizeof(*tmp));
+	if (!tmp) return XE_ENOMEM;
+	h->fwms = tmp;
+	h->fwms[h->nfwm] = w;
+	h->committed = 0;
+	return (int)h->nfwm++;
+}
+
+extern "C" int
+xe_gpu_fwm_info(const xe_gpu *h, int fwm, size_t *key_bytes, int *nvals, size_t *slots)
+{
+	if (!h || (fwm < 0) || ((size_t)fwm >= h->nfwm)) return XE_EINVAL;
+	if (key_bytes) *key_bytes = h->fwms[fwm].keybytes;
+	if (nvals) *nvals = (int)h->fwms[fwm].dev.nval;
+	if (slots) *slots = h->fwms[fwm].slots;
+	return XE_OK;
+}
+
+extern "C" long
+xe_gpu_fwm_read(xe_gpu *h, int fwm, uint8_t *keys, uint64_t *vals, size_t max_rows, uint64_t *dropped)
+{
+	struct fwm_host *w;
+	uint32_t *st = NULL;
+	uint64_t *k = NULL, *v = NULL;
+	size_t n = 0, nv;
+	long rc = XE_ENOMEM;
+
+	if (!h || (fwm < 0) || ((size_t)fwm >= h->nfwm)) return XE_EINVAL;
+	w = &h->fwms[fwm];
+	nv = w->dev.nval ? w->dev.nval : 1;
+	HIPCHK(h, hipSetDevice(h->device));
+	HIPCHK(h, hipDeviceSynchronize());
+	st = (uint32_t *)malloc(w->slots * 4);
+	k = (uint64_t *)malloc(w->slots * w->dev.kwords * 8);
+	v = (uint64_t *)malloc(w->slots * nv * 8);
+	if (!st || !k || !v) goto out;
+	if ((hipMemcpy(st, w->dev.state, w->slots * 4, hipMemcpyDeviceToHost) != hipSuccess)
+		|| (hipMemcpy(k, w->dev.keys, w->slots * w->dev.kwords * 8, hipMemcpyDeviceToHost) != hipSuccess)
+		|| (hipMemcpy(v, w->dev.vals, w->slots * nv * 8, hipMemcpyDeviceToHost) != hipSuccess)
+		|| (dropped && (hipMemcpy(dropped, w->dev.dropped, 8, hipMemcpyDeviceToHost) != hipSuccess))) {
+		rc = XE_EHIP;
+		goto out;
+	}
+	for (size_t i = 0; i < w->slots; i++) {
+		if (st[i] != 2) continue;
+		if (n < max_rows) {
+			if (keys) memcpy(keys + n * w->keybytes, k + i * w->dev.kwords, w->keybytes);
+			if (vals) memcpy(vals + n * w->dev.nval, v + i * nv, (size_t)w->dev.nval * 8);
+		}
+		n++;
+	}
+	rc = (long)n;
+out:
+	free(st); free(k); free(v);
+	return rc;
+}
+
+extern "C" int
+xe_gpu_fwm_clear(xe_gpu *h, int fwm)
+{
+	struct fwm_host *w;
+	if (!h || (fwm < 0) || ((size_t)fwm >= h->nfwm)) return XE_EINVAL;
+	w = &h->fwms[fwm];
+	HIPCHK(h, hipSetDevice(h->device));
+	HIPCHK(h, hipDeviceSynchronize());
+	HIPCHK(h, hipMemset(w->dev.state, 0, w->slots * 4));
+	HIPCHK(h, hipMemset(w->dev.vals, 0, w->slots * (w->dev.nval ? w->dev.nval : 1) * 8));
+	HIPCHK(h, hipMemset(w->dev.dropped, 0, 8));
+	return XE_OK;
+}
+
 extern "C" size_t
 xe_gpu_batch_unsupported_sets(const xe_batch *b)
 {
@@ -1132,6 +1280,13 @@ xe_gpu_commit(xe_gpu *h)
 		free(ft);
 		free(fp);
 	}
+	if ((rc == XE_OK) && h->nfwm) {
+		struct xe_fwm_dev *dv = (struct xe_fwm_dev *)malloc(h->nfwm * sizeof(*dv));
+		if (!dv) rc = XE_ENOMEM;
+		for (size_t i = 0; dv && (i < h->nfwm); i++) dv[i] = h->fwms[i].dev;
+		if (rc == XE_OK) rc = upload(h, &h->d_fwmdesc, dv, h->nfwm * sizeof(*dv));
+		free(dv);
+	}
 	if (rc == XE_OK) rc = upload(h, &h->d_progs, progs.p, progs.n * sizeof(struct xe_prog));
 	if (rc == XE_OK) rc = upload(h, &h->d_ops, ops.p, ops.n * 4);
 	if (rc == XE_OK) rc = upload(h, &h->d_terms, terms.p, terms.n * sizeof(struct xe_term));
@@ -1381,7 +1536,7 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 		b->kp.nslowrec = (uint32_t)slowrec;
 		b->kp.fast_r = R;
 		b->kp.fast_dwords = 4 * maxchunk + 1;   /* + 1: field reads look one dword ahead */
-		b->kp.fast_want_dev = (uint32_t)h->want_dev;
+		b->kp.fast_want_dev = (uint32_t)(h->want_dev || h->fwm_devip);
 		b->kp.nterms = h->nterms;
 		b->kp.fterms = (const struct xe_fterm *)h->d_fterms;
 		b->kp.tneed = (const uint32_t *)h->d_tneed;
@@ -1491,6 +1646,8 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 	b->marks_off = off;    if (h->hs.ndevs) off = ALIGN_UP(off + b->ntot * 4, 256);
 	b->counters_off = off; off = ALIGN_UP(off + (size_t)(h->nmo ? h->nmo : 1) * 24, 256);
 	b->sfhas_off = off;    off = ALIGN_UP(off + b->plan.nsf * 4, 256);
+	b->rates_off = off;    if (h->nfwm) off = ALIGN_UP(off + b->ntot * 4, 256);
+	b->devips_off = off;   if (h->fwm_devip) off = ALIGN_UP(off + b->ntot * 4, 256);
 	for (f = 0; f < XE_NFIELDS; f++) {
 		b->kp.col_off[f] = ~0ull;
 		b->kp.vsize_off[f] = ~0ull;
@@ -1635,6 +1792,8 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 	b->kp.marks = h->hs.ndevs ? (uint32_t *)((uint8_t *)b->d_out + b->marks_off) : NULL;
 	b->kp.counters = (unsigned long long *)((uint8_t *)b->d_out + b->counters_off);
 	b->kp.sf_has = (uint32_t *)((uint8_t *)b->d_out + b->sfhas_off);
+	b->kp.rates = h->nfwm ? (uint32_t *)((uint8_t *)b->d_out + b->rates_off) : NULL;
+	b->kp.devips = h->fwm_devip ? (uint32_t *)((uint8_t *)b->d_out + b->devips_off) : NULL;
 	XE_TICK();
 	if (dbg && (ntm_ == 7)) {
 		fprintf(stderr, "prepare: pre-pass %.2f, packets to device %.2f, plan tables %.2f, work lists %.2f, "
@@ -1655,6 +1814,10 @@ xe_gpu_batch_run(xe_batch *b, void *stream)
 	b->kp.tmpls = (const struct xe_tmpl *)b->h->d_tmpls;
 	b->kp.tents = (const struct xe_tent *)b->h->d_tents;
 	rc = xe_launch_batch(&b->kp, stream, b->timing ? (void **)b->ev : NULL);
+	if ((rc == XE_OK) && b->h->nfwm) {
+		rc = xe_launch_fwm(&b->kp, (const struct xe_fwm_dev *)b->h->d_fwmdesc, (uint32_t)b->h->nfwm, stream,
+			b->timing ? (void **)b->ev_fwm : NULL);
+	}
 	if (rc != XE_OK) {
 		snprintf(b->h->err, sizeof(b->h->err), "kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
 		return rc;
@@ -1679,8 +1842,19 @@ xe_gpu_batch_timing(xe_batch *b, int enable)
 	if (!b) return XE_EINVAL;
 	if (enable && !b->ev[0]) {
 		for (int i = 0; i < 6; i++) HIPCHK(b->h, hipEventCreate(&b->ev[i]));
+		for (int i = 0; i < 2; i++) HIPCHK(b->h, hipEventCreate(&b->ev_fwm[i]));
 	}
 	b->timing = enable ? 1 : 0;
+	return XE_OK;
+}
+
+extern "C" int
+xe_gpu_batch_fwm_ms(xe_batch *b, float *ms)
+{
+	if (!b || !ms) return XE_EINVAL;
+	if (!b->timing || !b->ran || !b->h->nfwm || !(b->plan.nrec + b->plan.nsf)) { *ms = -1.0f; return XE_OK; }
+	HIPCHK(b->h, hipStreamSynchronize(b->last_stream));
+	HIPCHK(b->h, hipEventElapsedTime(ms, b->ev_fwm[0], b->ev_fwm[1]));
 	return XE_OK;
 }
 

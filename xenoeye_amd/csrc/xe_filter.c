@@ -79,10 +79,10 @@ static const struct kfield kfields[] = {
 #define NKFIELDS ((int)(sizeof(kfields) / sizeof(kfields[0])))
 
 /* filter-ag.def:2-8 */
-static const struct { const char *kw; uint8_t field; } kaggr[] = {
-	{ "octets", XF_in_bytes }, { "bits", XF_in_bytes }, { "packets", XF_in_pkts },
-	{ "ioctets", XF_ioctets }, { "roctets", XF_roctets }, { "ipackets", XF_ipackets },
-	{ "rpackets", XF_rpackets },
+static const struct { const char *kw; uint8_t field; uint8_t scale; } kaggr[] = {
+	{ "octets", XF_in_bytes, 1 }, { "bits", XF_in_bytes, 8 }, { "packets", XF_in_pkts, 1 },
+	{ "ioctets", XF_ioctets, 1 }, { "roctets", XF_roctets, 1 }, { "ipackets", XF_ipackets, 1 },
+	{ "rpackets", XF_rpackets, 1 },
 };
 #define NKAGGR ((int)(sizeof(kaggr) / sizeof(kaggr[0])))
 
@@ -645,6 +645,73 @@ parse_expr(struct pctx *p)
 		emit_op(p, XE_OP_OR, 0);
 	}
 	return 1;
+}
+
+/* One field of a fixed-window table, `[src|dst] name [asc|desc]` or an
+ * aggregable name (parse_field(), filter-parser.c:396-484).  The function
+ * forms (div, min, mfreq, tfstr, portstr, ppstr, geoip, asn, asd) are
+ * recognised and reported as XE_EUNSUPPORTED. */
+int
+xe_field_parse(const char *text, struct xe_agfield *out, char *err, size_t errlen)
+{
+	struct pctx p;
+	int k, dir = XE_DIR_BOTH;
+
+	memset(&p, 0, sizeof(p));
+	memset(out, 0, sizeof(*out));
+	p.lx.s = text;
+	p.lx.t = T_ID;
+	next_token(&p.lx);
+	if (p.lx.failed) goto bad;
+	if (p.lx.at_end) { fail(&p.lx, "Empty field not allowed"); goto bad; }
+	switch (p.lx.t) {
+		case T_DIV: case T_DIV_R: case T_DIV_L: case T_MIN: case T_TFSTR: case T_OTHERFUNC:
+			if (err && errlen) snprintf(err, errlen, "function fields are not supported by this library");
+			return XE_EUNSUPPORTED;
+		default:
+			break;
+	}
+	if (p.lx.t == T_AGGR) {
+		out->aggr = 1;
+		out->field = kaggr[p.lx.val].field;
+		out->scale = kaggr[p.lx.val].scale;
+		out->size = 8;
+		next_token(&p.lx);
+	} else {
+		if (take(&p, T_SRC)) dir = XE_DIR_SRC;
+		else if (take(&p, T_DST)) dir = XE_DIR_DST;
+		if (p.lx.failed) goto bad;
+		if (p.lx.t != T_FIELD) {
+			char m[600];
+			snprintf(m, sizeof(m), "Unknown field '%.400s'", p.lx.text);
+			fail(&p.lx, m);
+			goto bad;
+		}
+		k = p.lx.val;
+		if ((dir == XE_DIR_BOTH) && (kfields[k].src != kfields[k].dst)) {
+			fail(&p.lx, "This field requires direction");
+			goto bad;
+		}
+		out->field = (dir == XE_DIR_DST) ? kfields[k].dst : kfields[k].src;
+		/* the three virtual fields have no entry in the field table the
+		 * reference maps names through (filter-parser.c:256-271) */
+		if (out->field >= XE_NTABLE_FIELDS) { fail(&p.lx, "Unknown field"); goto bad; }
+		out->size = xe_fields[out->field].size_max;
+		next_token(&p.lx);
+	}
+	if (p.lx.failed) goto bad;
+	if (!p.lx.at_end && take(&p, T_DESC)) out->descending = 1;
+	else if (!p.lx.at_end) (void)take(&p, T_ASC);
+	if (p.lx.failed) goto bad;
+	if (!p.lx.at_end) { fail(&p.lx, "Extra symbols after field name"); goto bad; }
+	if (!out->aggr && (xe_fields[out->field].type == XE_T_STR)) {
+		if (err && errlen) snprintf(err, errlen, "string fields are not supported as table keys by this library");
+		return XE_EUNSUPPORTED;
+	}
+	return XE_OK;
+bad:
+	if (err && errlen) snprintf(err, errlen, "%s", p.lx.msg);
+	return XE_EPARSE;
 }
 
 void

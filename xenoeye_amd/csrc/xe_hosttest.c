@@ -104,6 +104,17 @@ xe_ht_prepass(struct xe_host *hs, const uint8_t *data, const uint64_t *offs, con
 void xe_ht_plan_free(struct xe_plan *p) { if (p) { xe_plan_free(p); free(p); } }
 void xe_ht_set_prepass_threads(struct xe_host *hs, int n) { hs->prepass_threads = n; }
 
+/* a fixed-window field text: {aggr, offset in struct flow_info, size, scale, descending} */
+int
+xe_ht_field_parse(const char *text, int out[5], char *err, size_t errlen)
+{
+	struct xe_agfield f;
+	int rc = xe_field_parse(text, &f, err, errlen);
+	if (rc != XE_OK) return rc;
+	out[0] = f.aggr; out[1] = xe_fields[f.field].off; out[2] = (int)f.size; out[3] = f.scale; out[4] = f.descending;
+	return XE_OK;
+}
+
 /* stride of the flattened list nodes, for the tests' own walk */
 int xe_ht_node_bits(void) { return XE_NODE_BITS; }
 

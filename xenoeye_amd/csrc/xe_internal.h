@@ -394,6 +394,9 @@ int xe_filter_compile(const struct xe_iplists *reg, const char *text, struct xe_
 	char *err, size_t errlen);
 void xe_filter_free(struct xe_filter *f);
 int xe_filter_dump_text(const struct xe_iplists *reg, const struct xe_filter *f, char *out, size_t outlen);
+/* a field of a fixed-window table (struct field, monit-objects.h) */
+struct xe_agfield { uint8_t aggr, field, descending, scale; uint32_t size; };
+int xe_field_parse(const char *text, struct xe_agfield *out, char *err, size_t errlen);
 /* static analysis of the stack discipline (filter.c:960-1012): returns 1 and
  * sets *cval when the result does not depend on the record */
 int xe_filter_constant(const struct xe_filter *f, int *cval);

@@ -83,6 +83,8 @@ struct xe_kparams
 	uint64_t all_probes[XE_LK_WORDS]; /* byte i = i-th probe with non-empty tables, 0xFF = end */
 	uint32_t lw;                 /* 64-bit words of lookup bits per record: 1, or XE_LK_WORDS */
 	uint32_t motab_words;        /* u64 words of the atom table with its non-empty-row masks */
+	uint32_t *rates;             /* per record: sampling rate (only when fixed-window tables exist) */
+	uint32_t *devips;            /* per record: dev_ip bytes (only when a table is keyed by it) */
 	uint32_t per_object, pad_po;   /* per_object: run every object's program on its own (limits exceeded) */
 	const uint32_t *fflds;       /* [template slot][XE_NFIELDS] XE_FFLD_* words */
 	uint32_t nfruns, ntiles;
@@ -115,6 +117,29 @@ extern "C" {
 /* events: NULL, or 6 hipEvent_t = start/stop pairs recorded on `stream` around
  * the fast, general and sFlow kernel launches (only around those that run) */
 int xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events);
+
+/* Fixed-window table of one object on the device (the per-record part of
+ * monit_object_process_nf(), monit-objects.c:927-1023): an open-addressing
+ * hash table of `cap_mask + 1` slots; slot i = state[i] (0 free, 1 being
+ * written, 2 ready), keys[i][kwords] (the key fields' bytes as struct
+ * flow_info holds them, one after the other, zero padded to whole words) and
+ * vals[i][nval] (wrapping sums of value * scale * sampling rate). */
+#define XE_FWM_MAX_KEY_FIELDS 8
+#define XE_FWM_MAX_VALS 4
+#define XE_FWM_MAX_KWORDS 8
+struct xe_fwm_dev
+{
+	uint32_t mo, nkey, nval, kwords;
+	uint32_t cap_mask, pad;
+	uint32_t *state;
+	uint64_t *keys;
+	unsigned long long *vals;
+	unsigned long long *dropped;      /* records whose key found no free slot */
+	uint8_t kfield[XE_FWM_MAX_KEY_FIELDS], ksize[XE_FWM_MAX_KEY_FIELDS];
+	uint8_t vfield[XE_FWM_MAX_VALS], vscale[XE_FWM_MAX_VALS];
+};
+int xe_launch_fwm(const struct xe_kparams *kp, const struct xe_fwm_dev *tables, uint32_t ntables, void *stream,
+	void **events);
 /* n addresses (4 or 16 bytes each) against one flattened list */
 int xe_launch_trie_probe(const uint32_t *trie, struct xe_list_dev list, int family,
 	const uint8_t *addrs, uint32_t n, uint8_t *out, void *stream);

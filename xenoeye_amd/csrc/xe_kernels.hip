@@ -1444,6 +1444,8 @@ xe_nf_fast_kernel(const xe_kparams kp)
 				/* device_rules_check() without mark filters (devices.c:286-314):
 				 * the mark is present, its value 0 */
 				if (kp.marks) ((XE_GLOBAL uint32_t *)kp.marks)[ridx[r]] = C.hasdev[r] ? XE_MARK_HAS : 0u;
+				if (kp.rates) ((XE_GLOBAL uint32_t *)kp.rates)[ridx[r]] = rate[r];
+				if (kp.devips) ((XE_GLOBAL uint32_t *)kp.devips)[ridx[r]] = __builtin_bswap32(C.dev_ip[r]);
 			}
 			/* what the counters add (monit-objects.c:995-1007, scale 1) */
 			fld_get<R>(T, XF_in_bytes, r, has, fmax, hi, b);
@@ -1720,6 +1722,11 @@ xe_nf_general_kernel(const xe_kparams kp)
 
 		/* what the counters add: get_nf_val(8 bytes) * sampling_rate, wrapping */
 		uint64_t rate = rec.ex->sampling_rate;
+		if (kp.rates) kp.rates[ridx] = (uint32_t)rate;
+		if (kp.devips) {
+			const uint8_t *d = rec.ex->dev_ip;
+			kp.devips[ridx] = (uint32_t)d[0] | ((uint32_t)d[1] << 8) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 24);
+		}
 		bxr = nf_get(rec, XF_in_bytes, nullptr).v.lo * rate;
 		pxr = nf_get(rec, XF_in_pkts, nullptr).v.lo * rate;
 	}
@@ -2123,6 +2130,13 @@ xe_sf_kernel(const xe_kparams kp)
 		sf_store_all(kp, rec, ridx, std::make_integer_sequence<int, SF_NFIELDS>());
 		device = kp.exps[rec.q->exporter].device;
 		uint64_t rate = rec.q->sampling_rate;
+		if (kp.rates) kp.rates[ridx] = (uint32_t)rate;
+		if (kp.devips) {
+			/* dev_ip = the agent's address when it is an IPv4 one (sflow-impl.h:330-345) */
+			const uint8_t *d = rec.q->agent;
+			kp.devips[ridx] = (rec.q->agent_ver == 4)
+				? ((uint32_t)d[0] | ((uint32_t)d[1] << 8) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 24)) : 0u;
+		}
 		bxr = sf_get(rec, XF_in_bytes, nullptr).v.lo * rate;
 		pxr = sf_get(rec, XF_in_pkts, nullptr).v.lo * rate;
 		if (!deliver && kp.marks) kp.marks[ridx] = 0;
@@ -2132,6 +2146,116 @@ xe_sf_kernel(const xe_kparams kp)
 		for (uint32_t w = 0; w < kp.mask_words; w++) kp.masks[(size_t)ridx * kp.mask_words + w] = 0;
 	}
 	lane_kernel_flush(kp, lcnt);
+}
+
+/* ------------------------------------------------------------------ fixed-window tables */
+/*
+ * One thread per record, after classification: for every table whose object
+ * received the record, the key is put together from the decoded columns (the
+ * bytes struct flow_info holds, monit-objects.c:917-920), looked up or
+ * inserted, and value * scale * sampling rate is added to its sums
+ * (monit-objects.c:986-1008; wrapping u64, so the order of records and the
+ * split over batches and GPUs do not matter).
+ */
+__global__ void __launch_bounds__(XE_BLOCK)
+xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables)
+{
+	const uint32_t r = blockIdx.x * XE_BLOCK + threadIdx.x, ntot = kp.nrec + kp.nsf;
+	const bool active = r < ntot;
+
+	for (uint32_t f = 0; f < ntables; f++) {
+		const xe_fwm_dev F = tables[f];
+		bool hit = active && (((kp.masks[(size_t)r * kp.mask_words + (F.mo >> 6)] >> (F.mo & 63)) & 1) != 0);
+		if (!__ballot(hit)) continue;
+		if (!hit) continue;
+
+		/* the key: field bytes one after the other, packed into words */
+		uint64_t kw[XE_FWM_MAX_KWORDS];
+#pragma unroll
+		for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) kw[i] = 0;
+		uint32_t pos = 0;
+		for (uint32_t k = 0; k < F.nkey; k++) {
+			const uint32_t fld = F.kfield[k], size = F.ksize[k];
+			const uint64_t co = kp.col_off[fld];
+			for (uint32_t b = 0; b < size; b++, pos++) {
+				/* a field no template of the batch carries reads as zeros */
+				uint64_t by;
+				if (fld == XF_dev_ip) by = (kp.devips[r] >> (8 * b)) & 0xFF;   /* comes from the exporter */
+				else by = (co == ~0ull) ? 0 : kp.out_base[co + (size_t)r * c_colw[fld] + b];
+				const uint64_t sh = by << ((pos & 7) * 8);
+#pragma unroll
+				for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) kw[i] |= ((pos >> 3) == (uint32_t)i) ? sh : 0;
+			}
+		}
+		uint64_t h = 0xcbf29ce484222325ull;
+#pragma unroll
+		for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
+			if ((uint32_t)i < F.kwords) h = (h ^ kw[i]) * 0x100000001b3ull;
+		}
+		h ^= h >> 29;
+		const uint64_t rate = kp.rates[r];
+
+		uint32_t slot = (uint32_t)h & F.cap_mask, tried = 0;
+		bool done = false;
+		while (!done) {
+			uint32_t st = __hip_atomic_load(&F.state[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+			if (st == 0) {
+				const uint32_t old = atomicCAS(&F.state[slot], 0u, 1u);
+				if (old == 0) {
+					for (uint32_t i = 0; i < F.kwords; i++) {
+						uint64_t w = kw[0];
+#pragma unroll
+						for (int q = 1; q < XE_FWM_MAX_KWORDS; q++) w = (i == (uint32_t)q) ? kw[q] : w;
+						F.keys[(size_t)slot * F.kwords + i] = w;
+					}
+					__hip_atomic_store(&F.state[slot], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+					st = 2;
+				} else {
+					st = old;
+				}
+			}
+			if (st == 2) {
+				bool same = true;
+				for (uint32_t i = 0; i < F.kwords; i++) {
+					uint64_t w = kw[0];
+#pragma unroll
+					for (int q = 1; q < XE_FWM_MAX_KWORDS; q++) w = (i == (uint32_t)q) ? kw[q] : w;
+					same = same && (F.keys[(size_t)slot * F.kwords + i] == w);
+				}
+				if (same) {
+					for (uint32_t j = 0; j < F.nval; j++) {
+						const uint32_t vf = F.vfield[j];
+						const uint64_t co = kp.col_off[vf];
+						uint64_t v = 0;
+						if (co != ~0ull) v = __builtin_bswap64(((const uint64_t *)(kp.out_base + co))[r]);
+						atomicAdd(&F.vals[(size_t)slot * F.nval + j], (unsigned long long)(v * F.vscale[j] * rate));
+					}
+					done = true;
+				} else {
+					slot = (slot + 1) & F.cap_mask;
+					if (++tried > F.cap_mask) {
+						atomicAdd(F.dropped, 1ull);
+						done = true;
+					}
+				}
+			}
+			/* st == 1: another thread is writing the key; look again */
+		}
+	}
+}
+
+int
+xe_launch_fwm(const struct xe_kparams *kp, const struct xe_fwm_dev *tables, uint32_t ntables, void *stream, void **events)
+{
+	hipStream_t st = (hipStream_t)stream;
+	hipEvent_t *ev = (hipEvent_t *)events;
+	const uint32_t ntot = kp->nrec + kp->nsf;
+
+	if (!ntables || !ntot) return XE_OK;
+	if (ev) (void)hipEventRecord(ev[0], st);
+	hipLaunchKernelGGL(xe_fwm_kernel, dim3((ntot + XE_BLOCK - 1) / XE_BLOCK), dim3(XE_BLOCK), 0, st, *kp, tables, ntables);
+	if (ev) (void)hipEventRecord(ev[1], st);
+	return (hipGetLastError() == hipSuccess) ? XE_OK : XE_EHIP;
 }
 
 /* ------------------------------------------------------------------ list probe */
