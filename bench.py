@@ -42,6 +42,7 @@ def parse_args():
     ap.add_argument("--pipeline", type=int, default=2,
                     help="capture threads (one handle each) of the sustained host-inclusive measurement, 0/1 = skip")
     ap.add_argument("--pipeline-rounds", type=int, default=6)
+    ap.add_argument("--fwm", type=int, default=1, help="also time the fixed-window table kernel (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus > 1 (gloo: rehearsal of the multi-rank path on one GPU)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -256,6 +257,50 @@ def main():
         for e in engines:
             e.close()
 
+    # fixed-window tables (the consumer of the match masks, monit-objects.c:923-1023) on a handle of
+    # their own: the same batch with two tables, timed with and without the table kernel
+    fixed_window = None
+    if args.fwm and world == 1 and args.workload in ("c1", "c2", "c5"):
+        e = xenoeye_amd.Engine(device=local_rank)
+        for name, text in w["iplists"].items():
+            e.add_iplist(name, text)
+        for filt, parent in w["mos"]:
+            e.add_mo("mo", filt, parent)
+        allmo = e.add_mo("mo", "", -1)
+        t0_ = e.add_fwm(allmo, ["proto", "dst port", "octets", "packets"], 1 << 19)
+        t1_ = e.add_fwm(0, ["src host", "dst host", "bits desc"], 1 << 21)
+        e.commit()
+        fb = e.prepare(pinned)
+        fb.timing(True)
+        fb.run(stream)
+        torch.cuda.synchronize()
+        rows0, dr0 = e.fwm_read(t0_)
+        rows1, dr1 = e.fwm_read(t1_)
+        ms, ms_later = [], []
+        for _ in range(5):
+            e.fwm_clear(t0_)
+            e.fwm_clear(t1_)
+            fb.run(stream)
+            ms.append(fb.fwm_ms())          # first batch of a window: every key is new
+            fb.run(stream)
+            ms_later.append(fb.fwm_ms())    # later batches: the keys are in the table
+        fms = float(np.mean(ms_later))
+        fms_first = float(np.mean(ms))
+        cc = fb.counters()
+        # bytes the table kernel must move: per record its mask word and rate, per (record, table
+        # that takes it) the key fields and 8 bytes per summed field, read and added
+        alg_fwm = fb.records * (8 * fb.mask_words + 4) + int(cc[allmo, 0]) * (1 + 2 + 2 * 8 + 2 * 8) \
+            + int(cc[0, 0]) * (4 + 4 + 8 + 8)
+        fixed_window = {"tables": [{"object": "all records", "fields": ["proto", "dst port", "octets", "packets"],
+                                    "rows": len(rows0), "dropped": dr0},
+                                   {"object": "object 0", "fields": ["src host", "dst host", "bits desc"],
+                                    "rows": len(rows1), "dropped": dr1}],
+                        "kernel": "xe_fwm_kernel", "kernel_ms": fms, "kernel_ms_first_batch_of_window": fms_first,
+                        "records_per_s": fb.records / (fms * 1e-3),
+                        "algorithmic_bytes_per_launch": alg_fwm,
+                        "achieved_GBps": alg_fwm / (fms * 1e-3) / 1e9, "frac_of_hbm_peak": alg_fwm / (fms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        e.close()
+
     from xenoeye_amd import shard
     dev = torch.device("cuda", local_rank) if args.backend == "nccl" else None
     dt_all, tot, pay = shard.reduce_scalars([dt, nrec, batch.payload_bytes], ["max", "sum", "sum"],
@@ -297,6 +342,7 @@ def main():
                                "page_locked_input_s": t_e2e_pinned,
                                "page_locked_input_records_per_s": nrec / t_e2e_pinned,
                                "pipelined": piped},
+            "fixed_window": fixed_window,
         }
         if args.cpu_sample > 0:
             rps, n_cpu, nd, secs = cpu_baseline(w, args.cpu_sample)

@@ -152,8 +152,7 @@ xe_gpu_destroy(xe_gpu *h)
 	if (h->d_tmpls) (void)hipFree(h->d_tmpls);
 	if (h->d_tents) (void)hipFree(h->d_tents);
 	for (size_t i = 0; i < h->nfwm; i++) {
-		if (h->fwms[i].dev.state) (void)hipFree(h->fwms[i].dev.state);
-		if (h->fwms[i].dev.keys) (void)hipFree(h->fwms[i].dev.keys);
+		if (h->fwms[i].dev.slots) (void)hipFree(h->fwms[i].dev.slots);
 		if (h->fwms[i].dev.vals) (void)hipFree(h->fwms[i].dev.vals);
 		if (h->fwms[i].dev.dropped) (void)hipFree(h->fwms[i].dev.dropped);
 	}
@@ -720,11 +719,12 @@ xe_gpu_add_fwm(xe_gpu *h, int mo, const char *const *fields, int nfields, size_t
 	w.dev.cap_mask = (uint32_t)(w.slots - 1);
 
 	HIPCHK(h, hipSetDevice(h->device));
-	HIPCHK(h, hipMalloc((void **)&w.dev.state, w.slots * 4));
-	HIPCHK(h, hipMalloc((void **)&w.dev.keys, w.slots * w.dev.kwords * 8));
+	/* state + key, rounded up to a whole number of 16 bytes */
+	w.dev.swords = (1 + w.dev.kwords + 1) & ~1u;
+	HIPCHK(h, hipMalloc((void **)&w.dev.slots, w.slots * w.dev.swords * 8));
 	HIPCHK(h, hipMalloc((void **)&w.dev.vals, w.slots * (w.dev.nval ? w.dev.nval : 1) * 8));
 	HIPCHK(h, hipMalloc((void **)&w.dev.dropped, 8));
-	HIPCHK(h, hipMemset(w.dev.state, 0, w.slots * 4));
+	HIPCHK(h, hipMemset(w.dev.slots, 0, w.slots * w.dev.swords * 8));
 	HIPCHK(h, hipMemset(w.dev.vals, 0, w.slots * (w.dev.nval ? w.dev.nval : 1) * 8));
 	HIPCHK(h, hipMemset(w.dev.dropped, 0, 8));
 
@@ -750,38 +750,37 @@ extern "C" long
 xe_gpu_fwm_read(xe_gpu *h, int fwm, uint8_t *keys, uint64_t *vals, size_t max_rows, uint64_t *dropped)
 {
 	struct fwm_host *w;
-	uint32_t *st = NULL;
-	uint64_t *k = NULL, *v = NULL;
+	uint64_t *sl = NULL, *vl = NULL;
 	size_t n = 0, nv;
 	long rc = XE_ENOMEM;
 
 	if (!h || (fwm < 0) || ((size_t)fwm >= h->nfwm)) return XE_EINVAL;
 	w = &h->fwms[fwm];
-	nv = w->dev.nval ? w->dev.nval : 1;
 	HIPCHK(h, hipSetDevice(h->device));
 	HIPCHK(h, hipDeviceSynchronize());
-	st = (uint32_t *)malloc(w->slots * 4);
-	k = (uint64_t *)malloc(w->slots * w->dev.kwords * 8);
-	v = (uint64_t *)malloc(w->slots * nv * 8);
-	if (!st || !k || !v) goto out;
-	if ((hipMemcpy(st, w->dev.state, w->slots * 4, hipMemcpyDeviceToHost) != hipSuccess)
-		|| (hipMemcpy(k, w->dev.keys, w->slots * w->dev.kwords * 8, hipMemcpyDeviceToHost) != hipSuccess)
-		|| (hipMemcpy(v, w->dev.vals, w->slots * nv * 8, hipMemcpyDeviceToHost) != hipSuccess)
+	nv = w->dev.nval ? w->dev.nval : 1;
+	sl = (uint64_t *)malloc(w->slots * w->dev.swords * 8);
+	vl = (uint64_t *)malloc(w->slots * nv * 8);
+	if (!sl || !vl) goto out;
+	if ((hipMemcpy(sl, w->dev.slots, w->slots * w->dev.swords * 8, hipMemcpyDeviceToHost) != hipSuccess)
+		|| (hipMemcpy(vl, w->dev.vals, w->slots * nv * 8, hipMemcpyDeviceToHost) != hipSuccess)
 		|| (dropped && (hipMemcpy(dropped, w->dev.dropped, 8, hipMemcpyDeviceToHost) != hipSuccess))) {
 		rc = XE_EHIP;
 		goto out;
 	}
 	for (size_t i = 0; i < w->slots; i++) {
-		if (st[i] != 2) continue;
+		const uint64_t *S = sl + i * w->dev.swords;
+		if ((uint32_t)S[0] != 2) continue;
 		if (n < max_rows) {
-			if (keys) memcpy(keys + n * w->keybytes, k + i * w->dev.kwords, w->keybytes);
-			if (vals) memcpy(vals + n * w->dev.nval, v + i * nv, (size_t)w->dev.nval * 8);
+			if (keys) memcpy(keys + n * w->keybytes, S + 1, w->keybytes);
+			if (vals) memcpy(vals + n * w->dev.nval, vl + i * nv, (size_t)w->dev.nval * 8);
 		}
 		n++;
 	}
 	rc = (long)n;
 out:
-	free(st); free(k); free(v);
+	free(sl);
+	free(vl);
 	return rc;
 }
 
@@ -793,7 +792,7 @@ xe_gpu_fwm_clear(xe_gpu *h, int fwm)
 	w = &h->fwms[fwm];
 	HIPCHK(h, hipSetDevice(h->device));
 	HIPCHK(h, hipDeviceSynchronize());
-	HIPCHK(h, hipMemset(w->dev.state, 0, w->slots * 4));
+	HIPCHK(h, hipMemset(w->dev.slots, 0, w->slots * w->dev.swords * 8));
 	HIPCHK(h, hipMemset(w->dev.vals, 0, w->slots * (w->dev.nval ? w->dev.nval : 1) * 8));
 	HIPCHK(h, hipMemset(w->dev.dropped, 0, 8));
 	return XE_OK;

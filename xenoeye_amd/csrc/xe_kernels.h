@@ -120,19 +120,20 @@ int xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events);
 
 /* Fixed-window table of one object on the device (the per-record part of
  * monit_object_process_nf(), monit-objects.c:927-1023): an open-addressing
- * hash table of `cap_mask + 1` slots; slot i = state[i] (0 free, 1 being
- * written, 2 ready), keys[i][kwords] (the key fields' bytes as struct
- * flow_info holds them, one after the other, zero padded to whole words) and
- * vals[i][nval] (wrapping sums of value * scale * sampling rate). */
+ * hash table of `cap_mask + 1` slots.  slots[i] = `swords` 64-bit words: state
+ * (0 free, 1 being written, 2 ready) and kwords words of key (the key fields'
+ * bytes as struct flow_info holds them, one after the other, zero padded to
+ * whole words) - written once, then only read; vals[i][nval] = the sums
+ * (wrapping: value * scale * sampling rate), kept apart so that the atomic
+ * adds to a popular row do not fight with the readers of its key. */
 #define XE_FWM_MAX_KEY_FIELDS 8
 #define XE_FWM_MAX_VALS 4
 #define XE_FWM_MAX_KWORDS 8
 struct xe_fwm_dev
 {
 	uint32_t mo, nkey, nval, kwords;
-	uint32_t cap_mask, pad;
-	uint32_t *state;
-	uint64_t *keys;
+	uint32_t cap_mask, swords;
+	unsigned long long *slots;
 	unsigned long long *vals;
 	unsigned long long *dropped;      /* records whose key found no free slot */
 	uint8_t kfield[XE_FWM_MAX_KEY_FIELDS], ksize[XE_FWM_MAX_KEY_FIELDS];

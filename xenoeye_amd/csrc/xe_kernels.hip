@@ -2160,81 +2160,141 @@ xe_sf_kernel(const xe_kparams kp)
 __global__ void __launch_bounds__(XE_BLOCK)
 xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables)
 {
+	/* per wave: which lane speaks for a hash value, and the sums collected
+	 * for each speaking lane */
+	__shared__ uint32_t s_lane[XE_BLOCK / 64][128];
+	__shared__ unsigned long long s_sum[XE_BLOCK / 64][64][XE_FWM_MAX_VALS];
+	__shared__ uint32_t s_cnt[XE_BLOCK / 64][64];
+	/* where a lane puts its key together, byte by byte: [wave][word][lane] */
+	__shared__ uint64_t s_key[XE_BLOCK / 64][XE_FWM_MAX_KWORDS][64];
 	const uint32_t r = blockIdx.x * XE_BLOCK + threadIdx.x, ntot = kp.nrec + kp.nsf;
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const bool active = r < ntot;
 
 	for (uint32_t f = 0; f < ntables; f++) {
 		const xe_fwm_dev F = tables[f];
-		bool hit = active && (((kp.masks[(size_t)r * kp.mask_words + (F.mo >> 6)] >> (F.mo & 63)) & 1) != 0);
+		const bool hit = active && (((kp.masks[(size_t)r * kp.mask_words + (F.mo >> 6)] >> (F.mo & 63)) & 1) != 0);
 		if (!__ballot(hit)) continue;
-		if (!hit) continue;
 
 		/* the key: field bytes one after the other, packed into words */
 		uint64_t kw[XE_FWM_MAX_KWORDS];
+		unsigned long long val[XE_FWM_MAX_VALS];
 #pragma unroll
 		for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) kw[i] = 0;
-		uint32_t pos = 0;
-		for (uint32_t k = 0; k < F.nkey; k++) {
-			const uint32_t fld = F.kfield[k], size = F.ksize[k];
-			const uint64_t co = kp.col_off[fld];
-			for (uint32_t b = 0; b < size; b++, pos++) {
-				/* a field no template of the batch carries reads as zeros */
-				uint64_t by;
-				if (fld == XF_dev_ip) by = (kp.devips[r] >> (8 * b)) & 0xFF;   /* comes from the exporter */
-				else by = (co == ~0ull) ? 0 : kp.out_base[co + (size_t)r * c_colw[fld] + b];
-				const uint64_t sh = by << ((pos & 7) * 8);
 #pragma unroll
-				for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) kw[i] |= ((pos >> 3) == (uint32_t)i) ? sh : 0;
+		for (int j = 0; j < XE_FWM_MAX_VALS; j++) val[j] = 0;
+		uint64_t h = 0xcbf29ce484222325ull;
+		if (hit) {
+			uint32_t pos = 0;
+			for (uint32_t i = 0; i < F.kwords; i++) s_key[wave][i][lane] = 0;
+			for (uint32_t k = 0; k < F.nkey; k++) {
+				const uint32_t fld = F.kfield[k], size = F.ksize[k];
+				const uint64_t co = kp.col_off[fld];
+				for (uint32_t b = 0; b < size; b++, pos++) {
+					uint8_t by;
+					if (fld == XF_dev_ip) by = (uint8_t)(kp.devips[r] >> (8 * b));   /* comes from the exporter */
+					/* a field no template of the batch carries reads as zeros */
+					else by = (co == ~0ull) ? (uint8_t)0 : kp.out_base[co + (size_t)r * c_colw[fld] + b];
+					((uint8_t *)&s_key[wave][pos >> 3][lane])[pos & 7] = by;
+				}
+			}
+#pragma unroll
+			for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
+				if ((uint32_t)i < F.kwords) {
+					kw[i] = s_key[wave][i][lane];
+					h = (h ^ kw[i]) * 0x100000001b3ull;
+				}
+			}
+			h ^= h >> 29;
+			const uint64_t rate = kp.rates[r];
+#pragma unroll
+			for (int j = 0; j < XE_FWM_MAX_VALS; j++) {
+				if ((uint32_t)j >= F.nval) continue;
+				const uint64_t co = kp.col_off[F.vfield[j]];
+				uint64_t v = 0;
+				if (co != ~0ull) v = __builtin_bswap64(((const uint64_t *)(kp.out_base + co))[r]);
+				val[j] = v * F.vscale[j] * rate;
 			}
 		}
-		uint64_t h = 0xcbf29ce484222325ull;
+
+		/* Records of a wave with the same key are added up first (traffic is
+		 * full of repeated keys: a few ports, a few protocols), so that one
+		 * lane goes to the table for all of them: the lanes of a hash value
+		 * elect a speaker; those whose key is the speaker's hand it their
+		 * sums, the others (different key, same hash value) go themselves. */
+		const uint32_t hs = (uint32_t)(h >> 7) & 127;
+		if (hit) {
+			s_lane[wave][hs] = lane;
+#pragma unroll
+			for (int j = 0; j < XE_FWM_MAX_VALS; j++) s_sum[wave][lane][j] = 0;
+			s_cnt[wave][lane] = 0;
+		}
+		__builtin_amdgcn_wave_barrier();
+		const uint32_t spk = hit ? s_lane[wave][hs] : lane;
+		bool same = hit;
 #pragma unroll
 		for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
-			if ((uint32_t)i < F.kwords) h = (h ^ kw[i]) * 0x100000001b3ull;
+			if ((uint32_t)i >= F.kwords) break;
+			const uint64_t other = __shfl(kw[i], (int)spk, 64);
+			same = same && (other == kw[i]);
 		}
-		h ^= h >> 29;
-		const uint64_t rate = kp.rates[r];
+		if (same) {
+#pragma unroll
+			for (int j = 0; j < XE_FWM_MAX_VALS; j++) {
+				if ((uint32_t)j < F.nval) atomicAdd(&s_sum[wave][spk][j], val[j]);
+			}
+			atomicAdd(&s_cnt[wave][spk], 1u);
+		}
+		__builtin_amdgcn_wave_barrier();
+		const bool go = hit && (!same || (spk == lane));
+		uint32_t nspoken = 1;       /* records this lane speaks for */
+		if (hit && same && (spk == lane)) {
+			nspoken = s_cnt[wave][lane];
+#pragma unroll
+			for (int j = 0; j < XE_FWM_MAX_VALS; j++) val[j] = s_sum[wave][lane][j];
+		}
+		__builtin_amdgcn_wave_barrier();
+		if (!go) continue;
 
 		uint32_t slot = (uint32_t)h & F.cap_mask, tried = 0;
 		bool done = false;
 		while (!done) {
-			uint32_t st = __hip_atomic_load(&F.state[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+			unsigned long long *S = F.slots + (size_t)slot * F.swords;
+			uint32_t st = __hip_atomic_load((uint32_t *)S, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
 			if (st == 0) {
-				const uint32_t old = atomicCAS(&F.state[slot], 0u, 1u);
+				const uint32_t old = atomicCAS((uint32_t *)S, 0u, 1u);
 				if (old == 0) {
 					for (uint32_t i = 0; i < F.kwords; i++) {
 						uint64_t w = kw[0];
 #pragma unroll
 						for (int q = 1; q < XE_FWM_MAX_KWORDS; q++) w = (i == (uint32_t)q) ? kw[q] : w;
-						F.keys[(size_t)slot * F.kwords + i] = w;
+						S[1 + i] = w;
 					}
-					__hip_atomic_store(&F.state[slot], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+					__hip_atomic_store((uint32_t *)S, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 					st = 2;
 				} else {
 					st = old;
 				}
 			}
 			if (st == 2) {
-				bool same = true;
+				bool eq = true;
 				for (uint32_t i = 0; i < F.kwords; i++) {
 					uint64_t w = kw[0];
 #pragma unroll
 					for (int q = 1; q < XE_FWM_MAX_KWORDS; q++) w = (i == (uint32_t)q) ? kw[q] : w;
-					same = same && (F.keys[(size_t)slot * F.kwords + i] == w);
+					eq = eq && (S[1 + i] == w);
 				}
-				if (same) {
-					for (uint32_t j = 0; j < F.nval; j++) {
-						const uint32_t vf = F.vfield[j];
-						const uint64_t co = kp.col_off[vf];
-						uint64_t v = 0;
-						if (co != ~0ull) v = __builtin_bswap64(((const uint64_t *)(kp.out_base + co))[r]);
-						atomicAdd(&F.vals[(size_t)slot * F.nval + j], (unsigned long long)(v * F.vscale[j] * rate));
+				if (eq) {
+#pragma unroll
+					for (int j = 0; j < XE_FWM_MAX_VALS; j++) {
+						if ((uint32_t)j < F.nval) atomicAdd(&F.vals[(size_t)slot * F.nval + j], val[j]);
 					}
 					done = true;
 				} else {
 					slot = (slot + 1) & F.cap_mask;
 					if (++tried > F.cap_mask) {
-						atomicAdd(F.dropped, 1ull);
+						/* full: every record this lane speaks for is lost */
+						atomicAdd(F.dropped, (unsigned long long)nspoken);
 						done = true;
 					}
 				}
