@@ -2150,157 +2150,236 @@ xe_sf_kernel(const xe_kparams kp)
 
 /* ------------------------------------------------------------------ fixed-window tables */
 /*
- * One thread per record, after classification: for every table whose object
- * received the record, the key is put together from the decoded columns (the
- * bytes struct flow_info holds, monit-objects.c:917-920), looked up or
- * inserted, and value * scale * sampling rate is added to its sums
- * (monit-objects.c:986-1008; wrapping u64, so the order of records and the
- * split over batches and GPUs do not matter).
+ * After classification: for every table whose object received a record, the
+ * key is put together from the decoded columns (the bytes struct flow_info
+ * holds, monit-objects.c:917-920), looked up or inserted, and value * scale *
+ * sampling rate is added to its sums (monit-objects.c:986-1008; wrapping u64,
+ * so the order of records and the split over batches and GPUs do not matter).
+ *
+ * Traffic is full of repeated keys (a few protocols, a few ports, a few busy
+ * hosts), and atomic adds to one row of the table in HBM run one after the
+ * other.  So sums are collected on the way: equal keys of a wave first (the
+ * lanes of one hash value elect a speaker), then in a small table in LDS that
+ * the block keeps over all its records and writes out once at the end; only
+ * keys that find their LDS entry taken by another key go to HBM one by one.
  */
+#define XE_FWM_CACHE 256         /* entries of the block's table in LDS */
+#define XE_FWM_CHUNKS 16         /* 256-record chunks a block works through */
+
+/* one key with its sums into the table in HBM */
+__device__ __forceinline__ void
+fwm_global_add(const xe_fwm_dev &F, const uint64_t (&kw)[XE_FWM_MAX_KWORDS], uint64_t h,
+	const unsigned long long (&val)[XE_FWM_MAX_VALS], uint32_t nrecords)
+{
+	uint32_t slot = (uint32_t)h & F.cap_mask, tried = 0;
+	bool done = false;
+	while (!done) {
+		unsigned long long *S = F.slots + (size_t)slot * F.swords;
+		uint32_t st = __hip_atomic_load((uint32_t *)S, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+		if (st == 0) {
+			const uint32_t old = atomicCAS((uint32_t *)S, 0u, 1u);
+			if (old == 0) {
+#pragma unroll
+				for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
+					if ((uint32_t)i < F.kwords) S[1 + i] = kw[i];
+				}
+				__hip_atomic_store((uint32_t *)S, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+				st = 2;
+			} else {
+				st = old;
+			}
+		}
+		if (st == 2) {
+			bool eq = true;
+#pragma unroll
+			for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
+				if ((uint32_t)i < F.kwords) eq = eq && (S[1 + i] == kw[i]);
+			}
+			if (eq) {
+#pragma unroll
+				for (int j = 0; j < XE_FWM_MAX_VALS; j++) {
+					if ((uint32_t)j < F.nval) atomicAdd(&F.vals[(size_t)slot * F.nval + j], val[j]);
+				}
+				done = true;
+			} else {
+				slot = (slot + 1) & F.cap_mask;
+				if (++tried > F.cap_mask) {
+					/* full: the records behind this key are lost, and counted */
+					atomicAdd(F.dropped, (unsigned long long)nrecords);
+					done = true;
+				}
+			}
+		}
+		/* st == 1: another thread is writing the key; look again */
+	}
+}
+
 __global__ void __launch_bounds__(XE_BLOCK)
 xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables)
 {
-	/* per wave: which lane speaks for a hash value, and the sums collected
-	 * for each speaking lane */
+	/* per wave: which lane speaks for a hash value, and what it collects */
 	__shared__ uint32_t s_lane[XE_BLOCK / 64][128];
 	__shared__ unsigned long long s_sum[XE_BLOCK / 64][64][XE_FWM_MAX_VALS];
 	__shared__ uint32_t s_cnt[XE_BLOCK / 64][64];
 	/* where a lane puts its key together, byte by byte: [wave][word][lane] */
 	__shared__ uint64_t s_key[XE_BLOCK / 64][XE_FWM_MAX_KWORDS][64];
-	const uint32_t r = blockIdx.x * XE_BLOCK + threadIdx.x, ntot = kp.nrec + kp.nsf;
+	/* the block's table: state 0 free, 1 being written, 2 ready */
+	__shared__ uint32_t c_state[XE_FWM_CACHE], c_cnt[XE_FWM_CACHE];
+	__shared__ uint64_t c_hash[XE_FWM_CACHE];
+	__shared__ uint64_t c_key[XE_FWM_CACHE][XE_FWM_MAX_KWORDS];
+	__shared__ unsigned long long c_sum[XE_FWM_CACHE][XE_FWM_MAX_VALS];
+	const uint32_t ntot = kp.nrec + kp.nsf;
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const bool active = r < ntot;
+	const uint32_t r0 = blockIdx.x * (XE_BLOCK * XE_FWM_CHUNKS);
 
 	for (uint32_t f = 0; f < ntables; f++) {
 		const xe_fwm_dev F = tables[f];
-		const bool hit = active && (((kp.masks[(size_t)r * kp.mask_words + (F.mo >> 6)] >> (F.mo & 63)) & 1) != 0);
-		if (!__ballot(hit)) continue;
 
-		/* the key: field bytes one after the other, packed into words */
-		uint64_t kw[XE_FWM_MAX_KWORDS];
-		unsigned long long val[XE_FWM_MAX_VALS];
+		for (uint32_t i = threadIdx.x; i < XE_FWM_CACHE; i += XE_BLOCK) {
+			c_state[i] = 0;
+			c_cnt[i] = 0;
 #pragma unroll
-		for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) kw[i] = 0;
+			for (int j = 0; j < XE_FWM_MAX_VALS; j++) c_sum[i][j] = 0;
+		}
+		__syncthreads();
+
+		for (uint32_t chunk = 0; chunk < XE_FWM_CHUNKS; chunk++) {
+			const uint32_t r = r0 + chunk * XE_BLOCK + threadIdx.x;
+			const bool hit = (r < ntot)
+				&& (((kp.masks[(size_t)r * kp.mask_words + (F.mo >> 6)] >> (F.mo & 63)) & 1) != 0);
+			if (!__ballot(hit)) continue;
+
+			/* the key: field bytes one after the other, packed into words */
+			uint64_t kw[XE_FWM_MAX_KWORDS];
+			unsigned long long val[XE_FWM_MAX_VALS];
 #pragma unroll
-		for (int j = 0; j < XE_FWM_MAX_VALS; j++) val[j] = 0;
-		uint64_t h = 0xcbf29ce484222325ull;
-		if (hit) {
-			uint32_t pos = 0;
-			for (uint32_t i = 0; i < F.kwords; i++) s_key[wave][i][lane] = 0;
-			for (uint32_t k = 0; k < F.nkey; k++) {
-				const uint32_t fld = F.kfield[k], size = F.ksize[k];
-				const uint64_t co = kp.col_off[fld];
-				for (uint32_t b = 0; b < size; b++, pos++) {
-					uint8_t by;
-					if (fld == XF_dev_ip) by = (uint8_t)(kp.devips[r] >> (8 * b));   /* comes from the exporter */
-					/* a field no template of the batch carries reads as zeros */
-					else by = (co == ~0ull) ? (uint8_t)0 : kp.out_base[co + (size_t)r * c_colw[fld] + b];
-					((uint8_t *)&s_key[wave][pos >> 3][lane])[pos & 7] = by;
+			for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) kw[i] = 0;
+#pragma unroll
+			for (int j = 0; j < XE_FWM_MAX_VALS; j++) val[j] = 0;
+			uint64_t h = 0xcbf29ce484222325ull;
+			if (hit) {
+				uint32_t pos = 0;
+				for (uint32_t i = 0; i < F.kwords; i++) s_key[wave][i][lane] = 0;
+				for (uint32_t k = 0; k < F.nkey; k++) {
+					const uint32_t fld = F.kfield[k], size = F.ksize[k];
+					const uint64_t co = kp.col_off[fld];
+					for (uint32_t b = 0; b < size; b++, pos++) {
+						uint8_t by;
+						if (fld == XF_dev_ip) by = (uint8_t)(kp.devips[r] >> (8 * b));   /* comes from the exporter */
+						/* a field no template of the batch carries reads as zeros */
+						else by = (co == ~0ull) ? (uint8_t)0 : kp.out_base[co + (size_t)r * c_colw[fld] + b];
+						((uint8_t *)&s_key[wave][pos >> 3][lane])[pos & 7] = by;
+					}
+				}
+#pragma unroll
+				for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
+					if ((uint32_t)i < F.kwords) {
+						kw[i] = s_key[wave][i][lane];
+						h = (h ^ kw[i]) * 0x100000001b3ull;
+					}
+				}
+				/* final mix: keys that differ in a few low bits must spread over
+				 * all the index bits used below */
+				h ^= h >> 33; h *= 0xff51afd7ed558ccdull;
+				h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull;
+				h ^= h >> 33;
+				const uint64_t rate = kp.rates[r];
+#pragma unroll
+				for (int j = 0; j < XE_FWM_MAX_VALS; j++) {
+					if ((uint32_t)j >= F.nval) continue;
+					const uint64_t co = kp.col_off[F.vfield[j]];
+					uint64_t v = 0;
+					if (co != ~0ull) v = __builtin_bswap64(((const uint64_t *)(kp.out_base + co))[r]);
+					val[j] = v * F.vscale[j] * rate;
 				}
 			}
+
+			/* equal keys of the wave: one speaker per hash value; lanes whose key
+			 * is the speaker's hand it their sums, the others go on themselves */
+			const uint32_t hs = (uint32_t)(h >> 7) & 127;
+			if (hit) {
+				s_lane[wave][hs] = lane;
+#pragma unroll
+				for (int j = 0; j < XE_FWM_MAX_VALS; j++) s_sum[wave][lane][j] = 0;
+				s_cnt[wave][lane] = 0;
+			}
+			__builtin_amdgcn_wave_barrier();
+			const uint32_t spk = hit ? s_lane[wave][hs] : lane;
+			bool same = hit;
 #pragma unroll
 			for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
-				if ((uint32_t)i < F.kwords) {
-					kw[i] = s_key[wave][i][lane];
-					h = (h ^ kw[i]) * 0x100000001b3ull;
+				if ((uint32_t)i >= F.kwords) break;
+				const uint64_t other = __shfl(kw[i], (int)spk, 64);
+				same = same && (other == kw[i]);
+			}
+			if (same) {
+#pragma unroll
+				for (int j = 0; j < XE_FWM_MAX_VALS; j++) {
+					if ((uint32_t)j < F.nval) atomicAdd(&s_sum[wave][spk][j], val[j]);
 				}
+				atomicAdd(&s_cnt[wave][spk], 1u);
 			}
-			h ^= h >> 29;
-			const uint64_t rate = kp.rates[r];
+			__builtin_amdgcn_wave_barrier();
+			const bool go = hit && (!same || (spk == lane));
+			uint32_t nspoken = 1;       /* records this lane speaks for */
+			if (hit && same && (spk == lane)) {
+				nspoken = s_cnt[wave][lane];
 #pragma unroll
-			for (int j = 0; j < XE_FWM_MAX_VALS; j++) {
-				if ((uint32_t)j >= F.nval) continue;
-				const uint64_t co = kp.col_off[F.vfield[j]];
-				uint64_t v = 0;
-				if (co != ~0ull) v = __builtin_bswap64(((const uint64_t *)(kp.out_base + co))[r]);
-				val[j] = v * F.vscale[j] * rate;
+				for (int j = 0; j < XE_FWM_MAX_VALS; j++) val[j] = s_sum[wave][lane][j];
 			}
-		}
+			__builtin_amdgcn_wave_barrier();
+			if (!go) continue;
 
-		/* Records of a wave with the same key are added up first (traffic is
-		 * full of repeated keys: a few ports, a few protocols), so that one
-		 * lane goes to the table for all of them: the lanes of a hash value
-		 * elect a speaker; those whose key is the speaker's hand it their
-		 * sums, the others (different key, same hash value) go themselves. */
-		const uint32_t hs = (uint32_t)(h >> 7) & 127;
-		if (hit) {
-			s_lane[wave][hs] = lane;
-#pragma unroll
-			for (int j = 0; j < XE_FWM_MAX_VALS; j++) s_sum[wave][lane][j] = 0;
-			s_cnt[wave][lane] = 0;
-		}
-		__builtin_amdgcn_wave_barrier();
-		const uint32_t spk = hit ? s_lane[wave][hs] : lane;
-		bool same = hit;
-#pragma unroll
-		for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
-			if ((uint32_t)i >= F.kwords) break;
-			const uint64_t other = __shfl(kw[i], (int)spk, 64);
-			same = same && (other == kw[i]);
-		}
-		if (same) {
-#pragma unroll
-			for (int j = 0; j < XE_FWM_MAX_VALS; j++) {
-				if ((uint32_t)j < F.nval) atomicAdd(&s_sum[wave][spk][j], val[j]);
-			}
-			atomicAdd(&s_cnt[wave][spk], 1u);
-		}
-		__builtin_amdgcn_wave_barrier();
-		const bool go = hit && (!same || (spk == lane));
-		uint32_t nspoken = 1;       /* records this lane speaks for */
-		if (hit && same && (spk == lane)) {
-			nspoken = s_cnt[wave][lane];
-#pragma unroll
-			for (int j = 0; j < XE_FWM_MAX_VALS; j++) val[j] = s_sum[wave][lane][j];
-		}
-		__builtin_amdgcn_wave_barrier();
-		if (!go) continue;
-
-		uint32_t slot = (uint32_t)h & F.cap_mask, tried = 0;
-		bool done = false;
-		while (!done) {
-			unsigned long long *S = F.slots + (size_t)slot * F.swords;
-			uint32_t st = __hip_atomic_load((uint32_t *)S, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-			if (st == 0) {
-				const uint32_t old = atomicCAS((uint32_t *)S, 0u, 1u);
+			/* the block's table: one entry per hash value; taken by another key
+			 * (or still being written by another wave): straight to HBM */
+			const uint32_t ci = (uint32_t)(h >> 14) & (XE_FWM_CACHE - 1);
+			uint32_t cs = __hip_atomic_load(&c_state[ci], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (cs == 0) {
+				const uint32_t old = atomicCAS(&c_state[ci], 0u, 1u);
 				if (old == 0) {
-					for (uint32_t i = 0; i < F.kwords; i++) {
-						uint64_t w = kw[0];
+					c_hash[ci] = h;
 #pragma unroll
-						for (int q = 1; q < XE_FWM_MAX_KWORDS; q++) w = (i == (uint32_t)q) ? kw[q] : w;
-						S[1 + i] = w;
+					for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
+						if ((uint32_t)i < F.kwords) c_key[ci][i] = kw[i];
 					}
-					__hip_atomic_store((uint32_t *)S, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-					st = 2;
+					__hip_atomic_store(&c_state[ci], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+					cs = 2;
 				} else {
-					st = old;
+					cs = old;
 				}
 			}
-			if (st == 2) {
+			bool cached = false;
+			if (cs == 2) {
 				bool eq = true;
-				for (uint32_t i = 0; i < F.kwords; i++) {
-					uint64_t w = kw[0];
 #pragma unroll
-					for (int q = 1; q < XE_FWM_MAX_KWORDS; q++) w = (i == (uint32_t)q) ? kw[q] : w;
-					eq = eq && (S[1 + i] == w);
+				for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
+					if ((uint32_t)i < F.kwords) eq = eq && (c_key[ci][i] == kw[i]);
 				}
 				if (eq) {
 #pragma unroll
 					for (int j = 0; j < XE_FWM_MAX_VALS; j++) {
-						if ((uint32_t)j < F.nval) atomicAdd(&F.vals[(size_t)slot * F.nval + j], val[j]);
+						if ((uint32_t)j < F.nval) atomicAdd(&c_sum[ci][j], val[j]);
 					}
-					done = true;
-				} else {
-					slot = (slot + 1) & F.cap_mask;
-					if (++tried > F.cap_mask) {
-						/* full: every record this lane speaks for is lost */
-						atomicAdd(F.dropped, (unsigned long long)nspoken);
-						done = true;
-					}
+					atomicAdd(&c_cnt[ci], nspoken);
+					cached = true;
 				}
 			}
-			/* st == 1: another thread is writing the key; look again */
+			if (!cached) fwm_global_add(F, kw, h, val, nspoken);
 		}
+
+		/* what the block collected goes to the table once */
+		__syncthreads();
+		for (uint32_t i = threadIdx.x; i < XE_FWM_CACHE; i += XE_BLOCK) {
+			if (c_state[i] != 2) continue;
+			uint64_t kw[XE_FWM_MAX_KWORDS];
+			unsigned long long val[XE_FWM_MAX_VALS];
+#pragma unroll
+			for (int k = 0; k < XE_FWM_MAX_KWORDS; k++) kw[k] = ((uint32_t)k < F.kwords) ? c_key[i][k] : 0;
+#pragma unroll
+			for (int j = 0; j < XE_FWM_MAX_VALS; j++) val[j] = c_sum[i][j];
+			fwm_global_add(F, kw, c_hash[i], val, c_cnt[i]);
+		}
+		__syncthreads();
 	}
 }
 
@@ -2310,10 +2389,11 @@ xe_launch_fwm(const struct xe_kparams *kp, const struct xe_fwm_dev *tables, uint
 	hipStream_t st = (hipStream_t)stream;
 	hipEvent_t *ev = (hipEvent_t *)events;
 	const uint32_t ntot = kp->nrec + kp->nsf;
+	const uint32_t per_block = XE_BLOCK * XE_FWM_CHUNKS;
 
 	if (!ntables || !ntot) return XE_OK;
 	if (ev) (void)hipEventRecord(ev[0], st);
-	hipLaunchKernelGGL(xe_fwm_kernel, dim3((ntot + XE_BLOCK - 1) / XE_BLOCK), dim3(XE_BLOCK), 0, st, *kp, tables, ntables);
+	hipLaunchKernelGGL(xe_fwm_kernel, dim3((ntot + per_block - 1) / per_block), dim3(XE_BLOCK), 0, st, *kp, tables, ntables);
 	if (ev) (void)hipEventRecord(ev[1], st);
 	return (hipGetLastError() == hipSuccess) ? XE_OK : XE_EHIP;
 }
