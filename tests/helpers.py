@@ -3,7 +3,7 @@ with the same configuration and datagrams and compare everything they emit."""
 import numpy as np
 
 
-def configure(eng, orc, iplists=None, mos=(), devices=()):
+def configure(eng, orc, iplists=None, mos=(), devices=(), tables=()):
     for name, text in (iplists or {}).items():
         if eng is not None:
             eng.add_iplist(name, text)
@@ -16,6 +16,10 @@ def configure(eng, orc, iplists=None, mos=(), devices=()):
         if eng is not None:
             eng.add_mo("mo", filt, parent)
         orc.mo_add(filt, parent)
+    for mo, fields in tables:
+        if eng is not None:
+            eng.add_fwm(mo, fields)
+        orc.fwm_add(mo, fields)
     if eng is not None:
         eng.commit()
 

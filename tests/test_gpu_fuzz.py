@@ -150,7 +150,19 @@ def _case(seed):
         sf = synth.workload_c3(60, seed=seed)
         for p, a, k in zip(sf["batch"].pkts, sf["batch"].src, sf["batch"].kind):
             b.add(_damage(rng, p), a, k)
-    return dict(batch=b, iplists=lists, mos=mos, devices=devices)
+    # fixed-window tables over some objects
+    keyf = ["src host", "dst host", "src host6", "dst host6", "proto", "src port", "dst port", "tcp-flags", "src as",
+            "dst as", "src mac", "dst mac", "src ifidx", "dst ifidx", "src tos", "src vlan", "dev-ip", "src mask"]
+    valf = ["octets", "bits", "packets", "bits desc", "packets asc"]
+    tables = []
+    for _ in range(int(rng.integers(0, 4))):
+        nk = int(rng.integers(0, 4))
+        ks = [keyf[int(x)] for x in rng.integers(0, len(keyf), nk)]
+        vs = [valf[int(x)] for x in rng.integers(0, len(valf), int(rng.integers(1, 4)))]
+        fl = ks + vs
+        rng.shuffle(fl)
+        tables.append((int(rng.integers(0, nmo)), [str(x) for x in fl]))
+    return dict(batch=b, iplists=lists, mos=mos, devices=devices, tables=tables)
 
 
 import os
@@ -167,7 +179,7 @@ def test_random_configurations_and_damaged_datagrams(chunk, orc):
         try:
             orc.reset()
             try:
-                configure(eng, orc, w["iplists"], w["mos"], w["devices"])
+                configure(eng, orc, w["iplists"], w["mos"], w["devices"], tables=w["tables"])
             except (xenoeye_amd.XeError, ValueError) as e:
                 # a generated filter the reference rejects (or this library declares unsupported)
                 continue
@@ -182,6 +194,9 @@ def test_random_configurations_and_damaged_datagrams(chunk, orc):
                 compare(b, orc)
             except AssertionError as e:
                 raise AssertionError("seed %d: %s" % (seed, e))
+            for t in range(len(w["tables"])):
+                got, dropped = eng.fwm_read(t)
+                assert dropped == 0 and got == orc.fwm_read(t), "seed %d: fixed-window table %d differs" % (seed, t)
             compared += 1
             records += orc.nrecords()
         finally:
