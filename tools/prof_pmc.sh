@@ -7,7 +7,7 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 run() {
   name=$1; shift
-  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 $BENCH_ARGS > "$out/$name.log" 2>&1
+  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --pipeline 0 --fwm 0 $BENCH_ARGS > "$out/$name.log" 2>&1
   echo "$name rc=$?"
 }
 BENCH_ARGS="$*"
