@@ -104,6 +104,15 @@ int xe_gpu_commit(xe_gpu *h);
  * distinct keys to make room for (0: 65536); records whose key finds no room
  * are counted in `dropped` (the reference drops them on TKVDB_ENOMEM). */
 int xe_gpu_add_fwm(xe_gpu *h, int mo, const char *const *fields, int nfields, size_t max_keys);
+/* xe_gpu_load_mos() that also registers the "fwm" entries of every mo.conf
+ * (fwm_config(), monit-objects-fwm.c:139-205: "name" and "fields") as tables;
+ * entries with fields this library does not aggregate (functions, strings)
+ * are left to the reference's own consumer and counted in *skipped.  Returns
+ * the number of tables added. */
+int xe_gpu_load_mos_with_tables(xe_gpu *h, const char *mo_dir, size_t max_keys, int *skipped);
+int xe_gpu_fwm_count(const xe_gpu *h);
+int xe_gpu_fwm_object(const xe_gpu *h, int fwm);          /* index of the object it belongs to */
+const char *xe_gpu_fwm_name(const xe_gpu *h, int fwm);    /* "name" of the mo.conf entry, "" if added by hand */
 int xe_gpu_fwm_info(const xe_gpu *h, int fwm, size_t *key_bytes, int *nvals, size_t *slots);
 /* rows in no particular order (the reference sorts when it exports a window,
  * monit-objects-fwm.c:497-691): keys[row][key_bytes], vals[row][nvals].

@@ -140,3 +140,53 @@ def test_unsupported_fields_are_reported(eng):
     with pytest.raises(xenoeye_amd.XeError) as e:
         eng.add_fwm(0, ["host", "packets"])
     assert e.value.code == -4
+
+
+def test_tables_from_mo_conf(tmp_path, eng, orc):
+    """the "fwm" entries of mo.conf files become tables (the shape of the
+    reference's sample tree: total / proto / saddr ... per object)"""
+    import os
+
+    def mk(path, text):
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "mo.conf"), "w") as f:
+            f.write(text)
+    root = str(tmp_path / "mo")
+    mk(os.path.join(root, "ingress"), """{
+        "filter": "dst net mynet",
+        "debug": { "dump-flows": "none" },
+        "fwm": [
+            { "time": 15, "name": "total", "fields": ["packets", "octets"] },
+            { "time": 15, "name": "proto", "fields": ["packets desc", "octets desc", "proto"] },
+            { "time": 15, "name": "saddr", "fields": ["packets desc", "octets desc", "src host"], "limit": 20 },
+            { "name": "strange", "fields": ["div(octets, packets)", "packets"] }   // stays with the reference
+        ],
+        "mavg": []
+    }""")
+    mk(os.path.join(root, "ingress", "tcp"), """{ "filter": "proto 6",
+        "fwm": [ { "name": "ports", "fields": ["dst port", "bits desc"] } ] }""")
+    mk(os.path.join(root, "plain"), '{ "filter": "proto 17" }')
+    w = synth.workload_c1(6000)
+    eng.add_iplist("mynet", w["iplists"]["mynet"])
+    orc.iplist_add("mynet", w["iplists"]["mynet"])
+    added, skipped = eng.load_mos_with_tables(root, 1 << 16)
+    assert (added, skipped) == (4, 1)
+    names = [eng.mo_name(i) for i in range(eng.mo_count())]
+    tabs = eng.fwm_tables()
+    assert sorted(n for _, n in tabs) == ["ports", "proto", "saddr", "total"]
+    eng.commit()
+    # the same objects and tables for the oracle, in the library's object order
+    filters = {"ingress": "dst net mynet", "ingress_tcp": "proto 6", "plain": "proto 17"}
+    parents = {"ingress": -1, "ingress_tcp": names.index("ingress"), "plain": -1}
+    for n in names:
+        orc.mo_add(filters[n], parents[n])
+    fields = {"total": ["packets", "octets"], "proto": ["packets desc", "octets desc", "proto"],
+              "saddr": ["packets desc", "octets desc", "src host"], "ports": ["dst port", "bits desc"]}
+    for mo, n in tabs:
+        orc.fwm_add(mo, fields[n])
+    b = eng.prepare(w["batch"])
+    b.run()
+    run_oracle(orc, w["batch"], keep_flows=False)
+    compare(b, orc, flows=False)
+    same_tables(eng, orc, list(range(len(tabs))))
+    assert len(eng.fwm_read(0)[0]) >= 1

@@ -59,6 +59,10 @@ def load_library(path=LIB_PATH):
         "xe_gpu_fwm_info": (i32, [vp, i32, C.POINTER(C.c_size_t), C.POINTER(i32), C.POINTER(C.c_size_t)]),
         "xe_gpu_fwm_read": (C.c_long, [vp, i32, vp, vp, C.c_size_t, C.POINTER(C.c_uint64)]),
         "xe_gpu_fwm_clear": (i32, [vp, i32]),
+        "xe_gpu_load_mos_with_tables": (i32, [vp, C.c_char_p, C.c_size_t, C.POINTER(i32)]),
+        "xe_gpu_fwm_count": (i32, [vp]),
+        "xe_gpu_fwm_object": (i32, [vp, i32]),
+        "xe_gpu_fwm_name": (C.c_char_p, [vp, i32]),
         "xe_gpu_batch_fwm_ms": (i32, [vp, C.POINTER(C.c_float)]),
         "xe_gpu_host_alloc": (vp, [vp, C.c_size_t]),
         "xe_gpu_host_free": (None, [vp, vp]),
@@ -160,6 +164,17 @@ class Engine:
 
     def add_mo(self, name, filt, parent=-1):
         return self._chk(self.L.xe_gpu_add_mo(self._h, name.encode(), parent, filt.encode()))
+
+    def load_mos_with_tables(self, d, max_keys=0):
+        """objects and their "fwm" entries from a mo directory; returns (tables added, entries skipped)"""
+        sk = C.c_int()
+        n = self._chk(self.L.xe_gpu_load_mos_with_tables(self._h, d.encode(), int(max_keys), C.byref(sk)))
+        return n, int(sk.value)
+
+    def fwm_tables(self):
+        """[(object index, name)] of the registered tables"""
+        return [(self.L.xe_gpu_fwm_object(self._h, i), self.L.xe_gpu_fwm_name(self._h, i).decode())
+                for i in range(self.L.xe_gpu_fwm_count(self._h))]
 
     def load_mos(self, d):
         self._chk(self.L.xe_gpu_load_mos(self._h, d.encode()))

@@ -48,6 +48,7 @@ struct fwm_host
 	struct xe_fwm_dev dev;     /* with the device pointers */
 	size_t slots, max_keys;
 	uint32_t keybytes;
+	char name[256];            /* the entry's "name" in mo.conf, when it came from there */
 };
 
 struct xe_batch
@@ -326,7 +327,59 @@ extern "C" int
 xe_gpu_load_mos(xe_gpu *h, const char *mo_dir)
 {
 	if (!h || !mo_dir) return XE_EINVAL;
-	return xe_conf_load_mos(&h->hs, mo_dir, add_mo_cb, h);
+	return xe_conf_load_mos(&h->hs, mo_dir, add_mo_cb, NULL, h);
+}
+
+struct fwm_load_ctx { xe_gpu *h; size_t max_keys; int added, skipped; };
+
+static int
+add_mo_cb2(void *user, const char *name, int parent, const char *filter)
+{
+	return add_mo_cb(((struct fwm_load_ctx *)user)->h, name, parent, filter);
+}
+
+static int
+add_fwm_cb(void *user, int mo, const char *name, const char *const *fields, int nfields)
+{
+	struct fwm_load_ctx *c = (struct fwm_load_ctx *)user;
+	int rc = xe_gpu_add_fwm(c->h, mo, fields, nfields, c->max_keys);
+	if (rc == XE_EUNSUPPORTED) { c->skipped++; return 0; }   /* stays on the reference's CPU path */
+	if (rc < 0) return rc;
+	snprintf(c->h->fwms[rc].name, sizeof(c->h->fwms[rc].name), "%s", name);
+	c->added++;
+	return 0;
+}
+
+extern "C" int
+xe_gpu_load_mos_with_tables(xe_gpu *h, const char *mo_dir, size_t max_keys, int *skipped)
+{
+	struct fwm_load_ctx c;
+	int rc;
+	if (!h || !mo_dir) return XE_EINVAL;
+	c.h = h; c.max_keys = max_keys; c.added = 0; c.skipped = 0;
+	rc = xe_conf_load_mos(&h->hs, mo_dir, add_mo_cb2, add_fwm_cb, &c);
+	if (skipped) *skipped = c.skipped;
+	return (rc < 0) ? rc : c.added;
+}
+
+extern "C" int
+xe_gpu_fwm_count(const xe_gpu *h)
+{
+	return h ? (int)h->nfwm : 0;
+}
+
+extern "C" int
+xe_gpu_fwm_object(const xe_gpu *h, int fwm)
+{
+	if (!h || (fwm < 0) || ((size_t)fwm >= h->nfwm)) return XE_EINVAL;
+	return (int)h->fwms[fwm].dev.mo;
+}
+
+extern "C" const char *
+xe_gpu_fwm_name(const xe_gpu *h, int fwm)
+{
+	if (!h || (fwm < 0) || ((size_t)fwm >= h->nfwm)) return "";
+	return h->fwms[fwm].name;
 }
 
 extern "C" int

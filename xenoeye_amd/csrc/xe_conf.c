@@ -174,7 +174,10 @@ read_file(const char *path)
 }
 
 /* ------------------------------------------------------------------ mo.conf */
-struct mo_ctx { char filter[4096]; int seen; };
+#define MO_MAX_FWM 16
+#define MO_MAX_FWM_FIELDS 24
+struct mo_fwm_conf { char name[256]; char fields[MO_MAX_FWM_FIELDS][128]; int nfields; };
+struct mo_ctx { char filter[4096]; int seen; struct mo_fwm_conf *fwm; int nfwm; };
 
 static int
 mo_cb(void *vctx, const struct jpath_item *path, int depth, int type, const char *val)
@@ -185,12 +188,23 @@ mo_cb(void *vctx, const struct jpath_item *path, int depth, int type, const char
 		snprintf(c->filter, sizeof(c->filter), "%s", val);
 		c->seen = 1;
 	}
+	/* "fwm": [ { "name": ..., "fields": [ ... ] } ] (fwm_config(), monit-objects-fwm.c:139-205) */
+	if (c->fwm && (depth >= 3) && !path[0].is_index && !strcmp(path[0].key, "fwm") && path[1].is_index
+		&& (path[1].index >= 0) && (path[1].index < MO_MAX_FWM) && !path[2].is_index && (type == JV_STRING)) {
+		struct mo_fwm_conf *w = &c->fwm[path[1].index];
+		if (path[1].index >= c->nfwm) c->nfwm = (int)path[1].index + 1;
+		if ((depth == 3) && !strcmp(path[2].key, "name")) snprintf(w->name, sizeof(w->name), "%s", val);
+		if ((depth == 4) && !strcmp(path[2].key, "fields") && path[3].is_index && (w->nfields < MO_MAX_FWM_FIELDS)) {
+			snprintf(w->fields[w->nfields++], sizeof(w->fields[0]), "%s", val);
+		}
+	}
 	return 1;
 }
 
 static int
 load_mo_dir(struct xe_host *hs, const char *root, const char *suffix, int parent,
-	int (*add)(void *, const char *, int, const char *), void *user)
+	int (*add)(void *, const char *, int, const char *),
+	int (*add_fwm)(void *, int, const char *, const char *const *, int), void *user)
 {
 	char dirname[4096];
 	DIR *d;
@@ -219,12 +233,16 @@ load_mo_dir(struct xe_host *hs, const char *root, const char *suffix, int parent
 		if (!json) continue;   /* "Monitoring object not added": its sub-directories are not visited */
 		memset(&p, 0, sizeof(p));
 		memset(&ctx, 0, sizeof(ctx));
+		if (add_fwm) {
+			ctx.fwm = calloc(MO_MAX_FWM, sizeof(*ctx.fwm));
+			if (!ctx.fwm) { free(json); closedir(d); return XE_ENOMEM; }
+		}
 		p.s = json;
 		p.cb = mo_cb;
 		p.ctx = &ctx;
 		jvalue(&p);
 		free(json);
-		if (p.failed) continue;
+		if (p.failed) { free(ctx.fwm); continue; }
 
 		/* '/' in the name becomes '_' (monit-objects.c:162-167) */
 		snprintf(name, sizeof(name), "%s", inner);
@@ -233,10 +251,20 @@ load_mo_dir(struct xe_host *hs, const char *root, const char *suffix, int parent
 		idx = add(user, name, parent, ctx.seen ? ctx.filter : "");
 		if (idx < 0) {
 			closedir(d);
+			free(ctx.fwm);
 			snprintf(hs->err, sizeof(hs->err), "monitoring object '%s' rejected", name);
 			return idx;
 		}
-		idx = load_mo_dir(hs, root, inner, idx, add, user);
+		for (int k = 0; add_fwm && (k < ctx.nfwm); k++) {
+			const char *fl[MO_MAX_FWM_FIELDS];
+			int rc;
+			for (int q = 0; q < ctx.fwm[k].nfields; q++) fl[q] = ctx.fwm[k].fields[q];
+			if (!ctx.fwm[k].nfields) continue;
+			rc = add_fwm(user, idx, ctx.fwm[k].name, fl, ctx.fwm[k].nfields);
+			if (rc < 0) { closedir(d); free(ctx.fwm); return rc; }
+		}
+		free(ctx.fwm);
+		idx = load_mo_dir(hs, root, inner, idx, add, add_fwm, user);
 		if (idx < 0) { closedir(d); return idx; }
 	}
 	closedir(d);
@@ -245,9 +273,10 @@ load_mo_dir(struct xe_host *hs, const char *root, const char *suffix, int parent
 
 int
 xe_conf_load_mos(struct xe_host *hs, const char *mo_dir,
-	int (*add)(void *user, const char *name, int parent, const char *filter), void *user)
+	int (*add)(void *user, const char *name, int parent, const char *filter),
+	int (*add_fwm)(void *user, int mo, const char *name, const char *const *fields, int nfields), void *user)
 {
-	return load_mo_dir(hs, mo_dir, "", -1, add, user);
+	return load_mo_dir(hs, mo_dir, "", -1, add, add_fwm, user);
 }
 
 /* ------------------------------------------------------------------ devices.conf */

@@ -150,7 +150,7 @@ xe_ht_list_mos(const char *mo_dir, char *out, size_t outlen)
 	int rc;
 	xe_host_init(&hs);
 	if (outlen) out[0] = '\0';
-	rc = xe_conf_load_mos(&hs, mo_dir, collect_mo, &c);
+	rc = xe_conf_load_mos(&hs, mo_dir, collect_mo, NULL, &c);
 	xe_host_free(&hs);
 	return rc;
 }
