@@ -2480,6 +2480,10 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 			+ (kp->lds_counters ? (size_t)kp->nmo * 24 : 0)
 			+ (kp->motab_lds ? (size_t)kp->motab_words * 8 : 0);
 		if (blocks > 4096) blocks = 4096;
+		if (getenv("XE_FAST_BLOCKS")) {          /* diagnostic: grid size of the fast kernel */
+			uint32_t want = (uint32_t)atoi(getenv("XE_FAST_BLOCKS"));
+			if ((want >= 8) && (want < blocks)) blocks = want;
+		}
 		/* the kernel deals the tile list to 8 groups of blocks (blockIdx % 8):
 		 * every group needs at least one block */
 		if (blocks < 8) blocks = 8;
