@@ -2087,7 +2087,13 @@ sf_store_all(const xe_kparams &kp, const sf_rec &r, uint32_t ridx, std::integer_
 	(sf_store<FI>(kp, r, ridx), ...);
 }
 
+#ifndef XE_SF_WAVES
+#define XE_SF_WAVES 3      /* measured on MI355X: 2 (the compiler's choice, 189 VGPRs) 0.725 ms, 3 0.609 ms, 4 1.02 ms per 3.2 M samples */
+#endif
 __global__ void __launch_bounds__(XE_BLOCK)
+#if XE_SF_WAVES
+__attribute__((amdgpu_waves_per_eu(XE_SF_WAVES, XE_SF_WAVES)))
+#endif
 xe_sf_kernel(const xe_kparams kp)
 {
 	extern __shared__ uint64_t lane_lds[];
