@@ -206,6 +206,33 @@ int xe_gpu_batch_column(xe_batch *b, int field, void *out, size_t outlen, size_t
 int xe_gpu_batch_device_ptrs(xe_batch *b, const void **masks, const void **counters,
 	const void **nparsed);
 
+/* ---- capture-file replay (host only, needs no GPU) ----
+ * replaces pcap_packet() (pcapture.c:111-180) for frames read from a classic
+ * pcap file (micro- or nanosecond stamps, either byte order, Ethernet link
+ * type): 14-byte Ethernet header, IPv4 header of IHL*4 bytes and UDP header
+ * are stripped by the reference's rules, the IPv4 source address becomes the
+ * exporter address.  The reference selects frames with a BPF expression
+ * (pcapture.c:291-305); here udp_port > 0 keeps datagrams to that UDP
+ * destination port, 0 keeps every UDP datagram.
+ * On failure xe_pcap_open() still returns a reader in *out (when memory
+ * allowed) whose xe_pcap_error() gives the reason; close it. */
+typedef struct xe_pcap xe_pcap;
+int xe_pcap_open(const char *path, xe_pcap **out);
+void xe_pcap_close(xe_pcap *p);
+const char *xe_pcap_error(const xe_pcap *p);
+/* appends datagrams in file order, in the form xe_gpu_batch_prepare() takes,
+ * until max_datagrams are in, the next one would not fit into cap bytes (it
+ * is kept for the next call) or the file ends.  offsets has room for
+ * max_datagrams + 1 entries.  Returns the number of datagrams (0 = end of
+ * file) or a negative XE_E* code. */
+long xe_pcap_read(xe_pcap *p, int udp_port, uint8_t *data, size_t cap, uint64_t *offsets,
+	uint32_t *src_ip4, size_t max_datagrams);
+/* frames read; datagrams handed out; frames ignored by the reference's rules
+ * (short, not UDP, other port); frames dropped because their lengths
+ * contradict the captured bytes (undefined behaviour in the reference) */
+void xe_pcap_stats(const xe_pcap *p, uint64_t *frames, uint64_t *taken, uint64_t *ignored,
+	uint64_t *damaged);
+
 /* ---- field table (netflow.def:2-64 + the virtual fields of flow-info.h:19-30) ---- */
 int xe_field_count(void);
 const char *xe_field_name(int field);

@@ -89,6 +89,11 @@ def load_library(path=LIB_PATH):
         "xe_field_size_max": (i32, [i32]),
         "xe_field_offset": (sz, [i32]),
         "xe_gpu_iplist_match": (i32, [vp, cp, i32, vp, sz, vp]),
+        "xe_pcap_open": (i32, [cp, C.POINTER(vp)]),
+        "xe_pcap_close": (None, [vp]),
+        "xe_pcap_error": (cp, [vp]),
+        "xe_pcap_read": (C.c_long, [vp, i32, vp, sz, vp, vp, sz]),
+        "xe_pcap_stats": (None, [vp] + [C.POINTER(C.c_uint64)] * 4),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)   # AttributeError = the library lacks a declared symbol
@@ -114,6 +119,58 @@ def filter_check(text, engine=None):
     err = C.create_string_buffer(1024)
     rc = L.xe_filter_check(engine._h if engine else None, text.encode(), dump, len(dump), err, len(err))
     return rc, dump.value.decode(), err.value.decode(errors="replace")
+
+
+class PcapReader:
+    """Datagram batches out of a classic pcap file (xe_pcap_*): iterate over it
+    for (data, offsets, src, None) tuples that Engine.prepare() takes."""
+
+    def __init__(self, path, udp_port=0, max_bytes=64 << 20, max_datagrams=1 << 16):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.xe_pcap_open(os.fsencode(path), C.byref(h))
+        self._h = h
+        if rc != 0:
+            detail = self.L.xe_pcap_error(h).decode(errors="replace") if h else ""
+            self.close()
+            raise XeError(rc, detail)
+        self.udp_port, self.max_bytes, self.max_datagrams = int(udp_port), int(max_bytes), int(max_datagrams)
+
+    def close(self):
+        if self._h:
+            self.L.xe_pcap_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def read(self):
+        """the next batch, or None at the end of the file"""
+        data = np.empty(self.max_bytes, dtype=np.uint8)
+        offs = np.zeros(self.max_datagrams + 1, dtype=np.uint64)
+        src = np.zeros(self.max_datagrams, dtype=np.uint32)
+        n = self.L.xe_pcap_read(self._h, self.udp_port, data.ctypes.data, data.size, offs.ctypes.data,
+                                src.ctypes.data, self.max_datagrams)
+        if n < 0:
+            raise XeError(n, self.L.xe_pcap_error(self._h).decode(errors="replace"))
+        if n == 0:
+            return None
+        return data[:int(offs[n])], offs[:n + 1], src[:n], None
+
+    def __iter__(self):
+        while True:
+            b = self.read()
+            if b is None:
+                return
+            yield b
+
+    def stats(self):
+        v = [C.c_uint64() for _ in range(4)]
+        self.L.xe_pcap_stats(self._h, *[C.byref(x) for x in v])
+        return dict(zip(("frames", "taken", "ignored", "damaged"), [int(x.value) for x in v]))
 
 
 class Engine:

@@ -639,3 +639,37 @@ def workload_c3(nsamples, seed=SEED_C3, n_agents=32, per_packet=7):
            ("mac 00:11:22:33:44:55", -1), ("proto 17", -1), ("net list0", -1),
            ("tcp-flags 512", -1), ("not proto 6", -1)]
     return dict(batch=b, iplists=iplists, mos=mos, devices=[], nrec=nsamples)
+
+
+# ---------------------------------------------------------------- capture files
+def udp_frame(payload, src, dst=b"\x0a\x00\x00\x01", sport=40000, dport=2055, ip_options=b"",
+              ip_len=None, udp_len=None, proto=17, trailer=b""):
+    """Ethernet + IPv4 + UDP around one datagram (checksums left zero: the
+    collector does not look at them)."""
+    ihl = 5 + len(ip_options) // 4
+    if ip_len is None:
+        ip_len = 4 * ihl + 8 + len(payload)
+    if udp_len is None:
+        udp_len = 8 + len(payload)
+    eth = b"\x02\x00\x00\x00\x00\x01" + b"\x02\x00\x00\x00\x00\x02" + b"\x08\x00"
+    ip = struct.pack(">BBHHHBBH", 0x40 | ihl, 0, ip_len & 0xFFFF, 0, 0, 64, proto, 0) + bytes(src) + bytes(dst) + ip_options
+    udp = struct.pack(">HHHH", sport, dport, udp_len & 0xFFFF, 0)
+    return eth + ip + udp + bytes(payload) + trailer
+
+
+def write_pcap(path, frames, byte_order="<", nanosecond=False, linktype=1, snaplen=262144):
+    """classic pcap file out of raw frames (bytes, or (bytes, captured_length))"""
+    magic = 0xa1b23c4d if nanosecond else 0xa1b2c3d4
+    with open(path, "wb") as f:
+        f.write(struct.pack(byte_order + "IHHiIII", magic, 2, 4, 0, 0, snaplen, linktype))
+        for i, fr in enumerate(frames):
+            cap = None
+            if isinstance(fr, tuple):
+                fr, cap = fr
+            cap = len(fr) if cap is None else cap
+            f.write(struct.pack(byte_order + "IIII", 1700000000 + i // 1000, i % 1000, cap, len(fr)))
+            f.write(fr[:cap])
+
+
+def batch_to_pcap(path, batch, dport=2055, **kw):
+    write_pcap(path, [udp_frame(p, s, dport=dport) for p, s in zip(batch.pkts, batch.src)], **kw)
