@@ -118,6 +118,19 @@ int xe_gpu_fwm_info(const xe_gpu *h, int fwm, size_t *key_bytes, int *nvals, siz
  * monit-objects-fwm.c:497-691): keys[row][key_bytes], vals[row][nvals].
  * Returns the number of rows the table holds (copies at most max_rows). */
 long xe_gpu_fwm_read(xe_gpu *h, int fwm, uint8_t *keys, uint64_t *vals, size_t max_rows, uint64_t *dropped);
+/* "limit" (rows per export, 0 = all) and "time" (seconds per window) of the
+ * mo.conf entry the table came from (fwm_config(), monit-objects-fwm.c:179-190);
+ * both 0 for tables added by hand */
+int xe_gpu_fwm_window(const xe_gpu *h, int fwm, int *limit, int *seconds);
+/* the rows as fwm_sort_and_dump() + fwm_dump() write them
+ * (monit-objects-fwm.c:496-589, 405-449): sorted by the fields in the order
+ * of the entry (sums as big-endian numbers, `desc` fields inverted, bytewise
+ * ascending), cut after `limit` rows (0 = all, < 0 = the entry's own limit);
+ * others[nvals] receives the sums over the rows behind the cut ("others" row
+ * of the export), *hit_limit whether the reference would write that row.
+ * Returns the number of rows before the cut; at most max_rows are stored. */
+long xe_gpu_fwm_export(xe_gpu *h, int fwm, int limit, uint8_t *keys, uint64_t *vals, size_t max_rows,
+	uint64_t *others, int *hit_limit);
 /* end of a window: empties the table */
 int xe_gpu_fwm_clear(xe_gpu *h, int fwm);
 

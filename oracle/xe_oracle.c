@@ -1841,6 +1841,8 @@ struct ofwm
 	int mo;
 	struct ofield naggr[16], aggr[8];
 	size_t n_naggr, n_aggr, keysize;
+	struct ofield order[24];     /* all fields in the order given (mo_fwm.fieldset) */
+	size_t n_order;
 	/* keyed sums: open addressing over `cap` rows of keysize bytes + n_aggr u64 */
 	uint8_t *keys;
 	uint64_t *vals;
@@ -1938,6 +1940,7 @@ xo_fwm_add(int mo, const char *const *field_texts, int n, char *err, size_t errl
 	for (i = 0; i < n; i++) {
 		struct ofield f;
 		if (!parse_field(field_texts[i], &f, err, errlen)) return -1;
+		if (w.n_order < 24) w.order[w.n_order++] = f;
 		if (f.aggr) {
 			if (w.n_aggr == 8) { snprintf(err, errlen, "too many fields"); return -1; }
 			w.aggr[w.n_aggr++] = f;
@@ -2016,6 +2019,81 @@ xo_fwm_dump(int fwm, uint8_t *keys, uint64_t *vals)
 		memcpy(vals + r * w->n_aggr, w->vals + i * na, w->n_aggr * sizeof(uint64_t));
 		r++;
 	}
+}
+
+/* The export of a window.  fwm_sort_and_dump() (monit-objects-fwm.c:496-589)
+ * re-keys every row: the fields in fieldset order, a sum as htobe64(value), a
+ * key field as its bytes, both bitwise inverted when the field is `desc`; the
+ * rows go into an ordered tkvdb transaction, whose cursor walks keys in
+ * ascending byte order.  fwm_dump() (:405-449) writes rows until `limit` is
+ * reached (hit_limit is raised then, also when no row is left) and adds up
+ * the sums of the remaining rows as the "others" row. */
+static const uint8_t *export_sk;
+static size_t export_sklen;
+
+static int
+export_cmp(const void *a, const void *b)
+{
+	return memcmp(export_sk + *(const size_t *)a * export_sklen, export_sk + *(const size_t *)b * export_sklen,
+		export_sklen);
+}
+
+long
+xo_fwm_export(int fwm, int limit, uint8_t *keys, uint64_t *vals, uint64_t *others, int *hit_limit)
+{
+	struct ofwm *w = &fwms[fwm];
+	size_t n = w->n, r, i, sklen = 0, nout = 0;
+	uint8_t *rk, *sk;
+	uint64_t *rv;
+	size_t *idx;
+
+	*hit_limit = 0;
+	for (i = 0; i < w->n_aggr; i++) others[i] = 0;
+	if (!n) return 0;
+	for (i = 0; i < w->n_order; i++) sklen += w->order[i].size;
+	rk = malloc(n * (w->keysize ? w->keysize : 1));
+	rv = malloc(n * (w->n_aggr ? w->n_aggr : 1) * sizeof(uint64_t));
+	sk = malloc(n * (sklen ? sklen : 1));
+	idx = malloc(n * sizeof(size_t));
+	xo_fwm_dump(fwm, rk, rv);
+	for (r = 0; r < n; r++) {
+		uint8_t *kptr = sk + r * sklen;
+		const uint8_t *naggr = rk + r * w->keysize;
+		const uint64_t *aggr = rv + r * w->n_aggr;
+		for (i = 0; i < w->n_order; i++) {
+			const struct ofield *fld = &w->order[i];
+			if (fld->aggr) {
+				uint64_t v = htobe64(*aggr);
+				if (fld->descending) v = ~v;
+				memcpy(kptr, &v, sizeof(uint64_t));
+				kptr += sizeof(uint64_t);
+				aggr++;
+			} else {
+				size_t j;
+				for (j = 0; j < fld->size; j++) {
+					*kptr++ = fld->descending ? (uint8_t)~*naggr : *naggr;
+					naggr++;
+				}
+			}
+		}
+		idx[r] = r;
+	}
+	export_sk = sk;
+	export_sklen = sklen;
+	qsort(idx, n, sizeof(size_t), export_cmp);
+	for (r = 0; r < n; r++) {
+		const size_t s = idx[r];
+		if (!*hit_limit) {
+			memcpy(keys + nout * w->keysize, rk + s * w->keysize, w->keysize);
+			memcpy(vals + nout * w->n_aggr, rv + s * w->n_aggr, w->n_aggr * sizeof(uint64_t));
+			nout++;
+			if (limit && ((int)nout >= limit)) *hit_limit = 1;
+		} else {
+			for (i = 0; i < w->n_aggr; i++) others[i] += rv[s * w->n_aggr + i];
+		}
+	}
+	free(rk); free(rv); free(sk); free(idx);
+	return (long)nout;
 }
 
 static void

@@ -103,6 +103,9 @@ size_t xo_fwm_rows(int fwm);
 size_t xo_fwm_keysize(int fwm);
 size_t xo_fwm_nvals(int fwm);
 void xo_fwm_dump(int fwm, uint8_t *keys, uint64_t *vals);
+/* rows in the reference's export order, cut after `limit` rows (0 = all);
+ * others[nvals] = sums of the rows behind the cut (monit-objects-fwm.c:405-449, 496-589) */
+long xo_fwm_export(int fwm, int limit, uint8_t *keys, uint64_t *vals, uint64_t *others, int *hit_limit);
 /* text of a TCP flags byte, as tcp_flags_to_str() (utils.c:22-26) gives it */
 void xo_tcp_flags_str(uint8_t tf, char out[40]);
 

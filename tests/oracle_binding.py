@@ -38,6 +38,8 @@ class Oracle:
             getattr(L, f).restype = C.c_size_t
         L.xo_fwm_dump.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         L.xo_fwm_dump.restype = None
+        L.xo_fwm_export.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.xo_fwm_export.restype = C.c_long
         L.xo_device_add.argtypes = [C.c_int, C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.c_int,
                                     C.POINTER(C.c_char_p), C.c_int, C.c_char_p, C.c_size_t]
         L.xo_netflow_process.argtypes = [C.c_char_p, C.c_int, C.c_uint32]
@@ -121,6 +123,18 @@ class Oracle:
         if n:
             self.L.xo_fwm_dump(fwm, keys.ctypes.data, vals.ctypes.data)
         return {bytes(keys[i, :ks]): tuple(int(x) for x in vals[i, :nv]) for i in range(n)}
+
+    def fwm_export(self, fwm, limit=0):
+        """([(key bytes, sums)] in export order, others, hit_limit)"""
+        import numpy as np
+        n, ks, nv = self.L.xo_fwm_rows(fwm), self.L.xo_fwm_keysize(fwm), self.L.xo_fwm_nvals(fwm)
+        keys = np.zeros((max(n, 1), max(ks, 1)), dtype=np.uint8)
+        vals = np.zeros((max(n, 1), max(nv, 1)), dtype=np.uint64)
+        others = np.zeros(max(nv, 1), dtype=np.uint64)
+        hit = C.c_int()
+        m = self.L.xo_fwm_export(fwm, limit, keys.ctypes.data, vals.ctypes.data, others.ctypes.data, C.byref(hit))
+        return ([(bytes(keys[i, :ks]), tuple(int(x) for x in vals[i, :nv])) for i in range(m)],
+                tuple(int(x) for x in others[:nv]), bool(hit.value))
 
     def mo_add(self, filt, parent=-1):
         err = C.create_string_buffer(1100)

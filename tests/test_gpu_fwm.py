@@ -158,7 +158,7 @@ def test_tables_from_mo_conf(tmp_path, eng, orc):
         "fwm": [
             { "time": 15, "name": "total", "fields": ["packets", "octets"] },
             { "time": 15, "name": "proto", "fields": ["packets desc", "octets desc", "proto"] },
-            { "time": 15, "name": "saddr", "fields": ["packets desc", "octets desc", "src host"], "limit": 20 },
+            { "time": 15, "name": "saddr", "fields": ["packets desc", "octets desc", "src host"], "limit": 5 },
             { "name": "strange", "fields": ["div(octets, packets)", "packets"] }   // stays with the reference
         ],
         "mavg": []
@@ -190,3 +190,52 @@ def test_tables_from_mo_conf(tmp_path, eng, orc):
     compare(b, orc, flows=False)
     same_tables(eng, orc, list(range(len(tabs))))
     assert len(eng.fwm_read(0)[0]) >= 1
+    # "limit" and "time" of the entries, and the export cut by the entry's own limit
+    by_name = {n: t for t, (_, n) in enumerate(tabs)}
+    assert eng.fwm_window(by_name["saddr"]) == (5, 15)
+    assert eng.fwm_window(by_name["proto"]) == (0, 15)
+    assert eng.fwm_window(by_name["ports"]) == (0, 0)
+    for n, t in by_name.items():
+        lim = eng.fwm_window(t)[0]
+        assert eng.fwm_export(t) == orc.fwm_export(t, lim), n
+    rows, others, hit = eng.fwm_export(by_name["saddr"])
+    assert len(rows) == 5 and hit and others[0] > 0
+    # most packets first
+    assert [r[1][0] for r in rows] == sorted((r[1][0] for r in rows), reverse=True)
+
+
+def test_export_order_and_others(eng, orc):
+    """rows leave in the order of fwm_sort_and_dump() (monit-objects-fwm.c:496-589):
+    by the fields as listed, `desc` inverted; the rows behind the limit are
+    summed up (fwm_dump(), :405-449)"""
+    w = synth.workload_c2(25000, prefixes=200, seed=4)
+    w["mos"] = list(w["mos"]) + [("", -1)]
+    tables = [(16, ["packets desc", "proto", "dst port"]),
+              (16, ["proto desc", "src port", "octets", "packets desc"]),
+              (16, ["dst port desc", "bits"]),
+              (16, ["src host", "dst host desc", "packets"]),
+              (16, ["octets", "packets desc"]),                 # no key field
+              (0, ["dst host6 desc", "src as", "octets desc", "bits"]),
+              (16, ["proto", "tcp-flags desc"])]                # no sums
+    ids = setup(eng, orc, w, tables, max_keys=1 << 17)
+    b = eng.prepare(w["batch"])
+    b.run()
+    run_oracle(orc, w["batch"], keep_flows=False)
+    same_tables(eng, orc, ids)
+    for t in ids:
+        total = len(eng.fwm_read(t)[0])
+        for limit in (0, 1, 5, total - 1, total, total + 1, 1000000):
+            if limit < 0:
+                continue
+            got, want = eng.fwm_export(t, limit), orc.fwm_export(t, limit)
+            assert got == want, (t, limit)
+            rows, others, hit = got
+            assert len(rows) == (min(limit, total) if limit else total)
+            assert hit == (limit != 0 and total >= limit)
+    # the first table: descending packets, ties by proto then port ascending
+    rows, _, _ = eng.fwm_export(ids[0], 0)
+    order = [(-r[1][0], r[0]) for r in rows]
+    assert order == sorted(order)
+    # an empty table exports nothing
+    eng.fwm_clear(ids[2])
+    assert eng.fwm_export(ids[2], 3) == ([], (0,), False)

@@ -59,6 +59,8 @@ def load_library(path=LIB_PATH):
         "xe_gpu_fwm_info": (i32, [vp, i32, C.POINTER(C.c_size_t), C.POINTER(i32), C.POINTER(C.c_size_t)]),
         "xe_gpu_fwm_read": (C.c_long, [vp, i32, vp, vp, C.c_size_t, C.POINTER(C.c_uint64)]),
         "xe_gpu_fwm_clear": (i32, [vp, i32]),
+        "xe_gpu_fwm_window": (i32, [vp, i32, C.POINTER(i32), C.POINTER(i32)]),
+        "xe_gpu_fwm_export": (C.c_long, [vp, i32, i32, vp, vp, C.c_size_t, vp, C.POINTER(i32)]),
         "xe_gpu_load_mos_with_tables": (i32, [vp, C.c_char_p, C.c_size_t, C.POINTER(i32)]),
         "xe_gpu_fwm_count": (i32, [vp]),
         "xe_gpu_fwm_object": (i32, [vp, i32]),
@@ -277,6 +279,28 @@ class Engine:
         assert n2 == n
         return ({bytes(keys[i, :kb.value]): tuple(int(x) for x in vals[i, :nv.value]) for i in range(n)},
                 int(dropped.value))
+
+    def fwm_window(self, fwm):
+        """("limit", "time") of the mo.conf entry"""
+        lim, sec = C.c_int(), C.c_int()
+        self._chk(self.L.xe_gpu_fwm_window(self._h, fwm, C.byref(lim), C.byref(sec)))
+        return int(lim.value), int(sec.value)
+
+    def fwm_export(self, fwm, limit=-1):
+        """([(key bytes, sums)] in the reference's export order, cut after
+        `limit` rows (0 = all, -1 = the entry's own limit); sums of the rows
+        behind the cut; whether the cut was reached)"""
+        kb, nv, sl = C.c_size_t(), C.c_int(), C.c_size_t()
+        self._chk(self.L.xe_gpu_fwm_info(self._h, fwm, C.byref(kb), C.byref(nv), C.byref(sl)))
+        n = self._chk(self.L.xe_gpu_fwm_read(self._h, fwm, None, None, 0, None))
+        keys = np.zeros((max(n, 1), max(kb.value, 1)), dtype=np.uint8)
+        vals = np.zeros((max(n, 1), max(nv.value, 1)), dtype=np.uint64)
+        others = np.zeros(max(nv.value, 1), dtype=np.uint64)
+        hit = C.c_int()
+        m = self._chk(self.L.xe_gpu_fwm_export(self._h, fwm, int(limit), keys.ctypes.data, vals.ctypes.data, n,
+                                               others.ctypes.data, C.byref(hit)))
+        return ([(bytes(keys[i, :kb.value]), tuple(int(x) for x in vals[i, :nv.value])) for i in range(m)],
+                tuple(int(x) for x in others[:nv.value]), bool(hit.value))
 
     def fwm_clear(self, fwm):
         self._chk(self.L.xe_gpu_fwm_clear(self._h, fwm))

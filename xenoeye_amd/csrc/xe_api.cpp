@@ -49,6 +49,10 @@ struct fwm_host
 	size_t slots, max_keys;
 	uint32_t keybytes;
 	char name[256];            /* the entry's "name" in mo.conf, when it came from there */
+	int limit, time;           /* "limit" (rows exported, 0 = all) and "time" (window seconds) of the entry */
+	/* the fields in the order of the entry: what the export sorts by */
+	int nfields;
+	struct { uint8_t aggr, descending; uint16_t size; } order[XE_FWM_MAX_KEY_FIELDS + XE_FWM_MAX_VALS];
 };
 
 struct xe_batch
@@ -339,13 +343,15 @@ add_mo_cb2(void *user, const char *name, int parent, const char *filter)
 }
 
 static int
-add_fwm_cb(void *user, int mo, const char *name, const char *const *fields, int nfields)
+add_fwm_cb(void *user, int mo, const char *name, const char *const *fields, int nfields, int limit, int time)
 {
 	struct fwm_load_ctx *c = (struct fwm_load_ctx *)user;
 	int rc = xe_gpu_add_fwm(c->h, mo, fields, nfields, c->max_keys);
 	if (rc == XE_EUNSUPPORTED) { c->skipped++; return 0; }   /* stays on the reference's CPU path */
 	if (rc < 0) return rc;
 	snprintf(c->h->fwms[rc].name, sizeof(c->h->fwms[rc].name), "%s", name);
+	c->h->fwms[rc].limit = limit;
+	c->h->fwms[rc].time = time;
 	c->added++;
 	return 0;
 }
@@ -741,6 +747,10 @@ xe_gpu_add_fwm(xe_gpu *h, int mo, const char *const *fields, int nfields, size_t
 			snprintf(h->err, sizeof(h->err), "field '%.100s': %s", fields[i], err);
 			return rc;
 		}
+		w.order[w.nfields].aggr = f.aggr;
+		w.order[w.nfields].descending = f.descending;
+		w.order[w.nfields].size = (uint16_t)(f.aggr ? 8 : f.size);
+		if (w.nfields + 1 < (int)(sizeof(w.order) / sizeof(w.order[0]))) w.nfields++;
 		if (f.aggr) {
 			if (w.dev.nval == XE_FWM_MAX_VALS) {
 				snprintf(h->err, sizeof(h->err), "more than %d aggregable fields", XE_FWM_MAX_VALS);
@@ -834,6 +844,101 @@ xe_gpu_fwm_read(xe_gpu *h, int fwm, uint8_t *keys, uint64_t *vals, size_t max_ro
 out:
 	free(sl);
 	free(vl);
+	return rc;
+}
+
+extern "C" int
+xe_gpu_fwm_window(const xe_gpu *h, int fwm, int *limit, int *seconds)
+{
+	if (!h || (fwm < 0) || ((size_t)fwm >= h->nfwm)) return XE_EINVAL;
+	if (limit) *limit = h->fwms[fwm].limit;
+	if (seconds) *seconds = h->fwms[fwm].time;
+	return XE_OK;
+}
+
+/* rows in the order fwm_sort_and_dump() (monit-objects-fwm.c:496-589) gives
+ * them: per row a sort key = the fields in the order of the entry, sums as
+ * big-endian u64, key fields as stored, `desc` fields bitwise inverted;
+ * rows ascending by the bytes of that key. */
+struct fwm_sortrow { const uint8_t *sk; uint32_t row; };
+static int
+fwm_sort_cmp(const void *a, const void *b, void *len)
+{
+	return memcmp(((const struct fwm_sortrow *)a)->sk, ((const struct fwm_sortrow *)b)->sk, *(const size_t *)len);
+}
+
+extern "C" long
+xe_gpu_fwm_export(xe_gpu *h, int fwm, int limit, uint8_t *keys, uint64_t *vals, size_t max_rows,
+	uint64_t *others, int *hit_limit)
+{
+	struct fwm_host *w;
+	uint8_t *rk = NULL, *sk = NULL;
+	uint64_t *rv = NULL;
+	struct fwm_sortrow *idx = NULL;
+	size_t sklen = 0, nout;
+	long n, rc = XE_ENOMEM;
+
+	if (!h || (fwm < 0) || ((size_t)fwm >= h->nfwm)) return XE_EINVAL;
+	w = &h->fwms[fwm];
+	if (limit < 0) limit = w->limit;
+	n = xe_gpu_fwm_read(h, fwm, NULL, NULL, 0, NULL);
+	if (n < 0) return n;
+	if (hit_limit) *hit_limit = 0;
+	for (uint32_t j = 0; others && (j < w->dev.nval); j++) others[j] = 0;
+	if (n == 0) return 0;
+	for (int i = 0; i < w->nfields; i++) sklen += w->order[i].size;
+	rk = (uint8_t *)malloc((size_t)n * (w->keybytes ? w->keybytes : 1));
+	rv = (uint64_t *)malloc((size_t)n * (w->dev.nval ? w->dev.nval : 1) * 8);
+	sk = (uint8_t *)malloc((size_t)n * (sklen ? sklen : 1));
+	idx = (struct fwm_sortrow *)malloc((size_t)n * sizeof(*idx));
+	if (!rk || !rv || !sk || !idx) goto out;
+	rc = xe_gpu_fwm_read(h, fwm, rk, rv, (size_t)n, NULL);
+	if (rc < 0) goto out;
+	if (rc < n) n = rc;
+	for (long r = 0; r < n; r++) {
+		uint8_t *d = sk + (size_t)r * sklen;
+		const uint8_t *kp = rk + (size_t)r * w->keybytes;
+		const uint64_t *vp = rv + (size_t)r * w->dev.nval;
+		for (int i = 0; i < w->nfields; i++) {
+			if (w->order[i].aggr) {
+				uint64_t v = __builtin_bswap64(*vp++);
+				if (w->order[i].descending) v = ~v;
+				memcpy(d, &v, 8);
+				d += 8;
+			} else {
+				for (uint32_t j = 0; j < w->order[i].size; j++) {
+					*d++ = w->order[i].descending ? (uint8_t)~*kp : *kp;
+					kp++;
+				}
+			}
+		}
+		idx[r].sk = sk + (size_t)r * sklen;
+		idx[r].row = (uint32_t)r;
+	}
+	qsort_r(idx, (size_t)n, sizeof(*idx), fwm_sort_cmp, &sklen);
+
+	/* the first `limit` rows; the sums of all later rows go to `others`
+	 * (fwm_dump(), monit-objects-fwm.c:405-449: the flag is raised when the
+	 * limit is reached, even with nothing behind it) */
+	nout = (size_t)n;
+	if (limit && ((size_t)limit <= nout)) {
+		nout = (size_t)limit;
+		if (hit_limit) *hit_limit = 1;
+	}
+	for (size_t r = 0; r < (size_t)n; r++) {
+		const uint32_t s = idx[r].row;
+		if (r < nout) {
+			if (r < max_rows) {
+				if (keys) memcpy(keys + r * w->keybytes, rk + (size_t)s * w->keybytes, w->keybytes);
+				if (vals) memcpy(vals + r * w->dev.nval, rv + (size_t)s * w->dev.nval, (size_t)w->dev.nval * 8);
+			}
+		} else if (others) {
+			for (uint32_t j = 0; j < w->dev.nval; j++) others[j] += rv[(size_t)s * w->dev.nval + j];
+		}
+	}
+	rc = (long)nout;
+out:
+	free(rk); free(rv); free(sk); free(idx);
 	return rc;
 }
 

@@ -176,8 +176,8 @@ read_file(const char *path)
 /* ------------------------------------------------------------------ mo.conf */
 #define MO_MAX_FWM 16
 #define MO_MAX_FWM_FIELDS 24
-struct mo_fwm_conf { char name[256]; char fields[MO_MAX_FWM_FIELDS][128]; int nfields; };
-struct mo_ctx { char filter[4096]; int seen; struct mo_fwm_conf *fwm; int nfwm; };
+struct mo_fwm_conf { char name[256]; char fields[MO_MAX_FWM_FIELDS][128]; int nfields, limit, time; };
+struct mo_ctx { char filter[4096]; int seen, bad; struct mo_fwm_conf *fwm; int nfwm; };
 
 static int
 mo_cb(void *vctx, const struct jpath_item *path, int depth, int type, const char *val)
@@ -190,13 +190,18 @@ mo_cb(void *vctx, const struct jpath_item *path, int depth, int type, const char
 	}
 	/* "fwm": [ { "name": ..., "fields": [ ... ] } ] (fwm_config(), monit-objects-fwm.c:139-205) */
 	if (c->fwm && (depth >= 3) && !path[0].is_index && !strcmp(path[0].key, "fwm") && path[1].is_index
-		&& (path[1].index >= 0) && (path[1].index < MO_MAX_FWM) && !path[2].is_index && (type == JV_STRING)) {
+		&& (path[1].index >= 0) && (path[1].index < MO_MAX_FWM) && !path[2].is_index) {
 		struct mo_fwm_conf *w = &c->fwm[path[1].index];
 		if (path[1].index >= c->nfwm) c->nfwm = (int)path[1].index + 1;
-		if ((depth == 3) && !strcmp(path[2].key, "name")) snprintf(w->name, sizeof(w->name), "%s", val);
-		if ((depth == 4) && !strcmp(path[2].key, "fields") && path[3].is_index && (w->nfields < MO_MAX_FWM_FIELDS)) {
+		if ((type == JV_STRING) && (depth == 3) && !strcmp(path[2].key, "name")) snprintf(w->name, sizeof(w->name), "%s", val);
+		if ((type == JV_STRING) && (depth == 4) && !strcmp(path[2].key, "fields") && path[3].is_index
+			&& (w->nfields < MO_MAX_FWM_FIELDS)) {
 			snprintf(w->fields[w->nfields++], sizeof(w->fields[0]), "%s", val);
 		}
+		/* atoi() of the value's text whatever its JSON type; a negative
+		 * number fails the object's configuration (:179-190) */
+		if ((depth == 3) && val && !strcmp(path[2].key, "time")) { w->time = atoi(val); if (w->time < 0) c->bad = 1; }
+		if ((depth == 3) && val && !strcmp(path[2].key, "limit")) { w->limit = atoi(val); if (w->limit < 0) c->bad = 1; }
 	}
 	return 1;
 }
@@ -204,7 +209,7 @@ mo_cb(void *vctx, const struct jpath_item *path, int depth, int type, const char
 static int
 load_mo_dir(struct xe_host *hs, const char *root, const char *suffix, int parent,
 	int (*add)(void *, const char *, int, const char *),
-	int (*add_fwm)(void *, int, const char *, const char *const *, int), void *user)
+	int (*add_fwm)(void *, int, const char *, const char *const *, int, int, int), void *user)
 {
 	char dirname[4096];
 	DIR *d;
@@ -242,7 +247,7 @@ load_mo_dir(struct xe_host *hs, const char *root, const char *suffix, int parent
 		p.ctx = &ctx;
 		jvalue(&p);
 		free(json);
-		if (p.failed) { free(ctx.fwm); continue; }
+		if (p.failed || ctx.bad) { free(ctx.fwm); continue; }
 
 		/* '/' in the name becomes '_' (monit-objects.c:162-167) */
 		snprintf(name, sizeof(name), "%s", inner);
@@ -260,7 +265,7 @@ load_mo_dir(struct xe_host *hs, const char *root, const char *suffix, int parent
 			int rc;
 			for (int q = 0; q < ctx.fwm[k].nfields; q++) fl[q] = ctx.fwm[k].fields[q];
 			if (!ctx.fwm[k].nfields) continue;
-			rc = add_fwm(user, idx, ctx.fwm[k].name, fl, ctx.fwm[k].nfields);
+			rc = add_fwm(user, idx, ctx.fwm[k].name, fl, ctx.fwm[k].nfields, ctx.fwm[k].limit, ctx.fwm[k].time);
 			if (rc < 0) { closedir(d); free(ctx.fwm); return rc; }
 		}
 		free(ctx.fwm);
@@ -274,7 +279,8 @@ load_mo_dir(struct xe_host *hs, const char *root, const char *suffix, int parent
 int
 xe_conf_load_mos(struct xe_host *hs, const char *mo_dir,
 	int (*add)(void *user, const char *name, int parent, const char *filter),
-	int (*add_fwm)(void *user, int mo, const char *name, const char *const *fields, int nfields), void *user)
+	int (*add_fwm)(void *user, int mo, const char *name, const char *const *fields, int nfields, int limit, int time),
+	void *user)
 {
 	return load_mo_dir(hs, mo_dir, "", -1, add, add_fwm, user);
 }

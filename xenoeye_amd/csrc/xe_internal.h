@@ -483,7 +483,8 @@ void xe_plan_free(struct xe_plan *p);
 /* add_fwm (may be NULL): called for every "fwm" entry of an object right after the object */
 int xe_conf_load_mos(struct xe_host *hs, const char *mo_dir,
 	int (*add)(void *user, const char *name, int parent, const char *filter),
-	int (*add_fwm)(void *user, int mo, const char *name, const char *const *fields, int nfields), void *user);
+	int (*add_fwm)(void *user, int mo, const char *name, const char *const *fields, int nfields, int limit, int time),
+	void *user);
 int xe_conf_load_devices(struct xe_host *hs, const char *path,
 	int (*add)(void *user, int use_ip, uint32_t ip, int use_id, uint32_t id, int rate,
 		int skip_unmarked, const char *const *marks, int nmarks), void *user);
