@@ -32,6 +32,7 @@ struct xe_gpu
 	uint32_t ntneed;           /* terms the fast kernel has to evaluate */
 	uint32_t ncjgroups, ncjderived, nrgroups;
 	/* fixed-window tables: they live as long as the handle, batches add to them */
+	hipStream_t copy_stream;   /* datagrams travel on it while the host walks their headers */
 	struct fwm_host *fwms; size_t nfwm;
 	void *d_fwmdesc;
 	int fwm_devip;             /* some table is keyed by dev-ip: the kernels note it per record */
@@ -128,6 +129,12 @@ xe_gpu_create(xe_gpu **out, int device)
 		free(h);
 		return XE_EHIP;
 	}
+	if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+		(void)hipGetLastError();
+		xe_host_free(&h->hs);
+		free(h);
+		return XE_EHIP;
+	}
 	*out = h;
 	return XE_OK;
 }
@@ -163,6 +170,7 @@ xe_gpu_destroy(xe_gpu *h)
 	}
 	free(h->fwms);
 	if (h->d_fwmdesc) (void)hipFree(h->d_fwmdesc);
+	if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
 	xe_host_free(&h->hs);
 	free(h);
 }
@@ -1493,6 +1501,7 @@ xe_gpu_batch_free(xe_batch *b)
 	if (!b) return;
 	(void)hipSetDevice(b->h->device);
 	if (b->ran) (void)hipStreamSynchronize(b->last_stream);
+	if (b->h && b->h->copy_stream) (void)hipStreamSynchronize(b->h->copy_stream);
 	if (b->d_pkt) (void)hipFree(b->d_pkt);
 	if (b->d_sets) (void)hipFree(b->d_sets);
 	if (b->d_exps) (void)hipFree(b->d_exps);
@@ -1757,33 +1766,38 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 	b = (xe_batch *)calloc(1, sizeof(*b));
 	if (!b) return XE_ENOMEM;
 	b->h = h;
+	/* The datagram bytes start moving to the device before the header walk:
+	 * neither needs the other (from page-locked memory the copy runs beside
+	 * the walk; from ordinary memory the call returns when it is done).
+	 * 64 zero bytes follow them so that an unchecked wide load near the end
+	 * stays inside the allocation. */
+	total = n ? (size_t)offsets[n] : 0;
+	b->payload_bytes = total;
+	rc = upload(h, &b->d_pkt, NULL, total + 64);
+	if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
+	{
+		hipError_t e = hipSuccess;
+		if (total) e = hipMemcpyAsync(b->d_pkt, data, total, hipMemcpyHostToDevice, h->copy_stream);
+		if (e == hipSuccess) e = hipMemsetAsync((uint8_t *)b->d_pkt + total, 0, 64, h->copy_stream);
+		if (e != hipSuccess) {
+			(void)hipStreamSynchronize(h->copy_stream);
+			xe_gpu_batch_free(b);
+			return hip_fail(h, e, "hipMemcpyAsync(packets)");
+		}
+	}
 	XE_TICK();
 	rc = xe_prepass(&h->hs, data, offsets, src_ip4, kinds, n, &b->plan);
 	XE_TICK();
 	if (rc != XE_OK) {
 		snprintf(h->err, sizeof(h->err), "pre-pass failed: %s", xe_gpu_strerror(rc));
+		(void)hipStreamSynchronize(h->copy_stream);
+		(void)hipFree(b->d_pkt);
 		free(b);
 		return rc;
 	}
 	rc = sync_templates(h);
-	if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
-
-	total = n ? (size_t)offsets[n] : 0;
-	b->payload_bytes = total;
+	if (rc != XE_OK) { (void)hipStreamSynchronize(h->copy_stream); xe_gpu_batch_free(b); return rc; }
 	b->ntot = b->plan.nrec + b->plan.nsf;
-
-	/* input: packet bytes followed by 64 zero bytes so that an unchecked
-	 * wide load near the end stays inside the allocation */
-	rc = upload(h, &b->d_pkt, NULL, total + 64);
-	if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
-	if (total) {
-		hipError_t e = hipMemcpy(b->d_pkt, data, total, hipMemcpyHostToDevice);
-		if (e != hipSuccess) { xe_gpu_batch_free(b); return hip_fail(h, e, "hipMemcpy(packets)"); }
-	}
-	{
-		hipError_t e = hipMemset((uint8_t *)b->d_pkt + total, 0, 64);
-		if (e != hipSuccess) { xe_gpu_batch_free(b); return hip_fail(h, e, "hipMemset(pad)"); }
-	}
 	XE_TICK();
 	rc = upload(h, &b->d_sets, b->plan.sets.p, b->plan.sets.n * sizeof(struct xe_set));
 	if (rc == XE_OK) rc = upload(h, &b->d_exps, b->plan.exporters.p, b->plan.exporters.n * sizeof(struct xe_exporter));
@@ -1952,10 +1966,16 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 	b->kp.rates = h->nfwm ? (uint32_t *)((uint8_t *)b->d_out + b->rates_off) : NULL;
 	b->kp.devips = h->fwm_devip ? (uint32_t *)((uint8_t *)b->d_out + b->devips_off) : NULL;
 	XE_TICK();
-	if (dbg && (ntm_ == 7)) {
-		fprintf(stderr, "prepare: pre-pass %.2f, packets to device %.2f, plan tables %.2f, work lists %.2f, "
-			"outputs %.2f, decode plans %.2f ms\n", tm_[1] - tm_[0], tm_[2] - tm_[1], tm_[3] - tm_[2],
-			tm_[4] - tm_[3], tm_[5] - tm_[4], tm_[6] - tm_[5]);
+	{
+		/* the caller's buffer is free again, and the kernels may run on any stream */
+		hipError_t e = hipStreamSynchronize(h->copy_stream);
+		if (e != hipSuccess) { xe_gpu_batch_free(b); return hip_fail(h, e, "hipStreamSynchronize(packets)"); }
+	}
+	XE_TICK();
+	if (dbg && (ntm_ == 8)) {
+		fprintf(stderr, "prepare: pre-pass %.2f, plan tables %.2f, work lists %.2f, outputs %.2f, decode plans %.2f, "
+			"wait for the packets %.2f, all %.2f ms\n", tm_[1] - tm_[0], tm_[3] - tm_[2],
+			tm_[4] - tm_[3], tm_[5] - tm_[4], tm_[6] - tm_[5], tm_[7] - tm_[6], tm_[7] - tm_[0]);
 	}
 #undef XE_TICK
 	*out = b;
