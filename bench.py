@@ -39,9 +39,11 @@ def parse_args():
     ap.add_argument("--c4-lists", type=int, default=8, help="distinct lists of the c4 workload (objects = 256)")
     ap.add_argument("--cpu-sample", type=int, default=12000000, help="records timed on the CPU oracle (0 = skip)")
     ap.add_argument("--replicate", type=int, default=1, help="repeat the generated datagrams this many times")
-    ap.add_argument("--pipeline", type=int, default=2,
+    ap.add_argument("--pipeline", type=int, default=4,
                     help="capture threads (one handle each) of the sustained host-inclusive measurement, 0/1 = skip")
     ap.add_argument("--pipeline-rounds", type=int, default=6)
+    ap.add_argument("--pipeline-walkers", type=int, default=0,
+                    help="header-walking threads per capture thread of the pipelined measurement (0: 16 / threads)")
     ap.add_argument("--fwm", type=int, default=1, help="also time the fixed-window table kernel (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus > 1 (gloo: rehearsal of the multi-rank path on one GPU)")
@@ -200,11 +202,13 @@ def main():
     b2.free()
     del m
     # the same from a page-locked datagram buffer (xe_gpu_host_alloc), as a capture thread would fill it
+    # and into a page-locked result buffer that the thread keeps between batches
     pinned = (eng.pinned(packed[0]),) + tuple(packed[1:])
+    mbuf = eng.pinned_array((batch.records * batch.mask_words,), np.uint64)
     t1 = time.perf_counter()
     b3 = eng.prepare(pinned)
     b3.run(stream)
-    m = b3.masks()
+    m = b3.masks(out=mbuf)
     c3 = b3.counters()
     t_e2e_pinned = time.perf_counter() - t1
     assert (c3 == c).all()
@@ -227,25 +231,28 @@ def main():
                     e.add_iplist(name, text)
                 for filt, parent in w["mos"]:
                     e.add_mo("mo", filt, parent)
-                e.set_prepass_threads(max(1, 8 // nthr))
+                e.set_prepass_threads(args.pipeline_walkers if args.pipeline_walkers > 0 else max(1, 16 // nthr))
                 e.commit()
                 part = _sh.select(packed, t, nthr)
                 inputs.append((e.pinned(part[0]),) + tuple(part[1:]))
                 engines.append(e)
             done = [0] * nthr
+            mbufs = [None] * nthr
 
             def worker(t):
                 st = torch.cuda.Stream(device=local_rank)
                 for _ in range(rounds):
                     bb = engines[t].prepare(inputs[t])
                     bb.run(st.cuda_stream)
-                    bb.masks()
+                    bb.masks(out=mbufs[t])
                     bb.counters()
                     done[t] += bb.records
                     bb.free()
 
             for t in range(nthr):          # first batch of every handle untimed (templates, buffers)
-                bb = engines[t].prepare(inputs[t]); bb.run(stream); bb.counters(); bb.free()
+                bb = engines[t].prepare(inputs[t]); bb.run(stream); bb.counters()
+                mbufs[t] = engines[t].pinned_array((bb.records * bb.mask_words,), np.uint64)
+                bb.free()
             ths = [threading.Thread(target=worker, args=(t,)) for t in range(nthr)]
             t1 = time.perf_counter()
             for th in ths:

@@ -331,6 +331,18 @@ class Engine:
         out[:] = data
         return out
 
+    def pinned_array(self, shape, dtype):
+        """an uninitialised array in page-locked memory (freed with the engine),
+        e.g. a result buffer for PreparedBatch.masks(out=...)"""
+        dt = np.dtype(dtype)
+        n = max(int(np.prod(shape)) * dt.itemsize, 1)
+        p = self.L.xe_gpu_host_alloc(self._h, n)
+        if not p:
+            raise XeError(-2, "xe_gpu_host_alloc(%d) failed" % n)
+        self._pinned.append(p)
+        raw = np.ctypeslib.as_array((C.c_uint8 * n).from_address(p))
+        return raw[:int(np.prod(shape)) * dt.itemsize].view(dt).reshape(shape)
+
     def prepare(self, batch):
         """batch: synth.Batch or (data, offsets, src, kinds) arrays."""
         if hasattr(batch, "packed"):
@@ -392,8 +404,12 @@ class PreparedBatch:
         self.eng._chk(self.L.xe_gpu_batch_kernel_ms(self._b, ms))
         return tuple(ms)
 
-    def masks(self):
-        out = np.zeros((self.records, self.mask_words), dtype=np.uint64)
+    def masks(self, out=None):
+        if out is None:
+            out = np.zeros((self.records, self.mask_words), dtype=np.uint64)
+        else:   # a caller's buffer (page-locked memory copies at link speed)
+            assert out.dtype == np.uint64 and out.flags.c_contiguous and out.size >= self.records * self.mask_words
+            out = out.reshape(-1)[:self.records * self.mask_words].reshape(self.records, self.mask_words)
         self.eng._chk(self.L.xe_gpu_batch_masks(self._b, out.ctypes.data, out.size))
         return out
 

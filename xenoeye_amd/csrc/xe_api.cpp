@@ -16,6 +16,8 @@
 
 extern "C" int xe_launch_init_tables(void);
 
+#define XE_DPOOL 48   /* device buffers a handle keeps for reuse (a batch owns 12) */
+
 struct xe_gpu
 {
 	int device;
@@ -33,6 +35,10 @@ struct xe_gpu
 	uint32_t ncjgroups, ncjderived, nrgroups;
 	/* fixed-window tables: they live as long as the handle, batches add to them */
 	hipStream_t copy_stream;   /* datagrams travel on it while the host walks their headers */
+	/* device buffers of freed batches, kept for the next ones: hipMalloc and
+	 * hipFree of hundreds of MB cost about a millisecond each, and hipFree
+	 * waits for the whole device, which serialises handles that share a GPU */
+	struct { void *p; size_t cap; int busy; } dpool[XE_DPOOL];
 	struct fwm_host *fwms; size_t nfwm;
 	void *d_fwmdesc;
 	int fwm_devip;             /* some table is keyed by dev-ip: the kernels note it per record */
@@ -171,6 +177,7 @@ xe_gpu_destroy(xe_gpu *h)
 	free(h->fwms);
 	if (h->d_fwmdesc) (void)hipFree(h->d_fwmdesc);
 	if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+	for (int i = 0; i < XE_DPOOL; i++) if (h->dpool[i].p) (void)hipFree(h->dpool[i].p);
 	xe_host_free(&h->hs);
 	free(h);
 }
@@ -418,6 +425,60 @@ upload(xe_gpu *h, void **dst, const void *src, size_t bytes)
 	if (!bytes) bytes = 16;
 	HIPCHK(h, hipMalloc(dst, ALIGN_UP(bytes, 256)));
 	if (src) HIPCHK(h, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+	return XE_OK;
+}
+
+/* a device buffer for a batch: one that an earlier batch of the handle gave
+ * back if it is large enough and not more than twice too large, else a new one */
+static int
+dev_get(xe_gpu *h, void **dst, size_t bytes)
+{
+	int best = -1, empty = -1, victim = -1;
+
+	*dst = NULL;
+	bytes = ALIGN_UP(bytes ? bytes : 16, 256);
+	for (int i = 0; i < XE_DPOOL; i++) {
+		if (!h->dpool[i].p) { if (empty < 0) empty = i; continue; }
+		if (h->dpool[i].busy) continue;
+		if ((h->dpool[i].cap >= bytes) && (h->dpool[i].cap <= 2 * bytes + 65536)
+			&& ((best < 0) || (h->dpool[i].cap < h->dpool[best].cap))) best = i;
+		if ((victim < 0) || (h->dpool[i].cap < h->dpool[victim].cap)) victim = i;
+	}
+	if (best >= 0) {
+		h->dpool[best].busy = 1;
+		*dst = h->dpool[best].p;
+		return XE_OK;
+	}
+	if ((empty < 0) && (victim >= 0)) {
+		(void)hipFree(h->dpool[victim].p);
+		h->dpool[victim].p = NULL;
+		empty = victim;
+	}
+	HIPCHK(h, hipMalloc(dst, bytes));
+	if (empty >= 0) {
+		h->dpool[empty].p = *dst;
+		h->dpool[empty].cap = bytes;
+		h->dpool[empty].busy = 1;
+	}
+	return XE_OK;
+}
+
+static void
+dev_put(xe_gpu *h, void *p)
+{
+	if (!p) return;
+	for (int i = 0; i < XE_DPOOL; i++) {
+		if (h->dpool[i].p == p) { h->dpool[i].busy = 0; return; }
+	}
+	(void)hipFree(p);   /* the table was full when it was made */
+}
+
+static int
+upload_pooled(xe_gpu *h, void **dst, const void *src, size_t bytes)
+{
+	int rc = dev_get(h, dst, bytes);
+	if (rc != XE_OK) return rc;
+	if (src && bytes) HIPCHK(h, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
 	return XE_OK;
 }
 
@@ -1502,16 +1563,16 @@ xe_gpu_batch_free(xe_batch *b)
 	(void)hipSetDevice(b->h->device);
 	if (b->ran) (void)hipStreamSynchronize(b->last_stream);
 	if (b->h && b->h->copy_stream) (void)hipStreamSynchronize(b->h->copy_stream);
-	if (b->d_pkt) (void)hipFree(b->d_pkt);
-	if (b->d_sets) (void)hipFree(b->d_sets);
-	if (b->d_exps) (void)hipFree(b->d_exps);
-	if (b->d_sfrecs) (void)hipFree(b->d_sfrecs);
-	if (b->d_out) (void)hipFree(b->d_out);
+	dev_put(b->h, b->d_pkt);
+	dev_put(b->h, b->d_sets);
+	dev_put(b->h, b->d_exps);
+	dev_put(b->h, b->d_sfrecs);
+	dev_put(b->h, b->d_out);
 	for (int i = 0; i < 6; i++) if (b->ev[i]) (void)hipEventDestroy(b->ev[i]);
 	{
 		void *extra[] = { b->d_fruns, b->d_ftiles, b->d_ssets, b->d_swstart,
 			b->d_fplans, b->d_fops, b->d_fflds };
-		for (size_t i = 0; i < sizeof(extra) / sizeof(extra[0]); i++) if (extra[i]) (void)hipFree(extra[i]);
+		for (size_t i = 0; i < sizeof(extra) / sizeof(extra[0]); i++) dev_put(b->h, extra[i]);
 	}
 	xe_plan_free(&b->plan);
 	free(b);
@@ -1687,10 +1748,10 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 			}
 		}
 	}
-	rc = upload(h, &b->d_fruns, fr, nfast * sizeof(*fr));
-	if (rc == XE_OK) rc = upload(h, &b->d_ftiles, ft, ntiles * sizeof(*ft));
-	if (rc == XE_OK) rc = upload(h, &b->d_ssets, ss, nslow * sizeof(*ss));
-	if (rc == XE_OK) rc = upload(h, &b->d_swstart, sw, nslow * 4);
+	rc = upload_pooled(h, &b->d_fruns, fr, nfast * sizeof(*fr));
+	if (rc == XE_OK) rc = upload_pooled(h, &b->d_ftiles, ft, ntiles * sizeof(*ft));
+	if (rc == XE_OK) rc = upload_pooled(h, &b->d_ssets, ss, nslow * sizeof(*ss));
+	if (rc == XE_OK) rc = upload_pooled(h, &b->d_swstart, sw, nslow * 4);
 	if (rc == XE_OK) {
 		b->kp.fruns = (const struct xe_frun *)b->d_fruns;
 		b->kp.ftiles = (const struct xe_ftile *)b->d_ftiles;
@@ -1773,7 +1834,7 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 	 * stays inside the allocation. */
 	total = n ? (size_t)offsets[n] : 0;
 	b->payload_bytes = total;
-	rc = upload(h, &b->d_pkt, NULL, total + 64);
+	rc = upload_pooled(h, &b->d_pkt, NULL, total + 64);
 	if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
 	{
 		hipError_t e = hipSuccess;
@@ -1791,7 +1852,7 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 	if (rc != XE_OK) {
 		snprintf(h->err, sizeof(h->err), "pre-pass failed: %s", xe_gpu_strerror(rc));
 		(void)hipStreamSynchronize(h->copy_stream);
-		(void)hipFree(b->d_pkt);
+		dev_put(h, b->d_pkt);
 		free(b);
 		return rc;
 	}
@@ -1799,9 +1860,9 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 	if (rc != XE_OK) { (void)hipStreamSynchronize(h->copy_stream); xe_gpu_batch_free(b); return rc; }
 	b->ntot = b->plan.nrec + b->plan.nsf;
 	XE_TICK();
-	rc = upload(h, &b->d_sets, b->plan.sets.p, b->plan.sets.n * sizeof(struct xe_set));
-	if (rc == XE_OK) rc = upload(h, &b->d_exps, b->plan.exporters.p, b->plan.exporters.n * sizeof(struct xe_exporter));
-	if (rc == XE_OK) rc = upload(h, &b->d_sfrecs, b->plan.sfrecs.p, b->plan.sfrecs.n * sizeof(struct xe_sfrec));
+	rc = upload_pooled(h, &b->d_sets, b->plan.sets.p, b->plan.sets.n * sizeof(struct xe_set));
+	if (rc == XE_OK) rc = upload_pooled(h, &b->d_exps, b->plan.exporters.p, b->plan.exporters.n * sizeof(struct xe_exporter));
+	if (rc == XE_OK) rc = upload_pooled(h, &b->d_sfrecs, b->plan.sfrecs.p, b->plan.sfrecs.n * sizeof(struct xe_sfrec));
 	if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
 
 	memset(&b->kp, 0, sizeof(b->kp));
@@ -1861,8 +1922,9 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 	}
 	b->out_bytes = off ? off : 256;
 	{
-		hipError_t e = hipMalloc(&b->d_out, b->out_bytes);
-		if (e != hipSuccess) { xe_gpu_batch_free(b); return hip_fail(h, e, "hipMalloc(outputs)"); }
+		hipError_t e;
+		rc = dev_get(h, &b->d_out, b->out_bytes);
+		if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
 		/* records the kernels do not reach (none by construction) read as empty */
 		e = hipMemset(b->d_out, 0, b->out_bytes);
 		if (e != hipSuccess) { xe_gpu_batch_free(b); return hip_fail(h, e, "hipMemset(outputs)"); }
@@ -1926,9 +1988,9 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 				}
 			}
 		}
-		rc = upload(h, &b->d_fplans, pl, nt * sizeof(*pl));
-		if (rc == XE_OK) rc = upload(h, &b->d_fops, fo, nops * sizeof(*fo));
-		if (rc == XE_OK) rc = upload(h, &b->d_fflds, ff, nt * XE_NFIELDS * sizeof(uint32_t));
+		rc = upload_pooled(h, &b->d_fplans, pl, nt * sizeof(*pl));
+		if (rc == XE_OK) rc = upload_pooled(h, &b->d_fops, fo, nops * sizeof(*fo));
+		if (rc == XE_OK) rc = upload_pooled(h, &b->d_fflds, ff, nt * XE_NFIELDS * sizeof(uint32_t));
 		free(pl);
 		free(fo);
 		free(ff);
