@@ -39,6 +39,8 @@ struct xe_gpu
 	 * hipFree of hundreds of MB cost about a millisecond each, and hipFree
 	 * waits for the whole device, which serialises handles that share a GPU */
 	struct { void *p; size_t cap; int busy; } dpool[XE_DPOOL];
+	void *stage;               /* page-locked scratch the run list is built in (copies at link speed) */
+	size_t stage_cap;
 	struct fwm_host *fwms; size_t nfwm;
 	void *d_fwmdesc;
 	int fwm_devip;             /* some table is keyed by dev-ip: the kernels note it per record */
@@ -178,6 +180,7 @@ xe_gpu_destroy(xe_gpu *h)
 	if (h->d_fwmdesc) (void)hipFree(h->d_fwmdesc);
 	if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
 	for (int i = 0; i < XE_DPOOL; i++) if (h->dpool[i].p) (void)hipFree(h->dpool[i].p);
+	if (h->stage) (void)hipHostFree(h->stage);
 	xe_host_free(&h->hs);
 	free(h);
 }
@@ -1661,7 +1664,20 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 		while ((R > 1) && ((size_t)4 * R * 64 * 4 * (4 * maxchunk + 1) + cnt_bytes + 8192 > XE_FAST_LDS_BUDGET)) R >>= 1;
 	}
 	tilesz = 64 * R;
-	fr = (struct xe_frun *)malloc((nfast + 1) * sizeof(*fr));
+	if ((nfast + 1) * sizeof(*fr) > h->stage_cap) {
+		const size_t want = (nfast + 1) * sizeof(*fr) * 5 / 4;
+		if (h->stage) (void)hipHostFree(h->stage);
+		h->stage = NULL;
+		h->stage_cap = 0;
+		if (hipHostMalloc(&h->stage, want, hipHostMallocDefault) != hipSuccess) {
+			(void)hipGetLastError();
+			h->stage = NULL;
+			rc = XE_ENOMEM;
+			goto out;
+		}
+		h->stage_cap = want;
+	}
+	fr = (struct xe_frun *)h->stage;
 	ss = (struct xe_set *)malloc((nslow + 1) * sizeof(*ss));
 	sw = (uint32_t *)malloc((nslow + 1) * sizeof(uint32_t));
 	if (!fr || !ss || !sw) goto out;
@@ -1800,7 +1816,7 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 	}
 out:
 	free(tfast); free(is_fast); free(gcount); free(gpos);
-	free(fr); free(ss); free(sw); free(ft); free(rtmpl);
+	free(ss); free(sw); free(ft); free(rtmpl);
 	return rc;
 }
 
@@ -1860,8 +1876,9 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 	if (rc != XE_OK) { (void)hipStreamSynchronize(h->copy_stream); xe_gpu_batch_free(b); return rc; }
 	b->ntot = b->plan.nrec + b->plan.nsf;
 	XE_TICK();
-	rc = upload_pooled(h, &b->d_sets, b->plan.sets.p, b->plan.sets.n * sizeof(struct xe_set));
-	if (rc == XE_OK) rc = upload_pooled(h, &b->d_exps, b->plan.exporters.p, b->plan.exporters.n * sizeof(struct xe_exporter));
+	/* (the sets themselves stay on the host: the kernels read the run lists
+	 * build_work_lists() makes of them) */
+	rc = upload_pooled(h, &b->d_exps, b->plan.exporters.p, b->plan.exporters.n * sizeof(struct xe_exporter));
 	if (rc == XE_OK) rc = upload_pooled(h, &b->d_sfrecs, b->plan.sfrecs.p, b->plan.sfrecs.n * sizeof(struct xe_sfrec));
 	if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
 
