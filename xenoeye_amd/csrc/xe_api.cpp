@@ -119,6 +119,23 @@ xe_gpu_build_arch(void)
 	return XE_BUILD_ARCH;
 }
 
+static void *
+pinned_alloc(size_t bytes)
+{
+	void *p = NULL;
+	if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+		(void)hipGetLastError();
+		return NULL;
+	}
+	return p;
+}
+
+static void
+pinned_free(void *p)
+{
+	if (p) (void)hipHostFree(p);
+}
+
 extern "C" int
 xe_gpu_create(xe_gpu **out, int device)
 {
@@ -133,6 +150,8 @@ xe_gpu_create(xe_gpu **out, int device)
 	if (!h) return XE_ENOMEM;
 	h->device = device;
 	xe_host_init(&h->hs);
+	h->hs.big_alloc = pinned_alloc;
+	h->hs.big_free = pinned_free;
 	if (xe_launch_init_tables() != XE_OK) {
 		free(h);
 		return XE_EHIP;

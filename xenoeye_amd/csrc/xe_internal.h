@@ -448,6 +448,10 @@ struct xe_host
 	void *walkers; int nwalkers;
 	pthread_mutex_t pool_mu;
 	void *pool_p[8]; size_t pool_cap[8];
+	/* allocator of those big buffers (NULL: malloc / free); the GPU library
+	 * supplies page-locked memory so that the plan travels at link speed */
+	void *(*big_alloc)(size_t bytes);
+	void (*big_free)(void *p);
 	char err[512];
 };
 

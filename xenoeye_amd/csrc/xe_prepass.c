@@ -103,7 +103,15 @@ pool_get(struct xe_host *hs, size_t bytes, size_t *cap)
 	pthread_mutex_unlock(&hs->pool_mu);
 	if (p) return p;
 	*cap = bytes + bytes / 4;
-	return malloc(*cap);
+	return hs->big_alloc ? hs->big_alloc(*cap) : malloc(*cap);
+}
+
+static void
+pool_release(struct xe_host *hs, void *p)
+{
+	if (!p) return;
+	if (hs->big_free) hs->big_free(p);
+	else free(p);
 }
 
 static void
@@ -132,7 +140,7 @@ pool_put(struct xe_host *hs, void *p, size_t cap)
 		p = NULL;
 	}
 	pthread_mutex_unlock(&hs->pool_mu);
-	free(p);
+	pool_release(hs, p);
 }
 
 static void walkers_free(struct xe_host *hs);
@@ -175,7 +183,7 @@ xe_host_free(struct xe_host *hs)
 	free(hs->dev_tmpls.p);
 	free(hs->dev_tents.p);
 	walkers_free(hs);
-	for (i = 0; i < 8; i++) free(hs->pool_p[i]);
+	for (i = 0; i < 8; i++) pool_release(hs, hs->pool_p[i]);
 	pthread_mutex_destroy(&hs->pool_mu);
 	pthread_rwlock_destroy(&hs->tlock);
 	memset(hs, 0, sizeof(*hs));
@@ -810,10 +818,10 @@ sf_u32(struct sfcur *c)
 {
 	uint32_t v;
 	if (c->bad || ((c->p + 4) > c->d->len)) { c->bad = 1; return 0; }
-	v = ((uint32_t)g8(c->d, c->p) << 24) | ((uint32_t)g8(c->d, c->p + 1) << 16)
-		| ((uint32_t)g8(c->d, c->p + 2) << 8) | g8(c->d, c->p + 3);
+	/* the cursor only moves forward from 0, so the four bytes are inside */
+	memcpy(&v, c->d->p + c->p, 4);
 	c->p += 4;
-	return v;
+	return __builtin_bswap32(v);
 }
 
 static uint32_t
@@ -821,7 +829,7 @@ sf_raw32(struct sfcur *c)
 {
 	uint32_t v;
 	if (c->bad || ((c->p + 4) > c->d->len)) { c->bad = 1; return 0; }
-	v = g32raw(c->d, c->p);
+	memcpy(&v, c->d->p + c->p, 4);
 	c->p += 4;
 	return v;
 }
@@ -834,7 +842,15 @@ sf_flow_sample(struct xe_plan *plan, struct sfcur *c, int expanded, const struct
 	uint32_t nel, j, v;
 	int chained = 0;
 
-	sf_u32(c);                       /* length */
+	v = sf_u32(c);                   /* length */
+	/* only the first bytes of every sample are read, a cache line or two out
+	 * of several: ask for those of the samples to come, taking them to be as
+	 * long as this one (a wrong guess costs nothing) */
+	if (!c->bad && (v < 65536)) {
+		const uint8_t *nx = c->d->p + c->p + 3 * ((long)v + 8);
+		__builtin_prefetch(nx);
+		__builtin_prefetch(nx + 64);
+	}
 	sf_u32(c);                       /* sequence */
 	sf_u32(c);                       /* source id (or class) */
 	if (expanded) sf_u32(c);         /* source index */
