@@ -1630,7 +1630,10 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 	size_t nfast = 0, nslow = 0, ntiles = 0, work = 0, slowrec = 0;
 	/* the fast kernel addresses packet bytes with 32-bit offsets */
 	const int small = (total_bytes + 64) < 0xFFFF0000ull;
-	const int force_general = getenv("XE_FORCE_GENERAL") != NULL;   /* diagnostic: time the general kernel */
+	/* the fast kernel addresses a column element with a 32-bit byte offset
+	 * (16-byte columns: below 2^28 records); larger batches take the general
+	 * kernel.  The environment variable is a diagnostic: time the general kernel */
+	const int force_general = (getenv("XE_FORCE_GENERAL") != NULL) || (b->ntot >= (1u << 28));
 	uint32_t maxchunk = 1, R, tilesz;
 	size_t cnt_bytes = (h->hs.nmos <= XE_MAX_LDS_COUNTER_MOS) ? h->hs.nmos * 24 : 0;
 	int rc = XE_ENOMEM;
@@ -1975,7 +1978,7 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 		const struct xe_tent *te = (const struct xe_tent *)h->hs.dev_tents.p;
 		size_t nt = h->hs.dev_tmpls.n, ne = h->hs.dev_tents.n, nops = 0;
 		struct xe_fplan *pl = (struct xe_fplan *)calloc(nt ? nt : 1, sizeof(*pl));
-		struct xe_fop *fo = (struct xe_fop *)calloc(ne ? ne : 1, sizeof(*fo));
+		struct xe_fop *fo = (struct xe_fop *)calloc(ne + 4, sizeof(*fo));   /* + 4: the kernel loads four at a time */
 		uint32_t *ff = (uint32_t *)calloc((nt ? nt : 1) * XE_NFIELDS, sizeof(uint32_t));
 		if (!pl || !fo || !ff) { free(pl); free(fo); free(ff); xe_gpu_batch_free(b); return XE_ENOMEM; }
 		for (size_t t = 0; t < nt; t++) {
@@ -2025,7 +2028,7 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 			}
 		}
 		rc = upload_pooled(h, &b->d_fplans, pl, nt * sizeof(*pl));
-		if (rc == XE_OK) rc = upload_pooled(h, &b->d_fops, fo, nops * sizeof(*fo));
+		if (rc == XE_OK) rc = upload_pooled(h, &b->d_fops, fo, (nops + 4) * sizeof(*fo));
 		if (rc == XE_OK) rc = upload_pooled(h, &b->d_fflds, ff, nt * XE_NFIELDS * sizeof(uint32_t));
 		free(pl);
 		free(fo);

@@ -840,41 +840,51 @@ __device__ __forceinline__ void
 copy_ops(const xe_kparams &kp, const uint32_t *stg, uint32_t j0, uint32_t n,
 	const uint32_t (&ridx)[R], const bool (&live)[R])
 {
-	typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+	typedef uint64_t u64x8 __attribute__((ext_vector_type(8)));
 	if (!n) return;
-	u64x2 opn = *(const XE_CONST u64x2 *)(kp.fops + j0);
-	for (uint32_t j = 0; j < n; j++) {
-		const u64x2 opc = opn;
-		opn = *(const XE_CONST u64x2 *)(kp.fops + j0 + ((j + 1 < n) ? j + 1 : j));
-		const uint32_t off = (uint32_t)opc[0] & 0xFFFF, sh = off & 3;
-		const uint32_t *p = stg + (off >> 2) * (R * 64);
-		XE_GLOBAL uint8_t *col = (XE_GLOBAL uint8_t *)opc[1];
+	/* byte offset of the record's element in a column of this width: 32 bits
+	 * (the host keeps batches of the fast kernel below 2^28 records), so that
+	 * a store is "uniform column base + per-lane offset" */
+	uint32_t boff[R];
 #pragma unroll
-		for (int r = 0; r < R; r++) {
-			const uint32_t *q = p + r * 64;
-			if (LG == 0) {
-				const uint32_t w0 = q[0];
-				if (live[r]) col[ridx[r]] = (uint8_t)__builtin_amdgcn_alignbyte(w0, w0, sh);
-			} else if (LG <= 2) {
-				const uint32_t w0 = q[0], w1 = q[R * 64];
-				const uint32_t v = __builtin_amdgcn_alignbyte(w1, w0, sh);
-				if (live[r]) {
-					if (LG == 1) ((XE_GLOBAL uint16_t *)col)[ridx[r]] = (uint16_t)v;
-					else ((XE_GLOBAL uint32_t *)col)[ridx[r]] = v;
+	for (int r = 0; r < R; r++) boff[r] = ridx[r] << LG;
+	/* four micro-ops per scalar load (the host pads the list by four entries) */
+	for (uint32_t j = 0; j < n; j += 4) {
+		const u64x8 o = *(const XE_CONST u64x8 *)(kp.fops + j0 + j);
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			if (j + k >= n) break;
+			const uint32_t off = (uint32_t)o[2 * k] & 0xFFFF, sh = off & 3;
+			const uint32_t *p = stg + (off >> 2) * (R * 64);
+			XE_GLOBAL uint8_t *col = (XE_GLOBAL uint8_t *)o[2 * k + 1];
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				const uint32_t *q = p + r * 64;
+				XE_GLOBAL uint8_t *dst = col + boff[r];
+				if (LG == 0) {
+					const uint32_t w0 = q[0];
+					if (live[r]) *dst = (uint8_t)__builtin_amdgcn_alignbyte(w0, w0, sh);
+				} else if (LG <= 2) {
+					const uint32_t w0 = q[0], w1 = q[R * 64];
+					const uint32_t v = __builtin_amdgcn_alignbyte(w1, w0, sh);
+					if (live[r]) {
+						if (LG == 1) *(XE_GLOBAL uint16_t *)dst = (uint16_t)v;
+						else *(XE_GLOBAL uint32_t *)dst = v;
+					}
+				} else if (LG == 3) {
+					const uint32_t w0 = q[0], w1 = q[R * 64], w2 = q[2 * R * 64];
+					const uint32_t v0 = __builtin_amdgcn_alignbyte(w1, w0, sh);
+					const uint32_t v1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
+					if (live[r]) *(XE_GLOBAL uint64_t *)dst = (uint64_t)v0 | ((uint64_t)v1 << 32);
+				} else {
+					const uint32_t w0 = q[0], w1 = q[R * 64], w2 = q[2 * R * 64], w3 = q[3 * R * 64], w4 = q[4 * R * 64];
+					u32x4 v;
+					v.x = __builtin_amdgcn_alignbyte(w1, w0, sh);
+					v.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
+					v.z = __builtin_amdgcn_alignbyte(w3, w2, sh);
+					v.w = __builtin_amdgcn_alignbyte(w4, w3, sh);
+					if (live[r]) *(XE_GLOBAL u32x4 *)dst = v;
 				}
-			} else if (LG == 3) {
-				const uint32_t w0 = q[0], w1 = q[R * 64], w2 = q[2 * R * 64];
-				const uint32_t v0 = __builtin_amdgcn_alignbyte(w1, w0, sh);
-				const uint32_t v1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
-				if (live[r]) ((XE_GLOBAL uint64_t *)col)[ridx[r]] = (uint64_t)v0 | ((uint64_t)v1 << 32);
-			} else {
-				const uint32_t w0 = q[0], w1 = q[R * 64], w2 = q[2 * R * 64], w3 = q[3 * R * 64], w4 = q[4 * R * 64];
-				u32x4 v;
-				v.x = __builtin_amdgcn_alignbyte(w1, w0, sh);
-				v.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
-				v.z = __builtin_amdgcn_alignbyte(w3, w2, sh);
-				v.w = __builtin_amdgcn_alignbyte(w4, w3, sh);
-				if (live[r]) ((XE_GLOBAL u32x4 *)col)[ridx[r]] = v;
 			}
 		}
 	}
