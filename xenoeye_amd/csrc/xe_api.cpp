@@ -851,6 +851,10 @@ xe_gpu_add_fwm(xe_gpu *h, int mo, const char *const *fields, int nfields, size_t
 			w.dev.vscale[w.dev.nval] = f.scale;
 			w.dev.nval++;
 		} else {
+			if ((f.size > 16) || (f.size > xe_fields[f.field].col_width)) {
+				snprintf(h->err, sizeof(h->err), "field '%.100s': key fields of more than 16 bytes are not aggregated", fields[i]);
+				return XE_EUNSUPPORTED;
+			}
 			if ((w.dev.nkey == XE_FWM_MAX_KEY_FIELDS) || (pos + f.size > 8 * XE_FWM_MAX_KWORDS)) {
 				snprintf(h->err, sizeof(h->err), "key of more than %d fields or %d bytes",
 					XE_FWM_MAX_KEY_FIELDS, 8 * XE_FWM_MAX_KWORDS);

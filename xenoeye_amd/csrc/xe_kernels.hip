@@ -2277,14 +2277,31 @@ xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables)
 				uint32_t pos = 0;
 				for (uint32_t i = 0; i < F.kwords; i++) s_key[wave][i][lane] = 0;
 				for (uint32_t k = 0; k < F.nkey; k++) {
-					const uint32_t fld = F.kfield[k], size = F.ksize[k];
+					const uint32_t fld = F.kfield[k], size = F.ksize[k], colw = c_colw[fld];
 					const uint64_t co = kp.col_off[fld];
-					for (uint32_t b = 0; b < size; b++, pos++) {
-						uint8_t by;
-						if (fld == XF_dev_ip) by = (uint8_t)(kp.devips[r] >> (8 * b));   /* comes from the exporter */
-						/* a field no template of the batch carries reads as zeros */
-						else by = (co == ~0ull) ? (uint8_t)0 : kp.out_base[co + (size_t)r * c_colw[fld] + b];
-						((uint8_t *)&s_key[wave][pos >> 3][lane])[pos & 7] = by;
+					/* the field's column element with one load (two for 16 bytes);
+					 * a field no template of the batch carries reads as zeros */
+					uint64_t part[2] = {0, 0};
+					if (fld == XF_dev_ip) {
+						part[0] = kp.devips[r];                      /* comes from the exporter */
+					} else if (co != ~0ull) {
+						const uint8_t *p = kp.out_base + co + (size_t)r * colw;
+						if (colw == 1) part[0] = *p;
+						else if (colw == 2) part[0] = *(const uint16_t *)p;
+						else if (colw == 4) part[0] = *(const uint32_t *)p;
+						else if (colw == 8) part[0] = *(const uint64_t *)p;
+						else { part[0] = ((const uint64_t *)p)[0]; part[1] = ((const uint64_t *)p)[1]; }
+					}
+					/* its first `size` bytes go behind what the key holds so far */
+#pragma unroll
+					for (int h2 = 0; h2 < 2; h2++) {
+						if (size <= 8u * h2) break;
+						const uint32_t nb = (size - 8u * h2 < 8u) ? size - 8u * h2 : 8u;
+						const uint64_t x = (nb < 8) ? (part[h2] & ((1ull << (8 * nb)) - 1)) : part[h2];
+						const uint32_t w = pos >> 3, sh = (pos & 7) * 8;
+						s_key[wave][w][lane] |= x << sh;
+						if (sh && (sh + 8 * nb > 64)) s_key[wave][w + 1][lane] |= x >> (64 - sh);
+						pos += nb;
 					}
 				}
 #pragma unroll
