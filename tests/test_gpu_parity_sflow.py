@@ -167,3 +167,45 @@ def test_sflow_and_netflow_in_one_batch(eng, orc):
     run_oracle(orc, nf)
     run_oracle(orc, sf)
     compare(b, orc)
+
+
+def test_large_batches_take_the_threaded_header_walk(eng, orc):
+    """more than 4096 datagrams: the header walk is spread over host threads;
+    sFlow alone, then sFlow and IPFIX datagrams interleaved (an agent and an
+    exporter share an address), with every thread count"""
+    w = synth.workload_c3(42000, seed=31)
+    assert len(w["batch"].pkts) >= 4096
+    configure(eng, orc, w.get("iplists"), w["mos"], w.get("devices", ()))
+    w2 = synth.workload_c2(60000, prefixes=100, seed=32)
+    mixed = synth.Batch()
+    sf, nf = w["batch"], w2["batch"]
+    j = 0
+    for i, (p, s) in enumerate(zip(sf.pkts, sf.src)):
+        mixed.add(p, s, 1)
+        if i % 3 == 0 and j < len(nf.pkts):
+            # every 30th IPFIX datagram comes from the address of an sFlow agent
+            mixed.add(nf.pkts[j], sf.src[i] if j % 30 == 7 else nf.src[j], 0)
+            j += 1
+    assert len(mixed.pkts) >= 4096 and j > 1000
+    # the device numbers a batch's Netflow records first, then its sFlow elements
+    # (each in arrival order): the oracle is fed in that order
+    mixed_sorted = synth.Batch()
+    for kind in (0, 1):
+        for p, s, k in zip(mixed.pkts, mixed.src, mixed.kind):
+            if k == kind:
+                mixed_sorted.add(p, s, k)
+    for batch, for_oracle in ((w["batch"], w["batch"]), (mixed, mixed_sorted)):
+        ref = None
+        for threads in (1, 3, 8):
+            eng.set_prepass_threads(threads)
+            orc.log_clear()
+            b = eng.prepare(batch)
+            b.run()
+            if ref is None:
+                run_oracle(orc, for_oracle, keep_flows=True)
+                compare(b, orc)
+                ref = (b.masks().copy(), b.flow_info().copy(), b.counters().copy(), b.dropped().copy())
+            else:
+                assert np.array_equal(b.masks(), ref[0]) and np.array_equal(b.counters(), ref[2])
+                assert np.array_equal(b.dropped(), ref[3]) and np.array_equal(b.flow_info(), ref[1])
+            b.free()
