@@ -297,7 +297,16 @@ def test_prepass_with_threads_equals_single_thread():
                   bytes([10, 255, 0, e + 1]))
         if i % 1501 == 7:
             b.add(synth.v5_packet(synth.Rng(i), 9), bytes([10, 77, 0, i % 5]))
-    for batch in (w5["batch"], b):
+    # sFlow datagrams (dealt to the threads by position) between the others; some
+    # IPFIX datagrams come from an agent's address
+    w3 = synth.workload_c3(42000, seed=31)
+    mixed = synth.Batch()
+    for i, (p, s) in enumerate(zip(w3["batch"].pkts, w3["batch"].src)):
+        mixed.add(p, s, 1)
+        if i % 2 == 0 and i // 2 < len(w2["batch"].pkts):
+            j = i // 2
+            mixed.add(w2["batch"].pkts[j], s if j % 30 == 7 else w2["batch"].src[j], 0)
+    for batch in (w5["batch"], b, w3["batch"], mixed):
         assert len(batch) >= 4096
         plans = []
         for T in (1, 2, 7, 16):
@@ -306,6 +315,7 @@ def test_prepass_with_threads_equals_single_thread():
             h.close()
         for p in plans[1:]:
             assert p["nrec"] == plans[0]["nrec"] and p["skipped"] == plans[0]["skipped"]
+            assert p["nsf"] == plans[0]["nsf"]
             assert p["exporters"] == plans[0]["exporters"]
             assert len(p["sets"]) == len(plans[0]["sets"])
             for a, c in zip(p["sets"], plans[0]["sets"]):

@@ -1083,10 +1083,30 @@ pp_merge(struct pp_shared *sh, struct xe_plan *out)
 		if (!sh->th[t].eremap) { free(ef); return XE_ENOMEM; }
 	}
 	qsort(ef, ne, sizeof(*ef), pp_efirst_cmp);
-	for (k = 0; k < ne; k++) {
-		const struct xe_exporter *e = (const struct xe_exporter *)sh->th[ef[k].t].plan.exporters.p + ef[k].local;
-		sh->th[ef[k].t].eremap[ef[k].local] = (uint32_t)k;
-		if (!xe_blob_push(&out->exporters, e, sizeof(*e))) { free(ef); return XE_ENOMEM; }
+	/* an exporter met by several threads (sFlow datagrams are dealt out by
+	 * position, not by address) is one entry, at its first appearance */
+	{
+		size_t cap = 64, m;
+		uint32_t *hm;
+		while (cap < 2 * ne + 2) cap <<= 1;
+		m = cap - 1;
+		hm = calloc(cap, sizeof(uint32_t));
+		if (!hm) { free(ef); return XE_ENOMEM; }
+		for (k = 0; k < ne; k++) {
+			const struct xe_exporter *e = (const struct xe_exporter *)sh->th[ef[k].t].plan.exporters.p + ef[k].local;
+			uint64_t key;
+			size_t j;
+			memcpy(&key, e->dev_ip, 8);   /* address and source id lie side by side */
+			for (j = ((key * 0x9E3779B97F4A7C15ull) >> 32) & m; hm[j]; j = (j + 1) & m) {
+				if (!memcmp(((const struct xe_exporter *)out->exporters.p)[hm[j] - 1].dev_ip, e->dev_ip, 8)) break;
+			}
+			if (!hm[j]) {
+				hm[j] = (uint32_t)out->exporters.n + 1;
+				if (!xe_blob_push(&out->exporters, e, sizeof(*e))) { free(hm); free(ef); return XE_ENOMEM; }
+			}
+			sh->th[ef[k].t].eremap[ef[k].local] = hm[j] - 1;
+		}
+		free(hm);
 	}
 	free(ef);
 	out->pool = sh->hs;
@@ -1264,7 +1284,13 @@ prepass_threads(struct xe_host *hs, const uint8_t *data, const uint64_t *offs, c
 	if (!sh.own) return XE_ENOMEM;
 	{
 		size_t i;
-		for (i = 0; i < n; i++) sh.own[i] = (uint8_t)pp_owner(src[i], T);
+		/* Netflow: an exporter's datagrams stay on one thread, in order (its
+		 * templates are state).  sFlow datagrams carry no state from one to
+		 * the next: runs of 32 are dealt out in turn, whatever the agents */
+		for (i = 0; i < n; i++) {
+			if (kinds && (kinds[i] == XE_KIND_SFLOW)) sh.own[i] = (uint8_t)((i >> 5) % (size_t)T);
+			else sh.own[i] = (uint8_t)pp_owner(src[i], T);
+		}
 	}
 
 	struct timespec t0_, t1_, t2_, t3_;
