@@ -141,3 +141,48 @@ def test_replayed_batch_is_what_the_oracle_decodes(tmp_path):
     b = run(got)
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
+
+
+def test_damaged_captures_under_sanitizers(tmp_path):
+    """the reader, built with -fsanitize=address,undefined, over captures with
+    random bytes and length fields changed or cut short: no invalid access"""
+    import os
+    import random
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    exe = str(tmp_path / "pcap_drv")
+    cmd = ["gcc", "-std=gnu11", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-I", os.path.join(root, "xenoeye_amd", "csrc"), os.path.join(here, "pcap_reader_driver.c"),
+           os.path.join(root, "xenoeye_amd", "csrc", "xe_pcap.c"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and "san" in (r.stderr or "").lower():
+        pytest.skip("no sanitizer runtime")
+    assert r.returncode == 0, r.stderr[-2000:]
+    w = synth.workload_c2(2000, prefixes=50)
+    base = str(tmp_path / "base.pcap")
+    synth.batch_to_pcap(base, w["batch"])
+    raw = open(base, "rb").read()
+    rnd = random.Random(5)
+    files = [base]
+    for i in range(80):
+        b = bytearray(raw[:rnd.randrange(24, len(raw))] if i % 3 == 0 else raw)
+        for _ in range(rnd.randrange(1, 40)):
+            b[rnd.randrange(0, len(b))] = rnd.randrange(256)
+        if i % 5 == 0:
+            off = 24
+            for _ in range(rnd.randrange(1, 20)):
+                if off + 16 > len(b):
+                    break
+                cap = struct.unpack_from("<I", b, off + 8)[0]
+                if rnd.random() < 0.3:
+                    struct.pack_into("<I", b, off + 8, rnd.choice([0, 1, 63, 64, 65, cap + 1, max(cap, 1) - 1, 262144,
+                                                                      262145, 0xFFFFFFFF]))
+                    break
+                off += 16 + cap
+        path = str(tmp_path / ("f%03d.pcap" % i))
+        open(path, "wb").write(bytes(b))
+        files.append(path)
+    r = subprocess.run([exe] + files, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    assert r.stdout.startswith("datagrams ")
