@@ -476,7 +476,18 @@ dev_get(xe_gpu *h, void **dst, size_t bytes)
 		h->dpool[victim].p = NULL;
 		empty = victim;
 	}
-	HIPCHK(h, hipMalloc(dst, bytes));
+	if (hipMalloc(dst, bytes) != hipSuccess) {
+		/* out of device memory: what the handle keeps for reuse goes first */
+		(void)hipGetLastError();
+		for (int i = 0; i < XE_DPOOL; i++) {
+			if (h->dpool[i].p && !h->dpool[i].busy) {
+				(void)hipFree(h->dpool[i].p);
+				h->dpool[i].p = NULL;
+				if (empty < 0) empty = i;
+			}
+		}
+		HIPCHK(h, hipMalloc(dst, bytes));
+	}
 	if (empty >= 0) {
 		h->dpool[empty].p = *dst;
 		h->dpool[empty].cap = bytes;

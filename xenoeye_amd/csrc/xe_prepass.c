@@ -1144,14 +1144,22 @@ pp_walk(void *arg)
 	struct pp_thread *me = arg;
 	struct pp_shared *sh = me->sh;
 	struct xe_plan *plan = &me->plan;
-	size_t i, since = 0;
+	size_t i, since = 0, la = 0;
+	unsigned ahead = 0;
 
 	pthread_rwlock_rdlock(&sh->hs->tlock);
 	for (i = 0; (i < sh->n) && (me->rc == XE_OK); i++) {
 		struct pp_ent e;
 		size_t s0, r0, f0, e0;
 		if (sh->own[i] != me->t) continue;
-		if ((i + 32 < sh->n) && (sh->own[i + 32] == me->t)) __builtin_prefetch(sh->data + sh->offs[i + 32]);
+		/* only headers are read, a cache line per datagram, far apart: a cursor
+		 * runs ahead and asks for the first line of this thread's next eight */
+		if (la <= i) { la = i + 1; ahead = 0; }
+		else if (ahead) ahead--;
+		while ((ahead < 8) && (la < sh->n)) {
+			if (sh->own[la] == me->t) { __builtin_prefetch(sh->data + sh->offs[la]); ahead++; }
+			la++;
+		}
 		if (++since == 512) {
 			/* a thread that waits to store a template gets its turn */
 			pthread_rwlock_unlock(&sh->hs->tlock);
