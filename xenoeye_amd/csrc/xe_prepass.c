@@ -1338,8 +1338,13 @@ xe_prepass(struct xe_host *hs, const uint8_t *data, const uint64_t *offs, const 
 		T = e ? atoi(e) : 8;
 	}
 	if (T > 64) T = 64;
-	/* small batches are not worth the thread start */
-	if ((T > 1) && (n >= 4096)) return prepass_threads(hs, data, offs, src, kinds, n, plan, T);
+	/* small batches are not worth the thread start (the environment variable
+	 * lets tests send small batches through the threaded walk) */
+	{
+		const char *e = getenv("XE_PREPASS_MIN_DATAGRAMS");
+		const size_t least = e ? (size_t)atol(e) : 4096;
+		if ((T > 1) && (n >= least)) return prepass_threads(hs, data, offs, src, kinds, n, plan, T);
+	}
 	for (i = 0; i < n; i++) {
 		int rc;
 
