@@ -72,7 +72,7 @@ def test_replay_tool_counts_what_the_oracle_counts(tmp_path, capsys):
     run_oracle(orc, w["batch"])
     want = orc.counters()
 
-    rc = replay.main(["--pcap", path, "--mo-dir", str(root), "--iplists", str(lists), "--port", "2055"])
+    rc = replay.main(["--pcap", path, "--mo-dir", str(root), "--iplists", str(lists), "--port", "2055", "--rows", "2"])
     assert rc == 0
     out = json.loads(capsys.readouterr().out)
     assert out["taken"] == len(w["batch"].pkts) and out["records"] == orc.nrecords()
@@ -89,3 +89,8 @@ def test_replay_tool_counts_what_the_oracle_counts(tmp_path, capsys):
         k = names.index("o%03d" % i)
         assert got[names[k]] == tuple(int(x) for x in want[i]), (filt, dumps[k])
     assert len(out["fixed_window"]) == len(w["mos"]) and all(t["dropped"] == 0 for t in out["fixed_window"])
+    # rows by protocol number ascending ("proto", "packets"), sums as the counters have them
+    for t in out["fixed_window"]:
+        keys = [r["key"] for r in t["first_rows"]]
+        assert keys == sorted(keys) and 1 <= len(keys) <= 2
+    assert sum(sum(r["sums"]) for t in out["fixed_window"] for r in t["first_rows"]) > 0

@@ -7,7 +7,8 @@ reads the frames the way the reference's pcap capture does (pcapture.c:111-180),
 runs every batch on the GPU and prints per monitoring object the records,
 octets and packets it received (what monit_object_process_nf() would have been
 handed, monit-objects.c:923-1023) and, per fixed-window table of mo.conf, the
-number of rows.
+number of rows (with --rows N also the first rows in the order of the
+reference's window export, monit-objects-fwm.c:496-589).
 """
 import argparse
 import ctypes as C
@@ -69,6 +70,9 @@ def main(argv=None):
     ap.add_argument("--port", type=int, default=0, help="UDP destination port (0 = every UDP datagram)")
     ap.add_argument("--sflow", action="store_true", help="the datagrams are sFlow v5")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--rows", type=int, default=0,
+                    help="print this many rows of every fixed-window table, in the order and with the "
+                         "limit of the reference's window export (keys in hex)")
     a = ap.parse_args(argv)
 
     eng = Engine(device=a.device)
@@ -88,7 +92,13 @@ def main(argv=None):
     out["fixed_window"] = []
     for t, (mo, name) in enumerate(eng.fwm_tables()):
         rows, dropped = eng.fwm_read(t)
-        out["fixed_window"].append(dict(object=eng.mo_name(mo), name=name, rows=len(rows), dropped=dropped))
+        entry = dict(object=eng.mo_name(mo), name=name, rows=len(rows), dropped=dropped)
+        if a.rows > 0:
+            first, others, hit = eng.fwm_export(t)      # the entry's own "limit"
+            entry["first_rows"] = [dict(key=k.hex(), sums=list(v)) for k, v in first[:a.rows]]
+            if hit:
+                entry["others"] = list(others)
+        out["fixed_window"].append(entry)
     json.dump(out, sys.stdout, indent=1)
     sys.stdout.write("\n")
     eng.close()
