@@ -549,7 +549,7 @@ v9_data_set(struct xe_host *hs, struct xe_plan *plan, struct dgram *d, long *ptr
 	S = (t->varlen == 2) ? 0x10000 : t->stride;
 
 	/* records that fit completely: (k+1)*S <= length */
-	nfull = (S > 0) ? (length / S) : count;
+	nfull = (S > 0) ? ((length >= 0) ? (long)((uint32_t)length / (uint32_t)S) : length / S) : count;
 	if (nfull > count) nfull = count;
 	if (S == 0) {
 		/* every field is empty: `count` records, all at the set start */
@@ -698,12 +698,14 @@ ipfix_data_set(struct xe_host *hs, struct xe_plan *plan, struct dgram *d, long p
 		/* record k exists iff length - k*S >= field_count; a record that
 		 * reaches `length` ends the loop but is itself delivered */
 		if (length < fc) return 1;
-		nrec = (length - fc) / S + 1;
+		/* (all operands are 16-bit quantities and not negative here: 32-bit
+		 * unsigned division is several times cheaper than the 64-bit signed one) */
+		nrec = (long)((uint32_t)(length - fc) / (uint32_t)S) + 1;
 		/* record k gets every field iff its last field starts before
 		 * `length` (netflow.c:596-600); the rest of the run is cut short */
 		{
 			long off_last = t->nfields ? e[t->nfields - 1].off : 0;
-			long nfull = (length > off_last) ? ((length - off_last - 1) / S + 1) : 0;
+			long nfull = (length > off_last) ? (long)((uint32_t)(length - off_last - 1) / (uint32_t)S) + 1 : 0;
 			if (nfull > nrec) nfull = nrec;
 			if (!emit_set(plan, hs, d, ptr, (uint32_t)nfull, length, (uint32_t)S, ts->dev_slot, nfull * S, 0)) return -1;
 			if (!emit_set(plan, hs, d, ptr + nfull * S, (uint32_t)(nrec - nfull), length - nfull * S, (uint32_t)S,
