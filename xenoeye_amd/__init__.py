@@ -91,6 +91,7 @@ def load_library(path=LIB_PATH):
         "xe_field_size_max": (i32, [i32]),
         "xe_field_offset": (sz, [i32]),
         "xe_gpu_iplist_match": (i32, [vp, cp, i32, vp, sz, vp]),
+        "xe_gpu_iplist_match_noalloc": (i32, [vp, cp, i32, vp, sz, vp]),
         "xe_pcap_open": (i32, [cp, C.POINTER(vp)]),
         "xe_pcap_close": (None, [vp]),
         "xe_pcap_error": (cp, [vp]),
@@ -317,6 +318,14 @@ class Engine:
         n = a.size // (4 if family == 4 else 16)
         out = np.zeros(n, dtype=np.uint8)
         self._chk(self.L.xe_gpu_iplist_match(self._h, name.encode(), family, a.ctypes.data, n, out.ctypes.data))
+        return out
+
+    def iplist_match_noalloc(self, name, family, addrs):
+        """iplist_match() through the entry point that allocates nothing"""
+        a = np.ascontiguousarray(addrs, dtype=np.uint8)
+        n = a.size // (4 if family == 4 else 16)
+        out = np.zeros(n, dtype=np.uint8)
+        self._chk(self.L.xe_gpu_iplist_match_noalloc(self._h, name.encode(), family, a.ctypes.data, n, out.ctypes.data))
         return out
 
     def pinned(self, data):

@@ -2443,3 +2443,26 @@ xe_gpu_iplist_match(xe_gpu *h, const char *list, int family, const uint8_t *addr
 	if (d_o) (void)hipFree(d_o);
 	return rc;
 }
+
+/* the same probe without any allocation (static device staging area) */
+extern "C" int
+xe_gpu_iplist_match_noalloc(xe_gpu *h, const char *list, int family, const uint8_t *addrs, size_t n, uint8_t *out)
+{
+	int li, rc;
+
+	if (!h || !list || ((family != 4) && (family != 6)) || (n && (!addrs || !out))) return XE_EINVAL;
+	if (n > XE_GPU_NOALLOC_MAX_ADDRS) {
+		snprintf(h->err, sizeof(h->err), "xe_gpu_iplist_match_noalloc: %zu addresses, the static staging area holds %d",
+			n, XE_GPU_NOALLOC_MAX_ADDRS);
+		return XE_EINVAL;
+	}
+	if (!h->committed) return XE_ESTATE;
+	li = xe_iplist_find(&h->hs.lists, list);
+	if (li < 0) return XE_EINVAL;
+	if (!n) return XE_OK;
+	HIPCHK(h, hipSetDevice(h->device));
+	rc = xe_launch_trie_probe_static(h->device, (const uint32_t *)h->d_trie, h->h_lists[li], family, addrs,
+		(uint32_t)n, out, NULL);
+	if (rc == XE_EHIP) snprintf(h->err, sizeof(h->err), "xe_gpu_iplist_match_noalloc: %s", hipGetErrorString(hipGetLastError()));
+	return rc;
+}

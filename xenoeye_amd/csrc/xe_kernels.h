@@ -144,6 +144,10 @@ int xe_launch_fwm(const struct xe_kparams *kp, const struct xe_fwm_dev *tables, 
 /* n addresses (4 or 16 bytes each) against one flattened list */
 int xe_launch_trie_probe(const uint32_t *trie, struct xe_list_dev list, int family,
 	const uint8_t *addrs, uint32_t n, uint8_t *out, void *stream);
+/* the same without any allocation: staged in a static device array (at most
+ * XE_GPU_NOALLOC_MAX_ADDRS addresses); addrs / out are host memory */
+int xe_launch_trie_probe_static(int device, const uint32_t *trie, struct xe_list_dev list, int family,
+	const uint8_t *addrs, uint32_t n, uint8_t *out, void *stream);
 #ifdef __cplusplus
 }
 #endif

@@ -2452,6 +2452,17 @@ xe_trie_probe_kernel(const uint32_t *trie, xe_list_dev L, int family, const uint
 /* ------------------------------------------------------------------ launch */
 static int g_tables_ready = 0;
 
+/* Staging area of xe_launch_trie_probe_static(): addresses in, answers out.
+ * It is part of the code object, so every GPU the library runs on holds its
+ * own copy from the first use of the library on it until the process ends.
+ * In host code the name below is only a handle for hipGetSymbolAddress(); the
+ * memory is reached through the per-device address kept in g_scratch_ptr[]. */
+#define XE_SCRATCH_ADDR_BYTES ((size_t)XE_GPU_NOALLOC_MAX_ADDRS * 16)
+#define XE_SCRATCH_BYTES (XE_SCRATCH_ADDR_BYTES + (size_t)XE_GPU_NOALLOC_MAX_ADDRS)
+static __device__ __align__(256) uint8_t scratch[XE_SCRATCH_BYTES];
+#define XE_MAX_DEVICES 64
+static uint8_t *g_scratch_ptr[XE_MAX_DEVICES];
+
 static hipError_t
 upload_tables(void)
 {
@@ -2478,7 +2489,15 @@ xe_launch_init_tables(void)
 	/* constant tables live per device; the caller invokes this once per
 	 * handle with its device current */
 	hipError_t e = upload_tables();
+	int dev = -1;
 	if (e != hipSuccess) return XE_EHIP;
+	/* this device's copy of the static staging area */
+	if ((hipGetDevice(&dev) != hipSuccess) || (dev < 0) || (dev >= XE_MAX_DEVICES)) return XE_EHIP;
+	if (!g_scratch_ptr[dev]) {
+		uint8_t *p = NULL;
+		if ((hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)) != hipSuccess) || !p) return XE_EHIP;
+		g_scratch_ptr[dev] = p;
+	}
 	g_tables_ready = 1;
 	return XE_OK;
 }
@@ -2577,4 +2596,27 @@ xe_launch_trie_probe(const uint32_t *trie, struct xe_list_dev list, int family,
 	hipLaunchKernelGGL(xe_trie_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
 		trie, list, family, addrs, n, out);
 	return (hipGetLastError() == hipSuccess) ? XE_OK : XE_EHIP;
+}
+
+/* The same probe with nothing allocated: addresses and answers are staged in
+ * this device's static area (g_scratch_ptr[device], never the symbol's name).
+ * `device` must be the current device.  The call returns when `out` is filled. */
+extern "C" int
+xe_launch_trie_probe_static(int device, const uint32_t *trie, struct xe_list_dev list, int family,
+	const uint8_t *addrs, uint32_t n, uint8_t *out, void *stream)
+{
+	hipStream_t st = (hipStream_t)stream;
+	const size_t ab = (family == 4) ? 4 : 16;
+	uint8_t *ptr;
+
+	if ((device < 0) || (device >= XE_MAX_DEVICES) || !(ptr = g_scratch_ptr[device])) return XE_ESTATE;
+	if (n > XE_GPU_NOALLOC_MAX_ADDRS) return XE_EINVAL;
+	if (!n) return XE_OK;
+	if (hipMemcpyAsync(ptr, addrs, n * ab, hipMemcpyHostToDevice, st) != hipSuccess) return XE_EHIP;
+	hipLaunchKernelGGL(xe_trie_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, st,
+		trie, list, family, (const uint8_t *)ptr, n, ptr + XE_SCRATCH_ADDR_BYTES);
+	if (hipGetLastError() != hipSuccess) return XE_EHIP;
+	if (hipMemcpyAsync(out, ptr + XE_SCRATCH_ADDR_BYTES, n, hipMemcpyDeviceToHost, st) != hipSuccess) return XE_EHIP;
+	if (hipStreamSynchronize(st) != hipSuccess) return XE_EHIP;
+	return XE_OK;
 }
