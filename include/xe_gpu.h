@@ -63,6 +63,33 @@ int xe_gpu_add_iplist(xe_gpu *h, const char *name, const char *text, size_t len)
  * evaluated only for records its parent matched (netflow.c:213-244).  Returns
  * the object's index (= its bit in the match bitmask) or a negative code. */
 int xe_gpu_add_mo(xe_gpu *h, const char *name, int parent, const char *filter);
+/* Objects the device cannot decide.  A filter that compares strings, uses
+ * mfreq() (state between records, filter.c:712-751), the geo / AS functions
+ * (the caller's databases, filter.c:753-834), or portstr() / ppstr() on a
+ * handle without a port-name table is still added: the object keeps its index
+ * and its place in the tree, xe_gpu_mo_host_only() answers 1 for it, and on
+ * the device it takes every record its parent took.  Its bit in the match
+ * mask therefore means "candidate": the caller runs its own filter_match()
+ * (filter.h:331) for that object on the re-created flow_info and, when it
+ * says no, drops the bit together with the bits of the objects below it
+ * (shim/xenoeye_gpu_shim.c does exactly that).  Nothing inside this library
+ * evaluates such a filter on the CPU.  For a host-only object and every
+ * object below one (xe_gpu_mo_host_gated() answers 1) the counters of
+ * xe_gpu_batch_counters() count candidates, and fixed-window tables are
+ * refused (XE_EUNSUPPORTED).  Filters of devices.conf marks get no such
+ * treatment: a mark the device cannot evaluate fails xe_gpu_add_device(). */
+int xe_gpu_mo_host_only(const xe_gpu *h, int mo);
+const char *xe_gpu_mo_host_only_reason(const xe_gpu *h, int mo);   /* "" when it is not */
+int xe_gpu_mo_host_gated(const xe_gpu *h, int mo);
+/* Service names of the 65536 ports, what port_to_str() / ports_pair_to_str()
+ * (utils.c:28-77) put in front of "(port)": names[port] = the name, NULL or ""
+ * for a port without one (the reference's table is a static array of its
+ * utils.c; the binding derives the names from port_to_str(), see
+ * INTEGRATION.md).  With the table set, portstr() and ppstr() filters are
+ * lowered at commit to sets / conditions over the port values and evaluated
+ * on the device; must be called before the objects that use them are added.
+ * NULL removes the table. */
+int xe_gpu_set_port_names(xe_gpu *h, const char *const *names);
 /* replaces monit_objects_init() (monit-objects.c:470, directory walk :252-458):
  * every directory below mo_dir holding an mo.conf is an object, nested
  * directories are children.  Only the "filter" key is read. */
@@ -206,6 +233,12 @@ int xe_gpu_batch_counters(xe_batch *b, uint64_t *counters, size_t n_u64);
  * returned 0; 2 = sFlow sample whose sampled header did not reach the IP layer
  * and is therefore not classified at all (sflow.c:164-168) */
 int xe_gpu_batch_dropped(xe_batch *b, uint8_t *dropped, size_t n);
+/* dgram[record] = index (in the arrays given to xe_gpu_batch_prepare) of the
+ * datagram the record was decoded from: what a consumer needs to hand every
+ * record the arrival time of ITS datagram, as the reference does
+ * (fpi->time_ns, netflow.c:802 and :227-228, sflow.c:114-115).  Needs no
+ * device work; n >= xe_gpu_batch_records(). */
+int xe_gpu_batch_record_datagram(xe_batch *b, uint32_t *dgram, size_t n);
 /* re-creates the reference's struct flow_info (flow-info.h:10-33) of
  * records [first, first+count) from the structure-of-arrays output:
  * out[count][XE_FLOW_INFO_SIZE]; payload_ptr is NULL */

@@ -690,6 +690,10 @@ static const char *const geoip_kw[] = {
 	"CONTINENT", "COUNTRY_CODE", "COUNTRY", "STATE", "CITY", "ZIP", "LAT", "LONG"
 };
 
+/* which geo function the last TK_GEOIP token was (the reference has one token
+ * id per function; the oracle folds them into one and remembers the index) */
+static int last_geo_kw;
+
 /* filter-lexer.c:142-209; the order of the comparisons is the reference's */
 static int
 keyword(const char *s, int *id)
@@ -714,7 +718,7 @@ keyword(const char *s, int *id)
 	if (!strcasecmp(s, "portstr")) { *id = TK_PORTSTR; return 1; }
 	if (!strcasecmp(s, "ppstr")) { *id = TK_PPSTR; return 1; }
 	for (i = 0; i < 8; i++) {
-		if (!strcasecmp(s, geoip_kw[i])) { *id = TK_GEOIP; return 1; }
+		if (!strcasecmp(s, geoip_kw[i])) { *id = TK_GEOIP; last_geo_kw = i; return 1; }
 	}
 	if (!strcasecmp(s, "asn")) { *id = TK_ASN; return 1; }
 	if (!strcasecmp(s, "asd")) { *id = TK_ASD; return 1; }
@@ -808,7 +812,7 @@ read_token(struct finput *q)
 /* ------------------------------------------------------------------ */
 enum { DIR_NONE = 0, DIR_SRC = 1, DIR_DST = 2, DIR_BOTH = 3 };
 enum { OP_BASIC, OP_NOT, OP_AND, OP_OR };
-enum { FN_NONE, FN_DIV, FN_DIV_R, FN_DIV_L, FN_MIN, FN_TFSTR };
+enum { FN_NONE, FN_DIV, FN_DIV_R, FN_DIV_L, FN_MIN, FN_TFSTR, FN_PORTSTR, FN_PPSTR, FN_MFREQ, FN_GEO, FN_ASN, FN_ASD };
 
 struct bdata  /* filter.h:109-119 */
 {
@@ -833,6 +837,8 @@ struct basic  /* filter.h:234-254 */
 	/* div: filter.h:153-164, min: filter.h:166-174 */
 	unsigned int a_off, a_size, b_off, b_size;
 	int is_log, k;
+	uint64_t *freqmap;   /* mfreq: filter.h:176-186 */
+	int geo_field;       /* geo functions: enum GEOIP_FIELD, geoip.h:23-28 */
 };
 
 struct fop { int op; struct basic *arg; };
@@ -1169,22 +1175,60 @@ function_tfstr(struct finput *in, struct fexpr *e)
 	return id(in, e, BT_STRING);
 }
 
-/* filter-parser.c:107-156.  mfreq / portstr / ppstr / geoip / asn / asd
- * rules are outside the restated path: the oracle reports them as errors
- * instead of building stateful or database-backed terms. */
+/* mfreq (filter-parser-funcs.c:284-365), the geo functions (:368-444), asn /
+ * asd (:447-524), portstr (:582-637), ppstr (:639-705): one or two field
+ * arguments, then a value list */
+static int
+function_other(struct finput *in, struct fexpr *e)
+{
+	struct basic tmp, *fb;
+	int tok = in->tok.id, func, two = 0, type = BT_STRING;
+	const char *what;
+	char msg[64];
+
+	memset(&tmp, 0, sizeof(tmp));
+	switch (tok) {
+		case TK_MFREQ: func = FN_MFREQ; two = 1; type = BT_RANGE; what = "'mfreq'"; break;
+		case TK_PORTSTR: func = FN_PORTSTR; what = "'portstr'"; break;
+		case TK_PPSTR: func = FN_PPSTR; two = 1; what = "'ppstr'"; break;
+		case TK_GEOIP: func = FN_GEO; tmp.geo_field = last_geo_kw; what = "GeoIP function"; break;
+		case TK_ASN: func = FN_ASN; type = BT_RANGE; what = "AS function"; break;
+		case TK_ASD: func = FN_ASD; what = "AS function"; break;
+		default: return 0;
+	}
+	if (!accept_(in, tok)) return 0;
+	if (!accept_(in, TK_LPAREN)) {
+		snprintf(msg, sizeof(msg), "Expected '(' after %s", what);
+		mkerror(in, msg);
+		return 0;
+	}
+	if (!nonaggr_field(in, &tmp.a_off, &tmp.a_size)) { mkerror(in, "Incorrect field name"); return 0; }
+	if (two) {
+		if (!accept_(in, TK_COMMA)) { mkerror(in, "Expected ',' after field name"); return 0; }
+		if (!nonaggr_field(in, &tmp.b_off, &tmp.b_size)) { mkerror(in, "Incorrect field name after comma"); return 0; }
+	}
+	if (!accept_(in, TK_RPAREN)) { mkerror(in, "Expected ')'"); return 0; }
+	if (!add_basic(e, type, -1, DIR_NONE)) return 0;
+	fb = e->ops[e->n - 1].arg;
+	fb->func = func;
+	fb->a_off = tmp.a_off; fb->a_size = tmp.a_size;
+	fb->b_off = tmp.b_off; fb->b_size = tmp.b_size;
+	fb->geo_field = tmp.geo_field;
+	if (func == FN_MFREQ) {
+		fb->freqmap = calloc(65536, sizeof(uint64_t));
+		if (!fb->freqmap) return 0;
+	}
+	return id(in, e, type);
+}
+
+/* filter-parser.c:107-156 */
 static int
 rule(struct finput *q, struct fexpr *e)
 {
-	int t = q->tok.id;
-
 	if (function_div(q, e)) return 1;
 	if (function_min(q, e)) return 1;
 	if (function_tfstr(q, e)) return 1;
-	if ((t == TK_MFREQ) || (t == TK_PORTSTR) || (t == TK_PPSTR)
-		|| (t == TK_GEOIP) || (t == TK_ASN) || (t == TK_ASD)) {
-		mkerror(q, "function not restated by the oracle");
-		return 0;
-	}
+	if (function_other(q, e)) return 1;
 	if (rule_without_direction(q, e, DIR_BOTH)) return 1;
 	if (accept_(q, TK_SRC)) {
 		return rule_without_direction(q, e, DIR_SRC);
@@ -1275,6 +1319,7 @@ fexpr_free(struct fexpr *e)
 		if (fb) {
 			for (j = 0; j < fb->n; j++) free(fb->data[j].str);
 			free(fb->data);
+			free(fb->freqmap);
 			free(fb);
 		}
 	}
@@ -1416,6 +1461,12 @@ xdiv(uint64_t dividend, uint64_t divisor, int is_log, int k)  /* filter.h:396-41
 	return quotient;
 }
 
+int
+xo_xdiv(uint64_t dividend, uint64_t divisor, int is_log, int k)
+{
+	return xdiv(dividend, divisor, is_log, k);
+}
+
 /* the text of a TCP flags byte: the names of the set bits, most significant
  * first, joined with '+' (table utils-data.inc:4-261, reached through
  * tcp_flags_to_str(), utils.c:22-26) */
@@ -1450,10 +1501,132 @@ match_tfstr(struct basic *fb, struct xo_flow *flow)  /* filter.c:836-858 */
 	return 0;
 }
 
+/* filter.c:608-656.  With a direction the reference compares the operand
+ * with the field of that direction and then once more with a pointer and a
+ * length it never set (:645): that second comparison has no defined result
+ * and counts as "no match" here.  Without a direction only the source field
+ * is compared (:649).  strncmp over the field's recorded size: an absent
+ * field (size 0) equals every operand. */
+static int
+match_string(struct basic *fb, struct xo_flow *flow)
+{
+	const struct ffield *ff;
+	int fi;
+	size_t i;
+
+	if (fb->ffield < 0) return 0;
+	ff = &ffields[fb->ffield];
+	if (fb->direction == DIR_SRC) fi = ff->src;
+	else if (fb->direction == DIR_DST) fi = ff->dst;
+	else if (fb->direction == DIR_BOTH) fi = ff->src;
+	else return 0;
+	for (i = 0; i < fb->n; i++) {
+		/* an operand that is not a quoted string has no text in the reference */
+		if (!fb->data[i].str) continue;
+		if (strncmp(fb->data[i].str, (const char *)FBYTES(flow, fi), (size_t)FSIZE(flow, fi)) == 0) return 1;
+	}
+	return 0;
+}
+
+/* service names of the ports: the reference's table is generated data of its
+ * build (utils-data.inc:263-), so the oracle takes the names from its caller */
+static char *port_names[65536];
+
+void
+xo_set_port_names(const char *const *names)
+{
+	int i;
+	for (i = 0; i < 65536; i++) {
+		free(port_names[i]);
+		port_names[i] = (names && names[i] && names[i][0]) ? strdup(names[i]) : NULL;
+	}
+}
+
+void
+xo_port_to_str(char *res, uint16_t port)  /* utils.c:28-37 */
+{
+	const char *s = port_names[port] ? port_names[port] : "";
+	if (s[0]) {
+		sprintf(res, "%s (%d)", s, port);
+		return;
+	}
+	sprintf(res, "%d", port);
+}
+
+void
+xo_ports_pair_to_str(char *res, uint16_t port1, uint16_t port2)  /* utils.c:39-77 */
+{
+	const char *s1 = port_names[port1] ? port_names[port1] : "";
+	const char *s2 = port_names[port2] ? port_names[port2] : "";
+
+	if (s1[0] && s2[0]) { sprintf(res, "%s(%d) -> %s(%d)", s1, port1, s2, port2); return; }
+	if (port1 == port2) { sprintf(res, "%d -> %d", port1, port2); return; }
+	if (port1 < port2) {
+		if (!s1[0] && !s2[0]) { sprintf(res, "%d ->", port1); return; }
+		else if (!s1[0] && s2[0]) { sprintf(res, "%d -> %s(%d)", port1, s2, port2); return; }
+		else if (s1[0] && !s2[0]) { sprintf(res, "%s(%d) ->", s1, port1); return; }
+	} else {
+		if (!s1[0] && !s2[0]) { sprintf(res, "-> %d", port2); return; }
+		else if (!s1[0] && s2[0]) { sprintf(res, "-> %s(%d)", s2, port2); }
+		else if (s1[0] && !s2[0]) { sprintf(res, "%s(%d) -> %d", s1, port1, port2); return; }
+	}
+}
+
+static int
+match_portstr(struct basic *fb, struct xo_flow *flow)  /* filter.c:860-880 */
+{
+	uint16_t port = (uint16_t)get_nf_val((uint8_t *)flow + fb->a_off, fb->a_size);
+	char p[300];
+	size_t i;
+
+	xo_port_to_str(p, port);
+	for (i = 0; i < fb->n; i++) {
+		if (fb->data[i].str && (strcasecmp(fb->data[i].str, p) == 0)) return 1;
+	}
+	return 0;
+}
+
+static int
+match_ppstr(struct basic *fb, struct xo_flow *flow)  /* filter.c:882-904 */
+{
+	uint16_t port1 = (uint16_t)get_nf_val((uint8_t *)flow + fb->a_off, fb->a_size);
+	uint16_t port2 = (uint16_t)get_nf_val((uint8_t *)flow + fb->b_off, fb->b_size);
+	char pp[600];
+	size_t i;
+
+	xo_ports_pair_to_str(pp, port1, port2);
+	for (i = 0; i < fb->n; i++) {
+		if (fb->data[i].str && (strcasecmp(fb->data[i].str, pp) == 0)) return 1;
+	}
+	return 0;
+}
+
+/* filter.c:711-751, with its update of the map: arg1's count goes up twice,
+ * arg2's never (:736-739) */
+static int
+match_mfreq(struct basic *fb, struct xo_flow *flow)
+{
+	uint16_t arg1 = (uint16_t)get_nf_val((uint8_t *)flow + fb->a_off, fb->a_size);
+	uint16_t arg2 = (uint16_t)get_nf_val((uint8_t *)flow + fb->b_off, fb->b_size);
+	uint64_t freq1 = fb->freqmap[arg1], freq2 = fb->freqmap[arg2];
+	int64_t res;
+
+	if (freq1 != freq2) res = (freq1 > freq2) ? arg1 : arg2;
+	else res = (arg1 < arg2) ? arg1 : arg2;
+	fb->freqmap[arg1] += 2;
+	return in_ranges(fb, res);
+}
+
 static int
 basic_match(struct basic *fb, struct xo_flow *flow)  /* filter.c:907-958 */
 {
 	if (fb->func == FN_TFSTR) return match_tfstr(fb, flow);
+	if (fb->func == FN_PORTSTR) return match_portstr(fb, flow);
+	if (fb->func == FN_PPSTR) return match_ppstr(fb, flow);
+	if (fb->func == FN_MFREQ) return match_mfreq(fb, flow);
+	/* geo / AS functions: geoip_lookup4/6 and as_lookup4/6 answer 0 while no
+	 * database is loaded (geoip.c:33-88), and none can be here: no match */
+	if ((fb->func == FN_GEO) || (fb->func == FN_ASN) || (fb->func == FN_ASD)) return 0;
 	if (fb->func == FN_MIN) {  /* filter.c:685-709 */
 		uint64_t a = get_nf_val((uint8_t *)flow + fb->a_off, fb->a_size);
 		uint64_t b = get_nf_val((uint8_t *)flow + fb->b_off, fb->b_size);
@@ -1469,7 +1642,8 @@ basic_match(struct basic *fb, struct xo_flow *flow)  /* filter.c:907-958 */
 		case BT_ADDR6: return match_addr(fb, flow, 16);
 		case BT_RANGE: return match_range(fb, flow);
 		case BT_MAC: return match_mac(fb, flow);
-		default: return 0;   /* STRING terms are outside the restated path */
+		case BT_STRING: return match_string(fb, flow);
+		default: return 0;
 	}
 }
 
@@ -1534,10 +1708,16 @@ filter_dump(struct fexpr *e, FILE *f)
 			fprintf(f, "DIV_L ([offset %d]/[offset %d]/k %d)", (int)fb->a_off, (int)fb->b_off, fb->k);
 		} else if (fb->func == FN_MIN) {
 			fprintf(f, "MIN ([offset %d]/[offset %d])", (int)fb->a_off, (int)fb->b_off);
-		} else if (fb->func == FN_TFSTR) {
-			/* no case for it in filter.c:1113-1172: the default branch prints
+		} else if (fb->func == FN_MFREQ) {
+			fprintf(f, "MFREQ ([offset %d]/[offset %d])", (int)fb->a_off, (int)fb->b_off);
+		} else if (fb->func == FN_GEO) {
+			fprintf(f, "%s ([offset %d]/[size %d])", geoip_kw[fb->geo_field], (int)fb->a_off, (int)fb->a_size);
+		} else if ((fb->func == FN_ASN) || (fb->func == FN_ASD)) {
+			fprintf(f, "AS ([offset %d]/[size %d])", (int)fb->a_off, (int)fb->a_size);
+		} else if ((fb->func == FN_TFSTR) || (fb->func == FN_PORTSTR) || (fb->func == FN_PPSTR)) {
+			/* no case for them in filter.c:1113-1172: the default branch prints
 			 * the enum value (filter.h:130-151: 36 fields, then the functions) */
-			fprintf(f, "<Unknown name %d> ", 1 + N_FFIELDS + 5 + 8 + 2);
+			fprintf(f, "<Unknown name %d> ", 1 + N_FFIELDS + 5 + 8 + 2 + (fb->func - FN_TFSTR));
 		} else {
 			/* fprintf(f, #STR" ") stringifies the quoted keyword (filter.c:1117) */
 			fprintf(f, "\"%s\" ", ffields[fb->ffield].kw);
@@ -2916,4 +3096,15 @@ xo_reset(void)
 	free(tmpls); tmpls = NULL; n_tmpls = 0;
 	log_keep_flows = 0;
 	log_max = 0;
+	xo_set_port_names(NULL);
+}
+
+/* filter_match() of object `mo`'s own expression on a record given as struct
+ * flow_info bytes (what the reference's process_mo_*_rec() loops call per
+ * object, netflow.c:223) */
+int
+xo_mo_match(int mo, const void *flow)
+{
+	if ((mo < 0) || ((size_t)mo >= n_mos)) return 0;
+	return filter_match(mos[mo].expr, (struct xo_flow *)flow);
 }

@@ -74,6 +74,9 @@ int xo_device_add(int use_ip, uint32_t ip_net_order, int use_id, uint32_t id_hos
  * parent; returned index is the bit position in the match bitmask */
 int xo_mo_add(int parent, const char *filter, char *err, size_t errlen);
 int xo_nmo(void);
+/* filter_match() of object `mo`'s expression alone (no parent gating) on a
+ * record given as the 2312 bytes of struct flow_info */
+int xo_mo_match(int mo, const void *flow_info);
 
 /* ---- datagram entry points (netflow.c:788, sflow-impl.h:293) ---- */
 int xo_netflow_process(const uint8_t *pkt, int len, uint32_t src_ip4_net_order);
@@ -106,6 +109,14 @@ void xo_fwm_dump(int fwm, uint8_t *keys, uint64_t *vals);
 /* rows in the reference's export order, cut after `limit` rows (0 = all);
  * others[nvals] = sums of the rows behind the cut (monit-objects-fwm.c:405-449, 496-589) */
 long xo_fwm_export(int fwm, int limit, uint8_t *keys, uint64_t *vals, uint64_t *others, int *hit_limit);
+/* xdiv() of filter.h:396-418 (div / div_r / div_l) */
+int xo_xdiv(uint64_t dividend, uint64_t divisor, int is_log, int k);
+/* service names of the 65536 ports for portstr() / ppstr() (NULL or "" = the
+ * port has none; NULL table = no port has one); port_to_str() and
+ * ports_pair_to_str() of utils.c:28-77 over those names */
+void xo_set_port_names(const char *const *names);
+void xo_port_to_str(char *res, uint16_t port);
+void xo_ports_pair_to_str(char *res, uint16_t port1, uint16_t port2);
 /* text of a TCP flags byte, as tcp_flags_to_str() (utils.c:22-26) gives it */
 void xo_tcp_flags_str(uint8_t tf, char out[40]);
 

@@ -1,0 +1,357 @@
+/*
+ * xenoeye_gpu_shim.c -- netflow_process() / sflow_process() of the reference
+ * (netflow.h:156-158, sflow.h:17-19) as a batching front of the GPU flow path,
+ * and the replay of its results into monit_object_process_nf()
+ * (monit-objects.h:288-289).  See include/xenoeye_gpu_shim.h for the contract.
+ *
+ * Plain C over the C ABI of include/xe_gpu.h; nothing here decodes a record or
+ * evaluates a filter: records come back from the library as match masks and
+ * re-created struct flow_info bytes, and the only filters evaluated on the
+ * host are those of objects the library reports as host-only, through the
+ * caller's own filter_match() (filter.h:331).
+ */
+#define _GNU_SOURCE
+#include <errno.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include "xenoeye_gpu_shim.h"
+
+/* resolved by the program the shim is linked into, unless the configuration
+ * names other functions */
+extern int monit_object_process_nf(struct xe_data *globl, struct monit_object *mo, size_t thread_id,
+	uint64_t time_ns, struct flow_info *flow) __attribute__((weak));
+extern int filter_match(struct filter_expr *expr, struct flow_info *flow) __attribute__((weak));
+
+#define SHIM_CHUNK 2048      /* records whose flow_info is re-created at a time */
+
+struct shim_thread
+{
+	xe_gpu *h;
+	pthread_mutex_t *lock;       /* not NULL: the handle is shared with another thread */
+	/* the batch being collected */
+	uint8_t *data;               /* datagrams back to back, page-locked */
+	size_t used, cap;
+	uint64_t *off;               /* n + 1 offsets */
+	uint32_t *src;
+	uint8_t *kind;
+	uint64_t *time_ns;           /* arrival time of every datagram */
+	size_t n;
+	uint64_t first_mono;         /* monotonic clock at the arrival of the batch's first datagram */
+	/* results of the batch being delivered */
+	uint64_t *masks;
+	uint8_t *status;
+	uint32_t *dgram;
+	size_t rec_cap, mask_cap;
+	uint8_t *flows;              /* SHIM_CHUNK x XE_FLOW_INFO_SIZE */
+	uint64_t stats[5];
+	char err[320];
+};
+
+static struct
+{
+	int ready;
+	struct xe_shim_config cfg;
+	struct shim_thread *th;
+	pthread_mutex_t *locks;      /* one per distinct handle that several threads use */
+	size_t nlocks;
+	struct monit_object **mo;
+	struct filter_expr **expr;
+	uint8_t *host_only;          /* per object */
+	uint32_t *subtree_end;       /* per object: index behind its last descendant */
+	size_t nmo, mask_words;
+	xe_shim_process_nf_fn process_nf;
+	xe_shim_filter_match_fn filter_match;
+} S;
+
+static uint64_t
+mono_ns(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC_COARSE, &ts);
+	return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+
+void
+xenoeye_gpu_shim_shutdown(void)
+{
+	size_t t;
+
+	if (S.th) {
+		for (t = 0; t < S.cfg.nthreads; t++) {
+			struct shim_thread *T = &S.th[t];
+			if (T->data) xe_gpu_host_free(T->h, T->data);
+			free(T->off); free(T->src); free(T->kind); free(T->time_ns);
+			free(T->masks); free(T->status); free(T->dgram); free(T->flows);
+		}
+	}
+	free(S.th);
+	for (t = 0; t < S.nlocks; t++) pthread_mutex_destroy(&S.locks[t]);
+	free(S.locks);
+	free(S.mo); free(S.expr); free(S.host_only); free(S.subtree_end);
+	memset(&S, 0, sizeof(S));
+}
+
+int
+xenoeye_gpu_shim_init(const struct xe_shim_config *cfg)
+{
+	size_t t, m, u;
+	int rc = XE_ENOMEM;
+
+	if (!cfg || !cfg->nthreads || !cfg->gpu || (cfg->nmo && !cfg->mo)) return XE_EINVAL;
+	if (S.ready) xenoeye_gpu_shim_shutdown();
+	S.cfg = *cfg;
+	if (!S.cfg.max_datagrams) S.cfg.max_datagrams = 16384;
+	if (!S.cfg.max_bytes) S.cfg.max_bytes = 32u << 20;
+	if (S.cfg.max_bytes < MAX_NF_PACKET_SIZE) S.cfg.max_bytes = MAX_NF_PACKET_SIZE;
+	if (!S.cfg.max_wait_ns) S.cfg.max_wait_ns = 20000000ull;
+	S.process_nf = cfg->process_nf ? cfg->process_nf : monit_object_process_nf;
+	S.filter_match = cfg->filter_match ? cfg->filter_match : filter_match;
+	if (!S.process_nf) { rc = XE_EINVAL; goto fail; }
+	S.nmo = cfg->nmo;
+	S.mask_words = S.nmo ? (S.nmo + 63) / 64 : 1;
+
+	S.mo = calloc(S.nmo ? S.nmo : 1, sizeof(*S.mo));
+	S.expr = calloc(S.nmo ? S.nmo : 1, sizeof(*S.expr));
+	S.host_only = calloc(S.nmo ? S.nmo : 1, 1);
+	S.subtree_end = calloc(S.nmo ? S.nmo : 1, sizeof(uint32_t));
+	S.th = calloc(cfg->nthreads, sizeof(*S.th));
+	S.locks = calloc(cfg->nthreads, sizeof(*S.locks));
+	if (!S.mo || !S.expr || !S.host_only || !S.subtree_end || !S.th || !S.locks) goto fail;
+
+	for (t = 0; t < cfg->nthreads; t++) {
+		if (!cfg->gpu[t] || ((size_t)xe_gpu_mo_count(cfg->gpu[t]) != S.nmo)) { rc = XE_EINVAL; goto fail; }
+	}
+	for (m = 0; m < S.nmo; m++) {
+		const int parent = xe_gpu_mo_parent(cfg->gpu[0], (int)m);
+		S.mo[m] = cfg->mo[m];
+		S.expr[m] = cfg->expr ? cfg->expr[m] : NULL;
+		S.host_only[m] = (uint8_t)(xe_gpu_mo_host_only(cfg->gpu[0], (int)m) == 1);
+		/* bits low to high must be the reference's pre-order: the parent of an
+		 * object is the object before it or one of that object's ancestors */
+		if (parent >= (int)m) { rc = XE_EINVAL; goto fail; }
+		if (m && (parent != (int)m - 1)) {
+			int a = xe_gpu_mo_parent(cfg->gpu[0], (int)m - 1);
+			while ((a >= 0) && (a != parent)) a = xe_gpu_mo_parent(cfg->gpu[0], a);
+			if (a != parent) { rc = XE_EINVAL; goto fail; }
+		}
+		if (S.host_only[m] && (!S.expr[m] || !S.filter_match)) { rc = XE_EINVAL; goto fail; }
+	}
+	for (m = 0; m < S.nmo; m++) {
+		for (u = m + 1; (u < S.nmo) && (xe_gpu_mo_parent(cfg->gpu[0], (int)u) >= (int)m); u++) {}
+		S.subtree_end[m] = (uint32_t)u;
+	}
+
+	for (t = 0; t < cfg->nthreads; t++) {
+		struct shim_thread *T = &S.th[t];
+		const size_t nd = S.cfg.max_datagrams;
+		T->h = cfg->gpu[t];
+		for (u = 0; u < t; u++) {
+			if (S.th[u].h != T->h) continue;
+			if (!S.th[u].lock) {
+				pthread_mutex_init(&S.locks[S.nlocks], NULL);
+				S.th[u].lock = &S.locks[S.nlocks++];
+			}
+			T->lock = S.th[u].lock;
+			break;
+		}
+		T->cap = S.cfg.max_bytes;
+		T->data = xe_gpu_host_alloc(T->h, T->cap + 64);
+		T->off = calloc(nd + 1, sizeof(uint64_t));
+		T->src = calloc(nd, sizeof(uint32_t));
+		T->kind = calloc(nd, 1);
+		T->time_ns = calloc(nd, sizeof(uint64_t));
+		T->flows = malloc((size_t)SHIM_CHUNK * XE_FLOW_INFO_SIZE);
+		if (!T->data || !T->off || !T->src || !T->kind || !T->time_ns || !T->flows) goto fail;
+	}
+	S.ready = 1;
+	return XE_OK;
+fail:
+	xenoeye_gpu_shim_shutdown();
+	return rc;
+}
+
+/* the exit calls of one batch, on the calling thread: records in index order
+ * (= arrival order: a batch holds datagrams of one kind), objects low to high
+ * (= the reference's pre-order, netflow.c:213-244) */
+static int
+deliver(struct xe_data *globl, size_t thread_id, struct shim_thread *T, xe_batch *b, size_t nrec)
+{
+	const size_t w = S.mask_words;
+	size_t c0;
+	int rc;
+
+	if (nrec > T->rec_cap) {
+		const size_t cap = nrec + nrec / 4 + 1024;
+		free(T->masks); free(T->status); free(T->dgram);
+		T->masks = malloc(cap * w * sizeof(uint64_t));
+		T->status = malloc(cap);
+		T->dgram = malloc(cap * sizeof(uint32_t));
+		T->rec_cap = (T->masks && T->status && T->dgram) ? cap : 0;
+		if (!T->rec_cap) return XE_ENOMEM;
+	}
+	if ((rc = xe_gpu_batch_masks(b, T->masks, nrec * w)) != XE_OK) return rc;   /* waits for the kernels */
+	if ((rc = xe_gpu_batch_dropped(b, T->status, nrec)) != XE_OK) return rc;
+	if ((rc = xe_gpu_batch_record_datagram(b, T->dgram, nrec)) != XE_OK) return rc;
+
+	for (c0 = 0; c0 < nrec; c0 += SHIM_CHUNK) {
+		const size_t c1 = (c0 + SHIM_CHUNK < nrec) ? c0 + SHIM_CHUNK : nrec;
+		size_t first = c1, last = c0, r, k;
+
+		/* the records of this chunk that some object receives */
+		for (r = c0; r < c1; r++) {
+			uint64_t any = 0;
+			if (T->status[r]) continue;    /* dropped by device rules / sample never classified */
+			for (k = 0; k < w; k++) any |= T->masks[r * w + k];
+			if (!any) continue;
+			if (first == c1) first = r;
+			last = r;
+		}
+		if (first == c1) continue;
+		if ((rc = xe_gpu_batch_flow_info(b, first, last - first + 1, T->flows)) != XE_OK) return rc;
+		for (r = first; r <= last; r++) {
+			struct flow_info *flow = (struct flow_info *)(T->flows + (r - first) * XE_FLOW_INFO_SIZE);
+			const uint64_t *mk = &T->masks[r * w];
+			const uint64_t tns = T->time_ns[T->dgram[r]];
+			size_t m;
+
+			if (T->status[r]) continue;
+			for (m = 0; m < S.nmo; m++) {
+				if (!((mk[m >> 6] >> (m & 63)) & 1)) {
+					/* whole words without a bit are common: skip them */
+					if (!(m & 63) && !mk[m >> 6]) m += 63;
+					continue;
+				}
+				if (S.host_only[m] && !S.filter_match(S.expr[m], flow)) {
+					/* the object does not receive the record, and the objects
+					 * below it are not even looked at (netflow.c:223-243) */
+					m = S.subtree_end[m] - 1;
+					continue;
+				}
+				S.process_nf(globl, S.mo[m], thread_id, tns, flow);
+				T->stats[3]++;
+			}
+		}
+	}
+	return XE_OK;
+}
+
+static int
+run_batch(struct xe_data *globl, size_t thread_id, struct shim_thread *T)
+{
+	xe_batch *b = NULL;
+	size_t nrec;
+	int rc;
+
+	if (!T->n) return XE_OK;
+	if (T->lock) pthread_mutex_lock(T->lock);
+	rc = xe_gpu_batch_prepare(T->h, T->data, T->off, T->src, T->kind, T->n, &b);
+	if (rc == XE_OK) rc = xe_gpu_batch_run(b, NULL);
+	if (rc == XE_OK) {
+		nrec = xe_gpu_batch_records(b);
+		T->stats[2] += nrec;
+		rc = deliver(globl, thread_id, T, b, nrec);
+	}
+	if (rc != XE_OK) {
+		T->stats[4]++;
+		snprintf(T->err, sizeof(T->err), "batch of %zu datagrams lost: %s: %.200s", T->n, xe_gpu_strerror(rc),
+			xe_gpu_last_error(T->h));
+	}
+	if (b) xe_gpu_batch_free(b);
+	if (T->lock) pthread_mutex_unlock(T->lock);
+	T->stats[1]++;
+	T->n = 0;
+	T->used = 0;
+	return rc;
+}
+
+int
+xenoeye_gpu_shim_flush(struct xe_data *globl, size_t thread_id)
+{
+	if (!S.ready || (thread_id >= S.cfg.nthreads)) return XE_EINVAL;
+	return run_batch(globl, thread_id, &S.th[thread_id]);
+}
+
+int
+xenoeye_gpu_shim_poll(struct xe_data *globl, size_t thread_id)
+{
+	struct shim_thread *T;
+
+	if (!S.ready || (thread_id >= S.cfg.nthreads)) return XE_EINVAL;
+	T = &S.th[thread_id];
+	if (T->n && ((mono_ns() - T->first_mono) >= S.cfg.max_wait_ns)) return run_batch(globl, thread_id, T);
+	return XE_OK;
+}
+
+void
+xenoeye_gpu_shim_stats(size_t thread_id, uint64_t out[5])
+{
+	memset(out, 0, 5 * sizeof(uint64_t));
+	if (S.ready && (thread_id < S.cfg.nthreads)) memcpy(out, S.th[thread_id].stats, 5 * sizeof(uint64_t));
+}
+
+const char *
+xenoeye_gpu_shim_error(size_t thread_id)
+{
+	return (S.ready && (thread_id < S.cfg.nthreads)) ? S.th[thread_id].err : "";
+}
+
+/* one datagram into the thread's batch; the batch runs first when it is full,
+ * when the datagram is of the other kind (a batch holds one kind, so that
+ * record order is arrival order) or when its oldest datagram is due */
+static int
+take(struct xe_data *globl, size_t thread_id, struct flow_packet_info *fpi, int len, int kind)
+{
+	struct shim_thread *T;
+	struct timespec tmsp;
+	uint64_t now;
+
+	if (!S.ready || (thread_id >= S.cfg.nthreads) || !fpi) return 0;
+	/* the reference stamps the datagram first (netflow.c:798-802,
+	 * sflow-impl.h:316-320: seconds * 1e9 + nanoseconds in double) */
+	if (clock_gettime(CLOCK_REALTIME_COARSE, &tmsp) < 0) return 0;
+	fpi->time_ns = tmsp.tv_sec * 1e9 + tmsp.tv_nsec;
+	if ((len < 0) || (len > MAX_NF_PACKET_SIZE)) return 0;
+	if (kind == XE_KIND_NETFLOW) {
+		/* netflow.c:804-819: other versions are logged and left */
+		const unsigned version = (len >= 2) ? (((unsigned)fpi->rawpacket[0] << 8) | fpi->rawpacket[1]) : 0;
+		if ((version != 5) && (version != 9) && (version != 10)) return 0;
+	}
+	T = &S.th[thread_id];
+	now = mono_ns();
+	if (T->n && ((T->n >= S.cfg.max_datagrams) || (T->used + (size_t)len > T->cap) || (T->kind[0] != kind)
+		|| ((now - T->first_mono) >= S.cfg.max_wait_ns))) {
+		(void)run_batch(globl, thread_id, T);
+	}
+	if (!T->n) { T->off[0] = 0; T->first_mono = now; }
+	memcpy(T->data + T->used, fpi->rawpacket, (size_t)len);
+	T->used += (size_t)len;
+	T->src[T->n] = fpi->src_addr_ipv4;
+	T->kind[T->n] = (uint8_t)kind;
+	T->time_ns[T->n] = fpi->time_ns;
+	T->n++;
+	T->off[T->n] = T->used;
+	T->stats[0]++;
+	return 1;
+}
+
+/* netflow.c:824-837 fills the reference's table of per-field parse functions;
+ * the field table of this path lives in the library */
+void
+netflow_process_init(void)
+{
+}
+
+int
+netflow_process(struct xe_data *data, size_t thread_id, struct flow_packet_info *npi, int len)
+{
+	return take(data, thread_id, npi, len, XE_KIND_NETFLOW);
+}
+
+int
+sflow_process(struct xe_data *global, size_t thread_id, struct flow_packet_info *fpi, int len)
+{
+	return take(global, thread_id, fpi, len, XE_KIND_SFLOW);
+}

@@ -47,7 +47,9 @@ def compare(batch_out, orc, flows=True, sflow_states=None):
     dm = dm[sel]
     assert dm.shape == om.shape
     bad = np.nonzero((dm != om).any(axis=1))[0]
-    assert bad.size == 0, "match bitmask differs at records %s" % bad[:10]
+    assert bad.size == 0, "match bitmask differs at records %s: device / oracle words %s" % (
+        bad[:10], [("%x" % int(dm[r, w]), "%x" % int(om[r, w])) for r in bad[:4] for w in range(dm.shape[1])
+                   if dm[r, w] != om[r, w]])
     assert np.array_equal(dd, od), "dropped flags differ"
     assert np.array_equal(batch_out.counters(), orc.counters()), "counters differ"
     if flows and n:

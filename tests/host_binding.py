@@ -5,7 +5,22 @@ import ctypes as C
 
 import numpy as np
 
+import os
+
 import xenoeye_amd
+
+HOSTTEST_LIB = os.path.join(os.path.dirname(os.path.abspath(xenoeye_amd.__file__)), "libxe_hosttest.so")
+_lib = None
+
+
+def load_hosttest():
+    """the test hooks of xe_hosttest.c: a library of their own, beside the product library"""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(HOSTTEST_LIB):
+            raise RuntimeError("%s is missing: run `python __graft_entry__.py` (build()) first" % HOSTTEST_LIB)
+        _lib = C.CDLL(HOSTTEST_LIB)
+    return _lib
 
 
 class ListDev(C.Structure):
@@ -29,7 +44,7 @@ TERM = 0x80000000
 
 class Host:
     def __init__(self):
-        L = self.L = xenoeye_amd.load_library()
+        L = self.L = load_hosttest()
         L.xe_ht_create.restype = C.c_void_p
         L.xe_ht_free.argtypes = [C.c_void_p]
         L.xe_ht_add_iplist.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]
@@ -133,7 +148,7 @@ CHAIN = 0x40000000
 CHAIN_WORDS = 8
 
 
-NODE_BITS = int(xenoeye_amd.load_library().xe_ht_node_bits())
+NODE_BITS = int(load_hosttest().xe_ht_node_bits())
 
 
 def walk_flat(words, root, nodes, addr_bytes, bit=0, chains=0):

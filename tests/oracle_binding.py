@@ -153,6 +153,24 @@ class Oracle:
         if not ok:
             raise ValueError(err.value.decode(errors="replace"))
 
+    def set_port_names(self, names):
+        """65536 service names ('' / None = none) for portstr() / ppstr(); None removes them"""
+        if names is None:
+            self.L.xo_set_port_names(None)
+            return
+        arr = (C.c_char_p * 65536)(*[(n.encode() if isinstance(n, str) else n) if n else None for n in names])
+        self.L.xo_set_port_names(arr)
+
+    def port_to_str(self, port):
+        buf = C.create_string_buffer(400)
+        self.L.xo_port_to_str(buf, C.c_uint16(port))
+        return buf.value.decode()
+
+    def ports_pair_to_str(self, p1, p2):
+        buf = C.create_string_buffer(800)
+        self.L.xo_ports_pair_to_str(buf, C.c_uint16(p1), C.c_uint16(p2))
+        return buf.value.decode()
+
     def log_config(self, keep_flows=True, max_records=0):
         self.L.xo_log_config(int(keep_flows), max_records)
 
@@ -247,3 +265,41 @@ class RefUtils:
         L.mac_addr_read.argtypes = [C.c_char_p, C.c_char_p]
         L.tcp_flags_to_str.argtypes = [C.c_uint8]
         L.tcp_flags_to_str.restype = C.c_char_p
+        L.port_to_str.argtypes = [C.c_char_p, C.c_uint16]
+        L.ports_pair_to_str.argtypes = [C.c_char_p, C.c_uint16, C.c_uint16]
+
+    def port_to_str(self, port):
+        buf = C.create_string_buffer(400)
+        self.L.port_to_str(buf, port)
+        return buf.value.decode()
+
+    def ports_pair_to_str(self, p1, p2):
+        buf = C.create_string_buffer(800)
+        self.L.ports_pair_to_str(buf, p1, p2)
+        return buf.value.decode()
+
+    def port_names(self):
+        """the service name of every port, the way a binding gets them: port_to_str() prints
+        'name (port)' for a port with a name and the number alone otherwise (utils.c:28-37)"""
+        names = []
+        for p in range(65536):
+            t = self.port_to_str(p)
+            tail = " (%d)" % p
+            names.append(t[:-len(tail)] if t.endswith(tail) else "")
+        return names
+
+
+def port_names():
+    """the reference's service names when its utils.c was built here (oracle/_ref), else a made-up
+    table of the same shape: a few hundred named ports, names with digits, dashes and mixed case"""
+    if have_ref("libref_utils.so"):
+        return RefUtils().port_names()
+    names = [""] * 65536
+    for p, n in {20: "ftp-data", 21: "ftp", 22: "ssh", 23: "telnet", 25: "smtp", 53: "domain", 80: "http",
+                 110: "pop3", 123: "ntp", 143: "imap2", 161: "snmp", 179: "bgp", 443: "https", 445: "microsoft-ds",
+                 993: "imaps", 1194: "openvpn", 3306: "mysql", 3389: "ms-wbt-server", 5060: "sip", 8080: "http-alt",
+                 0: "reserved", 65535: "Last", 1: "tcpmux"}.items():
+        names[p] = n
+    for p in range(1024, 40000, 97):
+        names[p] = "svc%d-x" % (p % 1000)
+    return names

@@ -38,6 +38,26 @@ def test_library_exports_every_declared_symbol():
     for n in sorted(names):
         assert hasattr(L, n), "libxenoeye_gpu.so does not export %s" % n
     assert L.xe_gpu_build_arch().decode() == "gfx950"
+    # the test hooks of xe_hosttest.c are a library of their own, not part of the product library
+    assert not hasattr(L, "xe_ht_create")
+
+
+def test_shim_exports_the_reference_entry_points():
+    import ctypes
+    so = os.path.join(ROOT, "xenoeye_amd", "libxenoeye_gpu_shim.so")
+    assert os.path.exists(so), "build() makes the shim"
+    L = ctypes.CDLL(so)
+    text = open(os.path.join(ROOT, "include", "xenoeye_gpu_shim.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b((?:xenoeye_gpu_shim_|netflow_process|sflow_process)[a-z0-9_]*)\s*\(", text))
+    assert {"netflow_process_init", "netflow_process", "sflow_process", "xenoeye_gpu_shim_init"} <= names
+    for n in sorted(names):
+        assert hasattr(L, n), "libxenoeye_gpu_shim.so does not export %s" % n
+    # struct flow_packet_info as flow-info.h:35-46 lays it out on x86-64
+    import shim_binding
+    F = shim_binding.FlowPacketInfo
+    assert (F.src_addr_ipv4.offset, F.source_id.offset, F.epoch.offset, F.time_ns.offset, F.rawpacket.offset,
+            F.sampling_rate.offset, ctypes.sizeof(F)) == (16, 20, 24, 32, 40, 65576, 65584)
 
 
 def test_no_gpu_means_an_error_not_a_fallback():
@@ -140,15 +160,61 @@ def test_filter_compiler_matches_oracle_on_random_filters(host, orc):
         assert dump == want, f
 
 
-def test_unsupported_filters_are_reported(host):
-    for f in ["vashost 'example.com'", "class0 'web'", "proto tcp", "sni 'x'", "div_l(octets, packets, 10) 100",
-              "port aa:bb:cc:dd:ee:ff", "net 5"]:
+def test_filters_the_device_cannot_decide_are_reported(host, orc):
+    """they compile (same postfix program as the oracle's) and are flagged: objects with such a filter
+    stay with the caller's own filter_match()"""
+    for f in ["vashost 'example.com'", "class0 'web'", "proto tcp", "sni 'x'", "port aa:bb:cc:dd:ee:ff", "net 5",
+              "src vashost 'a' or 'b'", "mfreq(src port, dst port) 80 or 443", "asn(src host) 64512-65000",
+              "asd(dst host) 'EXAMPLE-AS'", "country(dst host) 'NL' or 'BE'", "CITY(src host6) 'x'",
+              "country_code(dst host) 'x'", "tfstr(vashost) 'SYN'",
+              # no port-name table on this side
+              "portstr(src port) 'http (80)'", "ppstr(src port, dst port) '-> 80'",
+              "proto 6 and (portstr(dst port) 'https (443)' or 'x') or not sni 'y'"]:
         rc, dump, err = host.filter_dump(f)
-        assert rc == -5 and err, (f, rc)
-    for f in ["portstr(src port) 'http (80)'", "ppstr(src port, dst port) '-> 80'", "mfreq(src port, dst port) 80",
-              "asn(src host) 64512", "country(dst host) 'NL'"]:
+        assert rc == -5 and err, (f, rc, err)
+        if f not in ("proto tcp", "port aa:bb:cc:dd:ee:ff", "net 5"):   # operands the reference never initialises
+            assert dump == orc.filter_dump(orc.filter_parse(f)), f
+    for f in ["div_l(octets, packets, 10) 100", "div_l(bits, packets, 2) 1-1024 or 4096"]:
         rc, dump, err = host.filter_dump(f)
-        assert rc == -5 and "not supported" in err and dump == "", (f, rc, err)
+        assert rc == 0 and dump == orc.filter_dump(orc.filter_parse(f)), (f, rc, err)
+    for f in ["mfreq(src port) 1", "mfreq src port", "portstr(octets) 'x'", "ppstr(src port) 'x'", "asn() 1",
+              "country(host, host) 'x'", "country_code(host) 'x'", "portstr(port) 'x'", "lat", "mfreq(src port, dst port)"]:
+        rc, dump, err = host.filter_dump(f)
+        assert rc == -4, (f, rc, dump)
+        with pytest.raises(ValueError):
+            orc.filter_parse(f)
+
+
+def test_div_l_steps_equal_the_oracle(host, orc):
+    """the pieces the quotient line is cut into at commit against xdiv() (filter.h:396-418) evaluated by
+    the oracle with the same libm: every piece end, and the neighbourhood of every power of k"""
+    import ctypes
+    L = host.L
+    L.xe_div_l_pieces.argtypes = [ctypes.c_int] + [ctypes.POINTER(ctypes.c_int32)] * 3 + [ctypes.c_int]
+    orc.L.xo_xdiv.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_int, ctypes.c_int]
+    for k in [2, 3, 7, 10, 16, 100, 1000, 46341, 1, 0, -1, -2, -10]:
+        lo, hi, val = [(ctypes.c_int32 * 80)() for _ in range(3)]
+        n = L.xe_div_l_pieces(k, lo, hi, val, 80)
+        assert n >= (3 if k > 1 else 1), (k, n)
+        assert lo[0] == -2 ** 31 and hi[n - 1] == 2 ** 31 - 1
+        probes = set()
+        for i in range(n):
+            if i:
+                assert lo[i] == hi[i - 1] + 1
+            for q in (lo[i], hi[i], (lo[i] + hi[i]) // 2):
+                probes.add((q, val[i]))
+        for q, want in probes:
+            # the reference divides u64 values and truncates the quotient to int: q / 1 with q as u64
+            got = orc.L.xo_xdiv(q & 0xFFFFFFFF if q >= 0 else (q + 2 ** 32), 1, 1, k)
+            assert got == want, (k, q, got, want)
+        if k > 1:
+            j = 1
+            while j < 2 ** 31:
+                for q in (j - 1, j, j + 1):
+                    if 0 < q < 2 ** 31:
+                        piece = [i for i in range(n) if lo[i] <= q <= hi[i]][0]
+                        assert orc.L.xo_xdiv(q, 1, 1, k) == val[piece], (k, q)
+                j *= k
 
 
 def test_flattened_lists_match_oracle(host, orc):
@@ -332,7 +398,7 @@ def test_prepass_threads_under_thread_sanitizer(tmp_path):
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xenoeye_amd", "csrc")
     exe = str(tmp_path / "pp_tsan")
     cmd = ["gcc", "-std=gnu11", "-O1", "-g", "-w", "-fsanitize=thread", "-pthread", "-I", csrc, src] + \
-          [os.path.join(csrc, f) for f in ("xe_prepass.c", "xe_fields.c", "xe_filter.c", "xe_iplist.c", "xe_conf.c")] + ["-o", exe]
+          [os.path.join(csrc, f) for f in ("xe_prepass.c", "xe_fields.c", "xe_filter.c", "xe_iplist.c", "xe_conf.c")] + ["-o", exe, "-lm"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0 and "tsan" in (r.stderr or "").lower():
         pytest.skip("no ThreadSanitizer runtime")

@@ -134,6 +134,34 @@ def test_tcp_flags_text_matches_reference(orc):
         assert _oracle_flags_text(orc, v) == ref.L.tcp_flags_to_str(v).decode(), v
 
 
+@needs_ref_utils
+def test_port_texts_match_reference(orc):
+    """port_to_str() / ports_pair_to_str() as the oracle restates them (utils.c:28-77) over the names
+    a binding derives from port_to_str(), against the reference's own functions: every port, and
+    pairs that cover all branches (both named, one named either side, none, equal, both orders)"""
+    ref = RefUtils()
+    names = ref.port_names()
+    named = [p for p in range(65536) if names[p]]
+    assert 1000 < len(named) < 60000 and names[80] and names[443]
+    orc.set_port_names(names)
+    for p in range(65536):
+        assert orc.port_to_str(p) == ref.port_to_str(p), p
+    rng = np.random.default_rng(7)
+    unnamed = [p for p in range(65536) if not names[p]]
+    pools = {"n": named, "u": unnamed}
+    pairs = [(p, p) for p in (0, 1, 80, 65535, unnamed[0], unnamed[-1])]
+    for a in "nu":
+        for b in "nu":
+            xs = rng.choice(pools[a], 600)
+            ys = rng.choice(pools[b], 600)
+            pairs += list(zip(xs.tolist(), ys.tolist()))
+    for p1, p2 in pairs:
+        if (p1 > p2) and not names[p1] and names[p2]:
+            # utils.c:70-71 has no `return` on this branch and falls off the end: same text either way
+            pass
+        assert orc.ports_pair_to_str(p1, p2) == ref.ports_pair_to_str(p1, p2), (p1, p2)
+
+
 def test_tcp_flags_text_known_answers(orc):
     # filter.c:836-858 compares these texts; values as the reference's table holds them
     for v, want in {0: "", 1: "FIN", 2: "SYN", 0x12: "ACK+SYN", 0x18: "ACK+PSH", 0x20: "URG", 0x40: "ECE",

@@ -44,6 +44,11 @@ def load_library(path=LIB_PATH):
         "xe_gpu_load_iplists": (i32, [vp, cp]),
         "xe_gpu_add_iplist": (i32, [vp, cp, cp, sz]),
         "xe_gpu_add_mo": (i32, [vp, cp, i32, cp]),
+        "xe_gpu_mo_host_only": (i32, [vp, i32]),
+        "xe_gpu_mo_host_only_reason": (cp, [vp, i32]),
+        "xe_gpu_mo_host_gated": (i32, [vp, i32]),
+        "xe_gpu_set_port_names": (i32, [vp, C.POINTER(cp)]),
+        "xe_gpu_batch_record_datagram": (i32, [vp, vp, sz]),
         "xe_gpu_load_mos": (i32, [vp, cp]),
         "xe_gpu_mo_count": (i32, [vp]),
         "xe_gpu_mo_name": (cp, [vp, i32]),
@@ -224,6 +229,25 @@ class Engine:
 
     def add_mo(self, name, filt, parent=-1):
         return self._chk(self.L.xe_gpu_add_mo(self._h, name.encode(), parent, filt.encode()))
+
+    def mo_host_only(self, i):
+        """the object's filter is left to the caller's own filter_match()"""
+        return bool(self._chk(self.L.xe_gpu_mo_host_only(self._h, i)))
+
+    def mo_host_only_reason(self, i):
+        return self.L.xe_gpu_mo_host_only_reason(self._h, i).decode()
+
+    def mo_host_gated(self, i):
+        return bool(self._chk(self.L.xe_gpu_mo_host_gated(self._h, i)))
+
+    def set_port_names(self, names):
+        """names: 65536 service names ('' or None = the port has none), or None to remove the table"""
+        if names is None:
+            self._chk(self.L.xe_gpu_set_port_names(self._h, None))
+            return
+        assert len(names) == 65536
+        arr = (C.c_char_p * 65536)(*[(n.encode() if isinstance(n, str) else n) if n else None for n in names])
+        self._chk(self.L.xe_gpu_set_port_names(self._h, arr))
 
     def load_mos_with_tables(self, d, max_keys=0):
         """objects and their "fwm" entries from a mo directory; returns (tables added, entries skipped)"""
@@ -439,6 +463,12 @@ class PreparedBatch:
         if count:
             self.eng._chk(self.L.xe_gpu_batch_flow_info(self._b, first, count, out.ctypes.data))
         return out
+
+    def record_datagram(self):
+        """per record the index of the datagram it was decoded from"""
+        out = np.zeros(max(self.records, 1), dtype=np.uint32)
+        self.eng._chk(self.L.xe_gpu_batch_record_datagram(self._b, out.ctypes.data, out.size))
+        return out[:self.records]
 
     def column(self, field):
         w = C.c_size_t()

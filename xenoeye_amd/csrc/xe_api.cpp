@@ -49,6 +49,10 @@ struct xe_gpu
 	size_t motab_words;        /* u64 words of the atom table and its non-empty-row masks */
 	int fast_ok, want_dev;     /* want_dev: some object program reads dev_ip / dev_id */
 	int reads_mark;            /* some object program reads dev_mark */
+	/* service names of the 65536 ports (NULL = none given; an entry is NULL or
+	 * "" for a port without a name): what portstr() / ppstr() compare against */
+	char **port_names;
+	uint32_t port_named_off;   /* word offset in the list tables of the "port has a name" set, 0 = none */
 	char err[512];
 };
 
@@ -200,6 +204,10 @@ xe_gpu_destroy(xe_gpu *h)
 	if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
 	for (int i = 0; i < XE_DPOOL; i++) if (h->dpool[i].p) (void)hipFree(h->dpool[i].p);
 	if (h->stage) (void)hipHostFree(h->stage);
+	if (h->port_names) {
+		for (int i = 0; i < 65536; i++) free(h->port_names[i]);
+		free(h->port_names);
+	}
 	xe_host_free(&h->hs);
 	free(h);
 }
@@ -237,23 +245,30 @@ prog_depth(const struct xe_filter *f)
 	return mx;
 }
 
+/* host_only == NULL: the filter must be evaluable on the device (device mark
+ * filters).  Else *host_only says whether the object is left to the caller's
+ * own filter_match() (why[128] then holds the reason). */
 static int
-compile_checked(xe_gpu *h, const char *text, struct xe_filter *f)
+compile_checked(xe_gpu *h, const char *text, struct xe_filter *f, int *host_only, char *why)
 {
 	char perr[600];
+	const char *reason = NULL;
 	int rc = xe_filter_compile(&h->hs.lists, text ? text : "", f, perr, sizeof(perr));
 
 	if (rc != XE_OK) {
 		snprintf(h->err, sizeof(h->err), "filter '%.200s': %.250s", text ? text : "", perr);
 		return rc;
 	}
-	if (!f->device_ok) {
-		snprintf(h->err, sizeof(h->err), "filter '%.200s': %s", text, f->why);
-		xe_filter_free(f);
-		return XE_EUNSUPPORTED;
-	}
-	if (prog_depth(f) > 64) {
-		snprintf(h->err, sizeof(h->err), "filter '%.200s': expression nests deeper than 64", text);
+	if (!f->device_ok) reason = f->why;
+	else if (f->needs_port_names && !h->port_names) reason = "portstr() / ppstr() without a port-name table (xe_gpu_set_port_names)";
+	else if (prog_depth(f) > 64) reason = "expression nests deeper than 64";
+	if (host_only) *host_only = reason != NULL;
+	if (reason) {
+		if (host_only) {
+			snprintf(why, 128, "%s", reason);
+			return XE_OK;
+		}
+		snprintf(h->err, sizeof(h->err), "filter '%.200s': %s", text ? text : "", reason);
 		xe_filter_free(f);
 		return XE_EUNSUPPORTED;
 	}
@@ -267,8 +282,11 @@ xe_gpu_add_mo(xe_gpu *h, const char *name, int parent, const char *filter)
 	struct xe_filter f;
 	int rc;
 
+	int host_only = 0;
+	char why[128] = "";
+
 	if (!h || (parent < -1) || (parent >= (int)h->hs.nmos)) return XE_EINVAL;
-	rc = compile_checked(h, filter, &f);
+	rc = compile_checked(h, filter, &f, &host_only, why);
 	if (rc != XE_OK) return rc;
 	nm = (struct xe_mo *)realloc(h->hs.mos, (h->hs.nmos + 1) * sizeof(*nm));
 	if (!nm) { xe_filter_free(&f); return XE_ENOMEM; }
@@ -278,8 +296,61 @@ xe_gpu_add_mo(xe_gpu *h, const char *name, int parent, const char *filter)
 	snprintf(nm->name, sizeof(nm->name), "%s", name ? name : "");
 	nm->parent = parent;
 	nm->filter = f;
+	nm->host_only = host_only;
+	memcpy(nm->why, why, sizeof(nm->why));
 	h->committed = 0;
 	return (int)h->hs.nmos++;
+}
+
+extern "C" int
+xe_gpu_mo_host_only(const xe_gpu *h, int mo)
+{
+	if (!h || (mo < 0) || ((size_t)mo >= h->hs.nmos)) return XE_EINVAL;
+	return h->hs.mos[mo].host_only;
+}
+
+extern "C" const char *
+xe_gpu_mo_host_only_reason(const xe_gpu *h, int mo)
+{
+	if (!h || (mo < 0) || ((size_t)mo >= h->hs.nmos) || !h->hs.mos[mo].host_only) return "";
+	return h->hs.mos[mo].why;
+}
+
+/* 1 when object `mo` or one of its ancestors is host-only: its match bit and
+ * counters are those of a candidate, not of a final match */
+static int
+mo_host_gated(const xe_gpu *h, int mo)
+{
+	for (; mo >= 0; mo = h->hs.mos[mo].parent) if (h->hs.mos[mo].host_only) return 1;
+	return 0;
+}
+
+extern "C" int
+xe_gpu_mo_host_gated(const xe_gpu *h, int mo)
+{
+	if (!h || (mo < 0) || ((size_t)mo >= h->hs.nmos)) return XE_EINVAL;
+	return mo_host_gated(h, mo);
+}
+
+extern "C" int
+xe_gpu_set_port_names(xe_gpu *h, const char *const *names)
+{
+	if (!h) return XE_EINVAL;
+	if (h->port_names) {
+		for (int i = 0; i < 65536; i++) free(h->port_names[i]);
+		free(h->port_names);
+		h->port_names = NULL;
+	}
+	h->committed = 0;
+	if (!names) return XE_OK;
+	h->port_names = (char **)calloc(65536, sizeof(char *));
+	if (!h->port_names) return XE_ENOMEM;
+	for (int i = 0; i < 65536; i++) {
+		if (!names[i] || !names[i][0]) continue;
+		h->port_names[i] = strdup(names[i]);
+		if (!h->port_names[i]) return XE_ENOMEM;
+	}
+	return XE_OK;
 }
 
 extern "C" int xe_gpu_mo_count(const xe_gpu *h) { return h ? (int)h->hs.nmos : XE_EINVAL; }
@@ -334,7 +405,7 @@ xe_gpu_add_device(xe_gpu *h, int use_ip, uint32_t ip, int use_id, uint32_t id, i
 		d.marks = (struct xe_filter *)calloc((size_t)nmarks, sizeof(struct xe_filter));
 		if (!d.marks) return XE_ENOMEM;
 		for (int i = 0; i < nmarks; i++) {
-			int rc = compile_checked(h, marks[i], &d.marks[i]);
+			int rc = compile_checked(h, marks[i], &d.marks[i], NULL, NULL);
 			if (rc != XE_OK) {
 				for (int j = 0; j < i; j++) xe_filter_free(&d.marks[j]);
 				free(d.marks);
@@ -515,6 +586,109 @@ upload_pooled(xe_gpu *h, void **dst, const void *src, size_t bytes)
 	return XE_OK;
 }
 
+/* texts of the portstr() operands of a configuration, each once */
+struct strpool { struct xe_blob chars, offs; };
+
+static int32_t
+strpool_intern(struct strpool *sp, const char *str)
+{
+	const uint32_t *off = (const uint32_t *)sp->offs.p;
+	uint32_t at = (uint32_t)sp->chars.n;
+
+	for (size_t i = 0; i < sp->offs.n; i++) {
+		if (!strcmp((const char *)sp->chars.p + off[i], str)) return (int32_t)i;
+	}
+	for (size_t k = 0; k <= strlen(str); k++) if (!xe_blob_push(&sp->chars, &str[k], 1)) return -1;
+	if (!xe_blob_push(&sp->offs, &at, 4)) return -1;
+	return (int32_t)(sp->offs.n - 1);
+}
+
+/* what the interning of terms needs besides the arrays it fills */
+struct intern_ctx
+{
+	xe_gpu *h;
+	struct xe_blob *terms, *opnds, *lookups;
+	struct strpool *strs;
+};
+
+static const char *
+port_name(const xe_gpu *h, uint32_t port)
+{
+	const char *n = h->port_names ? h->port_names[port & 0xFFFF] : NULL;
+	return n ? n : "";
+}
+
+/* port_to_str(), utils.c:28-37 */
+static void
+port_text(const xe_gpu *h, uint32_t port, char out[96])
+{
+	const char *n = port_name(h, port);
+	if (n[0]) snprintf(out, 96, "%.60s (%d)", n, (int)port);
+	else snprintf(out, 96, "%d", (int)port);
+}
+
+/* ports_pair_to_str(), utils.c:39-77 */
+static void
+port_pair_text(const xe_gpu *h, uint32_t p1, uint32_t p2, char out[192])
+{
+	const char *s1 = port_name(h, p1), *s2 = port_name(h, p2);
+
+	out[0] = '\0';
+	if (s1[0] && s2[0]) { snprintf(out, 192, "%.60s(%d) -> %.60s(%d)", s1, (int)p1, s2, (int)p2); return; }
+	if (p1 == p2) { snprintf(out, 192, "%d -> %d", (int)p1, (int)p2); return; }
+	if (p1 < p2) {
+		if (!s1[0] && !s2[0]) snprintf(out, 192, "%d ->", (int)p1);
+		else if (!s1[0]) snprintf(out, 192, "%d -> %.60s(%d)", (int)p1, s2, (int)p2);
+		else snprintf(out, 192, "%.60s(%d) ->", s1, (int)p1);
+	} else {
+		if (!s1[0] && !s2[0]) snprintf(out, 192, "-> %d", (int)p2);
+		else if (!s1[0]) snprintf(out, 192, "-> %.60s(%d)", s2, (int)p2);
+		else snprintf(out, 192, "%.60s(%d) -> %d", s1, (int)p1, (int)p2);
+	}
+}
+
+/* ppstr() 'text' as conditions on the two port values.  The text of a pair
+ * (ports_pair_to_str) names both ports only when both have a service name, or
+ * the named / smaller one otherwise, so an operand is
+ *   kind 1: port1 == X and port2 == Y
+ *   kind 2: port1 == X, port2 > X and port2 has no name    ("X ->", "name(X) ->")
+ *   kind 3: port2 == Y, port1 > Y and port1 has no name    ("-> Y", "-> name(Y)")
+ * or several of them.  Every candidate is checked by formatting it and
+ * comparing like the reference (strcasecmp, filter.c:894-901). */
+static int
+ppstr_lower(const xe_gpu *h, const char *text, struct xe_blob *out)
+{
+	char buf[192];
+	struct xe_dopnd d;
+	/* an unnamed port above p exists? (kinds 2 and 3 need one to ever match; kept anyway) */
+	memset(&d, 0, sizeof(d));
+#define PP_PUSH(K, X, Y) do { d.list = (K); d.low = (int32_t)(X); d.high = (int32_t)(Y); \
+	if (!xe_blob_push(out, &d, sizeof(d))) return XE_ENOMEM; } while (0)
+	for (uint32_t p1 = 0; p1 < 65536; p1++) {
+		const int named1 = port_name(h, p1)[0] != 0;
+		size_t plen;
+		/* kind 2: the text of (p1, an unnamed port above it) does not depend on that port */
+		snprintf(buf, sizeof(buf), named1 ? "%.60s(%d) ->" : "%.0s%d ->", port_name(h, p1), (int)p1);
+		if (!strcasecmp(text, buf)) PP_PUSH(2, p1, 0);
+		/* kind 3 with Y = p1 */
+		snprintf(buf, sizeof(buf), named1 ? "-> %.60s(%d)" : "-> %.0s%d", port_name(h, p1), (int)p1);
+		if (!strcasecmp(text, buf)) PP_PUSH(3, 0, p1);
+		/* exact pairs: every text of a pair that names p1 starts with p1's part and " -> " */
+		snprintf(buf, sizeof(buf), named1 ? "%.60s(%d) -> " : "%.0s%d -> ", port_name(h, p1), (int)p1);
+		plen = strlen(buf);
+		if (strncasecmp(text, buf, plen) != 0) continue;
+		for (uint32_t p2 = 0; p2 < 65536; p2++) {
+			const int named2 = port_name(h, p2)[0] != 0;
+			/* pairs whose text carries both ports */
+			if (!((named1 && named2) || (p1 == p2) || (!named1 && named2 && (p1 < p2)) || (named1 && !named2 && (p1 > p2)))) continue;
+			port_pair_text(h, p1, p2, buf);
+			if (!strcasecmp(text, buf)) PP_PUSH(1, p1, p2);
+		}
+	}
+#undef PP_PUSH
+	return XE_OK;
+}
+
 /* device form of one operand */
 /* the text of a TCP flags byte: the names of the set bits, most significant
  * first, joined with '+' (the reference's table utils-data.inc:4-261) */
@@ -605,34 +779,83 @@ intern_lookup(struct xe_blob *probes, uint32_t list, int family, uint8_t field)
 }
 
 static int
-intern_term(struct xe_blob *terms, struct xe_blob *opnds, struct xe_blob *lookups, const struct xe_filter *f,
-	size_t ti, uint32_t *id)
+intern_term(struct intern_ctx *cx, const struct xe_filter *f, size_t ti, uint32_t *id)
 {
+	struct xe_blob *terms = cx->terms, *opnds = cx->opnds;
 	struct xe_term t = f->terms[ti];
-	struct xe_dopnd tmp[64], *ops = tmp;
-	const struct xe_term *have = (const struct xe_term *)terms->p;
-	const struct xe_dopnd *hop = (const struct xe_dopnd *)opnds->p;
+	struct xe_blob dl = {0};          /* the term's device operands */
+	const struct xe_dopnd *ops;
+	const struct xe_term *have;
+	const struct xe_dopnd *hop;
 	int rc = XE_OK;
 
 	t.pad = 0;
-	if (t.nopnd > 64) {
-		ops = (struct xe_dopnd *)malloc(t.nopnd * sizeof(*ops));
-		if (!ops) return XE_ENOMEM;
-	}
-	for (uint32_t j = 0; j < t.nopnd; j++) {
-		ops[j] = make_dopnd(&t, &f->opnds[f->terms[ti].opnd_base + j]);
-		if (ops[j].is_list && (t.func == XE_FN_NONE) && ((t.type == XE_BT_ADDR4) || (t.type == XE_BT_ADDR6))) {
-			int fam = (t.type == XE_BT_ADDR4) ? 4 : 6;
-			ops[j].low = (t.dir & XE_DIR_SRC) ? intern_lookup(lookups, ops[j].list, fam, t.fsrc) : -1;
-			ops[j].high = (t.dir & XE_DIR_DST) ? intern_lookup(lookups, ops[j].list, fam, t.fdst) : -1;
+	for (uint32_t j = 0; (j < f->terms[ti].nopnd) && (rc == XE_OK); j++) {
+		const size_t oi = f->terms[ti].opnd_base + j;
+		const int32_t note = f->opnd_note[oi];
+		const char *text = ((t.type == XE_BT_STRING) && (note >= 0) && ((size_t)note < f->nstrs)) ? f->strs + note : NULL;
+		struct xe_dopnd d = make_dopnd(&t, &f->opnds[oi]);
+
+		if (t.func == XE_FN_PPSTR) {
+			/* conditions on the two port values instead of the text */
+			if (text) rc = ppstr_lower(cx->h, text, &dl);
+			continue;
 		}
+		if (t.func == XE_FN_PORTSTR) {
+			/* the set of ports whose text equals the operand is laid out behind
+			 * the list tables at the end of the commit; here: which text */
+			int32_t sid = text ? strpool_intern(cx->strs, text) : -1;
+			if (!text) continue;
+			if (sid < 0) { rc = XE_ENOMEM; break; }
+			d.list = (uint32_t)sid;
+		}
+		if (d.is_list && (t.func == XE_FN_NONE) && ((t.type == XE_BT_ADDR4) || (t.type == XE_BT_ADDR6))) {
+			int fam = (t.type == XE_BT_ADDR4) ? 4 : 6;
+			d.low = (t.dir & XE_DIR_SRC) ? intern_lookup(cx->lookups, d.list, fam, t.fsrc) : -1;
+			d.high = (t.dir & XE_DIR_DST) ? intern_lookup(cx->lookups, d.list, fam, t.fdst) : -1;
+		}
+		if (!xe_blob_push(&dl, &d, sizeof(d))) rc = XE_ENOMEM;
 	}
+	if ((rc == XE_OK) && (t.func == XE_FN_DIV_L)) {
+		/* div_l: the quotient goes through pow(k, (int)(log(q) / log(k)))
+		 * (filter.h:396-418), a step function of the int quotient.  Its steps
+		 * are found with this host's libm, and the operand ranges over the
+		 * result become ranges over the quotient itself.  A zero divisor gives
+		 * 0 without going through the logarithm (filter.h:401-403): whether 0
+		 * is inside the operand ranges is kept in `k`. */
+		int32_t lo[80], hi[80], val[80];
+		const int np = xe_div_l_pieces(t.k, lo, hi, val, 80);
+		struct xe_blob nl = {0};
+		const struct xe_dopnd *o = (const struct xe_dopnd *)dl.p;
+		int zero_hit = 0;
+		for (size_t j = 0; j < dl.n; j++) if ((0 >= o[j].low) && (0 <= o[j].high)) zero_hit = 1;
+		for (int i = 0; (i < np) && (rc == XE_OK); i++) {
+			int hit = 0;
+			for (size_t j = 0; j < dl.n; j++) if ((val[i] >= o[j].low) && (val[i] <= o[j].high)) hit = 1;
+			if (hit) {
+				struct xe_dopnd d;
+				memset(&d, 0, sizeof(d));
+				d.low = lo[i];
+				d.high = hi[i];
+				if (!xe_blob_push(&nl, &d, sizeof(d))) rc = XE_ENOMEM;
+			}
+		}
+		if (np < 0) rc = XE_EUNSUPPORTED;
+		free(dl.p);
+		dl = nl;
+		t.k = zero_hit;
+	}
+	if (rc != XE_OK) goto out;
+	t.nopnd = (uint32_t)dl.n;
+	ops = (const struct xe_dopnd *)dl.p;
+	have = (const struct xe_term *)terms->p;
+	hop = (const struct xe_dopnd *)opnds->p;
 	for (size_t k = 0; k < terms->n; k++) {
 		const struct xe_term *o = &have[k];
 		if ((o->type == t.type) && (o->dir == t.dir) && (o->fsrc == t.fsrc) && (o->fdst == t.fdst)
 			&& (o->func == t.func) && (o->fa == t.fa) && (o->fb == t.fb) && (o->k == t.k)
 			&& (o->nopnd == t.nopnd)
-			&& !memcmp(hop + o->opnd_base, ops, t.nopnd * sizeof(*ops))) {
+			&& (!t.nopnd || !memcmp(hop + o->opnd_base, ops, t.nopnd * sizeof(*ops)))) {
 			*id = (uint32_t)k;
 			goto out;
 		}
@@ -644,14 +867,14 @@ intern_term(struct xe_blob *terms, struct xe_blob *opnds, struct xe_blob *lookup
 	*id = (uint32_t)terms->n;
 	if (!xe_blob_push(terms, &t, sizeof(t))) rc = XE_ENOMEM;
 out:
-	if (ops != tmp) free(ops);
+	free(dl.p);
 	return rc;
 }
 
 /* append one compiled filter to the flat arrays */
 static int
-append_prog(struct xe_blob *progs, struct xe_blob *ops, struct xe_blob *terms, struct xe_blob *opnds,
-	struct xe_blob *lookups, const struct xe_filter *f, int parent)
+append_prog(struct xe_blob *progs, struct xe_blob *ops, struct intern_ctx *cx, const struct xe_filter *f, int parent,
+	int host_only)
 {
 	struct xe_prog pr;
 	int cval = 0;
@@ -659,6 +882,13 @@ append_prog(struct xe_blob *progs, struct xe_blob *ops, struct xe_blob *terms, s
 	memset(&pr, 0, sizeof(pr));
 	pr.parent = parent;
 	pr.op_base = (uint32_t)ops->n;
+	if (host_only) {
+		/* decided by the caller's own filter_match(): on the device the object
+		 * takes every record its parent took */
+		pr.flags = XE_PROG_CONST;
+		pr.cval = 1;
+		return xe_blob_push(progs, &pr, sizeof(pr)) ? XE_OK : XE_ENOMEM;
+	}
 	if (xe_filter_constant(f, &cval)) {
 		pr.flags = XE_PROG_CONST;
 		pr.cval = (uint16_t)cval;
@@ -669,7 +899,7 @@ append_prog(struct xe_blob *progs, struct xe_blob *ops, struct xe_blob *terms, s
 		uint32_t w = f->ops[i];
 		if ((w & 3) == XE_OP_BASIC) {
 			uint32_t id;
-			int rc = intern_term(terms, opnds, lookups, f, w >> 2, &id);
+			int rc = intern_term(cx, f, w >> 2, &id);
 			if (rc != XE_OK) return rc;
 			w = XE_OP_BASIC | (id << 2);
 		}
@@ -839,6 +1069,11 @@ xe_gpu_add_fwm(xe_gpu *h, int mo, const char *const *fields, int nfields, size_t
 	uint32_t pos = 0;
 
 	if (!h || !fields || (nfields < 1) || (mo < 0) || ((size_t)mo >= h->hs.nmos)) return XE_EINVAL;
+	if (mo_host_gated(h, mo)) {
+		snprintf(h->err, sizeof(h->err), "object %d (or an object above it) is matched by the caller's own "
+			"filter_match(): its records are not known on the device", mo);
+		return XE_EUNSUPPORTED;
+	}
 	memset(&w, 0, sizeof(w));
 	w.dev.mo = (uint32_t)mo;
 	for (int i = 0; i < nfields; i++) {
@@ -1101,6 +1336,8 @@ extern "C" int
 xe_gpu_commit(xe_gpu *h)
 {
 	struct xe_blob progs = {0}, ops = {0}, terms = {0}, opnds = {0}, trie = {0}, rules = {0}, lookups = {0};
+	struct strpool strs = { {0}, {0} };
+	struct intern_ctx cx = { h, &terms, &opnds, &lookups, &strs };
 	int rc = XE_OK;
 
 	if (!h) return XE_EINVAL;
@@ -1108,7 +1345,7 @@ xe_gpu_commit(xe_gpu *h)
 	free_config_dev(h);
 
 	for (size_t m = 0; (m < h->hs.nmos) && (rc == XE_OK); m++) {
-		rc = append_prog(&progs, &ops, &terms, &opnds, &lookups, &h->hs.mos[m].filter, h->hs.mos[m].parent);
+		rc = append_prog(&progs, &ops, &cx, &h->hs.mos[m].filter, h->hs.mos[m].parent, h->hs.mos[m].host_only);
 	}
 	if (rc == XE_OK) {
 		/* the fast kernel evaluates the object programs' terms [0, nterms);
@@ -1166,7 +1403,7 @@ xe_gpu_commit(xe_gpu *h)
 		r.nprogs = (uint32_t)h->hs.devs[d].nmarks;
 		r.skip_unmarked = (uint32_t)h->hs.devs[d].skip_unmarked;
 		for (size_t k = 0; (k < h->hs.devs[d].nmarks) && (rc == XE_OK); k++) {
-			rc = append_prog(&progs, &ops, &terms, &opnds, &lookups, &h->hs.devs[d].marks[k], -1);
+			rc = append_prog(&progs, &ops, &cx, &h->hs.devs[d].marks[k], -1, 0);
 		}
 		if ((rc == XE_OK) && !xe_blob_push(&rules, &r, sizeof(r))) rc = XE_ENOMEM;
 	}
@@ -1175,6 +1412,48 @@ xe_gpu_commit(xe_gpu *h)
 		if (!h->h_lists) rc = XE_ENOMEM;
 		else rc = xe_iplists_flatten(&h->hs.lists, &trie, h->h_lists);
 	}
+	h->port_named_off = 0;
+	if ((rc == XE_OK) && h->port_names && (strs.offs.n || 1)) {
+		/* behind the list tables: which ports have a service name (65536 bits),
+		 * then per portstr() text the set of ports whose text equals it
+		 * (port_to_str + strcasecmp, filter.c:861-880) */
+		const uint32_t zero = 0;
+		int uses_ports = 0;
+		const struct xe_term *tt = (const struct xe_term *)terms.p;
+		for (size_t t = 0; t < terms.n; t++) if ((tt[t].func == XE_FN_PORTSTR) || (tt[t].func == XE_FN_PPSTR)) uses_ports = 1;
+		if (uses_ports) {
+			uint32_t *set = (uint32_t *)calloc(2048, 4), *setoff = (uint32_t *)calloc(strs.offs.n + 1, 4);
+			if (!set || !setoff) rc = XE_ENOMEM;
+			if ((rc == XE_OK) && (trie.n == 0) && !xe_blob_push(&trie, &zero, 4)) rc = XE_ENOMEM;
+			while ((rc == XE_OK) && (trie.n % 4)) if (!xe_blob_push(&trie, &zero, 4)) rc = XE_ENOMEM;
+			if (rc == XE_OK) {
+				for (uint32_t p = 0; p < 65536; p++) if (port_name(h, p)[0]) set[p >> 5] |= 1u << (p & 31);
+				h->port_named_off = (uint32_t)trie.n;
+				for (int k = 0; (k < 2048) && (rc == XE_OK); k++) if (!xe_blob_push(&trie, &set[k], 4)) rc = XE_ENOMEM;
+			}
+			for (size_t i = 0; (i < strs.offs.n) && (rc == XE_OK); i++) {
+				const char *text = (const char *)strs.chars.p + ((const uint32_t *)strs.offs.p)[i];
+				memset(set, 0, 2048 * 4);
+				for (uint32_t p = 0; p < 65536; p++) {
+					char buf[96];
+					port_text(h, p, buf);
+					if (!strcasecmp(text, buf)) set[p >> 5] |= 1u << (p & 31);
+				}
+				setoff[i] = (uint32_t)trie.n;
+				for (int k = 0; (k < 2048) && (rc == XE_OK); k++) if (!xe_blob_push(&trie, &set[k], 4)) rc = XE_ENOMEM;
+			}
+			if (rc == XE_OK) {
+				struct xe_dopnd *oo = (struct xe_dopnd *)opnds.p;
+				for (size_t t = 0; t < terms.n; t++) {
+					if (tt[t].func != XE_FN_PORTSTR) continue;
+					for (uint32_t j = 0; j < tt[t].nopnd; j++) oo[tt[t].opnd_base + j].low = (int32_t)setoff[oo[tt[t].opnd_base + j].list];
+				}
+			}
+			free(set);
+			free(setoff);
+		}
+	}
+	if ((rc == XE_OK) && (trie.n > 0x7FFFFFF0u) && h->port_named_off) rc = XE_EUNSUPPORTED;
 	if ((rc == XE_OK) && (trie.n > 0xFFFFFFF0u)) rc = XE_EUNSUPPORTED;
 	if (rc == XE_OK) {
 		/* a probe walks the merged tables of its group of lists */
@@ -1572,6 +1851,7 @@ xe_gpu_commit(xe_gpu *h)
 		free_config_dev(h);
 	}
 	free(progs.p); free(ops.p); free(terms.p); free(opnds.p); free(trie.p); free(rules.p); free(lookups.p);
+	free(strs.chars.p); free(strs.offs.p);
 	return rc;
 }
 
@@ -2059,6 +2339,7 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 	b->kp.terms = (const struct xe_term *)h->d_terms;
 	b->kp.opnds = (const struct xe_dopnd *)h->d_opnds;
 	b->kp.trie = (const uint32_t *)h->d_trie;
+	b->kp.port_named_off = h->port_named_off;
 	b->kp.lists = (const struct xe_list_dev *)h->d_lists;
 	b->kp.devrules = (const struct xe_devrule *)h->d_devrules;
 	b->kp.nmo = h->nmo;
@@ -2234,6 +2515,20 @@ xe_gpu_batch_dropped(xe_batch *b, uint8_t *dropped, size_t n)
 		free(st);
 	}
 	return rc;
+}
+
+extern "C" int
+xe_gpu_batch_record_datagram(xe_batch *b, uint32_t *dgram, size_t n)
+{
+	const struct xe_plan *p;
+
+	if (!b || (n < b->ntot) || (b->ntot && !dgram)) return XE_EINVAL;
+	p = &b->plan;
+	for (size_t i = 0; i < p->ndg; i++) {
+		for (uint32_t r = p->dg_first_nf[i]; r < p->dg_first_nf[i + 1]; r++) dgram[r] = (uint32_t)i;
+		for (uint32_t r = p->dg_first_sf[i]; r < p->dg_first_sf[i + 1]; r++) dgram[p->nrec + r] = (uint32_t)i;
+	}
+	return XE_OK;
 }
 
 extern "C" int

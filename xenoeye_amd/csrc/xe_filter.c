@@ -22,6 +22,8 @@
 #include <string.h>
 #include <strings.h>
 #include <arpa/inet.h>
+#include <math.h>
+#include <limits.h>
 #include "xe_internal.h"
 
 #define TOK_MAX 512
@@ -30,7 +32,8 @@ enum tok
 {
 	T_ID, T_RANGE, T_MAC, T_STR, T_LP, T_RP, T_COMMA,
 	T_OR, T_AND, T_NOT, T_SRC, T_DST, T_ASC, T_DESC,
-	T_DIV, T_DIV_R, T_DIV_L, T_MIN, T_TFSTR, T_OTHERFUNC,
+	T_DIV, T_DIV_R, T_DIV_L, T_MIN, T_TFSTR, T_PORTSTR, T_PPSTR, T_MFREQ, T_ASN, T_ASD,
+	T_GEO,       /* val = index into kgeo */
 	T_FIELD,     /* val = index into kfields */
 	T_AGGR       /* val = index into kaggr */
 };
@@ -89,13 +92,13 @@ static const struct { const char *kw; uint8_t field; uint8_t scale; } kaggr[] = 
 static const struct { const char *kw; enum tok t; } kwords[] = {
 	{ "or", T_OR }, { "and", T_AND }, { "not", T_NOT }, { "asc", T_ASC }, { "desc", T_DESC },
 	{ "div", T_DIV }, { "div_r", T_DIV_R }, { "div_l", T_DIV_L }, { "min", T_MIN },
-	/* recognised so that they cannot be list names, but not compiled */
-	{ "mfreq", T_OTHERFUNC }, { "tfstr", T_TFSTR }, { "portstr", T_OTHERFUNC },
-	{ "ppstr", T_OTHERFUNC }, { "continent", T_OTHERFUNC }, { "country_code", T_OTHERFUNC },
-	{ "country", T_OTHERFUNC }, { "state", T_OTHERFUNC }, { "city", T_OTHERFUNC },
-	{ "zip", T_OTHERFUNC }, { "lat", T_OTHERFUNC }, { "long", T_OTHERFUNC },
-	{ "asn", T_OTHERFUNC }, { "asd", T_OTHERFUNC },
+	{ "mfreq", T_MFREQ }, { "tfstr", T_TFSTR }, { "portstr", T_PORTSTR }, { "ppstr", T_PPSTR },
+	{ "asn", T_ASN }, { "asd", T_ASD },
 };
+
+/* geoip.h:13-21, in the order of enum GEOIP_FIELD */
+static const char *const kgeo[] = { "continent", "country_code", "country", "state", "city", "zip", "lat", "long" };
+#define NKGEO ((int)(sizeof(kgeo) / sizeof(kgeo[0])))
 
 struct lexer
 {
@@ -114,9 +117,9 @@ struct pctx
 {
 	struct lexer lx;
 	const struct xe_iplists *reg;
-	struct xe_blob ops, terms, opnds, notes;
+	struct xe_blob ops, terms, opnds, notes, strs;
 	int device_ok;
-	int other_func;      /* a function this library does not compile was met */
+	int needs_port_names;
 	char why[128];
 };
 
@@ -234,6 +237,9 @@ classify_word(struct lexer *lx)
 	}
 	for (i = 0; i < sizeof(kwords) / sizeof(kwords[0]); i++) {
 		if (!strcasecmp(w, kwords[i].kw)) { lx->t = kwords[i].t; return; }
+	}
+	for (i = 0; i < (size_t)NKGEO; i++) {
+		if (!strcasecmp(w, kgeo[i])) { lx->t = T_GEO; lx->val = (int)i; return; }
 	}
 	for (i = 0; i < (size_t)NKAGGR; i++) {
 		if (!strcasecmp(w, kaggr[i].kw)) { lx->t = T_AGGR; lx->val = (int)i; return; }
@@ -401,6 +407,7 @@ add_operand(struct pctx *p, int type)
 	memset(&o, 0, sizeof(o));
 	switch (p->lx.t) {
 		case T_ID:
+			if (type == XE_BT_STRING) note = -1;
 			if ((type == XE_BT_ADDR4) || (type == XE_BT_ADDR6)) {
 				int li = p->reg ? xe_iplist_find(p->reg, p->lx.text) : -1;
 				if (li >= 0) {
@@ -418,21 +425,31 @@ add_operand(struct pctx *p, int type)
 			break;
 		case T_RANGE:
 			if (type != XE_BT_RANGE) not_on_device(p, "number used where an address, MAC or string is expected");
+			if (type == XE_BT_STRING) note = -1;
 			o.w[0] = (uint32_t)p->lx.lo;
 			o.w[1] = (uint32_t)p->lx.hi;
 			break;
 		case T_MAC:
 			if (type != XE_BT_MAC) not_on_device(p, "MAC address used where another operand type is expected");
+			if (type == XE_BT_STRING) note = -1;
 			memcpy(&o.w[0], p->lx.mac, 6);
 			break;
-		case T_STR:
-			if (((struct xe_term *)p->terms.p)[p->terms.n - 1].func == XE_FN_TFSTR) {
-				/* the text itself; turned into a set of flag bytes at commit */
+		case T_STR: {
+			const uint8_t fn = ((struct xe_term *)p->terms.p)[p->terms.n - 1].func;
+			size_t k, len = strlen(p->lx.text) + 1;
+			/* the text is kept for the dump (and for the lowering of tfstr /
+			 * portstr / ppstr at commit) */
+			note = (int32_t)p->strs.n;
+			for (k = 0; k < len; k++) if (!xe_blob_push(&p->strs, &p->lx.text[k], 1)) return;
+			if (fn == XE_FN_TFSTR) {
 				snprintf((char *)&o.w[0], sizeof(o.w), "%s", p->lx.text);
+			} else if ((fn == XE_FN_PORTSTR) || (fn == XE_FN_PPSTR)) {
+				if (type != XE_BT_STRING) not_on_device(p, "string operand");
 			} else {
 				not_on_device(p, "string operand");
 			}
 			break;
+		}
 		default:
 			return;
 	}
@@ -575,23 +592,73 @@ func_rule(struct pctx *p)
 			if (!take(p, T_RANGE)) { fail(&p->lx, "Expected INT"); return 0; }
 			t.k = k;
 		}
-		if (which == T_DIV_L) not_on_device(p, "div_l() needs the host's libm log/pow");
 	}
 	if (!take(p, T_RP)) { fail(&p->lx, "Expected ')'"); return 0; }
 	emit_term(p, &t);
 	return value_list(p, XE_BT_RANGE);
 }
 
+/* mfreq(f1, f2), portstr(f), ppstr(f1, f2), the geo functions, asn(f), asd(f)
+ * (filter-parser-funcs.c:285-524, :582-705).  portstr / ppstr are pure
+ * functions of 16-bit values and are lowered at commit when the handle has a
+ * port-name table; the others keep state or read the geo databases and stay
+ * with the caller's own filter_match(). */
+static int
+other_func_rule(struct pctx *p)
+{
+	struct xe_term t;
+	const enum tok which = p->lx.t;
+	const char *name;
+	int two_args = 0, type = XE_BT_STRING;
+
+	memset(&t, 0, sizeof(t));
+	t.dir = XE_DIR_NONE;
+	switch (which) {
+		case T_MFREQ: t.func = XE_FN_MFREQ; name = "'mfreq'"; two_args = 1; type = XE_BT_RANGE; break;
+		case T_PORTSTR: t.func = XE_FN_PORTSTR; name = "'portstr'"; break;
+		case T_PPSTR: t.func = XE_FN_PPSTR; name = "'ppstr'"; two_args = 1; break;
+		case T_GEO: t.func = XE_FN_GEO; t.k = p->lx.val; name = "GeoIP function"; break;
+		case T_ASN: t.func = XE_FN_ASN; name = "AS function"; type = XE_BT_RANGE; break;
+		case T_ASD: t.func = XE_FN_ASD; name = "AS function"; break;
+		default: return 0;
+	}
+	t.type = (uint8_t)type;
+	if (!take(p, which)) return 0;
+	if (!take(p, T_LP)) {
+		char m[64];
+		snprintf(m, sizeof(m), "Expected '(' after %s", name);
+		fail(&p->lx, m);
+		return 0;
+	}
+	if (!field_arg(p, &t.fa)) { fail(&p->lx, "Incorrect field name"); return 0; }
+	if (two_args) {
+		if (!take(p, T_COMMA)) { fail(&p->lx, "Expected ',' after field name"); return 0; }
+		if (!field_arg(p, &t.fb)) { fail(&p->lx, "Incorrect field name after comma"); return 0; }
+	}
+	if (!take(p, T_RP)) { fail(&p->lx, "Expected ')'"); return 0; }
+	if ((which == T_PORTSTR) || (which == T_PPSTR)) {
+		p->needs_port_names = 1;
+		/* the reference reads get_nf_val() of the field: 1, 2, 4 or 8 bytes */
+		if ((xe_fields[t.fa].type == XE_T_STR) || (two_args && (xe_fields[t.fb].type == XE_T_STR))) {
+			not_on_device(p, "portstr() / ppstr() over a string field");
+		}
+	} else {
+		not_on_device(p, (which == T_MFREQ) ? "mfreq() keeps state between records"
+			: "geo / AS functions read the caller's databases");
+	}
+	emit_term(p, &t);
+	return value_list(p, type);
+}
+
 static int
 parse_rule(struct pctx *p)
 {
 	if (func_rule(p)) return 1;
+	if (p->lx.failed) return 0;
 	if (tfstr_rule(p)) return 1;
-	if (p->lx.t == T_OTHERFUNC) {
-		p->other_func = 1;
-		fail(&p->lx, "function is not compiled");
-		return 0;
-	}
+	if (p->lx.failed) return 0;
+	if (other_func_rule(p)) return 1;
+	if (p->lx.failed) return 0;
 	if (plain_rule(p, XE_DIR_BOTH)) return 1;
 	if (take(p, T_SRC)) return plain_rule(p, XE_DIR_SRC);
 	if (take(p, T_DST)) return plain_rule(p, XE_DIR_DST);
@@ -665,7 +732,8 @@ xe_field_parse(const char *text, struct xe_agfield *out, char *err, size_t errle
 	if (p.lx.failed) goto bad;
 	if (p.lx.at_end) { fail(&p.lx, "Empty field not allowed"); goto bad; }
 	switch (p.lx.t) {
-		case T_DIV: case T_DIV_R: case T_DIV_L: case T_MIN: case T_TFSTR: case T_OTHERFUNC:
+		case T_DIV: case T_DIV_R: case T_DIV_L: case T_MIN: case T_TFSTR: case T_PORTSTR: case T_PPSTR:
+		case T_MFREQ: case T_ASN: case T_ASD: case T_GEO:
 			if (err && errlen) snprintf(err, errlen, "function fields are not supported by this library");
 			return XE_EUNSUPPORTED;
 		default:
@@ -721,6 +789,7 @@ xe_filter_free(struct xe_filter *f)
 	free(f->terms);
 	free(f->opnds);
 	free(f->opnd_note);
+	free(f->strs);
 	memset(f, 0, sizeof(*f));
 }
 
@@ -749,17 +818,12 @@ xe_filter_compile(const struct xe_iplists *reg, const char *text, struct xe_filt
 	out->terms = p.terms.p;   out->nterms = p.terms.n;
 	out->opnds = p.opnds.p;   out->nopnds = p.opnds.n;
 	out->opnd_note = p.notes.p;
+	out->strs = p.strs.p;     out->nstrs = p.strs.n;
 	out->device_ok = p.device_ok;
+	out->needs_port_names = p.needs_port_names;
 	memcpy(out->why, p.why, sizeof(out->why));
 	if (p.lx.failed) {
 		xe_filter_free(out);
-		if (p.other_func) {
-			/* valid in the reference (filter-parser-funcs.c:285-560), but
-			 * these need its geoip / string tables */
-			if (err && errlen) snprintf(err, errlen, "mfreq/portstr/ppstr/geoip/asn/asd "
-				"functions are not supported by this library");
-			return XE_EUNSUPPORTED;
-		}
 		if (err && errlen) snprintf(err, errlen, "%s", p.lx.msg);
 		return XE_EPARSE;
 	}
@@ -822,10 +886,30 @@ xe_filter_dump_text(const struct xe_iplists *reg, const struct xe_filter *f, cha
 			case XE_FN_MIN:
 				PUT("MIN ([offset %d]/[offset %d])", xe_fields[t->fa].off, xe_fields[t->fb].off);
 				break;
+			case XE_FN_MFREQ:
+				PUT("MFREQ ([offset %d]/[offset %d])", xe_fields[t->fa].off, xe_fields[t->fb].off);
+				break;
+			case XE_FN_GEO: {
+				/* the macro prints the enumerator's name (filter.c:1154-1160) */
+				char up[16];
+				size_t c;
+				for (c = 0; kgeo[t->k][c] && (c < sizeof(up) - 1); c++) {
+					up[c] = (char)(((kgeo[t->k][c] >= 'a') && (kgeo[t->k][c] <= 'z')) ? kgeo[t->k][c] - 32 : kgeo[t->k][c]);
+				}
+				up[c] = '\0';
+				PUT("%s ([offset %d]/[size %d])", up, xe_fields[t->fa].off, xe_fields[t->fa].size_max);
+				break;
+			}
+			case XE_FN_ASN:
+			case XE_FN_ASD:
+				PUT("AS ([offset %d]/[size %d])", xe_fields[t->fa].off, xe_fields[t->fa].size_max);
+				break;
 			case XE_FN_TFSTR:
-				/* filter.c:1113-1172 has no case for it: the default branch
+			case XE_FN_PORTSTR:
+			case XE_FN_PPSTR:
+				/* filter.c:1113-1172 has no case for them: the default branch
 				 * prints the enum value (filter.h:130-151) */
-				PUT("<Unknown name %d> ", 1 + NKFIELDS + 5 + 8 + 2);
+				PUT("<Unknown name %d> ", 1 + NKFIELDS + 5 + 8 + 2 + (int)(t->func - XE_FN_TFSTR));
 				break;
 			default:
 				PUT("\"%s\" ", kfields[t->pad].kw);
@@ -849,12 +933,75 @@ xe_filter_dump_text(const struct xe_iplists *reg, const struct xe_filter *f, cha
 				PUT(" %d-%d", (int32_t)o->w[0], (int32_t)o->w[1]);
 			} else if (t->type == XE_BT_MAC) {
 				PUT(" %02x:%02x:%02x:%02x:%02x:%02x", b[0], b[1], b[2], b[3], b[4], b[5]);
-			} else if (t->func == XE_FN_TFSTR) {
-				PUT(" %s", (const char *)b);
+			} else if (t->type == XE_BT_STRING) {
+				/* an operand that is not a quoted string has no text in the
+				 * reference (it prints an uninitialised pointer) */
+				PUT(" %s", ((note >= 0) && ((size_t)note < f->nstrs)) ? f->strs + note : "(null)");
 			}
 		}
 		PUT("\n");
 	}
 #undef PUT
 	return (int)pos;
+}
+
+/* ------------------------------------------------------------------ div_l */
+/* xdiv()'s is_log branch, filter.h:407-409, as the reference's compiler
+ * evaluates it on this host: double log / pow, conversions by truncation (a
+ * NaN or infinite ratio converts to INT_MIN on x86-64).  `volatile` keeps the
+ * compiler from folding the conversions at build time. */
+static int
+div_l_value(int quotient, int k)
+{
+	volatile double ratio = log((double)quotient) / log((double)k);
+	volatile int lg = (int)ratio;
+	volatile double p = pow((double)k, (double)lg);
+	return (int)p;
+}
+
+struct dl_out { int32_t *lo, *hi, *val; int n, cap, bad; };
+
+static void
+dl_piece(struct dl_out *o, int32_t lo, int32_t hi, int32_t val)
+{
+	if (o->n && (o->val[o->n - 1] == val) && (o->hi[o->n - 1] == lo - 1)) { o->hi[o->n - 1] = hi; return; }
+	if (o->n >= o->cap) { o->bad = 1; return; }
+	o->lo[o->n] = lo; o->hi[o->n] = hi; o->val[o->n] = val;
+	o->n++;
+}
+
+/* the value is a non-decreasing step function of a positive quotient (log,
+ * truncation and pow are monotone): equal ends = one piece, else cut in half */
+static void
+dl_split(struct dl_out *o, int k, int32_t lo, int32_t hi, int vlo, int vhi, int depth)
+{
+	int32_t mid;
+	if (o->bad) return;
+	if (vlo == vhi) { dl_piece(o, lo, hi, vlo); return; }
+	if (hi == lo + 1) { dl_piece(o, lo, lo, vlo); dl_piece(o, hi, hi, vhi); return; }
+	if (depth > 40) { o->bad = 1; return; }
+	mid = lo + (hi - lo) / 2;
+	{
+		const int vm = div_l_value(mid, k), vm1 = div_l_value(mid + 1, k);
+		dl_split(o, k, lo, mid, vlo, vm, depth + 1);
+		dl_split(o, k, mid + 1, hi, vm1, vhi, depth + 1);
+	}
+}
+
+int
+xe_div_l_pieces(int k, int32_t *lo, int32_t *hi, int32_t *val, int cap)
+{
+	struct dl_out o = { lo, hi, val, 0, cap, 0 };
+	int i;
+
+	/* a negative quotient has no logarithm: every one of them gives the value of -1 */
+	dl_piece(&o, INT_MIN, -1, div_l_value(-1, k));
+	dl_piece(&o, 0, 0, div_l_value(0, k));
+	dl_split(&o, k, 1, INT_MAX, div_l_value(1, k), div_l_value(INT_MAX, k), 0);
+	if (o.bad) return -1;
+	/* the pieces were found by bisection: look at both ends of each again */
+	for (i = 0; i < o.n; i++) {
+		if ((div_l_value(lo[i], k) != val[i]) || (div_l_value(hi[i], k) != val[i])) return -1;
+	}
+	return o.n;
 }

@@ -50,6 +50,10 @@ xe_ht_filter_dump(struct xe_host *hs, const char *text, char *out, size_t outlen
 	if (!f.device_ok) {
 		rc = XE_EUNSUPPORTED;
 		if (err && errlen) snprintf(err, errlen, "%s", f.why);
+	} else if (f.needs_port_names) {
+		/* no handle, no port-name table */
+		rc = XE_EUNSUPPORTED;
+		if (err && errlen) snprintf(err, errlen, "portstr() / ppstr() without a port-name table");
 	}
 	xe_filter_free(&f);
 	return rc;

@@ -147,7 +147,11 @@ struct xe_sfrec
 /* flat filter programs */
 enum { XE_OP_BASIC = 0, XE_OP_NOT = 1, XE_OP_AND = 2, XE_OP_OR = 3 };
 enum { XE_BT_ADDR4 = 0, XE_BT_ADDR6 = 1, XE_BT_RANGE = 2, XE_BT_MAC = 3, XE_BT_STRING = 4 };
-enum { XE_FN_NONE = 0, XE_FN_DIV = 1, XE_FN_DIV_R = 2, XE_FN_DIV_L = 3, XE_FN_MIN = 4, XE_FN_TFSTR = 5 };
+enum { XE_FN_NONE = 0, XE_FN_DIV = 1, XE_FN_DIV_R = 2, XE_FN_DIV_L = 3, XE_FN_MIN = 4, XE_FN_TFSTR = 5,
+	/* portstr / ppstr are lowered to sets over the port values when the handle
+	 * has a port-name table; the rest is parsed (for the dump and so that the
+	 * object keeps its place) and left to the caller's own filter_match() */
+	XE_FN_PORTSTR = 6, XE_FN_PPSTR = 7, XE_FN_MFREQ = 8, XE_FN_GEO = 9, XE_FN_ASN = 10, XE_FN_ASD = 11 };
 enum { XE_DIR_NONE = 0, XE_DIR_SRC = 1, XE_DIR_DST = 2, XE_DIR_BOTH = 3 };
 
 struct xe_term
@@ -385,9 +389,12 @@ struct xe_filter     /* one compiled expression, host form */
 	uint32_t *ops;  size_t nops;      /* op | term_index << 2 */
 	struct xe_term *terms; size_t nterms;
 	struct xe_opnd *opnds; size_t nopnds;
-	/* host-only operand annotations for the dump: mask length / list index */
+	/* host-only operand annotations for the dump: mask length / list index /
+	 * offset of a quoted string's text in strs (-1: the operand has no text) */
 	int32_t *opnd_note;
+	char *strs; size_t nstrs;         /* texts of the quoted-string operands, NUL-terminated */
 	int device_ok;                    /* 0: uses something the device cannot evaluate */
+	int needs_port_names;             /* has portstr() / ppstr() terms: evaluable with a port-name table only */
 	char why[128];
 };
 int xe_filter_compile(const struct xe_iplists *reg, const char *text, struct xe_filter *out,
@@ -400,6 +407,10 @@ int xe_field_parse(const char *text, struct xe_agfield *out, char *err, size_t e
 /* static analysis of the stack discipline (filter.c:960-1012): returns 1 and
  * sets *cval when the result does not depend on the record */
 int xe_filter_constant(const struct xe_filter *f, int *cval);
+/* div_l(): the int32 quotient line cut into pieces [lo, hi] on which
+ * (int)pow(k, (int)(log(q) / log(k))) (filter.h:407-409) has one value, found
+ * with this host's libm; returns the number of pieces (<= cap) or -1 */
+int xe_div_l_pieces(int k, int32_t *lo, int32_t *hi, int32_t *val, int cap);
 
 /* devices.conf entries */
 struct xe_device
@@ -414,6 +425,11 @@ struct xe_mo
 {
 	char name[256];
 	int parent;
+	/* the filter uses something only the caller's own filter_match() evaluates
+	 * (strings, mfreq, geo / AS functions ...): on the device the object matches
+	 * whenever its parent does, the caller decides the rest */
+	int host_only;
+	char why[128];
 	struct xe_filter filter;
 };
 
@@ -476,6 +492,12 @@ struct xe_plan
 	 * sets and the column bytes a complete record of it fills */
 	struct xe_blob tinfo;      /* struct xe_tinfo */
 	struct xe_host *pool;      /* not NULL: sets / sfrecs go back to this host's buffer pool */
+	/* per datagram i of the batch (ndg + 1 entries each): how many Netflow
+	 * records / sFlow records the datagrams before it produced, i.e. datagram i
+	 * owns Netflow records [dg_first_nf[i], dg_first_nf[i + 1]) and sFlow records
+	 * [dg_first_sf[i], dg_first_sf[i + 1]) */
+	uint32_t *dg_first_nf, *dg_first_sf;
+	size_t ndg;
 };
 struct xe_tinfo { uint64_t mask[2]; uint32_t width; uint32_t known; };
 

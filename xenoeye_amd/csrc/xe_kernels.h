@@ -102,6 +102,7 @@ struct xe_kparams
 	const struct xe_probe *probes;
 	uint32_t nprobes, pad2;
 	uint32_t lds_counters;       /* per-block counter staging fits in LDS */
+	uint32_t port_named_off;     /* word offset in `trie` of the 65536-bit set of ports with a service name, 0 = none */
 };
 
 #define XE_MAX_FAST_TERMS 256

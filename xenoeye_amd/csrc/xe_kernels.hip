@@ -277,6 +277,31 @@ tfstr_byte(uint64_t hi, uint64_t lo, uint32_t fmax)
 	return (uint32_t)(lo >> ((fmax - 1) * 8)) & 0xFF;
 }
 
+/* portstr() / ppstr() (filter.c:861-904) on the port values.  portstr: every
+ * operand is the set of ports whose text (port_to_str) equals the operand's,
+ * 65536 bits at word `low` of the list tables.  ppstr: every operand is a
+ * condition on the pair (see ppstr_lower() on the host): kind 1 both ports
+ * given, kind 2 port1 given and port2 any larger port without a service name,
+ * kind 3 the mirror image. */
+__device__ __forceinline__ bool
+port_text_match(const xe_kparams &kp, uint32_t func, const xe_dopnd *o, uint32_t n, uint32_t p1, uint32_t p2)
+{
+	bool res = false;
+	if (func == XE_FN_PORTSTR) {
+		for (uint32_t i = 0; i < n; i++) res |= ((kp.trie[(uint32_t)o[i].low + (p1 >> 5)] >> (p1 & 31)) & 1) != 0;
+		return res;
+	}
+	const uint32_t *named = kp.trie + kp.port_named_off;
+	const bool n1 = ((named[p1 >> 5] >> (p1 & 31)) & 1) != 0, n2 = ((named[p2 >> 5] >> (p2 & 31)) & 1) != 0;
+	for (uint32_t i = 0; i < n; i++) {
+		const uint32_t kind = o[i].list, X = (uint32_t)o[i].low, Y = (uint32_t)o[i].high;
+		res |= (kind == 1) && (p1 == X) && (p2 == Y);
+		res |= (kind == 2) && (p1 == X) && (p2 > p1) && !n2;
+		res |= (kind == 3) && (p2 == Y) && (p1 > p2) && !n1;
+	}
+	return res;
+}
+
 template <typename REC, fval (*GET)(const REC &, uint32_t, uint32_t *)>
 __device__ __forceinline__ bool
 term_match(const xe_kparams &kp, const REC &rec, const xe_term &t, walk_cache &wc)
@@ -293,6 +318,11 @@ term_match(const xe_kparams &kp, const REC &rec, const xe_term &t, walk_cache &w
 		}
 		return res;
 	}
+	if ((t.func == XE_FN_PORTSTR) || (t.func == XE_FN_PPSTR)) {
+		const uint32_t p1 = (uint32_t)nf_val(GET(rec, t.fa, nullptr), c_fmax[t.fa]) & 0xFFFF;
+		const uint32_t p2 = (t.func == XE_FN_PPSTR) ? ((uint32_t)nf_val(GET(rec, t.fb, nullptr), c_fmax[t.fb]) & 0xFFFF) : 0;
+		return port_text_match(kp, t.func, o, t.nopnd, p1, p2);
+	}
 	if (t.func != XE_FN_NONE) {
 		uint64_t a = nf_val(GET(rec, t.fa, nullptr), c_fmax[t.fa]);
 		uint64_t b = nf_val(GET(rec, t.fb, nullptr), c_fmax[t.fb]);
@@ -300,11 +330,15 @@ term_match(const xe_kparams &kp, const REC &rec, const xe_term &t, walk_cache &w
 			/* filter.c:685-709 */
 			return in_ranges(o, t.nopnd, (int64_t)((a < b) ? a : b));
 		}
-		/* xdiv(), filter.h:396-418: the quotient is truncated to int first */
+		/* xdiv(), filter.h:396-418: the quotient is truncated to int first.
+		 * div_l: the operands are ranges of the quotient (the logarithm was
+		 * applied to their bounds at commit), k = the answer for a zero divisor */
 		int32_t q = 0;
 		if (b != 0) {
 			q = (int32_t)(a / b);
 			if ((t.func == XE_FN_DIV_R) && (t.k > 1)) q = (q / t.k) * t.k;
+		} else if (t.func == XE_FN_DIV_L) {
+			return t.k != 0;
 		}
 		return in_ranges(o, t.nopnd, q);
 	}
@@ -775,13 +809,17 @@ fast_term(const xe_kparams &kp, const TT &T, const term_s &t, uint32_t r, const 
 	if (t.func != XE_FN_NONE) {
 		tile_get(T, t.fa, r, has, fmax, hi, lo);
 		uint64_t a = ((fmax == 1) || (fmax == 2) || (fmax == 4) || (fmax == 8)) ? lo : 0;
+		if (t.func == XE_FN_PORTSTR) return port_text_match(kp, t.func, o, t.nopnd, (uint32_t)a & 0xFFFF, 0);
 		tile_get(T, t.fb, r, has, fmax, hi, lo);
 		uint64_t b = ((fmax == 1) || (fmax == 2) || (fmax == 4) || (fmax == 8)) ? lo : 0;
+		if (t.func == XE_FN_PPSTR) return port_text_match(kp, t.func, o, t.nopnd, (uint32_t)a & 0xFFFF, (uint32_t)b & 0xFFFF);
 		if (t.func == XE_FN_MIN) return in_ranges_u(o, t.nopnd, (int64_t)((a < b) ? a : b));
 		int32_t q = 0;
 		if (b != 0) {
 			q = (int32_t)(a / b);
 			if ((t.func == XE_FN_DIV_R) && (t.k > 1)) q = (q / t.k) * t.k;
+		} else if (t.func == XE_FN_DIV_L) {
+			return t.k != 0;
 		}
 		return in_ranges_u(o, t.nopnd, q);
 	}

@@ -202,6 +202,7 @@ xe_plan_free(struct xe_plan *p)
 	free(p->exporters.p);
 	free(p->ehash);
 	free(p->tinfo.p);
+	free(p->dg_first_nf);
 	memset(p, 0, sizeof(*p));
 }
 
@@ -1066,10 +1067,14 @@ pp_merge(struct pp_shared *sh, struct xe_plan *out)
 		struct pp_ent *e;
 		t = sh->own[i];
 		e = (struct pp_ent *)sh->th[t].ents.p + cur[t]++;
+		out->dg_first_nf[i] = (uint32_t)nr;
+		out->dg_first_sf[i] = (uint32_t)nf;
 		e->base_sets = ns; ns += e->nsets;
 		e->base_rec = nr;  nr += e->nrec;
 		e->base_sf = nf;   nf += e->nsf;
 	}
+	out->dg_first_nf[sh->n] = (uint32_t)nr;
+	out->dg_first_sf[sh->n] = (uint32_t)nf;
 	if (nr > 0xFFFFFFF0u) return XE_EUNSUPPORTED;
 	for (t = 0; t < sh->T; t++) ne += sh->th[t].plan.exporters.n;
 	ef = malloc((ne ? ne : 1) * sizeof(*ef));
@@ -1335,6 +1340,11 @@ xe_prepass(struct xe_host *hs, const uint8_t *data, const uint64_t *offs, const 
 	int T = hs->prepass_threads;
 
 	memset(plan, 0, sizeof(*plan));
+	/* both per-datagram arrays in one allocation */
+	plan->dg_first_nf = malloc(2 * (n + 1) * sizeof(uint32_t));
+	if (!plan->dg_first_nf) return XE_ENOMEM;
+	plan->dg_first_sf = plan->dg_first_nf + (n + 1);
+	plan->ndg = n;
 	if (T <= 0) {
 		const char *e = getenv("XE_PREPASS_THREADS");
 		T = e ? atoi(e) : 8;
@@ -1345,7 +1355,11 @@ xe_prepass(struct xe_host *hs, const uint8_t *data, const uint64_t *offs, const 
 	{
 		const char *e = getenv("XE_PREPASS_MIN_DATAGRAMS");
 		const size_t least = e ? (size_t)atol(e) : 4096;
-		if ((T > 1) && (n >= least)) return prepass_threads(hs, data, offs, src, kinds, n, plan, T);
+		if ((T > 1) && (n >= least)) {
+			int rc = prepass_threads(hs, data, offs, src, kinds, n, plan, T);
+			if (rc != XE_OK) xe_plan_free(plan);   /* also after an early return */
+			return rc;
+		}
 	}
 	for (i = 0; i < n; i++) {
 		int rc;
@@ -1353,11 +1367,15 @@ xe_prepass(struct xe_host *hs, const uint8_t *data, const uint64_t *offs, const 
 		/* only headers are read, one cache line per datagram, far apart: ask
 		 * for the lines of the datagrams to come */
 		if (i + 16 < n) __builtin_prefetch(data + offs[i + 16]);
+		plan->dg_first_nf[i] = (uint32_t)plan->nrec;
+		plan->dg_first_sf[i] = (uint32_t)plan->nsf;
 		rc = walk_one(hs, plan, data, offs, src, kinds, i);
 		if (rc != XE_OK) {
 			xe_plan_free(plan);
 			return rc;
 		}
 	}
+	plan->dg_first_nf[n] = (uint32_t)plan->nrec;
+	plan->dg_first_sf[n] = (uint32_t)plan->nsf;
 	return XE_OK;
 }
