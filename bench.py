@@ -3,17 +3,25 @@
 
 One step = one pass of the HIP path (counter reset + decode/classify kernels)
 over one batch of synthetic export packets that already sits in HBM.  The
-workload is IPFIX from 64 exporters, 70 % IPv4
-records (46 B) / 30 % IPv6 records (62 B), 16 monitoring objects over 8 IP
-lists of 10 000 IPv4 + 10 000 IPv6 prefixes each.  With --gpus N every rank
-gets its own exporters (weak scaling, no data-path collective); rank 0 prints
-one JSON line.
+headline workload (C2) is IPFIX from 64 exporters, 70 % IPv4 records (46 B) /
+30 % IPv6 records (62 B), 16 monitoring objects over 8 IP lists of 10 000 IPv4
++ 10 000 IPv6 prefixes each.  With --gpus N every rank gets its own exporters
+(weak scaling, no data-path collective); rank 0 prints one JSON line.
 
 Besides the throughput the line carries
   roofline      algorithmic bytes per launch / mean kernel time (HIP events on
-                the launch stream) against the 8 TB/s HBM peak;
+                the launch stream) against the 8 TB/s HBM peak, the copy
+                bandwidth measured in this run as a second denominator, and
+                for the list-heavy workloads the measured random-gather rate;
+  workloads     the same measurement for the other configurations (C1, C3,
+                C4 at 8 x 1 M prefixes, C5) from the same run;
   cpu_baseline  the CPU oracle (a scalar restatement of the reference's
-                algorithm) on a bounded sample of the same workload.
+                algorithm) on a bounded sample of the same workload, one
+                thread; cpu_baseline_nproc: one process per host core, each
+                with its own exporters (the reference's thread-per-capture
+                model);
+  sustained     the headline step repeated for a few seconds (the K timed
+                steps last milliseconds).
 """
 import argparse
 import json
@@ -26,19 +34,25 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0
+KERNELS = ["xe_nf_fast_kernel", "xe_nf_general_kernel", "xe_sf_kernel"]
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--records", type=int, default=1 << 22, help="records per GPU per step")
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
     ap.add_argument("--c4-prefixes", type=int, default=1000000, help="prefixes per list of the c4 workload")
     ap.add_argument("--c4-lists", type=int, default=8, help="distinct lists of the c4 workload (objects = 256)")
-    ap.add_argument("--cpu-sample", type=int, default=12000000, help="records timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=8000000, help="records timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-procs", type=int, default=-1,
+                    help="processes of the all-cores CPU baseline (-1: the box's CPU share, 0 = skip)")
     ap.add_argument("--replicate", type=int, default=1, help="repeat the generated datagrams this many times")
+    ap.add_argument("--others", type=int, default=1, help="also measure the other configurations (0 = skip)")
+    ap.add_argument("--other-steps", type=int, default=100)
+    ap.add_argument("--sustain-seconds", type=float, default=3.0, help="repeat the headline step this long (0 = skip)")
     ap.add_argument("--pipeline", type=int, default=4,
                     help="capture threads (one handle each) of the sustained host-inclusive measurement, 0/1 = skip")
     ap.add_argument("--pipeline-rounds", type=int, default=6)
@@ -75,9 +89,31 @@ def build_workload(name, nrec, rank, c4_prefixes=1000000, world=1, c4_lists=8):
     return w, "C2 ipfix 64 exporters 70% v4(46B)/30% v6(62B) 16 objects x 10k+10k-prefix lists"
 
 
-def cpu_baseline(w, sample):
+def replicate(batch, times):
+    if times <= 1:
+        return
+    n0 = len(batch.pkts)
+    for _ in range(times - 1):
+        batch.pkts.extend(batch.pkts[:n0])
+        batch.src.extend(batch.src[:n0])
+        batch.kind.extend(batch.kind[:n0])
+
+
+def make_engine(w, device):
+    import xenoeye_amd
+    eng = xenoeye_amd.Engine(device=device)
+    for name, text in w["iplists"].items():
+        eng.add_iplist(name, text)
+    for filt, parent in w["mos"]:
+        eng.add_mo("mo", filt, parent)
+    eng.commit()
+    return eng
+
+
+def oracle_pass(w, sample, part=None):
     """Time the oracle on about `sample` records: whole passes over the batch's
-    datagrams (templates stay learnt between passes, as on a live collector)."""
+    datagrams (templates stay learnt between passes, as on a live collector).
+    part = (index, of): only the datagrams of the exporters of that share."""
     from oracle_binding import Oracle
     orc = Oracle()
     for name, text in w["iplists"].items():
@@ -87,7 +123,15 @@ def cpu_baseline(w, sample):
     orc.log_config(keep_flows=False)
     pkts, srcs = w["batch"].pkts, [int.from_bytes(s, "little") for s in w["batch"].src]
     kinds = w["batch"].kind
-    per_dgram = max(1.0, w["nrec"] / max(1, len(pkts)))
+    if part is not None:
+        from xenoeye_amd import shard
+        import numpy as np
+        own = shard.exporter_rank(np.array(srcs, dtype=np.uint64), part[1])
+        keep = [i for i in range(len(pkts)) if own[i] == part[0]]
+        pkts, srcs, kinds = [pkts[i] for i in keep], [srcs[i] for i in keep], [kinds[i] for i in keep]
+    if not pkts:
+        return 0.0, 0, 0, 0.0
+    per_dgram = max(1.0, w["nrec"] / max(1, len(w["batch"].pkts)))
     todo = int(sample / per_dgram) + 1
     L = orc.L
     nd = 0
@@ -108,6 +152,60 @@ def cpu_baseline(w, sample):
     return nrec / dt, nrec, nd, dt
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def host_cores():
+    """the CPU share of this job: the box exports it through the thread-count variables"""
+    for v in ("OMP_NUM_THREADS", "MAX_JOBS"):
+        try:
+            n = int(os.environ.get(v, ""))
+            if n > 0:
+                return min(n, os.cpu_count() or n)
+        except ValueError:
+            pass
+    return min(16, os.cpu_count() or 1)
+
+
+def cpu_baseline_nproc(w, sample, procs):
+    """one process per core, each with the datagrams of its own exporters (the
+    reference scales by pinning exporters to capture threads): records of all
+    processes / wall time from the common start to the last finish.  Must run
+    before this process touches the GPU (the workers are forked)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("fork")
+    barrier = ctx.Barrier(procs)
+    q = ctx.Queue()
+
+    def run(i):
+        try:
+            barrier.wait(timeout=120)
+            t0 = time.time()
+            _, nrec, _, _ = oracle_pass(w, sample // procs, (i, procs))
+            q.put((nrec, t0, time.time()))
+        except Exception:
+            q.put((0, time.time(), time.time()))
+
+    ps = [ctx.Process(target=run, args=(i,)) for i in range(procs)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=600) for _ in ps]
+    for p in ps:
+        p.join()
+    nrec = sum(r[0] for r in res)
+    wall = max(r[2] for r in res) - min(r[1] for r in res)
+    busy = sum(1 for r in res if r[0])
+    return nrec / wall if wall > 0 else 0.0, nrec, wall, busy
+
+
 def measured_traffic(workload, nrec):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3
     --pmc passes (profiles/traffic.json), when they were taken at this size"""
@@ -121,6 +219,132 @@ def measured_traffic(workload, nrec):
     return None
 
 
+def copy_bandwidth(torch, device, nbytes=1 << 30, reps=10):
+    """device-to-device copy of 1 GiB, read + write bytes per second: what the
+    memory system of this box delivers to a plain streaming kernel"""
+    a = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    b = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    a.zero_()
+    for _ in range(2):
+        b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del a, b
+    return 2.0 * nbytes / (ms * 1e-3) / 1e9
+
+
+def gather_rate(torch, device, table_bytes, n=1 << 24, reps=5):
+    """independent random 4-byte gathers per second from a table as large as the
+    workload's list tables: the ceiling of one table visit per record, if no
+    visit had to wait for the one before"""
+    words = max(1024, int(table_bytes) // 4)
+    table = torch.arange(words, dtype=torch.int32, device=device)
+    idx = torch.randint(0, words, (n,), dtype=torch.int64, device=device)
+    out = torch.empty(n, dtype=torch.int32, device=device)
+    for _ in range(2):
+        torch.index_select(table, 0, idx, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        torch.index_select(table, 0, idx, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del table, idx, out
+    return n / (ms * 1e-3)
+
+
+def time_steps(torch, batch, stream, steps, warmup, barrier=None):
+    """(seconds of exactly `steps` steps between two synchronisations, mean step ms by events,
+    mean ms of each kernel)"""
+    import numpy as np
+    for _ in range(warmup):
+        batch.run(stream)
+    (barrier or torch.cuda.synchronize)()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(steps, 64))]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if i < len(evs):
+            evs[i][0].record()
+        batch.run(stream)
+        if i < len(evs):
+            evs[i][1].record()
+    (barrier or torch.cuda.synchronize)()
+    dt = time.perf_counter() - t0
+    step_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    # the kernels alone: separate launches outside the timed region, events of the library on the launch stream
+    kms = []
+    for _ in range(min(steps, 20)):
+        batch.run(stream)
+        kms.append(batch.kernel_ms())
+    kms = np.array(kms, dtype=np.float64).mean(axis=0)
+    return dt, step_ms, kms
+
+
+def roofline_of(batch, kms, workload, nrec, traffic=None):
+    import numpy as np
+    kidx = int(np.argmax(kms))
+    kernel_ms = float(kms[kidx])
+    alg = batch.algorithmic_bytes
+    achieved = alg / (kernel_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": traffic if traffic is not None else measured_traffic(workload, nrec),
+            "kernel": KERNELS[kidx], "kernel_ms": kernel_ms,
+            "algorithmic_bytes_per_launch": alg, "algorithmic_bytes_per_record": alg / max(nrec, 1)}
+
+
+def measure_other(torch, name, args, device, stream):
+    """one of the other configurations, device-resident, same method as the headline"""
+    t0 = time.perf_counter()
+    # the sFlow generator builds every sampled header one by one: a smaller set of
+    # distinct datagrams, repeated (every copy is decoded and classified like the first)
+    nrec = {"c1": 1 << 22, "c3": 200000, "c4": 1 << 21, "c5": 1 << 22}[name]
+    rep = {"c3": 16}.get(name, 1)
+    w, wl_name = build_workload(name, nrec, 0, args.c4_prefixes, 1, args.c4_lists)
+    replicate(w["batch"], rep)
+    eng = make_engine(w, device)
+    packed = w["batch"].packed()
+    batch = eng.prepare(packed)
+    batch.timing(True)
+    dt, step_ms, kms = time_steps(torch, batch, stream, args.other_steps, 3)
+    n = batch.records
+    out = {"workload": wl_name, "records_per_step": n, "steps": args.other_steps,
+           "ms_per_step": dt / args.other_steps * 1e3, "records_per_s": n * args.other_steps / dt,
+           "payload_GBps": batch.payload_bytes * args.other_steps / dt / 1e9,
+           "roofline": roofline_of(batch, kms, name, n)}
+    if name == "c4":
+        out["list_table_bytes"] = tb = list_table_bytes(w)
+        out["random_gathers_per_s"] = gather_rate(torch, device, tb)
+    if rep > 1:
+        out["distinct_records"] = n // rep
+    batch.free()
+    eng.close()
+    out["setup_s"] = time.perf_counter() - t0 - dt
+    return out
+
+
+def list_table_bytes(w):
+    """size of the flattened list tables of a workload (the host-side flattening alone, no device)"""
+    try:
+        from host_binding import Host
+        h = Host()
+        for name, text in w["iplists"].items():
+            h.add_iplist(name, text)
+        words, _ = h.flatten()
+        h.close()
+        return int(len(words)) * 4
+    except Exception:
+        return 0
+
+
 def main():
     args = parse_args()
     import numpy as np
@@ -130,6 +354,28 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    t_start = time.perf_counter()
+    w, wl_name = build_workload(args.workload, args.records, rank, args.c4_prefixes, world, args.c4_lists)
+
+    # the CPU legs come first: the all-cores one forks its workers, which a process may only do
+    # while it has not touched the GPU.  Rank 0 of a one-GPU run only.
+    cpu = {}
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        rps, n_cpu, nd, secs = oracle_pass(w, args.cpu_sample)
+        cpu["cpu_baseline"] = {"value": rps, "unit": "records/s", "cores": 1, "kind": "port", "cpu": cpu_model(),
+                               "sample": "%d datagrams (%d records) of the same batch, %.1f s, "
+                                         "oracle/xe_oracle.c single thread" % (nd, n_cpu, secs)}
+        procs = host_cores() if args.cpu_procs < 0 else args.cpu_procs
+        if procs > 1:
+            try:
+                rps_n, n_all, wall, busy = cpu_baseline_nproc(w, args.cpu_sample * min(procs, 4), procs)
+                cpu["cpu_baseline_nproc"] = {
+                    "value": rps_n, "unit": "records/s", "cores": procs, "kind": "port", "cpu": cpu_model(),
+                    "sample": "%d records in %.1f s wall: %d processes, the exporters dealt to them by address "
+                              "hash (%d had exporters), each its own oracle" % (n_all, wall, procs, busy)}
+            except Exception as ex:
+                cpu["cpu_baseline_nproc"] = {"error": repr(ex)}
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the flow path has no CPU fallback")
     if args.share_gpu:
@@ -142,21 +388,8 @@ def main():
             dist.init_process_group(backend="gloo")
 
     import xenoeye_amd
-    w, wl_name = build_workload(args.workload, args.records, rank, args.c4_prefixes, world, args.c4_lists)
-    eng = xenoeye_amd.Engine(device=local_rank)
-    for name, text in w["iplists"].items():
-        eng.add_iplist(name, text)
-    for filt, parent in w["mos"]:
-        eng.add_mo("mo", filt, parent)
-    eng.commit()
-
-    if args.replicate > 1:
-        b0 = w["batch"]
-        n0 = len(b0.pkts)
-        for _ in range(args.replicate - 1):
-            b0.pkts.extend(b0.pkts[:n0])
-            b0.src.extend(b0.src[:n0])
-            b0.kind.extend(b0.kind[:n0])
+    eng = make_engine(w, local_rank)
+    replicate(w["batch"], args.replicate)
     packed = w["batch"].packed()
     t_prep0 = time.perf_counter()
     batch = eng.prepare(packed)
@@ -170,27 +403,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        batch.run(stream)
-    barrier()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for a, b in evs:
-        a.record()
-        batch.run(stream)
-        b.record()
-    barrier()
-    dt = time.perf_counter() - t0
-    step_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-    # the dominant kernel alone: separate untimed-for-throughput launches, one sync each
-    kms = []
-    for _ in range(min(args.steps, 10)):
-        batch.run(stream)
-        kms.append(batch.kernel_ms())
-    kms = np.array(kms, dtype=np.float64).mean(axis=0)
-    kidx = int(np.argmax(kms))
-    kernel_ms = float(kms[kidx])
-    kernel_name = ["xe_nf_fast_kernel", "xe_nf_general_kernel", "xe_sf_kernel"][kidx]
+    dt, step_ms, kms = time_steps(torch, batch, stream, args.steps, args.warmup, barrier)
+
+    # the headline step repeated for seconds: the K timed steps above last milliseconds, which no
+    # activity sampler sees; same batch, same launches
+    sustained = None
+    if args.sustain_seconds > 0 and world == 1:
+        per = max(dt / args.steps, 1e-5)
+        n_s = max(args.steps, int(args.sustain_seconds / per))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(n_s):
+            batch.run(stream)
+            if (i & 1023) == 1023:
+                torch.cuda.synchronize()      # bounded queue depth
+        torch.cuda.synchronize()
+        ds = time.perf_counter() - t1
+        sustained = {"steps": n_s, "seconds": ds, "records_per_s": nrec * n_s / ds, "ms_per_step": ds / n_s * 1e3}
 
     # end-to-end including host pre-pass + H2D + D2H of masks and counters (one pass, reported only)
     t1 = time.perf_counter()
@@ -324,8 +553,24 @@ def main():
     value = tot * args.steps / dt_all
 
     if rank == 0:
-        alg = batch.algorithmic_bytes
-        achieved = alg / (kernel_ms * 1e-3) / 1e9
+        roof = roofline_of(batch, kms, args.workload, nrec, args.traffic)
+        roof["step_ms_events"] = step_ms
+        # second denominator: what a plain device copy reaches on this box, measured now
+        try:
+            roof["peak_measured"] = copy_bandwidth(torch, torch.device("cuda", local_rank))
+            roof["frac_of_peak_measured"] = roof["achieved"] / roof["peak_measured"]
+        except Exception as ex:
+            roof["peak_measured"] = None
+            roof["peak_measured_error"] = repr(ex)
+        if args.workload in ("c2", "c4", "c5"):
+            try:
+                tb = list_table_bytes(w)
+                g = gather_rate(torch, torch.device("cuda", local_rank), tb)
+                roof["list_tables"] = {"bytes": tb, "random_gathers_per_s": g,
+                                       "note": "independent 4-byte gathers from a table of that size; the kernel's "
+                                               "list walks are chains of 2-4 dependent gathers per address"}
+            except Exception as ex:
+                roof["list_tables"] = {"error": repr(ex)}
         out = {
             "metric": "device-resident flow records/sec decoded+classified",
             "value": value,
@@ -346,11 +591,8 @@ def main():
             "merged_counters_object0": [int(x) for x in ctr[0]] if len(ctr) else [],
             "merged_records_per_object": [int(x) for x in ctr[:, 0]] if len(ctr) else [],
             "records_all_steps": int(tot) * args.steps,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": args.traffic if args.traffic is not None else measured_traffic(args.workload, nrec),
-                         "kernel": kernel_name, "kernel_ms": kernel_ms, "step_ms_events": step_ms,
-                         "algorithmic_bytes_per_launch": alg,
-                         "algorithmic_bytes_per_record": alg / max(nrec, 1)},
+            "roofline": roof,
+            "sustained": sustained,
             "host_inclusive": {"prepare_s": t_prep, "prepare_run_fetch_s": t_e2e,
                                "records_per_s": nrec / t_e2e,
                                "page_locked_input_s": t_e2e_pinned,
@@ -358,11 +600,20 @@ def main():
                                "pipelined": piped},
             "fixed_window": fixed_window,
         }
-        if args.cpu_sample > 0:
-            rps, n_cpu, nd, secs = cpu_baseline(w, args.cpu_sample)
-            out["cpu_baseline"] = {"value": rps, "unit": "records/s", "cores": 1, "kind": "port",
-                                   "sample": "%d datagrams (%d records) of the same batch, %.1f s, "
-                                             "oracle/xe_oracle.c single thread" % (nd, n_cpu, secs)}
+        batch.free()
+        eng.close()
+        if args.others and world == 1:
+            others = {}
+            for name in ("c1", "c2", "c3", "c4", "c5"):
+                if name == args.workload:
+                    continue
+                try:
+                    others[name] = measure_other(torch, name, args, local_rank, stream)
+                except Exception as ex:
+                    others[name] = {"error": repr(ex)}
+            out["workloads"] = others
+        out.update(cpu)
+        out["bench_wall_s"] = time.perf_counter() - t_start
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -214,6 +214,13 @@ int xe_gpu_batch_fwm_ms(xe_batch *b, float *ms);   /* the fixed-window kernel, -
  * record; the reference has no such limit): 0 in any sane stream */
 size_t xe_gpu_batch_unsupported_sets(const xe_batch *b);
 
+/* datagrams left out as a whole because they stand for more than 2^20 records:
+ * a Netflow v9 data set is iterated header.count times whatever it holds
+ * (netflow.c:272), so a datagram of empty sets for a known template id can
+ * claim tens of millions of empty records.  The reference would walk them
+ * all; no well-formed datagram comes near the bound.  0 in any sane stream. */
+size_t xe_gpu_batch_oversized_datagrams(const xe_batch *b);
+
 /* sizes */
 size_t xe_gpu_batch_records(const xe_batch *b);      /* records reaching classification */
 size_t xe_gpu_batch_mask_words(const xe_batch *b);   /* 64-bit words per record */

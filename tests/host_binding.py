@@ -63,7 +63,11 @@ class Host:
         L.xe_ht_field_parse.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
         L.xe_ht_set_prepass_threads.argtypes = [C.c_void_p, C.c_int]
         L.xe_ht_set_prepass_threads.restype = None
-        for f in ("nrec", "nsf", "nsets", "nexporters", "skipped"):
+        for f in ("dg_first_nf", "dg_first_sf"):
+            fn = getattr(L, "xe_ht_plan_" + f)
+            fn.argtypes = [C.c_void_p]
+            fn.restype = C.POINTER(C.c_uint32)
+        for f in ("nrec", "nsf", "nsets", "nexporters", "skipped", "oversized", "ndatagrams"):
             fn = getattr(L, "xe_ht_plan_" + f)
             fn.argtypes = [C.c_void_p]
             fn.restype = C.c_size_t
@@ -122,7 +126,11 @@ class Host:
         L = self.L
         ns = L.xe_ht_plan_nsets(p)
         sets = [L.xe_ht_plan_sets(p)[i] for i in range(ns)]
+        nd = L.xe_ht_plan_ndatagrams(p)
         out = dict(nrec=L.xe_ht_plan_nrec(p), nsf=L.xe_ht_plan_nsf(p), skipped=L.xe_ht_plan_skipped(p),
+                   oversized=L.xe_ht_plan_oversized(p),
+                   dg_first_nf=[L.xe_ht_plan_dg_first_nf(p)[i] for i in range(nd + 1)],
+                   dg_first_sf=[L.xe_ht_plan_dg_first_sf(p)[i] for i in range(nd + 1)],
                    sets=[dict(first_rec=s.first_rec, nrec=s.nrec, avail=s.avail, stride=s.stride, tmpl=s.tmpl,
                               flags=s.flags, data_off=s.data_off, exporter=s.exporter, dgram_left=s.dgram_left)
                          for s in sets],

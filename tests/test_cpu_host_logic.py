@@ -512,3 +512,38 @@ def test_devices_conf_reader(tmp_path, host):
     if os.path.exists("/root/reference/devices.conf"):
         rc, rows = host.list_devices("/root/reference/devices.conf")
         assert rc == 0 and len(rows) == 2 and rows[1][4] == "1000"
+
+
+def test_empty_sets_cannot_blow_a_batch_up(host, orc):
+    """count = 65535 and a datagram full of empty data sets of a known template: every 4 bytes stand
+    for 65535 empty records (netflow.c:272).  Such a datagram is left out and counted; its neighbours
+    are walked as ever, and the batch does not fail."""
+    b = synth.Batch()
+    b.add(synth.v9_template_packet(256, synth.TMPL_V9_C1, 77), EXP)
+    good = synth.workload_c1(128, per_packet=64)["batch"]
+    b.add(good.pkts[1], EXP)
+    hostile = synth.v9_header(65535, 77) + struct.pack(">HH", 256, 0) * 340
+    for _ in range(3):
+        b.add(hostile, EXP)
+    b.add(good.pkts[2], EXP)
+    # fewer empty sets stay under the bound and are walked like the reference walks them
+    mild = synth.v9_header(1000, 77) + struct.pack(">HH", 256, 0) * 10
+    b.add(mild, EXP)
+    for threads in (1, 4):
+        os.environ["XE_PREPASS_MIN_DATAGRAMS"] = "1"
+        try:
+            plan = host.prepass(b, threads=threads)
+        finally:
+            del os.environ["XE_PREPASS_MIN_DATAGRAMS"]
+        assert plan["oversized"] == 3 and plan["skipped"] >= 3
+        assert plan["nrec"] == 64 + 64 + 10 * 1000
+        # per datagram: the records it owns
+        first = plan["dg_first_nf"]
+        assert first == [0, 0, 64, 64, 64, 64, 128, 10128]
+        assert plan["dg_first_sf"] == [0] * 8
+    # the oracle walks the mild datagram the same way
+    orc.mo_add("", -1)
+    orc.log_config(keep_flows=False)
+    orc.netflow(b.pkts[0], EXP)
+    orc.netflow(mild, EXP)
+    assert orc.nrecords() == 10000

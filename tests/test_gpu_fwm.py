@@ -239,3 +239,37 @@ def test_export_order_and_others(eng, orc):
     # an empty table exports nothing
     eng.fwm_clear(ids[2])
     assert eng.fwm_export(ids[2], 3) == ([], (0,), False)
+
+
+def test_many_blocks_insert_the_same_new_keys(eng, orc):
+    """a few hundred distinct keys, every one of them met by every block of the table kernel at the
+    same moment in the first batch of a window, into the smallest table: each key must end up in
+    exactly one row (Engine.fwm_read refuses a table that holds a key twice), with the oracle's sums"""
+    rng = synth.Rng(0xF3)
+    n = 400000
+    fields = [(8, 4), (12, 4), (7, 2), (11, 2), (4, 1), (1, 8), (2, 8)]
+    recs = synth.flow_columns(rng, n, fields)
+    recs[:, 8:10] = synth._be(rng.below(n, 300), 2)           # 300 source ports
+    recs[:, 10:12] = synth._be(rng.below(n, 3) + 1, 2)        # 3 destination ports: 900 keys in the second table
+    recs[:, 12] = 6
+    b = synth.Batch()
+    exp = bytes([192, 0, 2, 1])
+    b.add(synth.v9_template_packet(256, fields, 77), exp)
+    b.extend(synth.v9_data_packets(256, recs, 48, 77), exp)
+    w = dict(batch=b, mos=[("", -1)])
+    ids = setup(eng, orc, w, [(0, ["src port", "octets", "packets"]), (0, ["src port", "dst port", "bits"]),
+                              (0, ["proto", "packets"])], max_keys=400)
+    out = eng.prepare(b)
+    for window in range(3):
+        out.run()
+        if window == 0:
+            run_oracle(orc, b, keep_flows=False)
+        got, dropped = eng.fwm_read(ids[0])
+        assert len(got) == 300 and dropped == 0
+        got1, dropped1 = eng.fwm_read(ids[1])
+        # 900 keys into a table made for 400 (1024 slots): all of them still fit
+        assert len(got1) == 900 and dropped1 == 0
+        assert got == orc.fwm_read(ids[0]) and got1 == orc.fwm_read(ids[1])
+        assert eng.fwm_read(ids[2])[0] == orc.fwm_read(ids[2])
+        for t in ids:
+            eng.fwm_clear(t)

@@ -60,6 +60,7 @@ def load_library(path=LIB_PATH):
         "xe_gpu_commit": (i32, [vp]),
         "xe_gpu_set_prepass_threads": (i32, [vp, i32]),
         "xe_gpu_batch_unsupported_sets": (C.c_size_t, [vp]),
+        "xe_gpu_batch_oversized_datagrams": (C.c_size_t, [vp]),
         "xe_gpu_add_fwm": (i32, [vp, i32, C.POINTER(C.c_char_p), i32, C.c_size_t]),
         "xe_gpu_fwm_info": (i32, [vp, i32, C.POINTER(C.c_size_t), C.POINTER(i32), C.POINTER(C.c_size_t)]),
         "xe_gpu_fwm_read": (C.c_long, [vp, i32, vp, vp, C.c_size_t, C.POINTER(C.c_uint64)]),
@@ -302,8 +303,10 @@ class Engine:
         dropped = C.c_uint64()
         n2 = self._chk(self.L.xe_gpu_fwm_read(self._h, fwm, keys.ctypes.data, vals.ctypes.data, n, C.byref(dropped)))
         assert n2 == n
-        return ({bytes(keys[i, :kb.value]): tuple(int(x) for x in vals[i, :nv.value]) for i in range(n)},
-                int(dropped.value))
+        rows = {bytes(keys[i, :kb.value]): tuple(int(x) for x in vals[i, :nv.value]) for i in range(n)}
+        if len(rows) != n:
+            raise XeError(-6, "fixed-window table %d holds %d rows for %d distinct keys" % (fwm, n, len(rows)))
+        return rows, int(dropped.value)
 
     def fwm_window(self, fwm):
         """("limit", "time") of the mo.conf entry"""
@@ -402,6 +405,7 @@ class PreparedBatch:
         self._b = handle
         self.records = self.L.xe_gpu_batch_records(handle)
         self.unsupported_sets = self.L.xe_gpu_batch_unsupported_sets(handle)
+        self.oversized_datagrams = self.L.xe_gpu_batch_oversized_datagrams(handle)
         self.mask_words = self.L.xe_gpu_batch_mask_words(handle)
         self.payload_bytes = self.L.xe_gpu_batch_payload_bytes(handle)
         self.algorithmic_bytes = self.L.xe_gpu_batch_algorithmic_bytes(handle)

@@ -1084,10 +1084,14 @@ xe_gpu_add_fwm(xe_gpu *h, int mo, const char *const *fields, int nfields, size_t
 			snprintf(h->err, sizeof(h->err), "field '%.100s': %s", fields[i], err);
 			return rc;
 		}
+		if (w.nfields >= (int)(sizeof(w.order) / sizeof(w.order[0]))) {
+			snprintf(h->err, sizeof(h->err), "more than %d fields in one table", (int)(sizeof(w.order) / sizeof(w.order[0])));
+			return XE_EUNSUPPORTED;
+		}
 		w.order[w.nfields].aggr = f.aggr;
 		w.order[w.nfields].descending = f.descending;
 		w.order[w.nfields].size = (uint16_t)(f.aggr ? 8 : f.size);
-		if (w.nfields + 1 < (int)(sizeof(w.order) / sizeof(w.order[0]))) w.nfields++;
+		w.nfields++;
 		if (f.aggr) {
 			if (w.dev.nval == XE_FWM_MAX_VALS) {
 				snprintf(h->err, sizeof(h->err), "more than %d aggregable fields", XE_FWM_MAX_VALS);
@@ -1125,16 +1129,23 @@ xe_gpu_add_fwm(xe_gpu *h, int mo, const char *const *fields, int nfields, size_t
 	HIPCHK(h, hipSetDevice(h->device));
 	/* state + key, rounded up to a whole number of 16 bytes */
 	w.dev.swords = (1 + w.dev.kwords + 1) & ~1u;
-	HIPCHK(h, hipMalloc((void **)&w.dev.slots, w.slots * w.dev.swords * 8));
-	HIPCHK(h, hipMalloc((void **)&w.dev.vals, w.slots * (w.dev.nval ? w.dev.nval : 1) * 8));
-	HIPCHK(h, hipMalloc((void **)&w.dev.dropped, 8));
-	HIPCHK(h, hipMemset(w.dev.slots, 0, w.slots * w.dev.swords * 8));
-	HIPCHK(h, hipMemset(w.dev.vals, 0, w.slots * (w.dev.nval ? w.dev.nval : 1) * 8));
-	HIPCHK(h, hipMemset(w.dev.dropped, 0, 8));
-
 	tmp = (struct fwm_host *)realloc(h->fwms, (h->nfwm + 1) * sizeof(*tmp));
 	if (!tmp) return XE_ENOMEM;
 	h->fwms = tmp;
+	{
+		hipError_t e = hipMalloc((void **)&w.dev.slots, w.slots * w.dev.swords * 8);
+		if (e == hipSuccess) e = hipMalloc((void **)&w.dev.vals, w.slots * (w.dev.nval ? w.dev.nval : 1) * 8);
+		if (e == hipSuccess) e = hipMalloc((void **)&w.dev.dropped, 8);
+		if (e == hipSuccess) e = hipMemset(w.dev.slots, 0, w.slots * w.dev.swords * 8);
+		if (e == hipSuccess) e = hipMemset(w.dev.vals, 0, w.slots * (w.dev.nval ? w.dev.nval : 1) * 8);
+		if (e == hipSuccess) e = hipMemset(w.dev.dropped, 0, 8);
+		if (e != hipSuccess) {
+			if (w.dev.slots) (void)hipFree(w.dev.slots);
+			if (w.dev.vals) (void)hipFree(w.dev.vals);
+			if (w.dev.dropped) (void)hipFree(w.dev.dropped);
+			return hip_fail(h, e, "device memory of a fixed-window table");
+		}
+	}
 	h->fwms[h->nfwm] = w;
 	h->committed = 0;
 	return (int)h->nfwm++;
@@ -1202,6 +1213,47 @@ xe_gpu_fwm_window(const xe_gpu *h, int fwm, int *limit, int *seconds)
  * big-endian u64, key fields as stored, `desc` fields bitwise inverted;
  * rows ascending by the bytes of that key. */
 struct fwm_sortrow { const uint8_t *sk; uint32_t row; };
+
+/* all rows of a table in freshly allocated arrays (the caller frees them):
+ * keys[row][keybytes], vals[row][nval]; returns the number of rows or a
+ * negative code */
+static long
+fwm_rows(xe_gpu *h, struct fwm_host *w, uint8_t **keys, uint64_t **vals)
+{
+	uint64_t *sl = NULL, *vl = NULL;
+	const size_t nv = w->dev.nval ? w->dev.nval : 1;
+	size_t n = 0, k = 0;
+	long rc = XE_ENOMEM;
+
+	*keys = NULL;
+	*vals = NULL;
+	HIPCHK(h, hipSetDevice(h->device));
+	HIPCHK(h, hipDeviceSynchronize());
+	sl = (uint64_t *)malloc(w->slots * w->dev.swords * 8);
+	vl = (uint64_t *)malloc(w->slots * nv * 8);
+	if (!sl || !vl) goto out;
+	if ((hipMemcpy(sl, w->dev.slots, w->slots * w->dev.swords * 8, hipMemcpyDeviceToHost) != hipSuccess)
+		|| (hipMemcpy(vl, w->dev.vals, w->slots * nv * 8, hipMemcpyDeviceToHost) != hipSuccess)) {
+		rc = hip_fail(h, hipGetLastError(), "hipMemcpy(fixed-window table)");
+		goto out;
+	}
+	for (size_t i = 0; i < w->slots; i++) if ((uint32_t)sl[i * w->dev.swords] == 2) n++;
+	*keys = (uint8_t *)malloc((n ? n : 1) * (size_t)(w->keybytes ? w->keybytes : 1));
+	*vals = (uint64_t *)malloc((n ? n : 1) * nv * 8);
+	if (!*keys || !*vals) goto out;
+	for (size_t i = 0; i < w->slots; i++) {
+		const uint64_t *S = sl + i * w->dev.swords;
+		if ((uint32_t)S[0] != 2) continue;
+		memcpy(*keys + k * w->keybytes, S + 1, w->keybytes);
+		memcpy(*vals + k * w->dev.nval, vl + i * nv, (size_t)w->dev.nval * 8);
+		k++;
+	}
+	rc = (long)n;
+out:
+	free(sl);
+	free(vl);
+	return rc;
+}
 static int
 fwm_sort_cmp(const void *a, const void *b, void *len)
 {
@@ -1222,20 +1274,15 @@ xe_gpu_fwm_export(xe_gpu *h, int fwm, int limit, uint8_t *keys, uint64_t *vals, 
 	if (!h || (fwm < 0) || ((size_t)fwm >= h->nfwm)) return XE_EINVAL;
 	w = &h->fwms[fwm];
 	if (limit < 0) limit = w->limit;
-	n = xe_gpu_fwm_read(h, fwm, NULL, NULL, 0, NULL);
-	if (n < 0) return n;
 	if (hit_limit) *hit_limit = 0;
 	for (uint32_t j = 0; others && (j < w->dev.nval); j++) others[j] = 0;
-	if (n == 0) return 0;
+	/* the table travels once: the rows are taken out of one copy of it */
+	n = fwm_rows(h, w, &rk, &rv);
+	if (n <= 0) { free(rk); free(rv); return n; }
 	for (int i = 0; i < w->nfields; i++) sklen += w->order[i].size;
-	rk = (uint8_t *)malloc((size_t)n * (w->keybytes ? w->keybytes : 1));
-	rv = (uint64_t *)malloc((size_t)n * (w->dev.nval ? w->dev.nval : 1) * 8);
 	sk = (uint8_t *)malloc((size_t)n * (sklen ? sklen : 1));
 	idx = (struct fwm_sortrow *)malloc((size_t)n * sizeof(*idx));
-	if (!rk || !rv || !sk || !idx) goto out;
-	rc = xe_gpu_fwm_read(h, fwm, rk, rv, (size_t)n, NULL);
-	if (rc < 0) goto out;
-	if (rc < n) n = rc;
+	if (!sk || !idx) goto out;
 	for (long r = 0; r < n; r++) {
 		uint8_t *d = sk + (size_t)r * sklen;
 		const uint8_t *kp = rk + (size_t)r * w->keybytes;
@@ -1301,6 +1348,12 @@ extern "C" size_t
 xe_gpu_batch_unsupported_sets(const xe_batch *b)
 {
 	return b ? b->plan.unsupported_sets : 0;
+}
+
+extern "C" size_t
+xe_gpu_batch_oversized_datagrams(const xe_batch *b)
+{
+	return b ? b->plan.oversized_datagrams : 0;
 }
 
 extern "C" void *
@@ -1862,15 +1915,23 @@ sync_templates(xe_gpu *h)
 	size_t nt = h->hs.dev_tmpls.n, ne = h->hs.dev_tents.n;
 	int rc;
 
-	if (h->d_tmpls && (nt == h->up_tmpls) && (ne == h->up_tents)) return XE_OK;
+	if (h->d_tmpls && h->d_tents && (nt == h->up_tmpls) && (ne == h->up_tents)) return XE_OK;
 	if (h->d_tmpls) (void)hipFree(h->d_tmpls);
 	if (h->d_tents) (void)hipFree(h->d_tents);
 	h->d_tmpls = h->d_tents = NULL;
 	rc = upload(h, &h->d_tmpls, h->hs.dev_tmpls.p, nt * sizeof(struct xe_tmpl));
 	if (rc == XE_OK) rc = upload(h, &h->d_tents, h->hs.dev_tents.p, ne * sizeof(struct xe_tent));
+	if (rc != XE_OK) {
+		/* nothing half-uploaded stays behind: the next batch starts over */
+		if (h->d_tmpls) (void)hipFree(h->d_tmpls);
+		if (h->d_tents) (void)hipFree(h->d_tents);
+		h->d_tmpls = h->d_tents = NULL;
+		h->up_tmpls = h->up_tents = 0;
+		return rc;
+	}
 	h->up_tmpls = nt;
 	h->up_tents = ne;
-	return rc;
+	return XE_OK;
 }
 
 extern "C" void
@@ -2183,7 +2244,8 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 	rc = xe_prepass(&h->hs, data, offsets, src_ip4, kinds, n, &b->plan);
 	XE_TICK();
 	if (rc != XE_OK) {
-		snprintf(h->err, sizeof(h->err), "pre-pass failed: %s", xe_gpu_strerror(rc));
+		snprintf(h->err, sizeof(h->err), "pre-pass failed: %s%s", xe_gpu_strerror(rc),
+			(rc == XE_EUNSUPPORTED) ? " (the batch would hold more than 2^32 records: prepare fewer datagrams at a time)" : "");
 		(void)hipStreamSynchronize(h->copy_stream);
 		dev_put(h, b->d_pkt);
 		free(b);
@@ -2259,9 +2321,12 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 		hipError_t e;
 		rc = dev_get(h, &b->d_out, b->out_bytes);
 		if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
-		/* records the kernels do not reach (none by construction) read as empty */
-		e = hipMemset(b->d_out, 0, b->out_bytes);
-		if (e != hipSuccess) { xe_gpu_batch_free(b); return hip_fail(h, e, "hipMemset(outputs)"); }
+		/* records the kernels do not reach (none by construction) read as empty.
+		 * On the handle's copy stream, which prepare waits for before it
+		 * returns: nothing is left to the ordering rules of the null stream,
+		 * and other handles' streams are not held up */
+		e = hipMemsetAsync(b->d_out, 0, b->out_bytes, h->copy_stream);
+		if (e != hipSuccess) { (void)hipStreamSynchronize(h->copy_stream); xe_gpu_batch_free(b); return hip_fail(h, e, "hipMemsetAsync(outputs)"); }
 	}
 
 	XE_TICK();
@@ -2384,6 +2449,8 @@ xe_gpu_batch_run(xe_batch *b, void *stream)
 {
 	int rc;
 	if (!b) return XE_EINVAL;
+	/* the calling thread may have another device current */
+	HIPCHK(b->h, hipSetDevice(b->h->device));
 	/* templates learnt by later batches may have moved the device tables */
 	b->kp.tmpls = (const struct xe_tmpl *)b->h->d_tmpls;
 	b->kp.tents = (const struct xe_tent *)b->h->d_tents;
@@ -2406,6 +2473,7 @@ xe_gpu_batch_sync(xe_batch *b)
 {
 	if (!b) return XE_EINVAL;
 	if (!b->ran) return XE_ESTATE;
+	HIPCHK(b->h, hipSetDevice(b->h->device));
 	HIPCHK(b->h, hipStreamSynchronize(b->last_stream));
 	return XE_OK;
 }
@@ -2414,6 +2482,7 @@ extern "C" int
 xe_gpu_batch_timing(xe_batch *b, int enable)
 {
 	if (!b) return XE_EINVAL;
+	HIPCHK(b->h, hipSetDevice(b->h->device));
 	if (enable && !b->ev[0]) {
 		for (int i = 0; i < 6; i++) HIPCHK(b->h, hipEventCreate(&b->ev[i]));
 		for (int i = 0; i < 2; i++) HIPCHK(b->h, hipEventCreate(&b->ev_fwm[i]));

@@ -127,6 +127,10 @@ size_t xe_ht_plan_nsf(const struct xe_plan *p) { return p->nsf; }
 size_t xe_ht_plan_nsets(const struct xe_plan *p) { return p->sets.n; }
 size_t xe_ht_plan_nexporters(const struct xe_plan *p) { return p->exporters.n; }
 size_t xe_ht_plan_skipped(const struct xe_plan *p) { return p->skipped_datagrams; }
+size_t xe_ht_plan_oversized(const struct xe_plan *p) { return p->oversized_datagrams; }
+size_t xe_ht_plan_ndatagrams(const struct xe_plan *p) { return p->ndg; }
+const uint32_t *xe_ht_plan_dg_first_nf(const struct xe_plan *p) { return p->dg_first_nf; }
+const uint32_t *xe_ht_plan_dg_first_sf(const struct xe_plan *p) { return p->dg_first_sf; }
 const struct xe_set *xe_ht_plan_sets(const struct xe_plan *p) { return p->sets.p; }
 const struct xe_exporter *xe_ht_plan_exporters(const struct xe_plan *p) { return p->exporters.p; }
 size_t xe_ht_ntemplates(const struct xe_host *hs) { return hs->dev_tmpls.n; }

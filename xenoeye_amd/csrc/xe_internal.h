@@ -81,6 +81,7 @@ struct xe_tent
 #define XE_TE_STR 2      /* string: left-aligned copy */
 #define XE_TE_REPEAT 4   /* an earlier entry of this template has the same destination */
 
+#define XE_MAX_RECORDS_PER_DATAGRAM (1u << 20)
 #define XE_TMPL_MAXF 254
 #define XE_TMPL_UNSUPPORTED 0xFFFFFFFFu   /* template slot: too many elements for the device form */
 #define XE_MODE_V9 0     /* field admitted while pos + len <= avail (netflow.c:284) */
@@ -484,7 +485,9 @@ struct xe_plan
 	size_t nsf;                /* sflow records */
 	uint64_t field_mask[2];    /* fields some template of the batch can set */
 	size_t soa_bytes_per_rec_sum; /* sum over records of stored widths (algorithmic bytes) */
-	size_t skipped_datagrams;  /* unknown version / aborted */
+	size_t skipped_datagrams;  /* unknown version / aborted / oversized */
+	size_t oversized_datagrams;/* left out: more than XE_MAX_RECORDS_PER_DATAGRAM records */
+	int too_many;              /* the batch would hold more records than 32 bits index */
 	size_t unsupported_sets;   /* data sets of templates with more than XE_TMPL_MAXF reachable elements */
 	/* exporter (address, source id) -> index: open addressing, index + 1 */
 	uint32_t *ehash; size_t ehash_cap;

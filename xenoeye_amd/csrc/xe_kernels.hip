@@ -2232,16 +2232,15 @@ fwm_global_add(const xe_fwm_dev &F, const uint64_t (&kw)[XE_FWM_MAX_KWORDS], uin
 		uint32_t st = __hip_atomic_load((uint32_t *)S, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
 		if (st == 0) {
 			const uint32_t old = atomicCAS((uint32_t *)S, 0u, 1u);
-			if (old == 0) {
+			/* lost the slot to another thread: whatever state it is in now, the
+			 * key may only be compared behind the acquire load above */
+			if (old != 0) continue;
 #pragma unroll
-				for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
-					if ((uint32_t)i < F.kwords) S[1 + i] = kw[i];
-				}
-				__hip_atomic_store((uint32_t *)S, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-				st = 2;
-			} else {
-				st = old;
+			for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
+				if ((uint32_t)i < F.kwords) S[1 + i] = kw[i];
 			}
+			__hip_atomic_store((uint32_t *)S, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+			st = 2;
 		}
 		if (st == 2) {
 			bool eq = true;

@@ -489,7 +489,7 @@ emit_set(struct xe_plan *plan, const struct xe_host *hs, const struct dgram *d, 
 	size_t i, w = 0;
 
 	if (!nrec) return 1;
-	if (plan->nrec + nrec > 0xFFFFFFF0u) return 0;
+	if (plan->nrec + nrec > 0xFFFFFFF0u) { plan->too_many = 1; return 0; }
 	memset(&s, 0, sizeof(s));
 	s.data_off = d->base + (uint64_t)rel_off;
 	s.first_rec = (uint32_t)plan->nrec;
@@ -995,6 +995,33 @@ walk_one(struct xe_host *hs, struct xe_plan *plan, const uint8_t *data, const ui
 	return XE_OK;
 }
 
+/* One datagram, with a bound on what it may expand to.  A Netflow v9 data set is
+ * iterated header.count times whatever it holds (netflow.c:272), and a set of
+ * length 0 moves the cursor by its 4 header bytes only, so a 1.4 KB datagram
+ * of empty sets for a known template id stands for tens of millions of empty
+ * records: the reference would grind through them, here each one would be a
+ * row of every output column.  A datagram that yields more than
+ * XE_MAX_RECORDS_PER_DATAGRAM records (no well-formed one comes near: 64 KiB
+ * of one-byte records are 65536) is left out as a whole and counted. */
+static int
+walk_one_bounded(struct xe_host *hs, struct xe_plan *plan, const uint8_t *data, const uint64_t *offs,
+	const uint32_t *src, const uint8_t *kinds, size_t i)
+{
+	const size_t s0 = plan->sets.n, r0 = plan->nrec, w0 = plan->soa_bytes_per_rec_sum;
+	int rc = walk_one(hs, plan, data, offs, src, kinds, i);
+
+	if ((rc == XE_OK) && (plan->nrec - r0 > XE_MAX_RECORDS_PER_DATAGRAM)) {
+		plan->sets.n = s0;
+		plan->nrec = r0;
+		plan->soa_bytes_per_rec_sum = w0;
+		plan->skipped_datagrams++;
+		plan->oversized_datagrams++;
+	}
+	/* more records than a batch can index is not a memory problem */
+	if ((rc == XE_ENOMEM) && plan->too_many) rc = XE_EUNSUPPORTED;
+	return rc;
+}
+
 /*
  * Several threads: all state of the walk is keyed by exporter (templates,
  * sampling rate), so thread t takes the datagrams of the exporter addresses
@@ -1131,6 +1158,7 @@ pp_merge(struct pp_shared *sh, struct xe_plan *out)
 		out->field_mask[1] |= p->field_mask[1];
 		out->soa_bytes_per_rec_sum += p->soa_bytes_per_rec_sum;
 		out->skipped_datagrams += p->skipped_datagrams;
+		out->oversized_datagrams += p->oversized_datagrams;
 		out->unsupported_sets += p->unsupported_sets;
 		for (i = 0; i < p->tinfo.n; i++) {
 			while (out->tinfo.n <= i) {
@@ -1174,7 +1202,7 @@ pp_walk(void *arg)
 			since = 0;
 		}
 		s0 = plan->sets.n; r0 = plan->nrec; f0 = plan->nsf; e0 = plan->exporters.n;
-		me->rc = walk_one(sh->hs, plan, sh->data, sh->offs, sh->src, sh->kinds, i);
+		me->rc = walk_one_bounded(sh->hs, plan, sh->data, sh->offs, sh->src, sh->kinds, i);
 		memset(&e, 0, sizeof(e));
 		e.nsets = (uint32_t)(plan->sets.n - s0);
 		e.nrec = (uint32_t)(plan->nrec - r0);
@@ -1267,6 +1295,8 @@ walker_reset(struct pp_thread *w)
 	p->field_mask[0] = p->field_mask[1] = 0;
 	p->soa_bytes_per_rec_sum = 0;
 	p->skipped_datagrams = 0;
+	p->oversized_datagrams = 0;
+	p->too_many = 0;
 	p->unsupported_sets = 0;
 	if (p->ehash) memset(p->ehash, 0, p->ehash_cap * sizeof(uint32_t));
 	w->ents.n = w->efirst.n = 0;
@@ -1369,7 +1399,7 @@ xe_prepass(struct xe_host *hs, const uint8_t *data, const uint64_t *offs, const 
 		if (i + 16 < n) __builtin_prefetch(data + offs[i + 16]);
 		plan->dg_first_nf[i] = (uint32_t)plan->nrec;
 		plan->dg_first_sf[i] = (uint32_t)plan->nsf;
-		rc = walk_one(hs, plan, data, offs, src, kinds, i);
+		rc = walk_one_bounded(hs, plan, data, offs, src, kinds, i);
 		if (rc != XE_OK) {
 			xe_plan_free(plan);
 			return rc;
