@@ -64,7 +64,16 @@ def parse_args():
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch from a rocprofv3 --pmc pass (reported as roofline.traffic)")
-    return ap.parse_args()
+    ap.add_argument("--quick", action="store_true",
+                    help="the headline measurement only (no CPU legs, other configurations, sustained / pipelined / table legs)")
+    a = ap.parse_args()
+    if a.quick:
+        a.cpu_sample = 0
+        a.others = 0
+        a.sustain_seconds = 0.0
+        a.pipeline = 0
+        a.fwm = 0
+    return a
 
 
 def build_workload(name, nrec, rank, c4_prefixes=1000000, world=1, c4_lists=8):

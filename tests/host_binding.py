@@ -159,17 +159,33 @@ CHAIN_WORDS = 8
 NODE_BITS = int(load_hosttest().xe_ht_node_bits())
 
 
+def _resolve(e, addr, nbits, depth):
+    """an entry that carries a short chain in itself -> 'ends here' with the
+    answers; `depth` = address bits the entry stands behind"""
+    if (e >> 30) != 3:
+        return e
+    if e & 0x20000000:
+        base, lst, ln, path = 0, (e >> 16) & 7, 15 + ((e >> 28) & 1), e & 0xFFFF
+    else:
+        base, lst, ln, path = e & 0xFF, (e >> 8) & 7, (e >> 11) & 15, (e >> 15) & 0x3FFF
+    left = ((addr << (128 - nbits)) << depth) & ((1 << 128) - 1)      # bits from `depth`, left-aligned
+    m = ((left >> (128 - 16)) >> (16 - ln)) == path
+    return TERM | base | (int(m) << lst)
+
+
 def walk_flat(words, root, nodes, addr_bytes, bit=0, chains=0):
     """Reference walker of the flattened list format (tests only): the
-    group's root table over the first 16 bits, then one directly indexed node
-    per NODE_BITS address bits, or a chain record that settles the rest
-    of the walk with one comparison; `bit` selects the list inside the group's
-    answer bits."""
+    group's root table over the first 16 bits, then one
+    directly indexed node per NODE_BITS address bits; a tail of one prefix is a
+    chain record or sits in the entry itself; `bit` selects the list inside the
+    group's answer bits."""
     if not root:
         return 0
     nbits = 8 * len(addr_bytes)
     addr = int.from_bytes(addr_bytes, "big")
-    e = int(words[root + (addr >> (nbits - 16))])
+    top = addr >> (nbits - 16)
+    e = int(words[root + top])
+    e = _resolve(e, addr, nbits, 16)
     depth = 16
     while not (e & TERM) and depth < nbits:
         if e & CHAIN:
@@ -182,5 +198,6 @@ def walk_flat(words, root, nodes, addr_bytes, bit=0, chains=0):
             e = TERM | (meta & 0xFF) | (int(m) << lst)
         else:
             e = int(words[nodes + e * (1 << NODE_BITS) + ((addr >> (nbits - depth - NODE_BITS)) & ((1 << NODE_BITS) - 1))])
+            e = _resolve(e, addr, nbits, depth + NODE_BITS)
         depth += NODE_BITS
     return ((e >> bit) & 1) if (e & TERM) else 0

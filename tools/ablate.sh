@@ -1,7 +1,7 @@
 #!/bin/bash
 # Diagnostic: time the benchmark kernel with phases switched off (XE_ABLATE bits).
 for a in "$@"; do
-  XE_ABLATE=$a timeout -k 10 200 python -u bench.py --steps 10 --warmup 2 --cpu-sample 0 $BENCH_ARGS 2>/dev/null > /tmp/ab.json || exit 1
+  XE_ABLATE=$a timeout -k 10 200 python -u bench.py --steps 10 --warmup 2 --quick $BENCH_ARGS 2>/dev/null > /tmp/ab.json || exit 1
   python - "$a" <<'PY'
 import json, sys
 d = json.load(open("/tmp/ab.json"))

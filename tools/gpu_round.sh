@@ -17,7 +17,7 @@ echo "== bench c1"
 timeout -k 10 300 python bench.py --workload c1 --cpu-sample 4000000 > "$out/bench_c1.json" 2> "$out/bench_c1.err" || { tail -20 "$out/bench_c1.err"; exit 1; }
 cat "$out/bench_c1.json"
 echo "== kernel trace"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_c2" -- python3 bench.py --cpu-sample 0 --pipeline 0 --fwm 0 > "$out/trace_c2.log" 2>&1 || { tail -20 "$out/trace_c2.log"; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_c2" -- python3 bench.py --quick --pipeline 0 --fwm 0 > "$out/trace_c2.log" 2>&1 || { tail -20 "$out/trace_c2.log"; exit 1; }
 find "$out/trace_c2" -name "*kernel_stats.csv" -exec cat {} \;
 echo "== counters"
 bash tools/prof_pmc.sh "$out/pmc_c2" > "$out/pmc_c2.txt" 2>&1 || { tail -20 "$out/pmc_c2.txt"; exit 1; }

@@ -8,7 +8,7 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 run() {
   name=$1; shift
-  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 ${BENCH_ARGS:-} > "$out/$name.log" 2>&1 || { tail -5 "$out/$name.log"; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -- python3 bench.py --steps 2 --warmup 1 --quick ${BENCH_ARGS:-} > "$out/$name.log" 2>&1 || { tail -5 "$out/$name.log"; exit 1; }
 }
 run l1 SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM_WR SQ_INSTS_SMEM SQ_INST_CYCLES_SMEM SQ_IFETCH SQ_IFETCH_LEVEL
 run l2 SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_SMEM SQ_INST_LEVEL_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VMEM_TA_ADDR_FIFO_FULL SQ_WAVE_CYCLES SQ_BUSY_CYCLES

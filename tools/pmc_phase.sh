@@ -8,7 +8,7 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for a in "$@"; do
   export XE_ABLATE=$a
-  timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS --output-format csv -d "$out/a$a" -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 ${BENCH_ARGS:-} > "$out/a$a.log" 2>&1 || exit 1
+  timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS --output-format csv -d "$out/a$a" -- python3 bench.py --steps 2 --warmup 1 --quick ${BENCH_ARGS:-} > "$out/a$a.log" 2>&1 || exit 1
   python3 - "$out/a$a" "$a" <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: [0.0, 0])

@@ -7,7 +7,7 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 run() {
   name=$1; shift
-  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -- python3 bench.py --steps 3 --warmup 1 --cpu-sample 0 --pipeline 0 --fwm 0 $BENCH_ARGS > "$out/$name.log" 2>&1
+  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$out/$name" -- python3 bench.py --steps 3 --warmup 1 --quick --pipeline 0 --fwm 0 $BENCH_ARGS > "$out/$name.log" 2>&1
   echo "$name rc=$?"
 }
 BENCH_ARGS="$*"
@@ -25,7 +25,7 @@ for d in sorted(glob.glob(out + "/*/")):
     for f in glob.glob(d + "**/*counter_collection.csv", recursive=True):
         acc = collections.defaultdict(lambda: [0.0, 0])
         for row in csv.DictReader(open(f)):
-            if "xe_nf" not in row["Kernel_Name"]:
+            if "xe_" not in row["Kernel_Name"] or "probe" in row["Kernel_Name"]:
                 continue
             k = (row["Kernel_Name"].split("(")[0], row["Counter_Name"])
             acc[k][0] += float(row["Counter_Value"]); acc[k][1] += 1

@@ -13,7 +13,8 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxenoeye_gpu.so")
+# XE_GPU_LIB: another build of the same library (kernel tuning experiments)
+LIB_PATH = os.environ.get("XE_GPU_LIB") or os.path.join(_HERE, "libxenoeye_gpu.so")
 FLOW_INFO_SIZE = 2312
 
 _lib = None

@@ -190,10 +190,17 @@ struct xe_prog
  * address bits, then nodes of 2^XE_NODE_BITS entries, one per value of the next
  * XE_NODE_BITS address bits.  8 bits per node measured faster on MI355X than 4
  * (tables a quarter of the size, but one more dependent load per walk).
- * An entry (root and node alike): bit 31 set = the walk ends here and bits
- * 0..7 are the answers of the group's lists (bit l = list l); bit 30 set =
- * index of a chain record; else the index of the node for the next address
- * bits.  A visit is one 4-byte load.
+ * An entry (root and node alike), by its top two bits:
+ *   10  the walk ends here, bits 0..7 are the answers of the group's lists
+ *       (bit l = list l);
+ *   00  index of the node for the next address bits;
+ *   01  index of a chain record;
+ *   11  a short chain kept in the entry itself (no further load):
+ *       bit 29 clear: answers of the other lists (bits 0-7) | l << 8 |
+ *                     len << 11 (1..14) | path << 15 (len bits, right-aligned)
+ *       bit 29 set:   len = 15 + bit 28, l << 16, path in bits 0-15, the other
+ *                     lists answer 0
+ * A visit is one 4-byte load.
  * Chain record (XE_CHAIN_WORDS words): only list `l` can still go deeper, along
  * one path of `len` bits that ends in a prefix:
  *   word 0      answers of the other lists (bits 0-7) | l << 8 | len << 11
@@ -201,6 +208,8 @@ struct xe_prog
  * the list's answer is 1 iff the next `len` address bits equal the path. */
 #define XE_TRIE_TERM 0x80000000u
 #define XE_TRIE_CHAIN 0x40000000u
+#define XE_TRIE_INLINE 0xC0000000u
+#define XE_TRIE_INLINE_LONG 0x20000000u
 #define XE_CHAIN_WORDS 8
 #define XE_LIST_GROUP 8
 #ifndef XE_NODE_BITS

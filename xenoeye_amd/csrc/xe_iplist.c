@@ -13,7 +13,8 @@
  * with one answer bit per list, or the index of the next node), so a lookup
  * is one 4-byte load per level, at most 1 + (bits-16)/8 of them, whatever the
  * number of lists; tails along which only one prefix of one list is left
- * are collapsed into one comparison (chain records).
+ * are collapsed into one comparison (chain records, or the entry itself when
+ * the tail is short).
  */
 #define _GNU_SOURCE
 #include <stdio.h>
@@ -331,7 +332,21 @@ child_entry(struct gfl_ctx *c, const struct gstate *child, uint32_t *entry)
 		return 1;
 	}
 	if (kind == 1) {
-		size_t idx = c->chains->n / XE_CHAIN_WORDS;
+		const uint32_t len = (rec[0] >> 11) & 127, l = (rec[0] >> 8) & 7, base = rec[0] & 0xFF;
+		size_t idx;
+
+		/* a path of up to 16 bits fits into the entry */
+		if (len <= 14) {
+			const uint32_t path = len ? (rec[3] >> (32 - len)) : 0;
+			*entry = XE_TRIE_INLINE | base | (l << 8) | (len << 11) | (path << 15);
+			return 1;
+		}
+		if ((len <= 16) && !base) {
+			const uint32_t path = rec[3] >> (32 - len);
+			*entry = XE_TRIE_INLINE | XE_TRIE_INLINE_LONG | ((len - 15) << 28) | (l << 16) | path;
+			return 1;
+		}
+		idx = c->chains->n / XE_CHAIN_WORDS;
 		if (idx >= 0x3FFFFFF0u) return 0;
 		for (k = 0; k < XE_CHAIN_WORDS; k++) {
 			if (!xe_blob_push(c->chains, &rec[k], 4)) return 0;
