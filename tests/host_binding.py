@@ -165,11 +165,12 @@ def _resolve(e, addr, nbits, depth):
     if (e >> 30) != 3:
         return e
     if e & 0x20000000:
-        base, lst, ln, path = 0, (e >> 16) & 7, 15 + ((e >> 28) & 1), e & 0xFFFF
+        base, lst, ln, path, sl = 0, (e >> 16) & 7, (e >> 20) & 31, e & 0xFFFF, (e >> 19) & 1
     else:
-        base, lst, ln, path = e & 0xFF, (e >> 8) & 7, (e >> 11) & 15, (e >> 15) & 0x3FFF
+        base, lst, ln, path, sl = e & 0xFF, (e >> 8) & 7, (e >> 11) & 15, (e >> 15) & 0x1FFF, (e >> 28) & 1
     left = ((addr << (128 - nbits)) << depth) & ((1 << 128) - 1)      # bits from `depth`, left-aligned
-    m = ((left >> (128 - 16)) >> (16 - ln)) == path
+    d = ((left >> (128 - 16)) >> (16 - ln)) ^ path
+    m = (d == 0) or (sl and ((d >> (ln - 1)) & 1))
     return TERM | base | (int(m) << lst)
 
 
@@ -191,10 +192,10 @@ def walk_flat(words, root, nodes, addr_bytes, bit=0, chains=0):
         if e & CHAIN:
             c = chains + (e & ~CHAIN) * CHAIN_WORDS
             meta = int(words[c])
-            ln, lst = (meta >> 11) & 127, (meta >> 8) & 7
+            ln, lst, sl = (meta >> 11) & 127, (meta >> 8) & 7, (meta >> 18) & 1
             pat = (int(words[c + 3]) << 96) | (int(words[c + 2]) << 64) | (int(words[c + 5]) << 32) | int(words[c + 4])
             rest = (addr << (128 - nbits + depth)) & ((1 << 128) - 1)   # address bits from `depth`, left-aligned
-            m = ((rest ^ pat) >> (128 - ln)) == 0
+            m = (((rest ^ pat) >> (128 - ln)) == 0) or (sl and ((rest ^ pat) >> 127))
             e = TERM | (meta & 0xFF) | (int(m) << lst)
         else:
             e = int(words[nodes + e * (1 << NODE_BITS) + ((addr >> (nbits - depth - NODE_BITS)) & ((1 << NODE_BITS) - 1))])

@@ -232,11 +232,18 @@ def test_flattened_lists_match_oracle(host, orc):
         orc.iplist_add(n, t)
     words, devs = host.flatten()
     probe4 = [struct.pack(">I", x) for x in [0, 0xFFFFFFFF, 0x0A010203, 0x0A010204, 0x0A010300, 0x0A020000,
-                                              0x07070707, 0x07070706, 0x09090909, 0x08000001, 0x7FFFFFFF, 0x80000000]]
+                                              0x07070707, 0x07070706, 0x09090909, 0x08000001, 0x7FFFFFFF, 0x80000000,
+                                              # below 10.1.2.0/24 towards 10.1.2.3/32: leaves with the first bit
+                                              # (stays at the /24), with a later one (ends at a node without a prefix)
+                                              0x0A010280, 0x0A010240, 0x0A010202, 0x0A010207]]
     r4 = (rng.u64(4000) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
     probe4 += [struct.pack(">I", int(x)) for x in r4]
     v4 = synth.prefix_list_v4(synth.Rng(1234), 4000, np.arange(1, 33), nested_frac=0.3)
-    probe4 += [struct.pack(">I", int(x)) for x in synth.addrs_in_prefixes_v4(rng, 3000, *v4)]
+    inside = synth.addrs_in_prefixes_v4(rng, 3000, *v4)
+    probe4 += [struct.pack(">I", int(x)) for x in inside]
+    # the same addresses with one bit flipped: walks that leave a path part of the way down
+    flip = (np.uint32(1) << (rng.u64(3000) % np.uint64(28)).astype(np.uint32))
+    probe4 += [struct.pack(">I", int(x)) for x in (inside.astype(np.uint32) ^ flip)]
     probe6 = [bytes(16), bytes([255] * 16), bytes.fromhex("20010db8000000000000000000000001")]
     probe6 += [bytes(r) for r in rng.bytes(1500 * 16).reshape(-1, 16)]
     for (name, _), (root4, root6, nodes4, nodes6, bit, chains4, chains6) in zip(lists.items(), devs):

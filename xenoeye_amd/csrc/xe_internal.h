@@ -197,15 +197,19 @@ struct xe_prog
  *   01  index of a chain record;
  *   11  a short chain kept in the entry itself (no further load):
  *       bit 29 clear: answers of the other lists (bits 0-7) | l << 8 |
- *                     len << 11 (1..14) | path << 15 (len bits, right-aligned)
- *       bit 29 set:   len = 15 + bit 28, l << 16, path in bits 0-15, the other
- *                     lists answer 0
+ *                     len << 11 (1..13) | path << 15 (len bits, right-aligned)
+ *                     | s << 28
+ *       bit 29 set:   path (bits 0-15) | l << 16 | s << 19 | len << 20 (1..16),
+ *                     the other lists answer 0
+ *       (s: see the chain record)
  * A visit is one 4-byte load.
  * Chain record (XE_CHAIN_WORDS words): only list `l` can still go deeper, along
  * one path of `len` bits that ends in a prefix:
- *   word 0      answers of the other lists (bits 0-7) | l << 8 | len << 11
+ *   word 0      answers of the other lists (bits 0-7) | l << 8 | len << 11 | s << 18
  *   words 2-5   the path, left-aligned in 128 bits (hi word pair first)
- * the list's answer is 1 iff the next `len` address bits equal the path. */
+ * the list's answer is 1 iff the next `len` address bits equal the path, or
+ * s is set (the path starts at a prefix of the list) and the first of them
+ * differs from the path's. */
 #define XE_TRIE_TERM 0x80000000u
 #define XE_TRIE_CHAIN 0x40000000u
 #define XE_TRIE_INLINE 0xC0000000u

@@ -277,15 +277,16 @@ struct gfl_ctx
  * a prefix with nothing below and no prefix on the way, the rest of the walk
  * is one comparison: the address follows the path to its end (answer 1 for
  * that list: the deepest node is the prefix's) or leaves it at an inner node
- * (answer 0).  Such a tail becomes a chain record instead of a node per
- * address byte.  Returns 1 and fills rec[] when `st` is such a state, 0 when
+ * (answer 0); when the node the tail starts at is itself a prefix, an address
+ * that leaves the path with its first bit stays at that prefix (answer 1).
+ * Such a tail becomes a chain record instead of a node per address byte.  Returns 1 and fills rec[] when `st` is such a state, 0 when
  * it is not, and 2 when the path ends without a prefix (answer 0 always).
  */
 static int
 chain_of(const struct xe_bnode *const *bt, const struct gstate *st, uint32_t rec[XE_CHAIN_WORDS])
 {
 	int l = -1, k;
-	uint32_t n, len = 0;
+	uint32_t n, len = 0, start_leaf = 0;
 	uint64_t pat[2] = { 0, 0 };
 
 	for (k = 0; k < XE_LIST_GROUP; k++) {
@@ -300,17 +301,21 @@ chain_of(const struct xe_bnode *const *bt, const struct gstate *st, uint32_t rec
 		const struct xe_bnode *b = &bt[l][n];
 		int c0 = b->next[0] != 0, c1 = b->next[1] != 0;
 		if (!c0 && !c1) break;
-		if ((c0 && c1) || b->is_leaf || (len >= 112)) return 0;
+		if ((c0 && c1) || (b->is_leaf && len) || (len >= 112)) return 0;
+		if (b->is_leaf) start_leaf = 1;
 		if (c1) pat[len >> 6] |= 1ull << (63 - (len & 63));
 		n = c1 ? b->next[1] : b->next[0];
 		len++;
 	}
 	memset(rec, 0, XE_CHAIN_WORDS * sizeof(uint32_t));
 	if (!bt[l][n].is_leaf) {
+		/* (a path that ends without a prefix comes from a mask beyond the
+		 * address width; with a prefix at its start it is left to a node) */
+		if (start_leaf) return 0;
 		rec[0] = st->res & (uint8_t)~(1u << l);
 		return 2;
 	}
-	rec[0] = (uint32_t)(st->res & (uint8_t)~(1u << l)) | ((uint32_t)l << 8) | (len << 11);
+	rec[0] = (uint32_t)(st->res & (uint8_t)~(1u << l)) | ((uint32_t)l << 8) | (len << 11) | (start_leaf << 18);
 	rec[2] = (uint32_t)pat[0];
 	rec[3] = (uint32_t)(pat[0] >> 32);
 	rec[4] = (uint32_t)pat[1];
@@ -333,17 +338,18 @@ child_entry(struct gfl_ctx *c, const struct gstate *child, uint32_t *entry)
 	}
 	if (kind == 1) {
 		const uint32_t len = (rec[0] >> 11) & 127, l = (rec[0] >> 8) & 7, base = rec[0] & 0xFF;
+		const uint32_t sl = (rec[0] >> 18) & 1;
 		size_t idx;
 
 		/* a path of up to 16 bits fits into the entry */
-		if (len <= 14) {
-			const uint32_t path = len ? (rec[3] >> (32 - len)) : 0;
-			*entry = XE_TRIE_INLINE | base | (l << 8) | (len << 11) | (path << 15);
+		if (len && (len <= 13)) {
+			const uint32_t path = rec[3] >> (32 - len);
+			*entry = XE_TRIE_INLINE | base | (l << 8) | (len << 11) | (path << 15) | (sl << 28);
 			return 1;
 		}
-		if ((len <= 16) && !base) {
+		if (len && (len <= 16) && !base) {
 			const uint32_t path = rec[3] >> (32 - len);
-			*entry = XE_TRIE_INLINE | XE_TRIE_INLINE_LONG | ((len - 15) << 28) | (l << 16) | path;
+			*entry = XE_TRIE_INLINE | XE_TRIE_INLINE_LONG | (len << 20) | (sl << 19) | (l << 16) | path;
 			return 1;
 		}
 		idx = c->chains->n / XE_CHAIN_WORDS;

@@ -76,7 +76,9 @@ chain_answer(const uint32_t w[6], uint64_t hi, uint64_t lo, uint32_t depth)
 	if (depth >= 64) { sh = lo << (depth - 64); sl = 0; }
 	else { sh = (hi << depth) | (lo >> (64 - depth)); sl = lo << depth; }
 	const uint64_t dh = sh ^ ph, dl = sl ^ pl;
-	const bool m = (len <= 64) ? ((dh >> (64 - len)) == 0) : ((dh == 0) && ((dl >> (128 - len)) == 0));
+	bool m = (len <= 64) ? ((dh >> (64 - len)) == 0) : ((dh == 0) && ((dl >> (128 - len)) == 0));
+	/* the path starts at a prefix: leaving it with the first bit stays there */
+	m |= ((meta >> 18) & 1) && (dh >> 63);
 	return XE_TRIE_TERM | (meta & 0xFF) | ((uint32_t)m << l);
 }
 
@@ -97,13 +99,16 @@ __device__ __forceinline__ uint32_t
 entry_resolve(uint32_t e, uint32_t next16)
 {
 	if ((e & XE_TRIE_INLINE) != XE_TRIE_INLINE) return e;
-	uint32_t base, l, len, path;
+	uint32_t base, l, len, path, sl;
 	if (e & XE_TRIE_INLINE_LONG) {
-		base = 0; l = (e >> 16) & 7; len = 15 + ((e >> 28) & 1); path = e & 0xFFFF;
+		base = 0; l = (e >> 16) & 7; len = (e >> 20) & 31; path = e & 0xFFFF; sl = (e >> 19) & 1;
 	} else {
-		base = e & 0xFF; l = (e >> 8) & 7; len = (e >> 11) & 15; path = (e >> 15) & 0x3FFF;
+		base = e & 0xFF; l = (e >> 8) & 7; len = (e >> 11) & 15; path = (e >> 15) & 0x1FFF; sl = (e >> 28) & 1;
 	}
-	const uint32_t m = ((next16 >> (16 - len)) == path) ? 1u : 0u;
+	/* the next len address bits against the path: all equal, or (sl) the
+	 * first one different */
+	const uint32_t d = (next16 >> (16 - len)) ^ path;
+	const uint32_t m = ((d == 0) || (sl && ((d >> (len - 1)) & 1))) ? 1u : 0u;
 	return XE_TRIE_TERM | base | (m << l);
 }
 
