@@ -530,6 +530,11 @@ store_col(const xe_kparams &kp, uint32_t f, uint32_t ridx, const val128 &v)
  */
 #define XE_CONST __attribute__((address_space(4)))
 #define XE_GLOBAL __attribute__((address_space(1)))
+#define XE_LDS __attribute__((address_space(3)))
+/* the block's counters and atom-table copy: named as LDS so that their
+ * accesses are LDS instructions wherever the compiler loses track of the
+ * pointer's origin (a generic pointer turns the adds into flat atomics) */
+typedef XE_LDS unsigned long long lds_u64;
 typedef const XE_CONST uint32_t *cu32;
 typedef const XE_CONST uint64_t *cu64;
 typedef const XE_CONST uint8_t *cu8;
@@ -1276,7 +1281,7 @@ template <int R, bool LEAN, int LW>
 __device__ __forceinline__ void
 classify_objects(const xe_kparams &kp, const bool (&live)[R], const uint64_t (&lk)[R][LW], const uint64_t (&tb)[R][4],
 	const uint32_t (&ridx)[R], const unsigned long long (&bxr)[R], const unsigned long long (&pxr)[R],
-	unsigned long long *lcnt, const uint64_t *lmt)
+	lds_u64 *lcnt, const lds_u64 *lmt)
 {
 		/* derived atoms: the multi-literal clauses of the conjunctive objects */
 		uint64_t dbits[R];
@@ -1292,6 +1297,64 @@ classify_objects(const xe_kparams &kp, const bool (&live)[R], const uint64_t (&l
 #pragma unroll
 				for (int w = 0; w < LW; w++) any |= (lk[r][w] & dq[w]) | (~lk[r][w] & dq[4 + w]);
 				dbits[r] |= (uint64_t)(any != 0) << j;
+			}
+		}
+
+		/* the conjunctive objects: an object fails when one of its needed atoms
+		 * is false or a forbidden one true; tables indexed by 8 atoms at once
+		 * give the failing objects.  A table row holds all mask words side by
+		 * side: up to four of them are fetched per visit, for all words at once */
+		uint64_t failw[R][4];
+		const bool cj_rows = !LEAN && kp.ncjgroups && (kp.mask_words <= 4) && !(kp.pad2 & 8);
+#pragma unroll
+		for (int r = 0; r < R; r++) failw[r][0] = failw[r][1] = failw[r][2] = failw[r][3] = 0;
+		if (cj_rows) {
+			typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+			const uint32_t mw = kp.mask_words;
+			for (uint32_t g0 = 0; g0 < kp.ncjgroups; g0 += XE_CJ_STEP) {
+				u64x2 ea[XE_CJ_STEP][R], eb[XE_CJ_STEP][R];
+#pragma unroll
+				for (int c = 0; c < XE_CJ_STEP; c++) {
+					cu32 gq = (cu32)(kp.cjgb + 2 * (g0 + c));
+					const uint32_t k = gq[0], ti = gq[1];
+#pragma unroll
+					for (int r = 0; r < R; r++) {
+						/* byte k: 0-31 lookup bits, 32-63 term bits, 64-71 derived */
+						uint64_t src = lk[r][0];
+#pragma unroll
+						for (int q = 1; q < LW; q++) src = ((k >> 3) == (uint32_t)q) ? lk[r][q] : src;
+						if (k >= 32) src = tb[r][0];
+						if (k >= 40) src = tb[r][1];
+						if (k >= 48) src = tb[r][2];
+						if (k >= 56) src = tb[r][3];
+						if (k >= 64) src = dbits[r];
+						const uint32_t by = (uint32_t)(src >> ((k & 7) * 8)) & 0xFF;
+						const XE_CONST uint64_t *row = (const XE_CONST uint64_t *)kp.cjtab + ((size_t)ti * 256 + by) * mw;
+						ea[c][r] = (u64x2){0, 0};
+						eb[c][r] = (u64x2){0, 0};
+						if (mw == 4) {
+							ea[c][r] = *(const XE_CONST u64x2 *)row;
+							eb[c][r] = *(const XE_CONST u64x2 *)(row + 2);
+						} else if (mw == 3) {
+							ea[c][r] = *(const XE_CONST u64x2 *)row;
+							eb[c][r].x = row[2];
+						} else if (mw == 2) {
+							ea[c][r] = *(const XE_CONST u64x2 *)row;
+						} else {
+							ea[c][r].x = row[0];
+						}
+					}
+				}
+#pragma unroll
+				for (int c = 0; c < XE_CJ_STEP; c++) {
+#pragma unroll
+					for (int r = 0; r < R; r++) {
+						failw[r][0] |= ea[c][r].x;
+						failw[r][1] |= ea[c][r].y;
+						failw[r][2] |= eb[c][r].x;
+						failw[r][3] |= eb[c][r].y;
+					}
+				}
 			}
 		}
 
@@ -1339,8 +1402,10 @@ classify_objects(const xe_kparams &kp, const bool (&live)[R], const uint64_t (&l
 				 * atoms at once give the failing objects, 4 groups per step */
 				uint64_t fail[R];
 #pragma unroll
-				for (int r = 0; r < R; r++) fail[r] = 0;
-				for (uint32_t g0 = 0; g0 < kp.ncjgroups; g0 += XE_CJ_STEP) {
+				for (int r = 0; r < R; r++) {
+					fail[r] = (w == 0) ? failw[r][0] : (w == 1) ? failw[r][1] : (w == 2) ? failw[r][2] : failw[r][3];
+				}
+				for (uint32_t g0 = 0; !cj_rows && (g0 < kp.ncjgroups); g0 += XE_CJ_STEP) {
 					uint64_t e[XE_CJ_STEP][R];
 #pragma unroll
 					for (int c = 0; c < XE_CJ_STEP; c++) {
@@ -1407,9 +1472,9 @@ classify_objects(const xe_kparams &kp, const bool (&live)[R], const uint64_t (&l
 					const uint32_t m = m0 + (uint32_t)__builtin_ctzll(x);
 					x &= x - 1;
 					if (kp.lds_counters) {
-						atomicAdd(lcnt + 3 * m + 0, 1ull);
-						atomicAdd(lcnt + 3 * m + 1, bxr[r]);
-						atomicAdd(lcnt + 3 * m + 2, pxr[r]);
+						__hip_atomic_fetch_add(lcnt + 3 * m + 0, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						__hip_atomic_fetch_add(lcnt + 3 * m + 1, bxr[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						__hip_atomic_fetch_add(lcnt + 3 * m + 2, pxr[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					} else {
 						atomicAdd(kp.counters + 3 * m + 0, 1ull);
 						atomicAdd(kp.counters + 3 * m + 1, bxr[r]);
@@ -1446,8 +1511,8 @@ xe_nf_fast_kernel(const xe_kparams kp)
 	/* staging: kp.fast_dwords dwords per record, [wave][dword][r][lane]; then
 	 * the block's counters and its copy of the atom table */
 	uint32_t *stg = lds32 + (size_t)wave * kp.fast_dwords * R * 64 + lane;
-	unsigned long long *lcnt = (unsigned long long *)(lds32 + (size_t)(XE_BLOCK / 64) * kp.fast_dwords * R * 64);
-	uint64_t *lmt = (uint64_t *)(lcnt + (kp.lds_counters ? (size_t)kp.nmo * 3 : 0));
+	lds_u64 *lcnt = (lds_u64 *)(lds32 + (size_t)(XE_BLOCK / 64) * kp.fast_dwords * R * 64);
+	lds_u64 *lmt = lcnt + (kp.lds_counters ? (size_t)kp.nmo * 3 : 0);
 	const bool want_dev = kp.fast_want_dev != 0;
 	const XE_GLOBAL uint8_t *pkt = (const XE_GLOBAL uint8_t *)kp.pkt;
 
@@ -1607,7 +1672,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 template <typename REC, fval (*GET)(const REC &, uint32_t, uint32_t *)>
 __device__ __forceinline__ void
 classify(const xe_kparams &kp, REC &rec, int32_t device, uint32_t ridx, bool active,
-	unsigned long long bytes_x_rate, unsigned long long pkts_x_rate, unsigned long long *lcnt, const uint64_t *lmt)
+	unsigned long long bytes_x_rate, unsigned long long pkts_x_rate, lds_u64 *lcnt, const lds_u64 *lmt)
 {
 	bool dropped = false;
 	walk_cache wc;
@@ -1699,10 +1764,10 @@ classify(const xe_kparams &kp, REC &rec, int32_t device, uint32_t ridx, bool act
 
 /* the block's LDS counters and atom-table copy of the per-lane kernels */
 __device__ __forceinline__ void
-lane_kernel_lds(const xe_kparams &kp, uint64_t *lds, unsigned long long *&lcnt, uint64_t *&lmt)
+lane_kernel_lds(const xe_kparams &kp, uint64_t *lds, lds_u64 *&lcnt, lds_u64 *&lmt)
 {
-	lcnt = (unsigned long long *)lds;
-	lmt = lds + (kp.lds_counters ? (size_t)kp.nmo * 3 : 0);
+	lcnt = (lds_u64 *)lds;
+	lmt = lcnt + (kp.lds_counters ? (size_t)kp.nmo * 3 : 0);
 	if (kp.lds_counters) {
 		for (uint32_t i = threadIdx.x; i < kp.nmo * 3; i += XE_BLOCK) lcnt[i] = 0;
 	}
@@ -1713,7 +1778,7 @@ lane_kernel_lds(const xe_kparams &kp, uint64_t *lds, unsigned long long *&lcnt, 
 }
 
 __device__ __forceinline__ void
-lane_kernel_flush(const xe_kparams &kp, const unsigned long long *lcnt)
+lane_kernel_flush(const xe_kparams &kp, const lds_u64 *lcnt)
 {
 	if (!kp.lds_counters) return;
 	__syncthreads();
@@ -1731,8 +1796,8 @@ __global__ void __launch_bounds__(XE_BLOCK)
 xe_nf_general_kernel(const xe_kparams kp)
 {
 	extern __shared__ uint64_t lane_lds[];
-	unsigned long long *lcnt;
-	uint64_t *lmt;
+	lds_u64 *lcnt;
+	lds_u64 *lmt;
 	lane_kernel_lds(kp, lane_lds, lcnt, lmt);
 	uint32_t g = blockIdx.x * XE_BLOCK + threadIdx.x;
 	bool active = g < kp.nslowrec;
@@ -2210,8 +2275,8 @@ __attribute__((amdgpu_waves_per_eu(XE_SF_WAVES, XE_SF_WAVES)))
 xe_sf_kernel(const xe_kparams kp)
 {
 	extern __shared__ uint64_t lane_lds[];
-	unsigned long long *lcnt;
-	uint64_t *lmt;
+	lds_u64 *lcnt;
+	lds_u64 *lmt;
 	lane_kernel_lds(kp, lane_lds, lcnt, lmt);
 	uint32_t g = blockIdx.x * XE_BLOCK + threadIdx.x;
 	bool active = g < kp.nsf;
