@@ -2170,6 +2170,7 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 		b->kp.rgroups = (const struct xe_rgroup *)h->d_rgroups;
 		b->kp.rgdata = (const uint32_t *)h->d_rgdata;
 		b->kp.nrgroups = (h->nrgroups + 3) & ~3u;
+		b->kp.nrgroups_used = h->nrgroups;
 		b->kp.cjderived = (const struct xe_cjderived *)h->d_cjderived;
 		b->kp.cjcand = (const uint64_t *)h->d_cjcand;
 		b->kp.ncjderived = h->ncjderived;

@@ -50,7 +50,8 @@ struct xe_kparams
 	const struct xe_set *sets;
 	const struct xe_exporter *exps;
 	const struct xe_sfrec *sfrecs;
-	uint32_t nsets, nrec, nsf, pad1;
+	uint32_t nsets, nrec, nsf;
+	uint32_t nrgroups_used;      /* range groups before the padding to a multiple of 4 */
 	/* batch output; record index space = [0,nrec) netflow then [nrec,nrec+nsf) sflow */
 	uint64_t *masks;
 	uint8_t *nparsed;            /* netflow: fields parsed; sflow: parser state | XE_SF_SKIPPED */

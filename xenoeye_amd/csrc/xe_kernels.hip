@@ -675,6 +675,12 @@ tile_get(const lane_tile<REC, GET> &T, uint32_t field, uint32_t r, bool &has, ui
 	lo = v.has ? v.v.lo : 0;
 }
 
+/* diagnostic phase timing (XE_ABLATE bit 6): wave-clock cycles per phase, summed
+ * over the waves' tiles into xe_fast_phase_cycles[] */
+__device__ unsigned long long xe_fast_phase_cycles[8];
+#define XE_PHASE(N) do { if (kp.pad2 & 64) { const uint64_t now_ = __builtin_readcyclecounter(); \
+	if (lane == 0) atomicAdd(&xe_fast_phase_cycles[N], (unsigned long long)(now_ - tprev)); tprev = now_; } } while (0)
+
 /*
  * All IP-list membership tests of a tile.  Per probe (one field against one
  * group of up to 8 lists) ONE walk of the group's merged tables per record: a
@@ -1147,16 +1153,18 @@ tile_issue(const xe_kparams &kp, const tile_lanes<R> &S, u32x4 (&q)[4][R])
 #ifndef XE_CJ_STEP
 #define XE_CJ_STEP 2
 #endif
+#ifndef XE_RG_SCALAR
+#define XE_RG_SCALAR 24  /* range groups of up to this many breakpoints are searched with scalar loads */
+#endif
 
 /* Range terms by field: one search of the field's value among the group's
  * breakpoints answers every range term that reads the field (a table entry
  * per interval holds the terms' bits).  Four groups advance together so their
  * dependent loads overlap. */
-template <int R, typename TT>
+template <int R, typename TT, int GC>
 __device__ __forceinline__ void
 range_groups(const xe_kparams &kp, const TT &T, uint64_t (&tb)[R][4])
 {
-	constexpr int GC = XE_RG_STEP;
 	typedef uint32_t u32x4r __attribute__((ext_vector_type(4)));
 
 	for (uint32_t g0 = 0; g0 < kp.nrgroups; g0 += GC) {
@@ -1166,7 +1174,10 @@ range_groups(const xe_kparams &kp, const TT &T, uint64_t (&tb)[R][4])
 		for (int c = 0; c < GC; c++) {
 			cu32 q = (cu32)(kp.rgroups + g0 + c);
 			const uint32_t field = q[0];
-			n[c] = q[1];
+			/* a group of the padding: nothing to search, entry 0 of a table that
+			 * is added again */
+			const bool used = g0 + c < kp.nrgroups_used;
+			n[c] = used ? q[1] : 0u;
 			bpo[c] = q[2];
 			tbo[c] = q[3];
 			if (n[c] > maxn) maxn = n[c];
@@ -1175,13 +1186,28 @@ range_groups(const xe_kparams &kp, const TT &T, uint64_t (&tb)[R][4])
 				bool has;
 				uint32_t fmax;
 				uint64_t hi, lo;
+				v[c][r] = 0;
+				pos[c][r] = 0;
+				if (!used) continue;
 				tile_get(T, field, r, has, fmax, hi, lo);
 				/* absent fields compare as 0; only 1/2/4-byte fields carry a value */
 				v[c][r] = (fmax <= 4) ? (int32_t)(uint32_t)lo : 0;
-				pos[c][r] = 0;
 			}
 		}
-		/* pos = number of breakpoints <= v */
+		/* pos = number of breakpoints <= v.  A few breakpoints: they are the
+		 * same for every lane, so they come through the scalar cache and are
+		 * counted with compares, no dependent gathers; many: binary search */
+		if (maxn <= XE_RG_SCALAR) {
+			for (uint32_t i = 0; i < maxn; i++) {
+#pragma unroll
+				for (int c = 0; c < GC; c++) {
+					const bool in = i < n[c];
+					const int32_t bi = ((const XE_CONST int32_t *)kp.rgdata)[bpo[c] + (in ? i : 0u)];
+#pragma unroll
+					for (int r = 0; r < R; r++) pos[c][r] += (in && (bi <= v[c][r])) ? 1u : 0u;
+				}
+			}
+		} else
 		for (uint32_t step = 1u << (31 - __builtin_clz(maxn)); step; step >>= 1) {
 			int32_t b[GC][R];
 #pragma unroll
@@ -1189,7 +1215,9 @@ range_groups(const xe_kparams &kp, const TT &T, uint64_t (&tb)[R][4])
 #pragma unroll
 				for (int r = 0; r < R; r++) {
 					const uint32_t cand = pos[c][r] + step;
-					const uint32_t idx = ((cand < n[c]) ? cand : n[c]) - 1;
+					/* (a group of the padding has n = 0: it reads word 0 and keeps pos = 0) */
+					const uint32_t top = (cand < n[c]) ? cand : n[c];
+					const uint32_t idx = top ? top - 1 : 0u;
 					b[c][r] = ((const XE_CONST int32_t *)kp.rgdata)[bpo[c] + idx];
 				}
 			}
@@ -1208,6 +1236,8 @@ range_groups(const xe_kparams &kp, const TT &T, uint64_t (&tb)[R][4])
 #pragma unroll
 			for (int r = 0; r < R; r++) {
 				const XE_CONST u32x4r *e = (const XE_CONST u32x4r *)(kp.rgdata + tbo[c] + (size_t)pos[c][r] * 8);
+				ea[c][r] = eb[c][r] = (u32x4r){0, 0, 0, 0};
+				if (g0 + c >= kp.nrgroups_used) continue;
 				ea[c][r] = e[0];
 				eb[c][r] = e[1];
 			}
@@ -1229,7 +1259,7 @@ range_groups(const xe_kparams &kp, const TT &T, uint64_t (&tb)[R][4])
 /* LEAN = the configuration has no range groups, conjunctive or listed objects
  * (objects with a single condition and no parent only): those parts are
  * compiled out, which keeps the common simple case small */
-template <int R, bool LEAN, int LW, typename TT>
+template <int R, bool LEAN, int LW, typename TT, int RGC = XE_RG_STEP>
 __device__ __forceinline__ void
 classify_atoms(const xe_kparams &kp, const TT &T, const uint64_t (&plist)[LW], uint64_t (&lk)[R][LW], uint64_t (&tb)[R][4])
 {
@@ -1240,11 +1270,19 @@ classify_atoms(const xe_kparams &kp, const TT &T, const uint64_t (&plist)[LW], u
 				for (int w = 0; w < LW; w++) lk[r][w] = 0;
 			}
 		} else {
+			uint64_t tprev = (kp.pad2 & 64) ? __builtin_readcyclecounter() : 0;
+			const uint32_t lane = threadIdx.x & 63;
 			fast_lookups<R, LW, TT>(kp, T, plist, lk);
+			XE_PHASE(6);
 		}
 #pragma unroll
 		for (int r = 0; r < R; r++) tb[r][0] = tb[r][1] = tb[r][2] = tb[r][3] = 0;
-		if (!LEAN && !(kp.pad2 & 2)) range_groups<R, TT>(kp, T, tb);
+		if (!LEAN && !(kp.pad2 & 2)) {
+			uint64_t tprev = (kp.pad2 & 64) ? __builtin_readcyclecounter() : 0;
+			const uint32_t lane = threadIdx.x & 63;
+			range_groups<R, TT, RGC>(kp, T, tb);
+			XE_PHASE(7);
+		}
 		for (uint32_t ti = 0; (ti < kp.ntneed) && !(kp.pad2 & 2); ti++) {
 			const uint32_t t = ((cu32)kp.tneed)[ti];
 			cu64 fq = (cu64)(kp.fterms + t);
@@ -1484,12 +1522,6 @@ classify_objects(const xe_kparams &kp, const bool (&live)[R], const uint64_t (&l
 			}
 		}
 }
-
-/* diagnostic phase timing (XE_ABLATE bit 6): wave-clock cycles per phase, summed
- * over the waves' tiles into xe_fast_phase_cycles[] */
-__device__ unsigned long long xe_fast_phase_cycles[8];
-#define XE_PHASE(N) do { if (kp.pad2 & 64) { const uint64_t now_ = __builtin_readcyclecounter(); \
-	if (lane == 0) atomicAdd(&xe_fast_phase_cycles[N], (unsigned long long)(now_ - tprev)); tprev = now_; } } while (0)
 
 /* measured on MI355X: the lean kernel at 6 waves per SIMD is 3-8 % faster than at the compiler's own choice */
 #ifndef XE_FAST_WAVES
@@ -1747,8 +1779,13 @@ classify(const xe_kparams &kp, REC &rec, int32_t device, uint32_t ridx, bool act
 	if (kp.lw == 1) {
 		uint64_t lk[1][1];
 		const uint64_t pl[1] = { kp.all_probes[0] };
-		classify_atoms<1, false, 1>(kp, T, pl, lk, tb);
+		uint64_t tprev = __builtin_readcyclecounter();
+		const uint32_t lane = threadIdx.x & 63;
+		/* per-lane kernels have registers to spare: four range groups at a time */
+		classify_atoms<1, false, 1, lane_tile<REC, GET>, 4>(kp, T, pl, lk, tb);
+		XE_PHASE(2);
 		classify_objects<1, false, 1>(kp, T.live, lk, tb, ri, bx, px, lcnt, lmt);
+		XE_PHASE(3);
 	} else {
 		uint64_t lk[1][XE_LK_WORDS];
 		uint64_t pl[XE_LK_WORDS];
@@ -1935,7 +1972,7 @@ enum { SFI_in_bytes, SFI_in_pkts, SFI_protocol, SFI_src_tos, SFI_dst_tos, SFI_tc
 	SFI_icmp_type, SFI_min_ttl, SFI_max_ttl, SFI_src_mac, SFI_dst_mac, SFI_src_vlan, SFI_dst_vlan,
 	SFI_src_cvlan, SFI_dst_cvlan };
 
-__device__ constexpr int
+__host__ __device__ constexpr int
 sf_field_of(int i)
 {
 	constexpr int t[SF_NFIELDS] = {
@@ -1947,12 +1984,46 @@ sf_field_of(int i)
 }
 
 /* maximum size of each of those fields in struct flow_info */
-__device__ constexpr int
+__host__ __device__ constexpr int
 sf_size_of(int i)
 {
 	constexpr int t[SF_NFIELDS] = { 8, 8, 1, 1, 1, 2, 2, 4, 4, 2, 4, 4, 16, 16, 2, 1, 1, 6, 6, 2, 2, 2, 2 };
 	return t[i];
 }
+
+/* For classification the decoded fields move from registers into the thread's
+ * LDS column (the staging area is free by then): the filter code asks for
+ * fields by number, which a table and an LDS read answer in a few
+ * instructions, where a choice among 23 registers costs a compare per field
+ * at every place a field is read.  Field i occupies sf_words_of(i) words from
+ * word sf_slot_of(i) on, bytes in memory order. */
+__host__ __device__ constexpr int
+sf_words_of(int i)
+{
+	return (sf_size_of(i) <= 4) ? 1 : (sf_size_of(i) <= 8) ? 2 : 4;
+}
+
+/* fields the decoder only ever sets together with another one, to the same
+ * bytes (sflow.c:47-62 and the VLAN hooks), share that one's words */
+__host__ __device__ constexpr int
+sf_alias_of(int i)
+{
+	return (i == SFI_ip6_dst) ? SFI_ip6_src : (i == SFI_max_ttl) ? SFI_min_ttl
+		: (i == SFI_dst_vlan) ? SFI_src_vlan : (i == SFI_dst_cvlan) ? SFI_src_cvlan : i;
+}
+
+__host__ __device__ constexpr int
+sf_slot_of(int i)
+{
+	int o = 0;
+	if (i < SF_NFIELDS) i = sf_alias_of(i);
+	for (int j = 0; j < i; j++) o += (sf_alias_of(j) == j) ? sf_words_of(j) : 0;
+	return o;
+}
+
+/* per flow field: (index among the sFlow fields << 8) | first word, 0xFFFF = the
+ * sFlow decoder never sets it */
+__constant__ uint16_t c_sf_slot[XE_NFIELDS];
 
 struct sf_rec
 {
@@ -1967,9 +2038,12 @@ struct sf_rec
 	const uint32_t *stg;
 	const uint8_t *p;
 	int32_t left;             /* bytes from p to the end of the datagram */
+	int32_t lim;              /* reads of whole words stay below min(left, staged bytes) */
 };
 
-#define SF_STAGE_DWORDS 40
+/* 112 bytes: Ethernet, two tags, two IPv6 headers and a TCP header up to its
+ * flags; at 28 KiB a block, five blocks (20 waves) share a CU's LDS */
+#define SF_STAGE_DWORDS 28
 #define SF_STAGE_BYTES (4 * SF_STAGE_DWORDS)
 
 /* byte `off` of the element; zero beyond the end of the datagram */
@@ -1981,15 +2055,54 @@ sf_byte(const sf_rec &r, int32_t off)
 	return r.p[off];
 }
 
+/* the rare way: n bytes at `off` one by one, zero beyond the datagram's end
+ * (kept out of line: dozens of call sites) */
+__device__ __attribute__((noinline)) uint64_t
+sf_bytes_slow(const uint32_t *stg, const uint8_t *p, int32_t left, int32_t off, int n)
+{
+	uint64_t x = 0;
+	for (int i = 0; i < n; i++) {
+		const int32_t o = off + i;
+		uint32_t b = 0;
+		if (o < left) b = (o < SF_STAGE_BYTES) ? ((stg[(o >> 2) * XE_BLOCK] >> ((o & 3) * 8)) & 0xFF) : p[o];
+		x |= (uint64_t)b << (8 * i);
+	}
+	return x;
+}
+
+/* four staged bytes at `off` (off + 4 <= r.lim), packed little-endian: two
+ * aligned LDS words and a byte shift */
+__device__ __forceinline__ uint32_t
+sf_word(const sf_rec &r, int32_t off)
+{
+	const uint32_t *w = r.stg + (off >> 2) * XE_BLOCK;
+	return __builtin_amdgcn_alignbyte(w[XE_BLOCK], w[0], (uint32_t)off & 3);
+}
+
 /* N bytes of the sampled header at `off`, packed little-endian */
 template <int N>
 __device__ __forceinline__ uint64_t
 sf_bytes(const sf_rec &r, int32_t off)
 {
 	uint64_t x = 0;
+	/* the usual case: all of it staged and inside the datagram (lim leaves room
+	 * for the second word of the last read) */
+	if ((off >= 0) && (off + ((N + 3) & ~3) <= r.lim)) {
+		if (N <= 4) {
+			x = sf_word(r, off);
+			if (N < 4) x &= (1u << (8 * (N & 3))) - 1u;
+		} else {
+			x = sf_word(r, off);
 #pragma unroll
-	for (int i = 0; i < N; i++) x |= (uint64_t)sf_byte(r, off + i) << (8 * i);
-	return x;
+			for (int i = 4; i < N; i += 4) {
+				uint64_t w = sf_word(r, off + i);
+				if (N - i < 4) w &= (1u << (8 * ((N - i) & 3))) - 1u;
+				x |= w << (8 * i);
+			}
+		}
+		return x;
+	}
+	return sf_bytes_slow(r.stg, r.p, r.left, off, N);
 }
 
 /* COPY_TO_FLOW of sflow.c:26-33: N bytes to the START of the field */
@@ -2040,7 +2153,8 @@ sf_on_ip6(sf_rec &r, int32_t ip6h, uint32_t nexthdr)   /* sflow.c:57-62 */
 __device__ __forceinline__ uint32_t
 sf_be16(const sf_rec &r, int32_t off)
 {
-	return (sf_byte(r, off) << 8) | sf_byte(r, off + 1);
+	const uint32_t x = (uint32_t)sf_bytes<2>(r, off);
+	return ((x & 0xFF) << 8) | (x >> 8);
 }
 
 /* rawpacket_parse(), rawparse.h:89-281; returns the parser state 0..4 */
@@ -2133,34 +2247,76 @@ sf_rawparse(sf_rec &r, int32_t end, int type)
 	return 4;
 }
 
+/* what the decoder needs of an element's descriptor (struct xe_sfrec) */
+struct sf_elem
+{
+	uint64_t hdr_off;
+	uint32_t header_len, frame_len_be, kind, rp_type;
+	int32_t left;
+};
+
+/* the descriptor arrives as four 16-byte loads, all in flight together */
+struct sf_desc { u32x4 a, b, c, d; };
+
+__device__ __forceinline__ sf_desc
+sf_desc_load(const xe_sfrec *q)
+{
+	const u32x4 *qq = (const u32x4 *)q;
+	sf_desc x;
+	x.a = qq[0]; x.b = qq[1]; x.c = qq[2]; x.d = qq[3];
+	return x;
+}
+
+__device__ __forceinline__ sf_elem
+sf_elem_of(const sf_desc &x)
+{
+	sf_elem e;
+	e.hdr_off = (uint64_t)x.a.x | ((uint64_t)x.a.y << 32);
+	e.header_len = x.a.z;
+	e.left = (int32_t)x.a.w;
+	e.frame_len_be = x.b.x;
+	e.kind = x.c.x & 0xFF;
+	e.rp_type = (x.c.x >> 8) & 0xFF;
+	return e;
+}
+
 /* apply one element to the flow image; returns the parser state (4 for the
  * IPv4 structure element, which is always delivered) */
 __device__ __forceinline__ int
-sf_apply(const xe_kparams &kp, sf_rec &r, const xe_sfrec *q)
+sf_apply(const xe_kparams &kp, sf_rec &r, const sf_elem &q)
 {
-	r.p = kp.pkt + q->hdr_off;
-	r.left = q->dgram_left;
+	r.p = kp.pkt + q.hdr_off;
+	r.left = q.left;
+	/* a word read looks one dword ahead of the one it starts in */
+	r.lim = ((r.left < SF_STAGE_BYTES) ? r.left : SF_STAGE_BYTES) - 4;
 	{
-		/* wide loads of the element into this thread's LDS column; a piece that
-		 * starts inside the datagram may run past its end (the batch buffer is
-		 * padded), those bytes are never used */
+		/* wide loads of the element into this thread's LDS column, all issued
+		 * before the first one is used; a piece that starts inside the datagram
+		 * may run past its end (the batch buffer is padded), those bytes are
+		 * never used; a piece that starts beyond it is not read (the load goes
+		 * to the element's first bytes instead and its result is dropped) */
 		uint32_t *d = const_cast<uint32_t *>(r.stg);
+		u32x4 v[SF_STAGE_DWORDS / 4];
 #pragma unroll
 		for (int i = 0; i < SF_STAGE_DWORDS / 4; i++) {
-			u32x4 v = (u32x4){0, 0, 0, 0};
-			if (16 * i < r.left) __builtin_memcpy(&v, r.p + 16 * i, 16);
-			d[(4 * i + 0) * XE_BLOCK] = v.x;
-			d[(4 * i + 1) * XE_BLOCK] = v.y;
-			d[(4 * i + 2) * XE_BLOCK] = v.z;
-			d[(4 * i + 3) * XE_BLOCK] = v.w;
+			const bool in = 16 * i < r.left;
+			v[i] = *(const XE_GLOBAL u32x4 *)(r.p + (in ? 16 * i : 0));
+		}
+#pragma unroll
+		for (int i = 0; i < SF_STAGE_DWORDS / 4; i++) {
+			const bool in = 16 * i < r.left;
+			d[(4 * i + 0) * XE_BLOCK] = in ? v[i].x : 0u;
+			d[(4 * i + 1) * XE_BLOCK] = in ? v[i].y : 0u;
+			d[(4 * i + 2) * XE_BLOCK] = in ? v[i].z : 0u;
+			d[(4 * i + 3) * XE_BLOCK] = in ? v[i].w : 0u;
 		}
 	}
 	/* sflow-impl.h:164-171 / :224-234: in_bytes[4..8] = frame length as on
 	 * the wire, in_pkts[7] = 1 */
-	r.v[SFI_in_bytes] = (r.v[SFI_in_bytes] & 0xFFFFFFFFull) | ((uint64_t)q->frame_len_be << 32);
+	r.v[SFI_in_bytes] = (r.v[SFI_in_bytes] & 0xFFFFFFFFull) | ((uint64_t)q.frame_len_be << 32);
 	r.v[SFI_in_pkts] = (r.v[SFI_in_pkts] & 0x00FFFFFFFFFFFFFFull) | (1ull << 56);
 	r.has |= (1u << SFI_in_bytes) | (1u << SFI_in_pkts);
-	if (q->kind == 1) return sf_rawparse(r, (int32_t)q->header_len, q->rp_type);
+	if (q.kind == 1) return sf_rawparse(r, (int32_t)q.header_len, (int)q.rp_type);
 
 	/* IPv4 structure, sflow-impl.h:236-260: seven 4-byte words */
 	sf_set_byte0<SFI_protocol>(r, sf_byte(r, 3));
@@ -2239,34 +2395,110 @@ sf_get(const sf_rec &r, uint32_t f, uint32_t *size_out)
 	return out;
 }
 
-/* field FI to its column, if the record has it */
+/* the record as the classification code reads it: the field image in LDS */
+struct sf_img
+{
+	const uint32_t *img;      /* word w of this thread at img[w * XE_BLOCK] */
+	uint32_t has;
+	uint32_t mark;
+	const xe_sfrec *q;
+};
+
 template <int FI>
 __device__ __forceinline__ void
-sf_store(const xe_kparams &kp, const sf_rec &r, uint32_t ridx)
+sf_dump(const sf_rec &r, uint32_t *img)
 {
-	constexpr int f = sf_field_of(FI), n = sf_size_of(FI);
-	constexpr int w = (n <= 1) ? 1 : (n <= 2) ? 2 : (n <= 4) ? 4 : (n <= 8) ? 8 : 16;
-	if (!((r.has >> FI) & 1)) return;
-	uint8_t *dst = kp.out_base + kp.col_off[f] + (size_t)ridx * w;
-	if (w == 1) *dst = (uint8_t)r.v[FI];
-	else if (w == 2) *(uint16_t *)dst = (uint16_t)r.v[FI];
-	else if (w == 4) *(uint32_t *)dst = (uint32_t)r.v[FI];
-	else if (w == 8) *(uint64_t *)dst = r.v[FI];
-	else {
-		((uint64_t *)dst)[0] = r.v[FI];
-		((uint64_t *)dst)[1] = r.v6hi[FI - SFI_ip6_src];
+	constexpr int slot = sf_slot_of(FI), nw = sf_words_of(FI);
+	if (sf_alias_of(FI) != FI) return;
+	img[slot * XE_BLOCK] = (uint32_t)r.v[FI];
+	if (nw >= 2) img[(slot + 1) * XE_BLOCK] = (uint32_t)(r.v[FI] >> 32);
+	if (nw == 4) {
+		img[(slot + 2) * XE_BLOCK] = (uint32_t)r.v6hi[(FI >= SFI_ip6_src) ? FI - SFI_ip6_src : 0];
+		img[(slot + 3) * XE_BLOCK] = (uint32_t)(r.v6hi[(FI >= SFI_ip6_src) ? FI - SFI_ip6_src : 0] >> 32);
 	}
 }
 
 template <int... FI>
 __device__ __forceinline__ void
-sf_store_all(const xe_kparams &kp, const sf_rec &r, uint32_t ridx, std::integer_sequence<int, FI...>)
+sf_dump_all(const sf_rec &r, uint32_t *img, std::integer_sequence<int, FI...>)
 {
-	(sf_store<FI>(kp, r, ridx), ...);
+	(sf_dump<FI>(r, img), ...);
+}
+
+__device__ __forceinline__ fval
+sf_img_get(const sf_img &r, uint32_t f, uint32_t *size_out)
+{
+	fval out;
+	out.has = false;
+	out.v.hi = out.v.lo = 0;
+	(void)size_out;
+	if (f == XF_dev_id) {
+		const uint8_t *b = r.q->dev_id;
+		out.has = true;
+		out.v.lo = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3];
+		return out;
+	}
+	if ((f == XF_dev_ip) || (f == XF_dev_ip6)) {
+		bool v4 = r.q->agent_ver == 4;
+		if ((f == XF_dev_ip) != v4) return out;
+		out.has = true;
+		for (int i = 0; i < (v4 ? 4 : 16); i++) {
+			out.v.hi = (out.v.hi << 8) | (out.v.lo >> 56);
+			out.v.lo = (out.v.lo << 8) | r.q->agent[i];
+		}
+		return out;
+	}
+	if (f == XF_dev_mark) {
+		out.has = (r.mark & XE_MARK_HAS) != 0;
+		out.v.lo = r.mark & 0x3FFFFFFFu;
+		return out;
+	}
+	const uint32_t s = c_sf_slot[f];
+	if (s == 0xFFFF) return out;
+	const uint32_t n = c_fmax[f];
+	const uint32_t *w = r.img + (s & 0xFF) * XE_BLOCK;
+	out.has = ((r.has >> (s >> 8)) & 1) != 0;
+	/* the field's bytes read as one big-endian number */
+	if (n <= 4) {
+		out.v.lo = __builtin_bswap32(w[0]) >> (32 - 8 * n);
+	} else if (n <= 8) {
+		out.v.lo = __builtin_bswap64((uint64_t)w[0] | ((uint64_t)w[XE_BLOCK] << 32)) >> (64 - 8 * n);
+	} else {
+		out.v.hi = __builtin_bswap64((uint64_t)w[0] | ((uint64_t)w[XE_BLOCK] << 32));
+		out.v.lo = __builtin_bswap64((uint64_t)w[2 * XE_BLOCK] | ((uint64_t)w[3 * XE_BLOCK] << 32));
+	}
+	return out;
+}
+
+/* field FI from the thread's field image to its column, if the record has it */
+template <int FI>
+__device__ __forceinline__ void
+sf_store(const xe_kparams &kp, const uint32_t *img, uint32_t has, uint32_t ridx)
+{
+	constexpr int f = sf_field_of(FI), n = sf_size_of(FI), slot = sf_slot_of(FI);
+	constexpr int w = (n <= 1) ? 1 : (n <= 2) ? 2 : (n <= 4) ? 4 : (n <= 8) ? 8 : 16;
+	if (!((has >> FI) & 1)) return;
+	uint8_t *dst = kp.out_base + kp.col_off[f] + (size_t)ridx * w;
+	const uint32_t w0 = img[slot * XE_BLOCK];
+	if (w == 1) *dst = (uint8_t)w0;
+	else if (w == 2) *(uint16_t *)dst = (uint16_t)w0;
+	else if (w == 4) *(uint32_t *)dst = w0;
+	else if (w == 8) *(uint64_t *)dst = (uint64_t)w0 | ((uint64_t)img[(slot + 1) * XE_BLOCK] << 32);
+	else {
+		((uint64_t *)dst)[0] = (uint64_t)w0 | ((uint64_t)img[(slot + 1) * XE_BLOCK] << 32);
+		((uint64_t *)dst)[1] = (uint64_t)img[(slot + 2) * XE_BLOCK] | ((uint64_t)img[(slot + 3) * XE_BLOCK] << 32);
+	}
+}
+
+template <int... FI>
+__device__ __forceinline__ void
+sf_store_all(const xe_kparams &kp, const uint32_t *img, uint32_t has, uint32_t ridx, std::integer_sequence<int, FI...>)
+{
+	(sf_store<FI>(kp, img, has, ridx), ...);
 }
 
 #ifndef XE_SF_WAVES
-#define XE_SF_WAVES 3      /* measured on MI355X: 2 (the compiler's choice, 189 VGPRs) 0.725 ms, 3 0.609 ms, 4 1.02 ms per 3.2 M samples */
+#define XE_SF_WAVES 4      /* measured on MI355X (3.2 M samples): 4 waves 0.430 ms; 5 waves spill and take 0.526 ms */
 #endif
 __global__ void __launch_bounds__(XE_BLOCK)
 #if XE_SF_WAVES
@@ -2278,6 +2510,8 @@ xe_sf_kernel(const xe_kparams kp)
 	lds_u64 *lcnt;
 	lds_u64 *lmt;
 	lane_kernel_lds(kp, lane_lds, lcnt, lmt);
+	uint64_t tprev = __builtin_readcyclecounter();
+	const uint32_t lane = threadIdx.x & 63;
 	uint32_t g = blockIdx.x * XE_BLOCK + threadIdx.x;
 	bool active = g < kp.nsf;
 	uint32_t ridx = kp.nrec + g;
@@ -2297,35 +2531,55 @@ xe_sf_kernel(const xe_kparams kp)
 		+ (kp.motab_lds ? (size_t)kp.motab_words : 0)) + threadIdx.x;
 	rec.p = kp.pkt;
 	rec.left = 0;
+	rec.lim = 0;
 	if (active) {
+		rec.q = kp.sfrecs + g;
+		const sf_desc own = sf_desc_load(rec.q);
 		/* elements of one sample share the flow: replay the earlier ones */
 		uint32_t first = g;
-		while ((first > 0) && kp.sfrecs[first].chained) first--;
-		rec.q = kp.sfrecs + g;
+		if ((own.c.x >> 24) & 0xFF) {
+			first = g - 1;
+			while ((first > 0) && kp.sfrecs[first].chained) first--;
+		}
 		/* sf5_flow(), sflow-impl.h:106-143: interface indices, bytes as stored */
-		rec.v[SFI_input_snmp] = rec.q->in_if_be;
-		rec.v[SFI_output_snmp] = rec.q->out_if_be;
+		rec.v[SFI_input_snmp] = own.b.z;
+		rec.v[SFI_output_snmp] = own.b.w;
 		rec.has |= (1u << SFI_input_snmp) | (1u << SFI_output_snmp);
+		device = kp.exps[own.d.z].device;
 		int state = 4;
-		for (uint32_t k = first; k <= g; k++) state = sf_apply(kp, rec, kp.sfrecs + k);
+		for (uint32_t k = first; k <= g; k++) {
+			sf_desc x = own;
+			if (k != g) x = sf_desc_load(kp.sfrecs + k);
+			state = sf_apply(kp, rec, sf_elem_of(x));
+		}
 		deliver = state >= 2;   /* sflow.c:164-168 */
+		XE_PHASE(0);
 		kp.nparsed[ridx] = (uint8_t)(state | (deliver ? 0 : XE_SF_SKIPPED));
 		kp.sf_has[g] = rec.has;
-		sf_store_all(kp, rec, ridx, std::make_integer_sequence<int, SF_NFIELDS>());
-		device = kp.exps[rec.q->exporter].device;
-		uint64_t rate = rec.q->sampling_rate;
+		uint64_t rate = own.b.y;
 		if (kp.rates) kp.rates[ridx] = (uint32_t)rate;
 		if (kp.devips) {
-			/* dev_ip = the agent's address when it is an IPv4 one (sflow-impl.h:330-345) */
-			const uint8_t *d = rec.q->agent;
-			kp.devips[ridx] = (rec.q->agent_ver == 4)
-				? ((uint32_t)d[0] | ((uint32_t)d[1] << 8) | ((uint32_t)d[2] << 16) | ((uint32_t)d[3] << 24)) : 0u;
+			/* dev_ip = the agent's address when it is an IPv4 one (sflow-impl.h:330-345):
+			 * its four bytes in memory order */
+			kp.devips[ridx] = (((own.c.x >> 16) & 0xFF) == 4) ? own.c.z : 0u;
 		}
 		bxr = sf_get(rec, XF_in_bytes, nullptr).v.lo * rate;
 		pxr = sf_get(rec, XF_in_pkts, nullptr).v.lo * rate;
 		if (!deliver && kp.marks) kp.marks[ridx] = 0;
 	}
-	classify<sf_rec, sf_get>(kp, rec, device, ridx, active && deliver, bxr, pxr, lcnt, lmt);
+	/* the fields move to the thread's LDS column for the filter code */
+	static_assert(sf_slot_of(SF_NFIELDS) <= SF_STAGE_DWORDS, "the field image must fit the staging column");
+	sf_img im;
+	im.img = rec.stg;
+	im.has = rec.has;
+	im.mark = 0;
+	im.q = rec.q;
+	sf_dump_all(rec, const_cast<uint32_t *>(rec.stg), std::make_integer_sequence<int, SF_NFIELDS>());
+	XE_PHASE(1);
+	classify<sf_img, sf_img_get>(kp, im, device, ridx, active && deliver, bxr, pxr, lcnt, lmt);
+	/* the columns last: vector memory operations retire in order, and a list
+	 * walk issued behind these stores would wait for them */
+	if (active) sf_store_all(kp, rec.stg, rec.has, ridx, std::make_integer_sequence<int, SF_NFIELDS>());
 	if (active && !deliver) {
 		for (uint32_t w = 0; w < kp.mask_words; w++) kp.masks[(size_t)ridx * kp.mask_words + w] = 0;
 	}
@@ -2647,6 +2901,12 @@ upload_tables(void)
 	if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_fmax), mx, sizeof(mx))) != hipSuccess) return e;
 	if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_colw), cw, sizeof(cw))) != hipSuccess) return e;
 	if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_fstr), st, sizeof(st))) != hipSuccess) return e;
+	{
+		uint16_t sl[XE_NFIELDS];
+		for (int f = 0; f < XE_NFIELDS; f++) sl[f] = 0xFFFF;
+		for (int i = 0; i < SF_NFIELDS; i++) sl[sf_field_of(i)] = (uint16_t)((i << 8) | sf_slot_of(i));
+		if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_sf_slot), sl, sizeof(sl))) != hipSuccess) return e;
+	}
 	return hipSuccess;
 }
 
@@ -2751,6 +3011,16 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 		hipLaunchKernelGGL(xe_sf_kernel, dim3(blocks), dim3(XE_BLOCK), sf_lds, st, *kp);
 		if (ev) (void)hipEventRecord(ev[5], st);
 		if (hipGetLastError() != hipSuccess) return XE_EHIP;
+		if (kp->pad2 & 64) {
+			/* diagnostic: print and reset the per-phase wave cycles */
+			unsigned long long pc[8], z[8] = {0};
+			const double nw = (double)((kp->nsf + 63) / 64);
+			(void)hipStreamSynchronize(st);
+			(void)hipMemcpyFromSymbol(pc, HIP_SYMBOL(xe_fast_phase_cycles), sizeof(pc));
+			(void)hipMemcpyToSymbol(HIP_SYMBOL(xe_fast_phase_cycles), z, sizeof(z));
+			fprintf(stderr, "sflow phase cycles per wave: load+parse %.0f stores+image %.0f atoms %.0f (lookups %.0f range groups %.0f) objects %.0f\n",
+				(double)pc[0] / nw, (double)pc[1] / nw, (double)pc[2] / nw, (double)pc[6] / nw, (double)pc[7] / nw, (double)pc[3] / nw);
+		}
 	}
 	return XE_OK;
 }
