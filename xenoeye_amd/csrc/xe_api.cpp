@@ -2457,7 +2457,12 @@ xe_gpu_batch_run(xe_batch *b, void *stream)
 	b->kp.tents = (const struct xe_tent *)b->h->d_tents;
 	rc = xe_launch_batch(&b->kp, stream, b->timing ? (void **)b->ev : NULL);
 	if ((rc == XE_OK) && b->h->nfwm) {
-		rc = xe_launch_fwm(&b->kp, (const struct xe_fwm_dev *)b->h->d_fwmdesc, (uint32_t)b->h->nfwm, stream,
+		uint32_t kwmax = 1, nvmax = 1;
+		for (size_t i = 0; i < b->h->nfwm; i++) {
+			if (b->h->fwms[i].dev.kwords > kwmax) kwmax = b->h->fwms[i].dev.kwords;
+			if (b->h->fwms[i].dev.nval > nvmax) nvmax = b->h->fwms[i].dev.nval;
+		}
+		rc = xe_launch_fwm(&b->kp, (const struct xe_fwm_dev *)b->h->d_fwmdesc, (uint32_t)b->h->nfwm, kwmax, nvmax, stream,
 			b->timing ? (void **)b->ev_fwm : NULL);
 	}
 	if (rc != XE_OK) {

@@ -141,8 +141,9 @@ struct xe_fwm_dev
 	uint8_t kfield[XE_FWM_MAX_KEY_FIELDS], ksize[XE_FWM_MAX_KEY_FIELDS];
 	uint8_t vfield[XE_FWM_MAX_VALS], vscale[XE_FWM_MAX_VALS];
 };
-int xe_launch_fwm(const struct xe_kparams *kp, const struct xe_fwm_dev *tables, uint32_t ntables, void *stream,
-	void **events);
+/* kwmax / nvmax: the longest key (words) and the most sums among the tables */
+int xe_launch_fwm(const struct xe_kparams *kp, const struct xe_fwm_dev *tables, uint32_t ntables, uint32_t kwmax, uint32_t nvmax,
+	void *stream, void **events);
 /* n addresses (4 or 16 bytes each) against one flattened list */
 int xe_launch_trie_probe(const uint32_t *trie, struct xe_list_dev list, int family,
 	const uint8_t *addrs, uint32_t n, uint8_t *out, void *stream);

@@ -2602,7 +2602,9 @@ xe_sf_kernel(const xe_kparams kp)
  * keys that find their LDS entry taken by another key go to HBM one by one.
  */
 #define XE_FWM_CACHE 256         /* entries of the block's table in LDS */
+#ifndef XE_FWM_CHUNKS
 #define XE_FWM_CHUNKS 16         /* 256-record chunks a block works through */
+#endif
 
 /* one key with its sums into the table in HBM */
 __device__ __forceinline__ void
@@ -2651,23 +2653,51 @@ fwm_global_add(const xe_fwm_dev &F, const uint64_t (&kw)[XE_FWM_MAX_KWORDS], uin
 	}
 }
 
-__global__ void __launch_bounds__(XE_BLOCK)
-xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables)
+/* LDS of a block, sized at launch by the longest key (kwmax words) and the
+ * most sums (nvmax) among the tables: a block of the usual short keys takes a
+ * quarter of what the limits would, and three times as many blocks fit a CU */
+__host__ __device__ inline size_t
+fwm_lds_bytes(uint32_t kwmax, uint32_t nvmax)
 {
-	/* per wave: which lane speaks for a hash value, and what it collects */
-	__shared__ uint32_t s_lane[XE_BLOCK / 64][128];
-	__shared__ unsigned long long s_sum[XE_BLOCK / 64][64][XE_FWM_MAX_VALS];
-	__shared__ uint32_t s_cnt[XE_BLOCK / 64][64];
-	/* where a lane puts its key together, byte by byte: [wave][word][lane] */
-	__shared__ uint64_t s_key[XE_BLOCK / 64][XE_FWM_MAX_KWORDS][64];
+	const size_t waves = XE_BLOCK / 64;
+	return waves * 128 * 4                         /* s_lane */
+		+ waves * 64 * 4                           /* s_cnt */
+		+ XE_FWM_CACHE * 4 * 2                     /* c_state, c_cnt */
+		+ XE_FWM_CACHE * 8                         /* c_hash */
+		+ waves * 64 * (size_t)nvmax * 8           /* s_sum */
+		+ waves * (size_t)kwmax * 64 * 8           /* s_key */
+		+ XE_FWM_CACHE * (size_t)kwmax * 8         /* c_key */
+		+ XE_FWM_CACHE * (size_t)nvmax * 8;        /* c_sum */
+}
+
+__global__ void __launch_bounds__(XE_BLOCK)
+xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables, uint32_t kwmax, uint32_t nvmax)
+{
+	extern __shared__ uint64_t fwm_lds[];
+	constexpr uint32_t WAVES = XE_BLOCK / 64;
+	/* 8-byte arrays first, then the 4-byte ones */
 	/* the block's table: state 0 free, 1 being written, 2 ready */
-	__shared__ uint32_t c_state[XE_FWM_CACHE], c_cnt[XE_FWM_CACHE];
-	__shared__ uint64_t c_hash[XE_FWM_CACHE];
-	__shared__ uint64_t c_key[XE_FWM_CACHE][XE_FWM_MAX_KWORDS];
-	__shared__ unsigned long long c_sum[XE_FWM_CACHE][XE_FWM_MAX_VALS];
+	uint64_t *c_hash = fwm_lds;                                   /* [XE_FWM_CACHE] */
+	uint64_t *c_key_ = c_hash + XE_FWM_CACHE;                     /* [XE_FWM_CACHE][kwmax] */
+	unsigned long long *c_sum_ = (unsigned long long *)(c_key_ + (size_t)XE_FWM_CACHE * kwmax);   /* [XE_FWM_CACHE][nvmax] */
+	/* per wave: what the speaker of a hash value collects */
+	unsigned long long *s_sum_ = c_sum_ + (size_t)XE_FWM_CACHE * nvmax;      /* [wave][lane][nvmax] */
+	/* where a lane puts its key together, byte by byte: [wave][word][lane] */
+	uint64_t *s_key_ = (uint64_t *)(s_sum_ + (size_t)WAVES * 64 * nvmax);    /* [wave][kwmax][64] */
+	uint32_t *c_state = (uint32_t *)(s_key_ + (size_t)WAVES * kwmax * 64);   /* [XE_FWM_CACHE] */
+	uint32_t *c_cnt = c_state + XE_FWM_CACHE;
+	uint32_t *s_cnt_ = c_cnt + XE_FWM_CACHE;                      /* [wave][64] */
+	uint32_t *s_lane_ = s_cnt_ + WAVES * 64;                      /* [wave][128]: which lane speaks for a hash value */
+#define c_key(CI, I) c_key_[(size_t)(CI) * kwmax + (I)]
+#define c_sum(CI, J) c_sum_[(size_t)(CI) * nvmax + (J)]
+#define s_sum(W, L, J) s_sum_[((size_t)(W) * 64 + (L)) * nvmax + (J)]
+#define s_key(W, I, L) s_key_[((size_t)(W) * kwmax + (I)) * 64 + (L)]
+#define s_cnt(W, L) s_cnt_[(W) * 64 + (L)]
+#define s_lane(W, H) s_lane_[(W) * 128 + (H)]
 	const uint32_t ntot = kp.nrec + kp.nsf;
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint32_t r0 = blockIdx.x * (XE_BLOCK * XE_FWM_CHUNKS);
+	uint64_t tprev = __builtin_readcyclecounter();
 
 	for (uint32_t f = 0; f < ntables; f++) {
 		const xe_fwm_dev F = tables[f];
@@ -2676,14 +2706,19 @@ xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables)
 			c_state[i] = 0;
 			c_cnt[i] = 0;
 #pragma unroll
-			for (int j = 0; j < XE_FWM_MAX_VALS; j++) c_sum[i][j] = 0;
+			for (int j = 0; j < XE_FWM_MAX_VALS; j++) if ((uint32_t)j < nvmax) c_sum(i, j) = 0;
 		}
 		__syncthreads();
 
+		/* the mask word of a chunk is fetched while the chunk before it is worked on */
+		uint64_t mnext = (r0 + threadIdx.x < ntot) ? kp.masks[(size_t)(r0 + threadIdx.x) * kp.mask_words + (F.mo >> 6)] : 0;
 		for (uint32_t chunk = 0; chunk < XE_FWM_CHUNKS; chunk++) {
 			const uint32_t r = r0 + chunk * XE_BLOCK + threadIdx.x;
-			const bool hit = (r < ntot)
-				&& (((kp.masks[(size_t)r * kp.mask_words + (F.mo >> 6)] >> (F.mo & 63)) & 1) != 0);
+			const uint64_t mword = mnext;
+			mnext = ((chunk + 1 < XE_FWM_CHUNKS) && (r + XE_BLOCK < ntot))
+				? kp.masks[(size_t)(r + XE_BLOCK) * kp.mask_words + (F.mo >> 6)] : 0;
+			const bool hit = (r < ntot) && (((mword >> (F.mo & 63)) & 1) != 0);
+			XE_PHASE(0);
 			if (!__ballot(hit)) continue;
 
 			/* the key: field bytes one after the other, packed into words */
@@ -2696,23 +2731,41 @@ xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables)
 			uint64_t h = 0xcbf29ce484222325ull;
 			if (hit) {
 				uint32_t pos = 0;
-				for (uint32_t i = 0; i < F.kwords; i++) s_key[wave][i][lane] = 0;
-				for (uint32_t k = 0; k < F.nkey; k++) {
-					const uint32_t fld = F.kfield[k], size = F.ksize[k], colw = c_colw[fld];
+				/* every column element the key and the sums need, all loads in
+				 * flight together (a 16-byte field takes two); a field no template
+				 * of the batch carries reads as zeros */
+				uint64_t part0[XE_FWM_MAX_KEY_FIELDS], part1[XE_FWM_MAX_KEY_FIELDS], vraw[XE_FWM_MAX_VALS];
+#pragma unroll
+				for (int k = 0; k < XE_FWM_MAX_KEY_FIELDS; k++) {
+					part0[k] = part1[k] = 0;
+					if ((uint32_t)k >= F.nkey) continue;
+					const uint32_t fld = F.kfield[k], colw = c_colw[fld];
 					const uint64_t co = kp.col_off[fld];
-					/* the field's column element with one load (two for 16 bytes);
-					 * a field no template of the batch carries reads as zeros */
-					uint64_t part[2] = {0, 0};
 					if (fld == XF_dev_ip) {
-						part[0] = kp.devips[r];                      /* comes from the exporter */
+						part0[k] = kp.devips[r];                      /* comes from the exporter */
 					} else if (co != ~0ull) {
 						const uint8_t *p = kp.out_base + co + (size_t)r * colw;
-						if (colw == 1) part[0] = *p;
-						else if (colw == 2) part[0] = *(const uint16_t *)p;
-						else if (colw == 4) part[0] = *(const uint32_t *)p;
-						else if (colw == 8) part[0] = *(const uint64_t *)p;
-						else { part[0] = ((const uint64_t *)p)[0]; part[1] = ((const uint64_t *)p)[1]; }
+						if (colw == 1) part0[k] = *p;
+						else if (colw == 2) part0[k] = *(const uint16_t *)p;
+						else if (colw == 4) part0[k] = *(const uint32_t *)p;
+						else if (colw == 8) part0[k] = *(const uint64_t *)p;
+						else { part0[k] = ((const uint64_t *)p)[0]; part1[k] = ((const uint64_t *)p)[1]; }
 					}
+				}
+#pragma unroll
+				for (int j = 0; j < XE_FWM_MAX_VALS; j++) {
+					vraw[j] = 0;
+					if ((uint32_t)j >= F.nval) continue;
+					const uint64_t co = kp.col_off[F.vfield[j]];
+					if (co != ~0ull) vraw[j] = ((const uint64_t *)(kp.out_base + co))[r];
+				}
+				const uint64_t rate = kp.rates[r];
+				for (uint32_t i = 0; i < F.kwords; i++) s_key(wave, i, lane) = 0;
+#pragma unroll
+				for (int k = 0; k < XE_FWM_MAX_KEY_FIELDS; k++) {
+					if ((uint32_t)k >= F.nkey) continue;
+					const uint32_t size = F.ksize[k];
+					const uint64_t part[2] = { part0[k], part1[k] };
 					/* its first `size` bytes go behind what the key holds so far */
 #pragma unroll
 					for (int h2 = 0; h2 < 2; h2++) {
@@ -2720,15 +2773,15 @@ xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables)
 						const uint32_t nb = (size - 8u * h2 < 8u) ? size - 8u * h2 : 8u;
 						const uint64_t x = (nb < 8) ? (part[h2] & ((1ull << (8 * nb)) - 1)) : part[h2];
 						const uint32_t w = pos >> 3, sh = (pos & 7) * 8;
-						s_key[wave][w][lane] |= x << sh;
-						if (sh && (sh + 8 * nb > 64)) s_key[wave][w + 1][lane] |= x >> (64 - sh);
+						s_key(wave, w, lane) |= x << sh;
+						if (sh && (sh + 8 * nb > 64)) s_key(wave, w + 1, lane) |= x >> (64 - sh);
 						pos += nb;
 					}
 				}
 #pragma unroll
 				for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
 					if ((uint32_t)i < F.kwords) {
-						kw[i] = s_key[wave][i][lane];
+						kw[i] = s_key(wave, i, lane);
 						h = (h ^ kw[i]) * 0x100000001b3ull;
 					}
 				}
@@ -2737,28 +2790,25 @@ xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables)
 				h ^= h >> 33; h *= 0xff51afd7ed558ccdull;
 				h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull;
 				h ^= h >> 33;
-				const uint64_t rate = kp.rates[r];
 #pragma unroll
 				for (int j = 0; j < XE_FWM_MAX_VALS; j++) {
 					if ((uint32_t)j >= F.nval) continue;
-					const uint64_t co = kp.col_off[F.vfield[j]];
-					uint64_t v = 0;
-					if (co != ~0ull) v = __builtin_bswap64(((const uint64_t *)(kp.out_base + co))[r]);
-					val[j] = v * F.vscale[j] * rate;
+					val[j] = __builtin_bswap64(vraw[j]) * F.vscale[j] * rate;
 				}
 			}
 
+			XE_PHASE(1);
 			/* equal keys of the wave: one speaker per hash value; lanes whose key
 			 * is the speaker's hand it their sums, the others go on themselves */
 			const uint32_t hs = (uint32_t)(h >> 7) & 127;
 			if (hit) {
-				s_lane[wave][hs] = lane;
+				s_lane(wave, hs) = lane;
 #pragma unroll
-				for (int j = 0; j < XE_FWM_MAX_VALS; j++) s_sum[wave][lane][j] = 0;
-				s_cnt[wave][lane] = 0;
+				for (int j = 0; j < XE_FWM_MAX_VALS; j++) if ((uint32_t)j < nvmax) s_sum(wave, lane, j) = 0;
+				s_cnt(wave, lane) = 0;
 			}
 			__builtin_amdgcn_wave_barrier();
-			const uint32_t spk = hit ? s_lane[wave][hs] : lane;
+			const uint32_t spk = hit ? s_lane(wave, hs) : lane;
 			bool same = hit;
 #pragma unroll
 			for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
@@ -2769,19 +2819,20 @@ xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables)
 			if (same) {
 #pragma unroll
 				for (int j = 0; j < XE_FWM_MAX_VALS; j++) {
-					if ((uint32_t)j < F.nval) atomicAdd(&s_sum[wave][spk][j], val[j]);
+					if ((uint32_t)j < F.nval) atomicAdd(&s_sum(wave, spk, j), val[j]);
 				}
-				atomicAdd(&s_cnt[wave][spk], 1u);
+				atomicAdd(&s_cnt(wave, spk), 1u);
 			}
 			__builtin_amdgcn_wave_barrier();
 			const bool go = hit && (!same || (spk == lane));
 			uint32_t nspoken = 1;       /* records this lane speaks for */
 			if (hit && same && (spk == lane)) {
-				nspoken = s_cnt[wave][lane];
+				nspoken = s_cnt(wave, lane);
 #pragma unroll
-				for (int j = 0; j < XE_FWM_MAX_VALS; j++) val[j] = s_sum[wave][lane][j];
+				for (int j = 0; j < XE_FWM_MAX_VALS; j++) if ((uint32_t)j < nvmax) val[j] = s_sum(wave, lane, j);
 			}
 			__builtin_amdgcn_wave_barrier();
+			XE_PHASE(2);
 			if (!go) continue;
 
 			/* the block's table: one entry per hash value; taken by another key
@@ -2794,7 +2845,7 @@ xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables)
 					c_hash[ci] = h;
 #pragma unroll
 					for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
-						if ((uint32_t)i < F.kwords) c_key[ci][i] = kw[i];
+						if ((uint32_t)i < F.kwords) c_key(ci, i) = kw[i];
 					}
 					__hip_atomic_store(&c_state[ci], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 					cs = 2;
@@ -2807,18 +2858,20 @@ xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables)
 				bool eq = true;
 #pragma unroll
 				for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
-					if ((uint32_t)i < F.kwords) eq = eq && (c_key[ci][i] == kw[i]);
+					if ((uint32_t)i < F.kwords) eq = eq && (c_key(ci, i) == kw[i]);
 				}
 				if (eq) {
 #pragma unroll
 					for (int j = 0; j < XE_FWM_MAX_VALS; j++) {
-						if ((uint32_t)j < F.nval) atomicAdd(&c_sum[ci][j], val[j]);
+						if ((uint32_t)j < F.nval) atomicAdd(&c_sum(ci, j), val[j]);
 					}
 					atomicAdd(&c_cnt[ci], nspoken);
 					cached = true;
 				}
 			}
+			XE_PHASE(3);
 			if (!cached) fwm_global_add(F, kw, h, val, nspoken);
+			XE_PHASE(4);
 		}
 
 		/* what the block collected goes to the table once */
@@ -2828,17 +2881,25 @@ xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables)
 			uint64_t kw[XE_FWM_MAX_KWORDS];
 			unsigned long long val[XE_FWM_MAX_VALS];
 #pragma unroll
-			for (int k = 0; k < XE_FWM_MAX_KWORDS; k++) kw[k] = ((uint32_t)k < F.kwords) ? c_key[i][k] : 0;
+			for (int k = 0; k < XE_FWM_MAX_KWORDS; k++) kw[k] = ((uint32_t)k < F.kwords) ? c_key(i, k) : 0;
 #pragma unroll
-			for (int j = 0; j < XE_FWM_MAX_VALS; j++) val[j] = c_sum[i][j];
+			for (int j = 0; j < XE_FWM_MAX_VALS; j++) val[j] = ((uint32_t)j < nvmax) ? c_sum(i, j) : 0ull;
 			fwm_global_add(F, kw, c_hash[i], val, c_cnt[i]);
 		}
 		__syncthreads();
+		XE_PHASE(5);
 	}
 }
+#undef c_key
+#undef c_sum
+#undef s_sum
+#undef s_key
+#undef s_cnt
+#undef s_lane
 
 int
-xe_launch_fwm(const struct xe_kparams *kp, const struct xe_fwm_dev *tables, uint32_t ntables, void *stream, void **events)
+xe_launch_fwm(const struct xe_kparams *kp, const struct xe_fwm_dev *tables, uint32_t ntables, uint32_t kwmax, uint32_t nvmax,
+	void *stream, void **events)
 {
 	hipStream_t st = (hipStream_t)stream;
 	hipEvent_t *ev = (hipEvent_t *)events;
@@ -2846,9 +2907,27 @@ xe_launch_fwm(const struct xe_kparams *kp, const struct xe_fwm_dev *tables, uint
 	const uint32_t per_block = XE_BLOCK * XE_FWM_CHUNKS;
 
 	if (!ntables || !ntot) return XE_OK;
+	if (!kwmax || (kwmax > XE_FWM_MAX_KWORDS) || !nvmax || (nvmax > XE_FWM_MAX_VALS)) return XE_EINVAL;
+	struct xe_kparams kcopy;
+	if (getenv("XE_ABLATE")) {      /* diagnostic switches, as in xe_launch_batch() */
+		kcopy = *kp;
+		kcopy.pad2 = (uint32_t)atoi(getenv("XE_ABLATE"));
+		kp = &kcopy;
+	}
 	if (ev) (void)hipEventRecord(ev[0], st);
-	hipLaunchKernelGGL(xe_fwm_kernel, dim3((ntot + per_block - 1) / per_block), dim3(XE_BLOCK), 0, st, *kp, tables, ntables);
+	hipLaunchKernelGGL(xe_fwm_kernel, dim3((ntot + per_block - 1) / per_block), dim3(XE_BLOCK), fwm_lds_bytes(kwmax, nvmax), st,
+		*kp, tables, ntables, kwmax, nvmax);
 	if (ev) (void)hipEventRecord(ev[1], st);
+	if (kp->pad2 & 64) {
+		/* diagnostic: print and reset the per-phase wave cycles */
+		unsigned long long pc[8], z[8] = {0};
+		const double nw = (double)((ntot + per_block - 1) / per_block) * (XE_BLOCK / 64);
+		(void)hipStreamSynchronize(st);
+		(void)hipMemcpyFromSymbol(pc, HIP_SYMBOL(xe_fast_phase_cycles), sizeof(pc));
+		(void)hipMemcpyToSymbol(HIP_SYMBOL(xe_fast_phase_cycles), z, sizeof(z));
+		fprintf(stderr, "table kernel phase cycles per wave: mask %.0f key %.0f election %.0f block table %.0f global %.0f flush %.0f\n",
+			(double)pc[0] / nw, (double)pc[1] / nw, (double)pc[2] / nw, (double)pc[3] / nw, (double)pc[4] / nw, (double)pc[5] / nw);
+	}
 	return (hipGetLastError() == hipSuccess) ? XE_OK : XE_EHIP;
 }
 
