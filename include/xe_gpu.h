@@ -168,6 +168,19 @@ int xe_gpu_fwm_clear(xe_gpu *h, int fwm);
  * does not depend on the number of threads. */
 int xe_gpu_set_prepass_threads(xe_gpu *h, int nthreads);
 
+/* Where datagram, set and sample headers are walked (netflow.c:319-365,
+ * :628-678, :727-786; sflow-impl.h:68-405).  mode bit 0: sFlow datagrams on
+ * the device; bit 1: Netflow datagrams of the usual shape (one data set that
+ * ends with the datagram, template known before the batch, complete
+ * fixed-length records, exporter without mark rules) on the device, the others
+ * - every datagram that carries a template among them - on the host, which
+ * keeps the template store.  Default 3 (the environment's XE_DEVICE_WALK
+ * overrides it); 0 = the host walks everything.  Results do not depend on it. */
+int xe_gpu_set_device_walk(xe_gpu *h, int mode);
+/* what the device walked of a prepared batch: Netflow datagrams and their
+ * records, sFlow records (any pointer may be NULL) */
+int xe_gpu_batch_device_walked(const xe_batch *b, size_t *netflow_datagrams, size_t *netflow_records, size_t *sflow_records);
+
 /* Page-locked host memory for the datagram buffer handed to
  * xe_gpu_batch_prepare() and for result buffers: copies to and from such
  * memory run at the full speed of the link (the capture threads of the

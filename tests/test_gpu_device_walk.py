@@ -1,0 +1,254 @@
+"""Header walk on the device: batches whose templates the handle already knows
+are listed by the GPU itself (sFlow always).  Results must equal the oracle's
+and those of the host walk, whatever mixture of usual and unusual datagrams a
+batch holds, and whatever happens to the templates inside it."""
+import struct
+
+import numpy as np
+import pytest
+
+import xenoeye_amd
+from xenoeye_amd import synth
+from helpers import compare, configure, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _engines(orc, w, **kw):
+    dev = xenoeye_amd.Engine(device=0)
+    host = xenoeye_amd.Engine(device=0)
+    host.set_device_walk(0)
+    configure(dev, orc, w["iplists"], w["mos"], **kw)
+    for name, text in w["iplists"].items():
+        host.add_iplist(name, text)
+    for d in kw.get("devices", ()):
+        host.add_device(**d)
+    for filt, parent in w["mos"]:
+        host.add_mo("mo", filt, parent)
+    host.commit()
+    return dev, host
+
+
+def _is_template(p):
+    ver = struct.unpack(">H", p[:2])[0]
+    if ver == 9:
+        return struct.unpack(">H", p[20:22])[0] == 0
+    if ver == 10:
+        return struct.unpack(">H", p[16:18])[0] == 2
+    return False
+
+
+def _same(a, b):
+    assert a.records == b.records
+    assert np.array_equal(a.masks(), b.masks())
+    assert np.array_equal(a.counters(), b.counters())
+    assert np.array_equal(a.dropped(), b.dropped())
+    assert np.array_equal(a.record_datagram(), b.record_datagram())
+    if a.records:
+        assert np.array_equal(a.flow_info(), b.flow_info())
+
+
+def _round(dev, host, orc, batch, flows=True):
+    orc.log_clear()
+    a = dev.prepare(batch)
+    a.run()
+    b = host.prepare(batch)
+    b.run()
+    # the batch numbers its Netflow records before its sFlow records: the oracle
+    # sees the datagrams in that order (neither kind keeps state the other reads)
+    ordered = synth.Batch()
+    for kind in (0, 1):
+        for p, s, k in zip(batch.pkts, batch.src, batch.kind):
+            if k == kind:
+                ordered.add(p, s, k)
+    run_oracle(orc, ordered, keep_flows=flows)
+    compare(a, orc, flows=flows)
+    _same(a, b)
+    walked = a.device_walked()
+    a.free()
+    b.free()
+    return walked
+
+
+@pytest.mark.parametrize("name", ["c1", "c2", "c5"])
+def test_known_templates_are_walked_on_the_device(orc, name):
+    w = {"c1": lambda: synth.workload_c1(20000),
+         "c2": lambda: synth.workload_c2(30000, prefixes=400),
+         "c5": lambda: synth.workload_c5(40000, prefixes=300, n_exporters=64)}[name]()
+    dev, host = _engines(orc, w)
+    first = _round(dev, host, orc, w["batch"])
+    # the first batch brings the templates: its exporters are walked by the host
+    assert first[0] == 0
+    second = _round(dev, host, orc, w["batch"])
+    ndata = sum(1 for p in w["batch"].pkts if not _is_template(p))
+    assert second[0] == ndata, (second, ndata)
+    assert second[1] == w["nrec"]
+    dev.close()
+    host.close()
+
+
+def test_sflow_is_walked_on_the_device(orc):
+    w = synth.workload_c3(20000)
+    dev, host = _engines(orc, w)
+    got = _round(dev, host, orc, w["batch"])
+    assert got[2] >= 20000
+    dev.close()
+    host.close()
+
+
+def test_sflow_damaged_datagrams(orc):
+    """cut, stretched and corrupted sFlow datagrams: the same records, or none, on both walks"""
+    w = synth.workload_c3(3000, seed=77)
+    rng = synth.Rng(1234)
+    b = synth.Batch()
+    for p, s in zip(w["batch"].pkts, w["batch"].src):
+        p = bytearray(p)
+        k = int(rng.below(1, 6)[0])
+        if k == 0:
+            p = p[:int(rng.below(1, len(p))[0])]
+        elif k == 1:
+            for _ in range(3):
+                p[int(rng.below(1, len(p))[0])] = int(rng.below(1, 256)[0])
+        elif k == 2:
+            at = 4 * int(rng.below(1, len(p) // 4)[0])
+            p[at:at + 4] = struct.pack(">I", int(rng.below(1, 1 << 32)[0]))
+        elif k == 3:
+            p += bytes(rng.bytes(int(rng.below(1, 64)[0])))
+        b.add(bytes(p), s, kind=1)
+    dev, host = _engines(orc, w)
+    _round(dev, host, orc, b)
+    dev.close()
+    host.close()
+
+
+def test_mixed_kinds_and_unusual_datagrams(orc):
+    """Netflow v5 / v9 / IPFIX and sFlow interleaved; among the Netflow ones
+    template refreshes, two sets in a datagram, a count that exceeds the
+    records, trailing bytes, an unknown template: those go to the host walk,
+    the rest to the device, and every record keeps its place"""
+    w1 = synth.workload_c1(3000)
+    w2 = synth.workload_c2(4000, prefixes=200)
+    w3 = synth.workload_c3(1500)
+    rng = synth.Rng(99)
+    exp1 = bytes([192, 0, 2, 1])
+    mos = w1["mos"] + w2["mos"] + [("proto 6", -1), ("dst port 0-1023", 0)]
+    lists = dict(w1["iplists"])
+    lists.update(w2["iplists"])
+    w = dict(iplists=lists, mos=mos)
+    dev, host = _engines(orc, w)
+
+    first = synth.Batch()
+    for p, s in zip(w1["batch"].pkts[:3], w1["batch"].src[:3]):
+        first.add(p, s)
+    for p, s in zip(w2["batch"].pkts[:200], w2["batch"].src[:200]):
+        first.add(p, s)
+    first.add(synth.v5_packet(rng, 5), bytes([10, 9, 9, 9]))
+    _round(dev, host, orc, first)
+
+    second = synth.Batch()
+    streams = [list(zip(w1["batch"].pkts[1:], w1["batch"].src[1:], [0] * 10000)),
+               list(zip(w2["batch"].pkts[64:], w2["batch"].src[64:], [0] * 10000)),
+               list(zip(w3["batch"].pkts, w3["batch"].src, [1] * 10000))]
+    odd = []
+    data = w1["batch"].pkts[5]
+    # template refresh (unchanged), then data
+    odd.append((w1["batch"].pkts[0], exp1, 0))
+    # a count larger than the records of the set
+    p = bytearray(data); p[2:4] = struct.pack(">H", 70); odd.append((bytes(p), exp1, 0))
+    # a count smaller than the records
+    p = bytearray(data); p[2:4] = struct.pack(">H", 10); odd.append((bytes(p), exp1, 0))
+    # trailing bytes behind the set
+    odd.append((data + b"\xc0\xa8\x01\x01", exp1, 0))
+    # two data sets in one datagram
+    odd.append((data + data[20:], exp1, 0))
+    # a template nobody sent
+    p = bytearray(data); p[20:22] = struct.pack(">H", 999); odd.append((bytes(p), exp1, 0))
+    # cut short
+    odd.append((data[:500], exp1, 0))
+    odd.append((data[:22], exp1, 0))
+    # netflow v5, and a v5 datagram with a wrong length
+    v5 = synth.v5_packet(rng, 7)
+    odd.append((v5, bytes([10, 9, 9, 9]), 0))
+    odd.append((v5[:-3], bytes([10, 9, 9, 9]), 0))
+    odd.append((b"\x00\x07" + data[2:], exp1, 0))
+    j = 0
+    while any(streams):
+        for st in streams:
+            for _ in range(3):
+                if st:
+                    p, s, k = st.pop(0)
+                    second.add(p, s, kind=k)
+        if j < len(odd):
+            p, s, k = odd[j]
+            second.add(p, s, kind=k)
+            j += 1
+    got = _round(dev, host, orc, second)
+    assert got[0] > 100 and got[2] >= 1500
+    got2 = _round(dev, host, orc, second)
+    assert got2 == got
+    dev.close()
+    host.close()
+
+
+def test_template_change_inside_a_batch(orc):
+    """an exporter replaces its template half way through a batch whose other
+    datagrams the device has already listed with the old one: that exporter is
+    walked by the host from its first datagram on, the others stay"""
+    fields_a = synth.TMPL_V9_C1
+    fields_b = [(12, 4), (8, 4), (11, 2), (7, 2), (4, 1), (1, 4), (2, 4), (10, 4)]
+    rng = synth.Rng(5)
+    e1, e2 = bytes([192, 0, 2, 1]), bytes([192, 0, 2, 2])
+    w = synth.workload_c1(64)
+    w["mos"] = [("src net mynet", -1), ("dst net mynet", -1), ("proto 17", -1)]
+    dev, host = _engines(orc, w)
+    rec_a = synth.flow_columns(rng, 64 * 40, fields_a)
+    rec_b = synth.flow_columns(rng, 50 * 20, fields_b)
+    pk_a1 = synth.v9_data_packets(256, rec_a, 64, 77)
+    pk_a2 = synth.v9_data_packets(256, rec_a, 64, 78)
+    pk_b1 = synth.v9_data_packets(256, rec_b, 50, 77)
+
+    first = synth.Batch()
+    first.add(synth.v9_template_packet(256, fields_a, 77), e1)
+    first.add(synth.v9_template_packet(256, fields_a, 78), e2)
+    first.extend(pk_a1[:4], e1)
+    first.extend(pk_a2[:4], e2)
+    _round(dev, host, orc, first)
+
+    second = synth.Batch()
+    for i in range(10):
+        second.add(pk_a1[4 + i], e1)
+        second.add(pk_a2[4 + i], e2)
+    second.add(synth.v9_template_packet(256, fields_b, 77), e1)
+    for i in range(10):
+        second.add(pk_b1[i], e1)
+        second.add(pk_a2[14 + i], e2)
+    # the old layout again, now misread through the new template
+    second.add(pk_a1[20], e1)
+    got = _round(dev, host, orc, second)
+    assert got[0] == 20          # exporter 2 only
+    third = synth.Batch()
+    for i in range(5):
+        third.add(pk_b1[10 + i], e1)
+        third.add(pk_a2[24 + i], e2)
+    got = _round(dev, host, orc, third)
+    assert got[0] == 10
+    dev.close()
+    host.close()
+
+
+def test_devices_conf_exporters(orc):
+    """an exporter with only a sampling rate stays on the device walk, one with
+    mark filters goes to the host walk and the per-lane kernel"""
+    w = synth.workload_c5(6000, prefixes=100, n_exporters=8)
+    devices = [dict(ip="10.5.0.1", sampling_rate=100),
+               dict(ip="10.5.0.2", dev_id=2, sampling_rate=10),
+               dict(ip="10.5.0.6", sampling_rate=7, marks=["proto 6", "dst port 0-1023"]),
+               dict(dev_id=7, skip_unmarked=True, marks=["proto 17"])]
+    dev, host = _engines(orc, w, devices=devices)
+    _round(dev, host, orc, w["batch"])
+    got = _round(dev, host, orc, w["batch"])
+    n_marked = sum(1 for p, s in zip(w["batch"].pkts, w["batch"].src) if not _is_template(p) and s[3] in (6, 7))
+    n_data = sum(1 for p in w["batch"].pkts if not _is_template(p))
+    assert got[0] == n_data - n_marked
+    dev.close()
+    host.close()

@@ -60,6 +60,8 @@ def load_library(path=LIB_PATH):
         "xe_gpu_load_devices": (i32, [vp, cp]),
         "xe_gpu_commit": (i32, [vp]),
         "xe_gpu_set_prepass_threads": (i32, [vp, i32]),
+        "xe_gpu_set_device_walk": (i32, [vp, i32]),
+        "xe_gpu_batch_device_walked": (i32, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
         "xe_gpu_batch_unsupported_sets": (C.c_size_t, [vp]),
         "xe_gpu_batch_oversized_datagrams": (C.c_size_t, [vp]),
         "xe_gpu_add_fwm": (i32, [vp, i32, C.POINTER(C.c_char_p), i32, C.c_size_t]),
@@ -338,6 +340,10 @@ class Engine:
         """host threads that walk datagram headers in prepare() (1 = calling thread only)"""
         self._chk(self.L.xe_gpu_set_prepass_threads(self._h, int(n)))
 
+    def set_device_walk(self, mode):
+        """which headers the device walks itself: bit 0 sFlow, bit 1 Netflow datagrams of the usual shape"""
+        self._chk(self.L.xe_gpu_set_device_walk(self._h, int(mode)))
+
     def commit(self):
         self._chk(self.L.xe_gpu_commit(self._h))
 
@@ -468,6 +474,12 @@ class PreparedBatch:
         if count:
             self.eng._chk(self.L.xe_gpu_batch_flow_info(self._b, first, count, out.ctypes.data))
         return out
+
+    def device_walked(self):
+        """(Netflow datagrams, their records, sFlow records) whose headers the device walked"""
+        a, b, c = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        self.eng._chk(self.L.xe_gpu_batch_device_walked(self._b, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def record_datagram(self):
         """per record the index of the datagram it was decoded from"""

@@ -16,7 +16,7 @@
 
 extern "C" int xe_launch_init_tables(void);
 
-#define XE_DPOOL 48   /* device buffers a handle keeps for reuse (a batch owns 12) */
+#define XE_DPOOL 64   /* device buffers a handle keeps for reuse (a batch owns up to 15) */
 
 struct xe_gpu
 {
@@ -53,8 +53,17 @@ struct xe_gpu
 	 * "" for a port without a name): what portstr() / ppstr() compare against */
 	char **port_names;
 	uint32_t port_named_off;   /* word offset in the list tables of the "port has a name" set, 0 = none */
+	/* header walk on the device (xe_walk.hip): bit 0 sFlow, bit 1 Netflow */
+	int device_walk;
+	void *d_devkeys;           /* struct xe_devkey per devices.conf entry */
+	void *d_thash, *d_twalk;   /* the template store and the device templates as the walk reads them */
+	uint32_t thash_mask;
+	size_t twalk_n;
+	uint64_t walk_epoch;       /* hs.tmpl_epoch the two tables were built from (+ 1) */
+	void *wstage;              /* small page-locked buffer for counts coming back */
 	char err[512];
 };
+#define XE_WSTAGE_BYTES (64 * 1024)
 
 struct fwm_host
 {
@@ -66,6 +75,35 @@ struct fwm_host
 	/* the fields in the order of the entry: what the export sorts by */
 	int nfields;
 	struct { uint8_t aggr, descending; uint16_t size; } order[XE_FWM_MAX_KEY_FIELDS + XE_FWM_MAX_VALS];
+};
+
+/* what the header walk on the device leaves for one batch */
+struct walk_dev
+{
+	int mode;                  /* bit 0: the sFlow datagrams were walked on the device, bit 1: Netflow ones of the usual shape */
+	size_t n;                  /* datagrams */
+	void *arena, *tiles;       /* device allocations the pointers below are carved from */
+	uint64_t *d_offs;
+	uint32_t *d_src;
+	uint8_t *d_kinds;
+	uint32_t *d_sfcnt, *d_sfbase;
+	unsigned long long *d_total;   /* [0] sFlow records, [1] Netflow records */
+	void *d_temp; size_t temp_bytes;
+	struct xe_dgrun *d_dgruns;
+	uint8_t *d_walked;
+	uint32_t *d_hostfirst, *d_nfcnt, *d_recbase, *d_key, *d_val, *d_key2, *d_val2, *d_gtotal, *d_gruns, *d_snrec, *d_sscan;
+	struct xe_wgroup *d_groups;
+	struct xe_frun *d_fruns2;
+	struct xe_ftile *d_ftiles2;
+	uint32_t nfruns2, ntiles2, maxchunk2;
+	size_t nrec2;              /* records in those runs */
+	/* host side */
+	uint8_t *kinds2;           /* the kinds with XE_KIND_ON_DEVICE on what the host walk passes by */
+	uint8_t *h_walked;         /* per datagram: its Netflow records were listed on the device */
+	uint32_t *h_src;           /* exporter addresses (the caller's array is gone after prepare) */
+	/* fetched when somebody asks for them */
+	uint32_t *h_recbase, *h_sfbase;
+	struct xe_dgrun *h_dgruns;
 };
 
 struct xe_batch
@@ -82,6 +120,7 @@ struct xe_batch
 	int timing;              /* record events around each kernel launch */
 	hipEvent_t ev[6];
 	hipEvent_t ev_fwm[2];      /* around the fixed-window kernel */
+	struct walk_dev w;
 };
 
 #define ALIGN_UP(x, a) (((x) + (a) - 1) / (a) * (a))
@@ -166,6 +205,15 @@ xe_gpu_create(xe_gpu **out, int device)
 		free(h);
 		return XE_EHIP;
 	}
+	h->wstage = pinned_alloc(XE_WSTAGE_BYTES);
+	if (!h->wstage) {
+		(void)hipStreamDestroy(h->copy_stream);
+		xe_host_free(&h->hs);
+		free(h);
+		return XE_EHIP;
+	}
+	h->device_walk = 3;
+	if (getenv("XE_DEVICE_WALK")) h->device_walk = atoi(getenv("XE_DEVICE_WALK")) & 3;   /* diagnostic */
 	*out = h;
 	return XE_OK;
 }
@@ -204,6 +252,10 @@ xe_gpu_destroy(xe_gpu *h)
 	if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
 	for (int i = 0; i < XE_DPOOL; i++) if (h->dpool[i].p) (void)hipFree(h->dpool[i].p);
 	if (h->stage) (void)hipHostFree(h->stage);
+	pinned_free(h->wstage);
+	if (h->d_devkeys) (void)hipFree(h->d_devkeys);
+	if (h->d_thash) (void)hipFree(h->d_thash);
+	if (h->d_twalk) (void)hipFree(h->d_twalk);
 	if (h->port_names) {
 		for (int i = 0; i < 65536; i++) free(h->port_names[i]);
 		free(h->port_names);
@@ -1896,6 +1948,25 @@ xe_gpu_commit(xe_gpu *h)
 		else if (lookups.n) memcpy(h->h_probes, lookups.p, lookups.n * sizeof(struct xe_probe));
 	}
 	if (rc == XE_OK) {
+		/* devices.conf as the header walk on the device looks exporters up */
+		struct xe_devkey *dk = (struct xe_devkey *)calloc(h->hs.ndevs ? h->hs.ndevs : 1, sizeof(*dk));
+		if (!dk) rc = XE_ENOMEM;
+		for (size_t i = 0; dk && (i < h->hs.ndevs); i++) {
+			const struct xe_device *d = &h->hs.devs[i];
+			dk[i].use_ip = (uint32_t)d->use_ip;
+			dk[i].use_id = (uint32_t)d->use_id;
+			dk[i].ip = d->ip;
+			dk[i].id = d->id;
+			dk[i].rate = (uint32_t)d->sampling_rate;
+			dk[i].plain = ((d->nmarks == 0) && !d->skip_unmarked && !h->reads_mark) ? 1u : 0u;
+		}
+		if (h->d_devkeys) (void)hipFree(h->d_devkeys);
+		h->d_devkeys = NULL;
+		if (rc == XE_OK) rc = upload(h, &h->d_devkeys, dk, h->hs.ndevs * sizeof(*dk));
+		free(dk);
+		h->walk_epoch = 0;   /* which templates the fast kernel takes depends on the configuration */
+	}
+	if (rc == XE_OK) {
 		h->nmo = (uint32_t)h->hs.nmos;
 		h->mask_words = h->nmo ? (h->nmo + 63) / 64 : 1;
 		h->nprogs_total = (uint32_t)progs.n;
@@ -1934,6 +2005,386 @@ sync_templates(xe_gpu *h)
 	return XE_OK;
 }
 
+/* ------------------------------------------------------------------ header walk on the device */
+static int tmpl_fast(const xe_gpu *h, const struct xe_tmpl *t, const struct xe_tent *te);
+
+/* the template store and the device templates in the form xe_walk.hip reads,
+ * uploaded again whenever the store has changed */
+static int
+walk_tables_sync(xe_gpu *h)
+{
+	const struct xe_host *hs = &h->hs;
+	const struct xe_tmpl *tm = (const struct xe_tmpl *)hs->dev_tmpls.p;
+	const struct xe_tent *te = (const struct xe_tent *)hs->dev_tents.p;
+	size_t nt = hs->dev_tmpls.n, cap = 16, live = 0;
+	struct xe_twalk *tw;
+	struct xe_thent *th;
+	int rc;
+
+	if (h->walk_epoch == hs->tmpl_epoch + 1) return XE_OK;
+	for (size_t i = 0; i < hs->ntslots; i++) if (hs->tslots[i].raw && (hs->tslots[i].dev_slot != XE_TMPL_UNSUPPORTED)) live++;
+	while (cap < 2 * live + 2) cap <<= 1;
+	tw = (struct xe_twalk *)calloc(nt ? nt : 1, sizeof(*tw));
+	th = (struct xe_thent *)calloc(cap, sizeof(*th));
+	if (!tw || !th) { free(tw); free(th); return XE_ENOMEM; }
+	for (size_t t = 0; t < nt; t++) {
+		tw[t].stride = tm[t].stride;
+		tw[t].nfields = tm[t].nfields;
+		tw[t].off_last = tm[t].nfields ? te[tm[t].ent_base + tm[t].nfields - 1].off : 0;
+		tw[t].fast = (uint8_t)tmpl_fast(h, &tm[t], te);
+		tw[t].mode = tm[t].mode;
+	}
+	for (size_t i = 0; i < hs->ntslots; i++) {
+		const struct xe_tslot *ts = &hs->tslots[i];
+		struct xe_thent e;
+		size_t j;
+		if (!ts->raw || (ts->dev_slot == XE_TMPL_UNSUPPORTED) || (ts->raw_len < 4)) continue;
+		memset(&e, 0, sizeof(e));
+		e.ver_tid = ((uint32_t)ts->key.ver << 16) | ts->key.tid;
+		e.src_ip = ts->key.src_ip;
+		e.source_id = ts->key.source_id;
+		e.slot = ts->dev_slot;
+		e.fc = ((uint32_t)ts->raw[2] << 8) | ts->raw[3];
+		for (j = xe_thent_hash(e.ver_tid, e.src_ip, e.source_id) & (cap - 1); th[j].ver_tid; j = (j + 1) & (cap - 1)) {}
+		th[j] = e;
+	}
+	if (h->d_thash) (void)hipFree(h->d_thash);
+	if (h->d_twalk) (void)hipFree(h->d_twalk);
+	h->d_thash = h->d_twalk = NULL;
+	rc = upload(h, &h->d_thash, th, cap * sizeof(*th));
+	if (rc == XE_OK) rc = upload(h, &h->d_twalk, tw, nt * sizeof(*tw));
+	free(tw);
+	free(th);
+	if (rc != XE_OK) {
+		if (h->d_thash) (void)hipFree(h->d_thash);
+		if (h->d_twalk) (void)hipFree(h->d_twalk);
+		h->d_thash = h->d_twalk = NULL;
+		h->walk_epoch = 0;
+		return rc;
+	}
+	h->thash_mask = (uint32_t)(cap - 1);
+	h->twalk_n = nt;
+	h->walk_epoch = hs->tmpl_epoch + 1;
+	return XE_OK;
+}
+
+static void
+walk_free(xe_gpu *h, struct walk_dev *w)
+{
+	dev_put(h, w->arena);
+	dev_put(h, w->tiles);
+	free(w->kinds2);
+	free(w->h_walked);
+	free(w->h_src);
+	free(w->h_recbase);
+	free(w->h_sfbase);
+	free(w->h_dgruns);
+	memset(w, 0, sizeof(*w));
+}
+
+static void
+walk_input(const xe_gpu *h, const xe_batch *b, struct xe_walk_in *in)
+{
+	const struct walk_dev *w = &b->w;
+	memset(in, 0, sizeof(*in));
+	in->pkt = (const uint8_t *)b->d_pkt;
+	in->offs = w->d_offs;
+	in->src = w->d_src;
+	in->kinds = w->d_kinds;
+	in->n = (uint32_t)w->n;
+	in->ndevs = (uint32_t)h->hs.ndevs;
+	in->devs = (const struct xe_devkey *)h->d_devkeys;
+	in->thash = (const struct xe_thent *)h->d_thash;
+	in->thash_mask = h->thash_mask;
+	in->v5_slot_plus1 = h->hs.v5_slot_plus1;
+	in->twalk = (const struct xe_twalk *)h->d_twalk;
+	in->ntmpl = (uint32_t)h->twalk_n;
+}
+
+/* First half, before the host walk: the per-datagram arrays go to the device,
+ * the sFlow datagrams are counted, the Netflow datagrams sorted into those the
+ * device lists itself and those the host must walk (w->kinds2 tells the host
+ * walk which to pass by).  Everything is enqueued on the copy stream behind
+ * the datagram bytes. */
+static int
+walk_begin(xe_gpu *h, xe_batch *b, const uint64_t *offsets, const uint32_t *src, const uint8_t *kinds, size_t n, int mode)
+{
+	struct walk_dev *w = &b->w;
+	hipStream_t st = h->copy_stream;
+	const size_t nt = h->hs.dev_tmpls.n;
+	struct xe_walk_in in;
+	size_t off = 0;
+	uint8_t *base;
+	int rc;
+
+	w->mode = mode;
+	w->n = n;
+	if (mode & 2) {
+		rc = walk_tables_sync(h);
+		if (rc != XE_OK) return rc;
+	}
+	w->temp_bytes = xe_walk_temp_bytes(n + 1);
+#define CARVE(BYTES) (off = ALIGN_UP(off, 256), off += (BYTES), off - (BYTES))
+	const size_t o_offs = CARVE(8 * (n + 1)), o_src = CARVE(4 * n), o_kinds = CARVE(n), o_sfcnt = CARVE(4 * (n + 2)),
+		o_sfbase = CARVE(4 * (n + 2)), o_total = CARVE(16), o_temp = CARVE(w->temp_bytes);
+	size_t o_dgruns = 0, o_walked = 0, o_hostfirst = 0, o_nfcnt = 0, o_recbase = 0, o_key = 0, o_val = 0, o_key2 = 0, o_val2 = 0,
+		o_gtotal = 0, o_gruns = 0, o_snrec = 0, o_sscan = 0, o_groups = 0, o_fruns2 = 0;
+	if (mode & 2) {
+		o_dgruns = CARVE(sizeof(struct xe_dgrun) * n); o_walked = CARVE(n); o_hostfirst = CARVE(4 * (n + 2));
+		o_nfcnt = CARVE(4 * (n + 2)); o_recbase = CARVE(4 * (n + 2));
+		o_key = CARVE(4 * n); o_val = CARVE(4 * n); o_key2 = CARVE(4 * n); o_val2 = CARVE(4 * n);
+		o_gtotal = CARVE(4 * (nt + 2)); o_gruns = CARVE(4 * (nt + 2)); o_snrec = CARVE(4 * (n + 2)); o_sscan = CARVE(4 * (n + 2));
+		o_groups = CARVE(sizeof(struct xe_wgroup) * (nt + 2)); o_fruns2 = CARVE(sizeof(struct xe_frun) * (n + 1));
+	}
+#undef CARVE
+	rc = dev_get(h, &w->arena, off + 256);
+	if (rc != XE_OK) return rc;
+	base = (uint8_t *)w->arena;
+	w->d_offs = (uint64_t *)(base + o_offs);
+	w->d_src = (uint32_t *)(base + o_src);
+	w->d_kinds = kinds ? base + o_kinds : NULL;
+	w->d_sfcnt = (uint32_t *)(base + o_sfcnt);
+	w->d_sfbase = (uint32_t *)(base + o_sfbase);
+	w->d_total = (unsigned long long *)(base + o_total);
+	w->d_temp = base + o_temp;
+	if (mode & 2) {
+		w->d_dgruns = (struct xe_dgrun *)(base + o_dgruns);
+		w->d_walked = base + o_walked;
+		w->d_hostfirst = (uint32_t *)(base + o_hostfirst);
+		w->d_nfcnt = (uint32_t *)(base + o_nfcnt);
+		w->d_recbase = (uint32_t *)(base + o_recbase);
+		w->d_key = (uint32_t *)(base + o_key);
+		w->d_val = (uint32_t *)(base + o_val);
+		w->d_key2 = (uint32_t *)(base + o_key2);
+		w->d_val2 = (uint32_t *)(base + o_val2);
+		w->d_gtotal = (uint32_t *)(base + o_gtotal);
+		w->d_gruns = (uint32_t *)(base + o_gruns);
+		w->d_snrec = (uint32_t *)(base + o_snrec);
+		w->d_sscan = (uint32_t *)(base + o_sscan);
+		w->d_groups = (struct xe_wgroup *)(base + o_groups);
+		w->d_fruns2 = (struct xe_frun *)(base + o_fruns2);
+	}
+	HIPCHK(h, hipMemcpyAsync(w->d_offs, offsets, 8 * (n + 1), hipMemcpyHostToDevice, st));
+	HIPCHK(h, hipMemcpyAsync(w->d_src, src, 4 * n, hipMemcpyHostToDevice, st));
+	if (kinds) HIPCHK(h, hipMemcpyAsync(w->d_kinds, kinds, n, hipMemcpyHostToDevice, st));
+	HIPCHK(h, hipMemsetAsync(w->d_total, 0, 16, st));
+	walk_input(h, b, &in);
+	w->kinds2 = (uint8_t *)malloc(n ? n : 1);
+	w->h_src = (uint32_t *)malloc((n ? n : 1) * 4);
+	if (!w->kinds2 || !w->h_src) return XE_ENOMEM;
+	memcpy(w->h_src, src, 4 * n);
+	if (mode & 2) {
+		rc = xe_walk_nf_shape(&in, w->d_dgruns, w->d_walked, st);
+		if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (Netflow)");
+		w->h_walked = (uint8_t *)malloc(n ? n : 1);
+		if (!w->h_walked) return XE_ENOMEM;
+		HIPCHK(h, hipMemcpyAsync(w->h_walked, w->d_walked, n, hipMemcpyDeviceToHost, st));
+	}
+	if (mode & 1) {
+		rc = xe_walk_sf_count(&in, w->d_sfcnt, w->d_total, st);
+		if (rc == XE_OK) rc = xe_walk_scan(w->d_temp, w->temp_bytes, w->d_sfcnt, w->d_sfbase, n, st);
+		if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (sFlow)");
+		HIPCHK(h, hipMemcpyAsync(h->wstage, w->d_total, 8, hipMemcpyDeviceToHost, st));
+	}
+	/* the host walk needs the verdict on the Netflow datagrams; with only sFlow
+	 * on the device it starts at once and the device counts beside it */
+	if (mode & 2) HIPCHK(h, hipStreamSynchronize(st));
+	for (size_t i = 0; i < n; i++) {
+		uint8_t k = kinds ? kinds[i] : (uint8_t)XE_KIND_NETFLOW;
+		if (k == XE_KIND_SFLOW) { if (mode & 1) k |= XE_KIND_ON_DEVICE; }
+		else if ((mode & 2) && w->h_walked[i]) k |= XE_KIND_ON_DEVICE;
+		w->kinds2[i] = k;
+	}
+	return XE_OK;
+}
+
+/* The host walk over what the device left it, with the template changes of
+ * the batch logged: Netflow datagrams the device listed were decided with the
+ * templates known when the batch began, so an exporter whose templates change
+ * inside the batch is walked by the host from its first datagram on (the store
+ * is put back to where it was and the walk repeated). */
+static int
+walk_host_part(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets, const uint32_t *src, size_t n)
+{
+	struct walk_dev *w = &b->w;
+	int rc;
+
+	if (!(w->mode & 2)) return xe_prepass(&h->hs, data, offsets, src, w->kinds2, n, &b->plan);
+	rc = xe_prepass(&h->hs, data, offsets, src, w->kinds2, n, &b->plan);
+	if ((rc == XE_OK) && xe_host_undo_count(&h->hs)) {
+		const size_t nu = xe_host_undo_count(&h->hs);
+		uint32_t *ips = (uint32_t *)malloc(nu * 4);
+		size_t nips = 0, changed = 0;
+		if (!ips) { xe_plan_free(&b->plan); return XE_ENOMEM; }
+		for (size_t i = 0; i < nu; i++) {
+			const uint32_t ip = xe_host_undo_src_ip(&h->hs, i);
+			size_t j;
+			for (j = 0; (j < nips) && (ips[j] != ip); j++) {}
+			if (j == nips) ips[nips++] = ip;
+		}
+		for (size_t i = 0; i < n; i++) {
+			if (!w->h_walked[i]) continue;
+			for (size_t j = 0; j < nips; j++) {
+				if (ips[j] == src[i]) {
+					w->h_walked[i] = 0;
+					w->kinds2[i] &= (uint8_t)~XE_KIND_ON_DEVICE;
+					changed++;
+					break;
+				}
+			}
+		}
+		free(ips);
+		if (changed) {
+			hipError_t e;
+			xe_host_undo_rollback(&h->hs);
+			xe_plan_free(&b->plan);
+			rc = xe_prepass(&h->hs, data, offsets, src, w->kinds2, n, &b->plan);
+			e = hipMemcpyAsync(w->d_walked, w->h_walked, n, hipMemcpyHostToDevice, h->copy_stream);
+			if ((rc == XE_OK) && (e != hipSuccess)) { xe_plan_free(&b->plan); rc = hip_fail(h, e, "hipMemcpyAsync(walked)"); }
+		}
+	}
+	return rc;
+}
+
+#define XE_WALK_RETRY_ON_HOST 1   /* walk_finish(): the batch needs the host walk for everything */
+
+/* Second half, after the host walk: record indices in arrival order over both
+ * walks, the sFlow element descriptors, the run and tile tables of the
+ * Netflow datagrams the device listed. */
+static int
+walk_finish(xe_gpu *h, xe_batch *b)
+{
+	struct walk_dev *w = &b->w;
+	struct xe_plan *plan = &b->plan;
+	hipStream_t st = h->copy_stream;
+	const size_t n = w->n, nt = h->twalk_n;
+	struct xe_walk_in in;
+	int rc;
+
+	walk_input(h, b, &in);
+	if (w->mode & 1) {
+		unsigned long long nsf;
+		HIPCHK(h, hipStreamSynchronize(st));
+		nsf = *(volatile unsigned long long *)h->wstage;
+		if (nsf + plan->nrec > 0xFFFFFFF0ull) return XE_EUNSUPPORTED;
+		rc = dev_get(h, &b->d_sfrecs, (size_t)nsf * sizeof(struct xe_sfrec));
+		if (rc != XE_OK) return rc;
+		rc = xe_walk_sf_emit(&in, w->d_sfbase, (struct xe_sfrec *)b->d_sfrecs, st);
+		if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (sFlow elements)");
+		plan->nsf = (size_t)nsf;
+	}
+	if (w->mode & 2) {
+		uint32_t *cnt = (uint32_t *)h->wstage;   /* [0, nt) records, [nt, 2 nt) runs per template, then the total */
+		struct xe_wgroup *gr;
+		const struct xe_tmpl *tm = (const struct xe_tmpl *)h->hs.dev_tmpls.p;
+		uint64_t total, dev_total = 0, work = 0, nruns = 0, ntiles = 0;
+		unsigned bits = 1, ngroups = 0;
+
+		if ((2 * nt + 4) * 4 + 16 > XE_WSTAGE_BYTES) return XE_WALK_RETRY_ON_HOST;
+		if (plan->nrec) HIPCHK(h, hipMemcpyAsync(w->d_hostfirst, plan->dg_first_nf, 4 * (n + 1), hipMemcpyHostToDevice, st));
+		else HIPCHK(h, hipMemsetAsync(w->d_hostfirst, 0, 4 * (n + 1), st));
+		HIPCHK(h, hipMemsetAsync(w->d_gtotal, 0, 4 * (nt + 2), st));
+		HIPCHK(h, hipMemsetAsync(w->d_gruns, 0, 4 * (nt + 2), st));
+		rc = xe_walk_nf_counts(&in, w->d_dgruns, w->d_walked, w->d_hostfirst, w->d_nfcnt, w->d_key, w->d_val,
+			w->d_gtotal, w->d_gruns, w->d_total + 1, st);
+		if (rc == XE_OK) rc = xe_walk_scan(w->d_temp, w->temp_bytes, w->d_nfcnt, w->d_recbase, n, st);
+		while ((1ull << bits) < nt + 1) bits++;
+		if (rc == XE_OK) rc = xe_walk_sort(w->d_temp, w->temp_bytes, w->d_key, w->d_key2, w->d_val, w->d_val2, n, bits, st);
+		if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (record indices)");
+		HIPCHK(h, hipMemcpyAsync(cnt, w->d_gtotal, 4 * nt, hipMemcpyDeviceToHost, st));
+		HIPCHK(h, hipMemcpyAsync(cnt + nt, w->d_gruns, 4 * nt, hipMemcpyDeviceToHost, st));
+		HIPCHK(h, hipMemcpyAsync(cnt + 2 * nt + 2, w->d_total + 1, 8, hipMemcpyDeviceToHost, st));
+		HIPCHK(h, hipStreamSynchronize(st));
+		memcpy(&total, cnt + 2 * nt + 2, 8);
+		if (total + plan->nsf > 0xFFFFFFF0ull) return XE_EUNSUPPORTED;
+		/* from 2^28 records on the fast kernel is out (32-bit column offsets) */
+		if (total + plan->nsf >= (1ull << 28)) return XE_WALK_RETRY_ON_HOST;
+		gr = (struct xe_wgroup *)malloc((nt + 2) * sizeof(*gr));
+		if (!gr) return XE_ENOMEM;
+		w->maxchunk2 = 1;
+		for (size_t t = 0; t < nt; t++) {
+			gr[t].pos0 = (uint32_t)work;
+			gr[t].run0 = (uint32_t)nruns;
+			gr[t].tile0 = (uint32_t)ntiles;
+			gr[t].pad = 0;
+			if (!cnt[nt + t]) continue;
+			ngroups++;
+			dev_total += cnt[t];
+			work += ((uint64_t)cnt[t] + 63) / 64 * 64;
+			nruns += cnt[nt + t];
+			ntiles = work / 64;
+			if (((uint32_t)tm[t].stride + 15) / 16 > w->maxchunk2) w->maxchunk2 = ((uint32_t)tm[t].stride + 15) / 16;
+			if (!xe_plan_note_template(plan, &h->hs, (uint32_t)t, cnt[t])) { free(gr); return XE_ENOMEM; }
+		}
+		gr[nt].pos0 = (uint32_t)work;
+		gr[nt].run0 = (uint32_t)nruns;
+		gr[nt].tile0 = (uint32_t)ntiles;
+		gr[nt].pad = 0;
+		if (work > 0xFFFFFF00ull) { free(gr); return XE_WALK_RETRY_ON_HOST; }
+		w->nfruns2 = (uint32_t)nruns;
+		w->ntiles2 = (uint32_t)ntiles;
+		if (nruns) {
+			hipError_t e = hipMemcpyAsync(w->d_groups, gr, (nt + 1) * sizeof(*gr), hipMemcpyHostToDevice, st);
+			/* (pageable source: the copy has left `gr` when the call returns) */
+			free(gr);
+			if (e != hipSuccess) return hip_fail(h, e, "hipMemcpyAsync(groups)");
+			rc = xe_walk_nf_gather(w->d_dgruns, w->d_val2, w->nfruns2, w->d_snrec, st);
+			if (rc == XE_OK) rc = xe_walk_scan(w->d_temp, w->temp_bytes, w->d_snrec, w->d_sscan, w->nfruns2, st);
+			if (rc == XE_OK) rc = xe_walk_nf_runs(&in, w->d_dgruns, w->d_val2, w->d_key2, w->d_sscan, w->d_recbase, w->d_groups,
+				w->nfruns2, w->d_fruns2, st);
+			if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (runs)");
+			{
+				/* tiles, then (several templates) the tile list in the order of the
+				 * batch index of each tile's first record */
+				const size_t nti = w->ntiles2, tb = xe_walk_temp_bytes(nti);
+				size_t off = 0;
+				uint8_t *tbase;
+				const size_t o_a = off; off += ALIGN_UP(16 * nti, 256);
+				const size_t o_b = off; off += ALIGN_UP(16 * nti, 256);
+				const size_t o_k = off; off += ALIGN_UP(4 * nti, 256);
+				const size_t o_v = off; off += ALIGN_UP(4 * nti, 256);
+				const size_t o_k2 = off; off += ALIGN_UP(4 * nti, 256);
+				const size_t o_v2 = off; off += ALIGN_UP(4 * nti, 256);
+				const size_t o_t = off; off += tb;
+				rc = dev_get(h, &w->tiles, off);
+				if (rc != XE_OK) return rc;
+				tbase = (uint8_t *)w->tiles;
+				rc = xe_walk_nf_tiles(w->d_fruns2, w->d_groups, (uint32_t)nt, w->ntiles2, (struct xe_ftile *)(tbase + o_a),
+					(uint32_t *)(tbase + o_k), (uint32_t *)(tbase + o_v), st);
+				w->d_ftiles2 = (struct xe_ftile *)(tbase + o_a);
+				if ((rc == XE_OK) && (ngroups > 1)) {
+					rc = xe_walk_sort(tbase + o_t, tb, (uint32_t *)(tbase + o_k), (uint32_t *)(tbase + o_k2),
+						(uint32_t *)(tbase + o_v), (uint32_t *)(tbase + o_v2), nti, 32, st);
+					if (rc == XE_OK) rc = xe_walk_nf_tiles_place((struct xe_ftile *)(tbase + o_a), (uint32_t *)(tbase + o_v2),
+						w->ntiles2, (struct xe_ftile *)(tbase + o_b), st);
+					w->d_ftiles2 = (struct xe_ftile *)(tbase + o_b);
+				}
+				if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (tiles)");
+			}
+		} else {
+			free(gr);
+		}
+		/* the host walk numbered its records among themselves: move them to
+		 * their places in arrival order over all datagrams */
+		if (plan->sets.n) {
+			struct xe_set *sets = (struct xe_set *)plan->sets.p;
+			size_t k = 0;
+			w->h_recbase = (uint32_t *)malloc(4 * (n + 1));
+			if (!w->h_recbase) return XE_ENOMEM;
+			HIPCHK(h, hipMemcpy(w->h_recbase, w->d_recbase, 4 * (n + 1), hipMemcpyDeviceToHost));
+			for (size_t i = 0; (i < n) && (k < plan->sets.n); i++) {
+				while ((k < plan->sets.n) && (sets[k].first_rec < plan->dg_first_nf[i + 1])) {
+					sets[k].first_rec = w->h_recbase[i] + (sets[k].first_rec - plan->dg_first_nf[i]);
+					k++;
+				}
+			}
+		}
+		w->nrec2 = (size_t)dev_total;
+		plan->nrec = (size_t)total;
+	}
+	return XE_OK;
+}
+
 extern "C" void
 xe_gpu_batch_free(xe_batch *b)
 {
@@ -1952,6 +2403,7 @@ xe_gpu_batch_free(xe_batch *b)
 			b->d_fplans, b->d_fops, b->d_fflds };
 		for (size_t i = 0; i < sizeof(extra) / sizeof(extra[0]); i++) dev_put(b->h, extra[i]);
 	}
+	walk_free(b->h, &b->w);
 	xe_plan_free(&b->plan);
 	free(b);
 }
@@ -1962,6 +2414,27 @@ xe_gpu_batch_free(xe_batch *b)
  * exporter has no devices.conf entry.  Regular runs are grouped by template
  * (stable, so arrival order is kept inside a group) and each group is padded
  * to whole 64-record tiles: a wave then works on one template only. */
+/* can the fast kernel decode records of this template (fixed length, no
+ * repeated, string or over-long element, staging fits the LDS)? */
+static int
+tmpl_fast(const xe_gpu *h, const struct xe_tmpl *t, const struct xe_tent *te)
+{
+	/* a block stages 4 tiles of 64 records in LDS, beside the counters and
+	 * the atom-table copy: long records only while all of it fits */
+	const size_t cnt_bytes = (h->hs.nmos <= XE_MAX_LDS_COUNTER_MOS) ? h->hs.nmos * 24 : 0;
+	const size_t motab_bytes = (h->motab_words * 8 <= 8192 + 64) ? h->motab_words * 8 : 0;
+	const size_t stage_bytes = (size_t)4 * 64 * 4 * (4 * (((size_t)t->stride + 15) / 16) + 1);
+	int ok = h->fast_ok && !t->varlen && !t->repeats
+		&& (t->stride > 0) && (t->stride <= XE_FAST_MAX_STRIDE)
+		&& (stage_bytes + cnt_bytes + motab_bytes <= XE_FAST_LDS_BUDGET);
+	for (uint32_t j = 0; ok && (j < t->nfields); j++) {
+		const struct xe_tent *e = &te[t->ent_base + j];
+		if ((e->field != XE_F_NONE) && (e->flags & XE_TE_STR)) ok = 0;
+		if (((e->len > 16) || (e->len == 0)) && (e->flags & XE_TE_VALID) && (e->field != XE_F_NONE)) ok = 0;
+	}
+	return ok;
+}
+
 static int
 ftile_cmp(const void *a, const void *b)
 {
@@ -1999,22 +2472,7 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 	gcount = (uint64_t *)calloc(nt + 1, sizeof(uint64_t));
 	gpos = (uint64_t *)calloc(nt + 1, sizeof(uint64_t));
 	if (!tfast || !is_fast || !gcount || !gpos) goto out;
-	for (i = 0; i < nt; i++) {
-		/* a block stages 4 tiles of 64 records in LDS, beside the counters and
-		 * the atom-table copy: long records only while all of it fits */
-		const size_t motab_bytes = (h->motab_words * 8 <= 8192 + 64) ? h->motab_words * 8 : 0;
-		const size_t stage_bytes = (size_t)4 * 64 * 4 * (4 * (((size_t)tm[i].stride + 15) / 16) + 1);
-		int ok = h->fast_ok && small && !tm[i].varlen && !tm[i].repeats
-			&& (tm[i].stride > 0) && (tm[i].stride <= XE_FAST_MAX_STRIDE)
-			&& (stage_bytes + cnt_bytes + motab_bytes <= XE_FAST_LDS_BUDGET);
-		for (uint32_t j = 0; ok && (j < tm[i].nfields); j++) {
-			if ((te[tm[i].ent_base + j].field != XE_F_NONE) && (te[tm[i].ent_base + j].flags & XE_TE_STR)) ok = 0;
-			if (((te[tm[i].ent_base + j].len > 16) || (te[tm[i].ent_base + j].len == 0))
-				&& (te[tm[i].ent_base + j].flags & XE_TE_VALID)
-				&& (te[tm[i].ent_base + j].field != XE_F_NONE)) ok = 0;
-		}
-		tfast[i] = (uint8_t)ok;
-	}
+	for (i = 0; i < nt; i++) tfast[i] = (uint8_t)(small && tmpl_fast(h, &tm[i], te));
 	for (i = 0; i < ns; i++) {
 		/* an exporter with a devices.conf entry that only sets the sampling rate
 		 * (no mark filters, nothing dropped) needs no per-record rule check */
@@ -2199,9 +2657,45 @@ out:
 	return rc;
 }
 
+static int
+prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint32_t *src_ip4,
+	const uint8_t *kinds, size_t n, xe_batch **out, int walk_mode);
+
 extern "C" int
 xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint32_t *src_ip4,
 	const uint8_t *kinds, size_t n, xe_batch **out)
+{
+	int rc;
+	if (!h) return XE_EINVAL;
+	rc = prepare_impl(h, data, offsets, src_ip4, kinds, n, out, h->device_walk);
+	/* a batch the device walk cannot take (2^28 records and more) */
+	if (rc == XE_WALK_RETRY_ON_HOST) rc = prepare_impl(h, data, offsets, src_ip4, kinds, n, out, 0);
+	return rc;
+}
+
+extern "C" int
+xe_gpu_batch_device_walked(const xe_batch *b, size_t *netflow_datagrams, size_t *netflow_records, size_t *sflow_records)
+{
+	size_t nd = 0;
+	if (!b) return XE_EINVAL;
+	if (b->w.mode & 2) for (size_t i = 0; i < b->w.n; i++) nd += b->w.h_walked[i] ? 1 : 0;
+	if (netflow_datagrams) *netflow_datagrams = nd;
+	if (netflow_records) *netflow_records = b->w.nrec2;
+	if (sflow_records) *sflow_records = (b->w.mode & 1) ? b->plan.nsf : 0;
+	return XE_OK;
+}
+
+extern "C" int
+xe_gpu_set_device_walk(xe_gpu *h, int mode)
+{
+	if (!h || (mode < 0) || (mode > 3)) return XE_EINVAL;
+	h->device_walk = mode;
+	return XE_OK;
+}
+
+static int
+prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint32_t *src_ip4,
+	const uint8_t *kinds, size_t n, xe_batch **out, int walk_mode)
 {
 	xe_batch *b;
 	int rc;
@@ -2242,30 +2736,67 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 		}
 	}
 	XE_TICK();
-	rc = xe_prepass(&h->hs, data, offsets, src_ip4, kinds, n, &b->plan);
+	/* which headers the device walks itself: all sFlow datagrams; Netflow ones
+	 * while the fast kernel is in use at all (its 32-bit packet offsets, no
+	 * diagnostic override of its shape) */
+	{
+		int has_sf = 0, has_nf = 0;
+		for (size_t i = 0; i < n; i++) {
+			if (kinds && (kinds[i] == XE_KIND_SFLOW)) has_sf = 1; else has_nf = 1;
+		}
+		if (!has_sf) walk_mode &= ~1;
+		if (!has_nf || !h->fast_ok || ((total + 64) >= 0xFFFF0000ull) || getenv("XE_FORCE_GENERAL") || getenv("XE_FAST_R")) walk_mode &= ~2;
+		if (n >= 0x7FFFFFF0ull) walk_mode = 0;
+	}
+	if (walk_mode) {
+		rc = walk_begin(h, b, offsets, src_ip4, kinds, n, walk_mode);
+		if (rc != XE_OK) { (void)hipStreamSynchronize(h->copy_stream); xe_gpu_batch_free(b); return rc; }
+		if (walk_mode & 2) xe_host_undo_begin(&h->hs);
+		rc = walk_host_part(h, b, data, offsets, src_ip4, n);
+	} else {
+		rc = xe_prepass(&h->hs, data, offsets, src_ip4, kinds, n, &b->plan);
+	}
 	XE_TICK();
 	if (rc != XE_OK) {
 		snprintf(h->err, sizeof(h->err), "pre-pass failed: %s%s", xe_gpu_strerror(rc),
 			(rc == XE_EUNSUPPORTED) ? " (the batch would hold more than 2^32 records: prepare fewer datagrams at a time)" : "");
+		if (walk_mode & 2) xe_host_undo_end(&h->hs);
 		(void)hipStreamSynchronize(h->copy_stream);
 		dev_put(h, b->d_pkt);
+		walk_free(h, &b->w);
 		free(b);
 		return rc;
 	}
 	rc = sync_templates(h);
+	if ((rc == XE_OK) && walk_mode) {
+		rc = walk_finish(h, b);
+		/* the whole batch goes to the host walk: with the template store as it
+		 * was when the batch came in */
+		if ((rc == XE_WALK_RETRY_ON_HOST) && (walk_mode & 2)) xe_host_undo_rollback(&h->hs);
+		if (rc == XE_EUNSUPPORTED) snprintf(h->err, sizeof(h->err),
+			"the batch would hold more than 2^32 records: prepare fewer datagrams at a time");
+	}
+	if (walk_mode & 2) xe_host_undo_end(&h->hs);
 	if (rc != XE_OK) { (void)hipStreamSynchronize(h->copy_stream); xe_gpu_batch_free(b); return rc; }
 	b->ntot = b->plan.nrec + b->plan.nsf;
 	XE_TICK();
 	/* (the sets themselves stay on the host: the kernels read the run lists
 	 * build_work_lists() makes of them) */
 	rc = upload_pooled(h, &b->d_exps, b->plan.exporters.p, b->plan.exporters.n * sizeof(struct xe_exporter));
-	if (rc == XE_OK) rc = upload_pooled(h, &b->d_sfrecs, b->plan.sfrecs.p, b->plan.sfrecs.n * sizeof(struct xe_sfrec));
+	if ((rc == XE_OK) && !(b->w.mode & 1)) rc = upload_pooled(h, &b->d_sfrecs, b->plan.sfrecs.p, b->plan.sfrecs.n * sizeof(struct xe_sfrec));
 	if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
 
 	memset(&b->kp, 0, sizeof(b->kp));
 	XE_TICK();
 	rc = build_work_lists(h, b, total);
 	if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
+	if (b->w.ntiles2) {
+		b->kp.fruns2 = b->w.d_fruns2;
+		b->kp.ftiles2 = b->w.d_ftiles2;
+		b->kp.nfruns2 = b->w.nfruns2;
+		b->kp.ntiles2 = b->w.ntiles2;
+		if (4 * b->w.maxchunk2 + 1 > b->kp.fast_dwords) b->kp.fast_dwords = 4 * b->w.maxchunk2 + 1;
+	}
 	XE_TICK();
 
 	/* output layout */
@@ -2592,16 +3123,51 @@ xe_gpu_batch_dropped(xe_batch *b, uint8_t *dropped, size_t n)
 	return rc;
 }
 
+/* per-datagram results of the header walk on the device, fetched when a caller
+ * asks for something that needs them: what: 1 = first Netflow record of every
+ * datagram, 2 = first sFlow record, 4 = the runs */
+static int
+walk_fetch(xe_batch *b, int what)
+{
+	struct walk_dev *w = &b->w;
+	xe_gpu *h = b->h;
+	const size_t n = w->n;
+
+	HIPCHK(h, hipSetDevice(h->device));
+	if ((what & 1) && (w->mode & 2) && !w->h_recbase) {
+		w->h_recbase = (uint32_t *)malloc(4 * (n + 1));
+		if (!w->h_recbase) return XE_ENOMEM;
+		HIPCHK(h, hipMemcpy(w->h_recbase, w->d_recbase, 4 * (n + 1), hipMemcpyDeviceToHost));
+	}
+	if ((what & 2) && (w->mode & 1) && !w->h_sfbase) {
+		w->h_sfbase = (uint32_t *)malloc(4 * (n + 1));
+		if (!w->h_sfbase) return XE_ENOMEM;
+		HIPCHK(h, hipMemcpy(w->h_sfbase, w->d_sfbase, 4 * (n + 1), hipMemcpyDeviceToHost));
+	}
+	if ((what & 4) && (w->mode & 2) && !w->h_dgruns) {
+		w->h_dgruns = (struct xe_dgrun *)malloc(sizeof(struct xe_dgrun) * (n ? n : 1));
+		if (!w->h_dgruns) return XE_ENOMEM;
+		HIPCHK(h, hipMemcpy(w->h_dgruns, w->d_dgruns, sizeof(struct xe_dgrun) * n, hipMemcpyDeviceToHost));
+	}
+	return XE_OK;
+}
+
 extern "C" int
 xe_gpu_batch_record_datagram(xe_batch *b, uint32_t *dgram, size_t n)
 {
 	const struct xe_plan *p;
+	const uint32_t *nf_first, *sf_first;
+	int rc;
 
 	if (!b || (n < b->ntot) || (b->ntot && !dgram)) return XE_EINVAL;
 	p = &b->plan;
+	rc = walk_fetch(b, 3);
+	if (rc != XE_OK) return rc;
+	nf_first = (b->w.mode & 2) ? b->w.h_recbase : p->dg_first_nf;
+	sf_first = (b->w.mode & 1) ? b->w.h_sfbase : p->dg_first_sf;
 	for (size_t i = 0; i < p->ndg; i++) {
-		for (uint32_t r = p->dg_first_nf[i]; r < p->dg_first_nf[i + 1]; r++) dgram[r] = (uint32_t)i;
-		for (uint32_t r = p->dg_first_sf[i]; r < p->dg_first_sf[i + 1]; r++) dgram[p->nrec + r] = (uint32_t)i;
+		for (uint32_t r = nf_first[i]; r < nf_first[i + 1]; r++) dgram[r] = (uint32_t)i;
+		for (uint32_t r = sf_first[i]; r < sf_first[i + 1]; r++) dgram[p->nrec + r] = (uint32_t)i;
 	}
 	return XE_OK;
 }
@@ -2680,8 +3246,10 @@ xe_gpu_batch_flow_info(xe_batch *b, size_t first, size_t count, void *out)
 	const struct xe_tent *te;
 	const struct xe_exporter *ex;
 	const struct xe_sfrec *sf;
+	struct xe_sfrec *sf_slice = NULL;   /* element descriptors that exist on the device only */
+	size_t sf_slice_first = 0;
 	int rc = XE_OK;
-	size_t si = 0;
+	size_t si = 0, di = 0;
 
 	if (!b || !out || (first + count > b->ntot)) return XE_EINVAL;
 	if (!count) return XE_OK;
@@ -2708,6 +3276,26 @@ xe_gpu_batch_flow_info(xe_batch *b, size_t first, size_t count, void *out)
 		if (!s.sfhas) { rc = XE_ENOMEM; goto done; }
 		rc = fetch(b, s.sfhas + (b->plan.nrec + sf_first - first), b->sfhas_off + sf_first * 4, sf_count * 4);
 		if (rc != XE_OK) goto done;
+		if (b->w.mode & 1) {
+			sf_slice = (struct xe_sfrec *)malloc((sf_count + 1) * sizeof(struct xe_sfrec));
+			if (!sf_slice) { rc = XE_ENOMEM; goto done; }
+			if (hipMemcpy(sf_slice, (const struct xe_sfrec *)b->d_sfrecs + sf_first, sf_count * sizeof(struct xe_sfrec),
+				hipMemcpyDeviceToHost) != hipSuccess) { rc = hip_fail(h, hipGetLastError(), "hipMemcpy(sFlow elements)"); goto done; }
+			sf_slice_first = sf_first;
+		}
+	}
+	if ((b->w.mode & 2) && (first < b->plan.nrec)) {
+		rc = walk_fetch(b, 5);
+		if (rc != XE_OK) goto done;
+		/* the datagram of record `first`: the last one that starts at or before it */
+		{
+			size_t lo = 0, hi = b->w.n;
+			while (lo + 1 < hi) {
+				size_t mid = (lo + hi) / 2;
+				if (b->w.h_recbase[mid] <= first) lo = mid; else hi = mid;
+			}
+			di = lo;
+		}
 	}
 
 	sets = (const struct xe_set *)b->plan.sets.p;
@@ -2716,7 +3304,7 @@ xe_gpu_batch_flow_info(xe_batch *b, size_t first, size_t count, void *out)
 	ex = (const struct xe_exporter *)b->plan.exporters.p;
 	sf = (const struct xe_sfrec *)b->plan.sfrecs.p;
 
-	if (first < b->plan.nrec) {
+	if ((first < b->plan.nrec) && b->plan.sets.n) {
 		size_t lo = 0, hi = b->plan.sets.n - 1;
 		while (lo < hi) {
 			size_t mid = (lo + hi + 1) / 2;
@@ -2734,11 +3322,30 @@ xe_gpu_batch_flow_info(xe_batch *b, size_t first, size_t count, void *out)
 			const struct xe_tmpl *t;
 			const struct xe_tent *en;
 			uint32_t np = s.nparsed[k];
+			struct xe_exporter from_dev;
+			int on_dev = 0;
 
-			while (r >= (size_t)sets[si].first_rec + sets[si].nrec) si++;
-			t = &tm[sets[si].tmpl];
+			if (b->w.mode & 2) {
+				while (r >= b->w.h_recbase[di + 1]) di++;
+				on_dev = b->w.h_walked[di];
+			}
+			if (on_dev) {
+				/* a datagram the device listed: template, source id and sampling
+				 * rate are in its run, the exporter address came with the datagram */
+				const struct xe_dgrun *g = &b->w.h_dgruns[di];
+				const uint32_t idb = htonl(g->dev_id);
+				t = &tm[g->tmpl];
+				memcpy(from_dev.dev_ip, &b->w.h_src[di], 4);
+				memcpy(from_dev.dev_id, &idb, 4);
+				from_dev.sampling_rate = g->rate & 0x7FFFFFFFu;
+				from_dev.device = -1;
+				e = &from_dev;
+			} else {
+				while (r >= (size_t)sets[si].first_rec + sets[si].nrec) si++;
+				t = &tm[sets[si].tmpl];
+				e = &ex[sets[si].exporter];
+			}
 			en = &te[t->ent_base];
-			e = &ex[sets[si].exporter];
 			if (np > t->nfields) np = t->nfields;   /* never trust a count beyond the template */
 			for (uint32_t j = 0; j < np; j++) {
 				int f = en[j].field;
@@ -2757,7 +3364,7 @@ xe_gpu_batch_flow_info(xe_batch *b, size_t first, size_t count, void *out)
 			put_field(fi, XF_dev_id, e->dev_id, 4);
 			rate = e->sampling_rate;
 		} else {
-			const struct xe_sfrec *q = &sf[r - b->plan.nrec];
+			const struct xe_sfrec *q = sf_slice ? &sf_slice[r - b->plan.nrec - sf_slice_first] : &sf[r - b->plan.nrec];
 			uint32_t hb = s.sfhas[k];
 			static const int order[] = { XF_in_bytes, XF_in_pkts, XF_protocol, XF_src_tos, XF_dst_tos,
 				XF_tcp_flags, XF_l4_src_port, XF_ip4_src_addr, XF_input_snmp, XF_l4_dst_port,
@@ -2783,6 +3390,7 @@ xe_gpu_batch_flow_info(xe_batch *b, size_t first, size_t count, void *out)
 	}
 done:
 	slice_free(&s);
+	free(sf_slice);
 	return rc;
 #undef GRAB
 }

@@ -482,8 +482,20 @@ struct xe_host
 	 * supplies page-locked memory so that the plan travels at link speed */
 	void *(*big_alloc)(size_t bytes);
 	void (*big_free)(void *p);
+	/* counts every change of the template store (what the device's copy of
+	 * it is compared with) */
+	uint64_t tmpl_epoch;
+	/* log of the changes since xe_host_undo_begin() */
+	int undo_on;
+	struct xe_blob undo;        /* struct xe_tundo */
 	char err[512];
 };
+struct xe_tundo { uint32_t slot; uint32_t dev_slot; uint8_t *raw; size_t raw_len; };
+void xe_host_undo_begin(struct xe_host *hs);
+size_t xe_host_undo_count(const struct xe_host *hs);
+uint32_t xe_host_undo_src_ip(const struct xe_host *hs, size_t i);   /* exporter address of change i */
+void xe_host_undo_rollback(struct xe_host *hs);
+void xe_host_undo_end(struct xe_host *hs);
 
 void xe_host_init(struct xe_host *hs);
 void xe_host_free(struct xe_host *hs);
@@ -517,6 +529,9 @@ struct xe_plan
 };
 struct xe_tinfo { uint64_t mask[2]; uint32_t width; uint32_t known; };
 
+/* internal flag on a datagram's kind: the device walks it, the host walk passes it by */
+#define XE_KIND_ON_DEVICE 0x80
+int xe_plan_note_template(struct xe_plan *plan, const struct xe_host *hs, uint32_t tmpl, size_t nrec);
 int xe_prepass(struct xe_host *hs, const uint8_t *data, const uint64_t *offs, const uint32_t *src,
 	const uint8_t *kinds, size_t n, struct xe_plan *plan);
 void xe_plan_free(struct xe_plan *p);

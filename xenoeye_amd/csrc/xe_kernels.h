@@ -104,6 +104,11 @@ struct xe_kparams
 	uint32_t nprobes, pad2;
 	uint32_t lds_counters;       /* per-block counter staging fits in LDS */
 	uint32_t port_named_off;     /* word offset in `trie` of the 65536-bit set of ports with a service name, 0 = none */
+	/* a second run / tile table pair for the fast kernel: what the header walk
+	 * on the device listed (the first pair is the host walk's) */
+	const struct xe_frun *fruns2;
+	const struct xe_ftile *ftiles2;
+	uint32_t nfruns2, ntiles2;
 };
 
 #define XE_MAX_FAST_TERMS 256
@@ -151,6 +156,120 @@ int xe_launch_trie_probe(const uint32_t *trie, struct xe_list_dev list, int fami
  * XE_GPU_NOALLOC_MAX_ADDRS addresses); addrs / out are host memory */
 int xe_launch_trie_probe_static(int device, const uint32_t *trie, struct xe_list_dev list, int family,
 	const uint8_t *addrs, uint32_t n, uint8_t *out, void *stream);
+#ifdef __cplusplus
+}
+#endif
+
+/* ------------------------------------------------------------------ header walk on the device
+ * The walk over datagram, set and sample headers (netflow.c:319-365, :628-678,
+ * :727-786; sflow-impl.h:68-405) for datagrams that carry no template: one
+ * thread per datagram.  sFlow datagrams keep no state from one to the next, so
+ * all of them are walked here.  Of the Netflow datagrams those of the usual
+ * shape are (one data set that ends with the datagram, of a template the
+ * handle already knows, fixed-length records, all of them complete); anything
+ * else - template sets, several sets, cut-short records, unknown templates,
+ * exporters with mark rules - is left to the host walk, which keeps the
+ * template store. */
+
+/* devices.conf entry as device_find() tests it (devices.c:205-232) */
+struct xe_devkey
+{
+	uint32_t use_ip, use_id, ip, id;   /* ip: bytes as stored; id: htonl(value) */
+	uint32_t rate;
+	uint32_t plain;                    /* no mark filters, nothing dropped */
+	uint32_t pad[2];
+};
+
+/* template store entry for the device: open addressing over `cap` entries
+ * (a power of two), ver == 0 marks a free entry */
+struct xe_thent
+{
+	uint32_t ver_tid;     /* version << 16 | template id in the byte order of the wire */
+	uint32_t src_ip, source_id;
+	uint32_t slot;        /* device template */
+	uint32_t fc;          /* field count the template set announced */
+	uint32_t pad[3];
+};
+
+#ifdef __HIPCC__
+#define XE_HD __host__ __device__
+#else
+#define XE_HD
+#endif
+static inline XE_HD uint32_t
+xe_thent_hash(uint32_t ver_tid, uint32_t src_ip, uint32_t source_id)
+{
+	uint32_t h = (ver_tid * 0x9E3779B1u) ^ (src_ip * 0x85EBCA77u) ^ (source_id * 0xC2B2AE3Du);
+	return h ^ (h >> 15);
+}
+
+/* what the Netflow walk needs of a device template */
+struct xe_twalk
+{
+	uint16_t stride, nfields, off_last;
+	uint8_t fast;         /* the fast kernel decodes it */
+	uint8_t mode;
+};
+
+/* a datagram the device walked: one run of complete records */
+struct xe_dgrun
+{
+	uint32_t nrec;        /* 0: not walked here */
+	uint32_t tmpl;
+	uint32_t dev_id;      /* source id / observation domain as a big-endian number */
+	uint32_t rate;        /* sampling rate | has a devices.conf entry << 31 */
+};
+
+struct xe_walk_in
+{
+	const uint8_t *pkt;
+	const uint64_t *offs;          /* n + 1 */
+	const uint32_t *src;
+	const uint8_t *kinds;          /* NULL: all Netflow */
+	uint32_t n;
+	uint32_t ndevs;
+	const struct xe_devkey *devs;
+	const struct xe_thent *thash;  /* NULL: no template known */
+	uint32_t thash_mask;
+	uint32_t v5_slot_plus1;        /* device template of the v5 record, 0 = not built yet */
+	const struct xe_twalk *twalk;  /* per device template */
+	uint32_t ntmpl;
+	uint32_t pad;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* bytes of scratch the scans and sorts below need for up to n items */
+size_t xe_walk_temp_bytes(size_t n);
+/* out[0..n] = exclusive prefix sums of in[0..n) (out[n] = the total); in must have n + 1 entries, in[n] is overwritten with 0 */
+int xe_walk_scan(void *temp, size_t temp_bytes, uint32_t *in, uint32_t *out, size_t n, void *stream);
+/* stable sort of (key, value) pairs by the low `bits` bits of the key */
+int xe_walk_sort(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
+	size_t n, unsigned bits, void *stream);
+
+/* sFlow: cnt[i] = records datagram i yields (0 for other kinds); *total += their sum */
+int xe_walk_sf_count(const struct xe_walk_in *in, uint32_t *cnt, unsigned long long *total, void *stream);
+/* sFlow: the records of datagram i to out[base[i] ...] */
+int xe_walk_sf_emit(const struct xe_walk_in *in, const uint32_t *base, struct xe_sfrec *out, void *stream);
+
+/* Netflow: per datagram, the run it yields when its shape is the usual one
+ * (runs[i].nrec > 0, regular[i] = 1), else regular[i] = 0 */
+int xe_walk_nf_shape(const struct xe_walk_in *in, struct xe_dgrun *runs, uint8_t *regular, void *stream);
+/* cnt[i] = walked[i] ? runs[i].nrec : hostfirst[i + 1] - hostfirst[i] (what the host walk made of the datagram);
+ * key[i] = walked[i] ? runs[i].tmpl : ntmpl; val[i] = i; *total += the counts;
+ * gtotal[t] += records, gruns[t] += 1 per walked datagram of template t */
+int xe_walk_nf_counts(const struct xe_walk_in *in, const struct xe_dgrun *runs, const uint8_t *walked, const uint32_t *hostfirst,
+	uint32_t *cnt, uint32_t *key, uint32_t *val, uint32_t *gtotal, uint32_t *gruns, unsigned long long *total, void *stream);
+/* snrec[j] = runs[ord[j]].nrec for j < nruns (the runs in template order) */
+int xe_walk_nf_gather(const struct xe_dgrun *runs, const uint32_t *ord, uint32_t nruns, uint32_t *snrec, void *stream);
+/* per template group t: first position, first run, first tile (ntmpl + 1 entries each) */
+struct xe_wgroup { uint32_t pos0, run0, tile0, pad; };
+int xe_walk_nf_runs(const struct xe_walk_in *in, const struct xe_dgrun *runs, const uint32_t *ord, const uint32_t *keys,
+	const uint32_t *sscan, const uint32_t *recbase, const struct xe_wgroup *groups, uint32_t nruns, struct xe_frun *out, void *stream);
+int xe_walk_nf_tiles(const struct xe_frun *fruns, const struct xe_wgroup *groups, uint32_t ntmpl, uint32_t ntiles,
+	struct xe_ftile *tiles, uint32_t *tkey, uint32_t *tval, void *stream);
+int xe_walk_nf_tiles_place(const struct xe_ftile *tiles, const uint32_t *order, uint32_t ntiles, struct xe_ftile *out, void *stream);
 #ifdef __cplusplus
 }
 #endif

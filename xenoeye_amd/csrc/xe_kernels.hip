@@ -2316,7 +2316,9 @@ sf_apply(const xe_kparams &kp, sf_rec &r, const sf_elem &q)
 	r.v[SFI_in_bytes] = (r.v[SFI_in_bytes] & 0xFFFFFFFFull) | ((uint64_t)q.frame_len_be << 32);
 	r.v[SFI_in_pkts] = (r.v[SFI_in_pkts] & 0x00FFFFFFFFFFFFFFull) | (1ull << 56);
 	r.has |= (1u << SFI_in_bytes) | (1u << SFI_in_pkts);
-	if (q.kind == 1) return sf_rawparse(r, (int32_t)q.header_len, (int)q.rp_type);
+	/* the declared length is unsigned (sflow.c:132-134: `end = p + header_len`):
+	 * from 2^31 on no bounds test of the parse can fail, as with the largest int */
+	if (q.kind == 1) return sf_rawparse(r, (q.header_len > 0x7FFFFFFFu) ? 0x7FFFFFFF : (int32_t)q.header_len, (int)q.rp_type);
 
 	/* IPv4 structure, sflow-impl.h:236-260: seven 4-byte words */
 	sf_set_byte0<SFI_protocol>(r, sf_byte(r, 3));
@@ -2545,7 +2547,9 @@ xe_sf_kernel(const xe_kparams kp)
 		rec.v[SFI_input_snmp] = own.b.z;
 		rec.v[SFI_output_snmp] = own.b.w;
 		rec.has |= (1u << SFI_input_snmp) | (1u << SFI_output_snmp);
-		device = kp.exps[own.d.z].device;
+		/* element descriptors the device walk wrote name the devices.conf entry
+		 * itself (top bit set: entry + 1), the host walk's name the exporter */
+		device = (own.d.z & 0x80000000u) ? (int32_t)(own.d.z & 0x7FFFFFFFu) - 1 : kp.exps[own.d.z].device;
 		int state = 4;
 		for (uint32_t k = first; k <= g; k++) {
 			sf_desc x = own;
@@ -3014,6 +3018,7 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 	hipStream_t st = (hipStream_t)stream;
 	hipEvent_t *ev = (hipEvent_t *)events;   /* NULL or 3 start/stop pairs */
 	struct xe_kparams kcopy;
+	bool fast_started = false;
 
 	if (!g_tables_ready) return XE_ESTATE;
 	/* XE_ABLATE (diagnostic): bit 0 skip list lookups, 1 terms, 2 counters,
@@ -3029,14 +3034,28 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 			return XE_EHIP;
 		}
 	}
-	if (kp->ntiles) {
+	/* the runs the host walk listed, then the runs the device walk listed: the
+	 * same kernel over either table pair */
+	for (int part = 0; part < 2; part++) {
+		struct xe_kparams kpart;
+		const struct xe_kparams *kq = kp;
+		if (part == 1) {
+			if (!kp->ntiles2) break;
+			kpart = *kp;
+			kpart.fruns = kp->fruns2;
+			kpart.ftiles = kp->ftiles2;
+			kpart.nfruns = kp->nfruns2;
+			kpart.ntiles = kp->ntiles2;
+			kq = &kpart;
+		}
+		if (!kq->ntiles) continue;
 		/* grid-stride over tiles: enough blocks to fill 256 CUs several times
 		 * over, few enough that the per-block counter flush stays cheap */
 		uint32_t per_block = XE_BLOCK / 64;
-		uint32_t blocks = (kp->ntiles + per_block - 1) / per_block;
-		size_t shmem = (size_t)per_block * kp->fast_dwords * kp->fast_r * 64 * 4
-			+ (kp->lds_counters ? (size_t)kp->nmo * 24 : 0)
-			+ (kp->motab_lds ? (size_t)kp->motab_words * 8 : 0);
+		uint32_t blocks = (kq->ntiles + per_block - 1) / per_block;
+		size_t shmem = (size_t)per_block * kq->fast_dwords * kq->fast_r * 64 * 4
+			+ (kq->lds_counters ? (size_t)kq->nmo * 24 : 0)
+			+ (kq->motab_lds ? (size_t)kq->motab_words * 8 : 0);
 		if (blocks > 4096) blocks = 4096;
 		if (getenv("XE_FAST_BLOCKS")) {          /* diagnostic: grid size of the fast kernel */
 			uint32_t want = (uint32_t)atoi(getenv("XE_FAST_BLOCKS"));
@@ -3045,26 +3064,27 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 		/* the kernel deals the tile list to 8 groups of blocks (blockIdx % 8):
 		 * every group needs at least one block */
 		if (blocks < 8) blocks = 8;
-		if (ev) (void)hipEventRecord(ev[0], st);
-		const bool lean = !kp->nrgroups && !kp->ncjgroups && !kp->ncjderived && !kp->nfprogs && (kp->lw == 1);
-		if (kp->lw != 1) hipLaunchKernelGGL((xe_nf_fast_kernel<1, false, XE_LK_WORDS>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
-		else if (kp->fast_r == 4) hipLaunchKernelGGL((xe_nf_fast_kernel<4, false, 1>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
-		else if (kp->fast_r == 2) hipLaunchKernelGGL((xe_nf_fast_kernel<2, false, 1>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
-		else if (lean) hipLaunchKernelGGL((xe_nf_fast_kernel<1, true, 1>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
-		else hipLaunchKernelGGL((xe_nf_fast_kernel<1, false, 1>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kp);
-		if (ev) (void)hipEventRecord(ev[1], st);
+		if (ev && !fast_started) (void)hipEventRecord(ev[0], st);
+		fast_started = true;
+		const bool lean = !kq->nrgroups && !kq->ncjgroups && !kq->ncjderived && !kq->nfprogs && (kq->lw == 1);
+		if (kq->lw != 1) hipLaunchKernelGGL((xe_nf_fast_kernel<1, false, XE_LK_WORDS>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kq);
+		else if (kq->fast_r == 4) hipLaunchKernelGGL((xe_nf_fast_kernel<4, false, 1>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kq);
+		else if (kq->fast_r == 2) hipLaunchKernelGGL((xe_nf_fast_kernel<2, false, 1>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kq);
+		else if (lean) hipLaunchKernelGGL((xe_nf_fast_kernel<1, true, 1>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kq);
+		else hipLaunchKernelGGL((xe_nf_fast_kernel<1, false, 1>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kq);
 		if (hipGetLastError() != hipSuccess) return XE_EHIP;
-		if (kp->pad2 & 64) {
+		if (kq->pad2 & 64) {
 			/* diagnostic: print and reset the per-phase wave cycles */
 			unsigned long long pc[8], z[8] = {0};
 			(void)hipStreamSynchronize(st);
 			(void)hipMemcpyFromSymbol(pc, HIP_SYMBOL(xe_fast_phase_cycles), sizeof(pc));
 			(void)hipMemcpyToSymbol(HIP_SYMBOL(xe_fast_phase_cycles), z, sizeof(z));
 			fprintf(stderr, "phase cycles per tile: runs %.0f stage %.0f lookups %.0f terms %.0f decode %.0f programs %.0f\n",
-				(double)pc[0] / kp->ntiles, (double)pc[1] / kp->ntiles, (double)pc[2] / kp->ntiles,
-				(double)pc[3] / kp->ntiles, (double)pc[4] / kp->ntiles, (double)pc[5] / kp->ntiles);
+				(double)pc[0] / kq->ntiles, (double)pc[1] / kq->ntiles, (double)pc[2] / kq->ntiles,
+				(double)pc[3] / kq->ntiles, (double)pc[4] / kq->ntiles, (double)pc[5] / kq->ntiles);
 		}
 	}
+	if (ev && fast_started) (void)hipEventRecord(ev[1], st);
 	const size_t lane_lds = (kp->lds_counters ? (size_t)kp->nmo * 24 : 0)
 		+ (kp->motab_lds ? (size_t)kp->motab_words * 8 : 0) + 16;
 	if (kp->nslowrec) {

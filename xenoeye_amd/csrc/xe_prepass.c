@@ -180,6 +180,8 @@ xe_host_free(struct xe_host *hs)
 	for (i = 0; i < hs->ntslots; i++) free(hs->tslots[i].raw);
 	free(hs->tslots);
 	free(hs->thash);
+	xe_host_undo_end(hs);
+	free(hs->undo.p);
 	free(hs->dev_tmpls.p);
 	free(hs->dev_tents.p);
 	walkers_free(hs);
@@ -295,7 +297,7 @@ tkey_eq(const struct xe_tkey *a, const struct xe_tkey *b)
 /* netflow_template_find() (netflow-templates.c:140-181) reduced to "latest
  * template for (version, template id as on the wire, exporter, source id)" */
 static struct xe_tslot *
-tmpl_find(struct xe_host *hs, const struct xe_tkey *k)
+tmpl_find_any(struct xe_host *hs, const struct xe_tkey *k)
 {
 	size_t m, i;
 	if (!hs->thash_cap) return NULL;
@@ -305,6 +307,15 @@ tmpl_find(struct xe_host *hs, const struct xe_tkey *k)
 		if (!v) return NULL;
 		if (tkey_eq(&hs->tslots[v - 1].key, k)) return &hs->tslots[v - 1];
 	}
+}
+
+/* (a slot without bytes is one whose first template was taken back by
+ * xe_host_undo_rollback(): it keeps its place in the hash, nothing else) */
+static struct xe_tslot *
+tmpl_find(struct xe_host *hs, const struct xe_tkey *k)
+{
+	struct xe_tslot *s = tmpl_find_any(hs, k);
+	return (s && s->raw) ? s : NULL;
 }
 
 static int
@@ -414,13 +425,13 @@ dev_template(struct xe_host *hs, int mode, const uint16_t *types, const uint16_t
 static int
 tmpl_put(struct xe_host *hs, const struct xe_tkey *k, const uint8_t *raw, size_t raw_len)
 {
-	struct xe_tslot *s = tmpl_find(hs, k);
+	struct xe_tslot *s = tmpl_find_any(hs, k);
 	uint16_t *types, *lens;
 	size_t n, i, step, first;
 	int rc, mode;
 	uint32_t slot;
 
-	if (s && (s->raw_len == raw_len) && !memcmp(s->raw, raw, raw_len)) return XE_OK;
+	if (s && s->raw && (s->raw_len == raw_len) && !memcmp(s->raw, raw, raw_len)) return XE_OK;
 
 	n = ((size_t)raw[2] << 8) | raw[3];
 	if (k->ver == 9) { mode = XE_MODE_V9; step = 4; first = 4; }
@@ -454,13 +465,75 @@ tmpl_put(struct xe_host *hs, const struct xe_tkey *k, const uint8_t *raw, size_t
 		if (!thash_insert(hs, (uint32_t)hs->ntslots)) return XE_ENOMEM;
 		hs->ntslots++;
 	}
+	if (hs->undo_on) {
+		/* what the slot held goes to the log instead of being freed */
+		struct xe_tundo u;
+		u.slot = (uint32_t)(s - hs->tslots);
+		u.raw = s->raw;
+		u.raw_len = s->raw_len;
+		u.dev_slot = s->dev_slot;
+		if (!xe_blob_push(&hs->undo, &u, sizeof(u))) return XE_ENOMEM;
+		s->raw = NULL;
+	}
 	free(s->raw);
 	s->raw = malloc(raw_len ? raw_len : 1);
 	if (!s->raw) return XE_ENOMEM;
 	memcpy(s->raw, raw, raw_len);
 	s->raw_len = raw_len;
 	s->dev_slot = slot;
+	hs->tmpl_epoch++;
 	return XE_OK;
+}
+
+/* Template changes of one batch can be taken back: between undo_begin and
+ * undo_end every change is logged with what it replaced. */
+void
+xe_host_undo_begin(struct xe_host *hs)
+{
+	hs->undo.n = 0;
+	hs->undo_on = 1;
+}
+
+size_t
+xe_host_undo_count(const struct xe_host *hs)
+{
+	return hs->undo.n;
+}
+
+uint32_t
+xe_host_undo_src_ip(const struct xe_host *hs, size_t i)
+{
+	return hs->tslots[((const struct xe_tundo *)hs->undo.p)[i].slot].key.src_ip;
+}
+
+/* the store as it was at undo_begin (device templates made meanwhile stay in
+ * their table, unused) */
+void
+xe_host_undo_rollback(struct xe_host *hs)
+{
+	struct xe_tundo *u = hs->undo.p;
+	size_t i;
+
+	for (i = hs->undo.n; i-- > 0;) {
+		struct xe_tslot *s = &hs->tslots[u[i].slot];
+		free(s->raw);
+		s->raw = u[i].raw;
+		s->raw_len = u[i].raw_len;
+		s->dev_slot = u[i].dev_slot;
+	}
+	if (hs->undo.n) hs->tmpl_epoch++;
+	hs->undo.n = 0;
+}
+
+void
+xe_host_undo_end(struct xe_host *hs)
+{
+	struct xe_tundo *u = hs->undo.p;
+	size_t i;
+
+	for (i = 0; i < hs->undo.n; i++) free(u[i].raw);
+	hs->undo.n = 0;
+	hs->undo_on = 0;
 }
 
 /* tmpl_put() for the walkers: a template that is already stored unchanged
@@ -479,14 +552,46 @@ tmpl_store(struct xe_host *hs, const struct xe_tkey *k, const uint8_t *raw, size
 }
 
 /* ------------------------------------------------------------------ set emission */
+/* `nrec` more records of device template `tmpl` in the batch: the fields it
+ * sets and the column bytes a complete record fills, computed once per
+ * template and batch */
+int
+xe_plan_note_template(struct xe_plan *plan, const struct xe_host *hs, uint32_t tmpl, size_t nrec)
+{
+	const struct xe_tmpl *t = (const struct xe_tmpl *)hs->dev_tmpls.p + tmpl;
+	const struct xe_tent *e = (const struct xe_tent *)hs->dev_tents.p + t->ent_base;
+	struct xe_tinfo *ti;
+	size_t i, w = 0;
+
+	while (plan->tinfo.n <= tmpl) {
+		struct xe_tinfo z;
+		memset(&z, 0, sizeof(z));
+		if (!xe_blob_push(&plan->tinfo, &z, sizeof(z))) return 0;
+	}
+	ti = (struct xe_tinfo *)plan->tinfo.p + tmpl;
+	if (!ti->known) {
+		for (i = 0; i < t->nfields; i++) {
+			if ((e[i].field != XE_F_NONE) && (e[i].flags & XE_TE_VALID)) {
+				int f = e[i].field;
+				ti->mask[f >> 6] |= 1ull << (f & 63);
+				if (!(e[i].flags & XE_TE_REPEAT)) w += xe_fields[f].col_width;
+			}
+		}
+		ti->width = (uint32_t)w;
+		ti->known = 1;
+		plan->field_mask[0] |= ti->mask[0];
+		plan->field_mask[1] |= ti->mask[1];
+	}
+	plan->soa_bytes_per_rec_sum += (size_t)ti->width * nrec;
+	return 1;
+}
+
 static int
 emit_set(struct xe_plan *plan, const struct xe_host *hs, const struct dgram *d, long rel_off,
 	uint32_t nrec, long avail, uint32_t stride, uint32_t tmpl, long extent, uint32_t flags)
 {
 	struct xe_set s;
 	const struct xe_tmpl *t = (const struct xe_tmpl *)hs->dev_tmpls.p + tmpl;
-	const struct xe_tent *e = (const struct xe_tent *)hs->dev_tents.p + t->ent_base;
-	size_t i, w = 0;
 
 	if (!nrec) return 1;
 	if (plan->nrec + nrec > 0xFFFFFFF0u) { plan->too_many = 1; return 0; }
@@ -504,30 +609,7 @@ emit_set(struct xe_plan *plan, const struct xe_host *hs, const struct dgram *d, 
 	 * may look at; past the datagram end the kernels must substitute zeros */
 	if ((extent < 0) || ((rel_off + extent) > d->len) || (rel_off < 0) || t->varlen) s.flags |= XE_SET_CHECKED;
 	plan->nrec += nrec;
-	/* what the template's records fill: computed once per template and batch */
-	{
-		struct xe_tinfo *ti;
-		while (plan->tinfo.n <= tmpl) {
-			struct xe_tinfo z;
-			memset(&z, 0, sizeof(z));
-			if (!xe_blob_push(&plan->tinfo, &z, sizeof(z))) return 0;
-		}
-		ti = (struct xe_tinfo *)plan->tinfo.p + tmpl;
-		if (!ti->known) {
-			for (i = 0; i < t->nfields; i++) {
-				if ((e[i].field != XE_F_NONE) && (e[i].flags & XE_TE_VALID)) {
-					int f = e[i].field;
-					ti->mask[f >> 6] |= 1ull << (f & 63);
-					if (!(e[i].flags & XE_TE_REPEAT)) w += xe_fields[f].col_width;
-				}
-			}
-			ti->width = (uint32_t)w;
-			ti->known = 1;
-			plan->field_mask[0] |= ti->mask[0];
-			plan->field_mask[1] |= ti->mask[1];
-		}
-		plan->soa_bytes_per_rec_sum += (size_t)ti->width * nrec;
-	}
+	if (!xe_plan_note_template(plan, hs, tmpl, nrec)) return 0;
 	return xe_blob_push(&plan->sets, &s, sizeof(s));
 }
 
@@ -802,7 +884,7 @@ walk_v5(struct xe_host *hs, struct xe_plan *plan, struct dgram *d)
 		tl_write(hs);
 		if (!hs->v5_slot_plus1) {
 			rc = v5_template(hs, &slot);
-			if (rc == XE_OK) hs->v5_slot_plus1 = slot + 1;
+			if (rc == XE_OK) { hs->v5_slot_plus1 = slot + 1; hs->tmpl_epoch++; }
 		}
 		slot = hs->v5_slot_plus1;
 		tl_write_done(hs);
@@ -979,6 +1061,8 @@ walk_one(struct xe_host *hs, struct xe_plan *plan, const uint8_t *data, const ui
 {
 	struct dgram d;
 
+	/* walked on the device: nothing to do here */
+	if (kinds && (kinds[i] & XE_KIND_ON_DEVICE)) return XE_OK;
 	memset(&d, 0, sizeof(d));
 	d.p = data + offs[i];
 	d.len = (long)(offs[i + 1] - offs[i]);
@@ -1192,7 +1276,10 @@ pp_walk(void *arg)
 		if (la <= i) { la = i + 1; ahead = 0; }
 		else if (ahead) ahead--;
 		while ((ahead < 8) && (la < sh->n)) {
-			if (sh->own[la] == me->t) { __builtin_prefetch(sh->data + sh->offs[la]); ahead++; }
+			if ((sh->own[la] == me->t) && !(sh->kinds && (sh->kinds[la] & XE_KIND_ON_DEVICE))) {
+				__builtin_prefetch(sh->data + sh->offs[la]);
+				ahead++;
+			}
 			la++;
 		}
 		if (++since == 512) {
@@ -1396,7 +1483,7 @@ xe_prepass(struct xe_host *hs, const uint8_t *data, const uint64_t *offs, const 
 
 		/* only headers are read, one cache line per datagram, far apart: ask
 		 * for the lines of the datagrams to come */
-		if (i + 16 < n) __builtin_prefetch(data + offs[i + 16]);
+		if ((i + 16 < n) && !(kinds && (kinds[i + 16] & XE_KIND_ON_DEVICE))) __builtin_prefetch(data + offs[i + 16]);
 		plan->dg_first_nf[i] = (uint32_t)plan->nrec;
 		plan->dg_first_sf[i] = (uint32_t)plan->nsf;
 		rc = walk_one_bounded(hs, plan, data, offs, src, kinds, i);

@@ -1,0 +1,540 @@
+/*
+ * xe_walk.hip -- the header walk on the device (gfx950).
+ *
+ * One thread per datagram follows the reference's cursor arithmetic over
+ * datagram, set and sample headers and leaves what the decode kernels work
+ * from: sFlow element descriptors (struct xe_sfrec) and, for Netflow datagrams
+ * of the usual shape, runs of complete records grouped by template with their
+ * tile list.  Prefix sums give every record the index the walk in arrival
+ * order gives it.  Datagrams that touch the template store (or are unusual in
+ * any other way) are not decided here: they are flagged and the host walks
+ * them.
+ *
+ * The prefix sums and the two stable sorts are rocPRIM's device-wide
+ * primitives; everything that knows about flow export formats is below.
+ */
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+#include <stdint.h>
+#include "xe_kernels.h"
+
+#define XW_BLOCK 256
+
+static __device__ __forceinline__ uint32_t
+ld32(const uint8_t *p)
+{
+	uint32_t v;
+	__builtin_memcpy(&v, p, 4);
+	return v;
+}
+
+static __device__ __forceinline__ uint32_t
+be16(const uint8_t *p)
+{
+	return ((uint32_t)p[0] << 8) | p[1];
+}
+
+/* device_find(), devices.c:205-232 / :246-270: the second test is `if`, not `else if` */
+static __device__ int
+dev_find(const xe_walk_in &in, uint32_t ip, uint32_t id)
+{
+	for (uint32_t i = 0; i < in.ndevs; i++) {
+		const xe_devkey d = in.devs[i];
+		if (d.use_ip && d.use_id) {
+			if ((ip == d.ip) && (id == d.id)) return (int)i;
+		} else if (d.use_ip) {
+			if (ip == d.ip) return (int)i;
+		}
+		if (d.use_id) {
+			if (id == d.id) return (int)i;
+		}
+	}
+	return -1;
+}
+
+/* ------------------------------------------------------------------ sFlow v5 */
+struct sfcur { const uint8_t *p; int64_t pos, len; bool bad; };
+
+/* READ_SF_BYTES / READ32_H, sflow-impl.h:51-65 */
+static __device__ __forceinline__ uint32_t
+sf_raw32(sfcur &c)
+{
+	if (c.bad || ((c.pos + 4) > c.len)) { c.bad = true; return 0; }
+	const uint32_t v = ld32(c.p + c.pos);
+	c.pos += 4;
+	return v;
+}
+
+static __device__ __forceinline__ uint32_t
+sf_u32(sfcur &c)
+{
+	return __builtin_bswap32(sf_raw32(c));
+}
+
+struct sfproto
+{
+	uint32_t agent_ver, agent[4], dev_id, exporter;
+	uint64_t base;
+};
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <bool EMIT>
+static __device__ __forceinline__ void
+sf_put(xe_sfrec *out, uint32_t at, const sfproto &pr, const sfcur &c, uint32_t header_len, uint32_t frame_len_be,
+	uint32_t rate, uint32_t in_if_be, uint32_t out_if_be, uint32_t kind, uint32_t rp_type, uint32_t chained)
+{
+	if (!EMIT) return;
+	const uint64_t hdr_off = pr.base + (uint64_t)c.pos;
+	u32x4 *q = (u32x4 *)(out + at);
+	q[0] = (u32x4){ (uint32_t)hdr_off, (uint32_t)(hdr_off >> 32), header_len, (uint32_t)(int32_t)(c.len - c.pos) };
+	q[1] = (u32x4){ frame_len_be, rate, in_if_be, out_if_be };
+	q[2] = (u32x4){ kind | (rp_type << 8) | (pr.agent_ver << 16) | (chained << 24), pr.dev_id, pr.agent[0], pr.agent[1] };
+	q[3] = (u32x4){ pr.agent[2], pr.agent[3], pr.exporter, 0u };
+}
+
+/* sf5_flow(), sflow-impl.h:68-272: one flow sample; returns the records it yields */
+template <bool EMIT>
+static __device__ uint32_t
+sf_flow_sample(sfcur &c, bool expanded, const sfproto &pr, xe_sfrec *out, uint32_t at)
+{
+	uint32_t nout = 0, v, nel, rate, in_if_be, out_if_be, frame_len_be = 0, kind = 0, rp_type = 0, chained = 0;
+
+	sf_u32(c);                       /* length */
+	sf_u32(c);                       /* sequence */
+	sf_u32(c);                       /* source id (or class) */
+	if (expanded) sf_u32(c);         /* source index */
+	rate = sf_u32(c);
+	sf_u32(c);                       /* pool */
+	sf_u32(c);                       /* drops */
+	if (expanded) sf_u32(c);         /* input format */
+	v = sf_u32(c);
+	if (!expanded) v &= 0x3fffffff;
+	in_if_be = __builtin_bswap32(v);
+	if (expanded) sf_u32(c);         /* output format */
+	v = sf_u32(c);
+	if (!expanded) v &= 0x3fffffff;
+	out_if_be = __builtin_bswap32(v);
+	nel = sf_u32(c);
+	if (c.bad) return 0;
+
+	for (uint32_t j = 0; j < nel; j++) {
+		const uint32_t tag = sf_u32(c), ell = sf_u32(c);
+		if (c.bad) return nout;
+		if (tag == 1) {
+			const uint32_t hp = sf_u32(c);
+			frame_len_be = sf_raw32(c);
+			sf_u32(c);               /* stripped */
+			const uint32_t hl = sf_u32(c);
+			if (c.bad) return nout;
+			if (hp == 1) rp_type = 0;
+			else if (hp == 11) rp_type = 1;
+			else if (hp == 12) rp_type = 2;
+			else { c.bad = true; return nout; }
+			kind = 1;
+			sf_put<EMIT>(out, at + nout, pr, c, hl, frame_len_be, rate, in_if_be, out_if_be, kind, rp_type, chained);
+			nout++;
+			chained = 1;
+			c.pos += (hl % 4) ? (int64_t)hl + (4 - (hl % 4)) : (int64_t)hl;
+		} else if (tag == 1001) {
+			sf_u32(c); sf_u32(c); sf_u32(c); sf_u32(c);
+		} else if (tag == 3) {
+			frame_len_be = sf_raw32(c);
+			if (c.bad) return nout;
+			/* the 7 words after the length are read one by one and a short
+			 * datagram aborts before the record is delivered */
+			if ((c.pos + 28) > c.len) { c.bad = true; return nout; }
+			kind = 3;
+			sf_put<EMIT>(out, at + nout, pr, c, 28, frame_len_be, rate, in_if_be, out_if_be, kind, rp_type, chained);
+			nout++;
+			chained = 1;
+			c.pos += 28;
+		} else {
+			c.pos += ell;
+		}
+	}
+	return nout;
+}
+
+/* sflow_process(), sflow-impl.h:293-405 */
+template <bool EMIT>
+static __device__ uint32_t
+sf_walk(const xe_walk_in &in, uint32_t i, xe_sfrec *out, uint32_t at)
+{
+	const uint64_t off = in.offs[i];
+	int64_t len = (int64_t)(in.offs[i + 1] - off);
+	if (len > 65536) len = 65536;
+	sfcur c = { in.pkt + off, 0, len, false };
+	sfproto pr;
+	uint32_t v, n, nout = 0;
+
+	pr.base = off;
+	pr.agent[0] = pr.agent[1] = pr.agent[2] = pr.agent[3] = 0;
+	if (sf_u32(c) != 5) return 0;
+	v = sf_u32(c);
+	if (c.bad) return 0;
+	if (v == 1) {
+		pr.agent_ver = 4;
+		if ((c.pos + 4) > len) return 0;
+		pr.agent[0] = ld32(c.p + c.pos);
+		c.pos += 4;
+	} else if (v == 2) {
+		pr.agent_ver = 6;
+		if ((c.pos + 16) > len) return 0;
+		for (int k = 0; k < 4; k++) pr.agent[k] = ld32(c.p + c.pos + 4 * k);
+		c.pos += 16;
+	} else {
+		return 0;
+	}
+	pr.dev_id = sf_raw32(c);
+	sf_u32(c);
+	sf_u32(c);
+	n = sf_u32(c);
+	if (c.bad) return 0;
+	/* device rules use the UDP source and the packet's source_id field, which
+	 * sflow_process() never sets: 0.  The decode kernel takes the devices.conf
+	 * entry from the top bit form of `exporter` */
+	pr.exporter = 0x80000000u | (uint32_t)(dev_find(in, in.src[i], 0) + 1);
+
+	for (uint32_t s = 0; s < n; s++) {
+		v = sf_u32(c);
+		if (c.bad) break;
+		if ((v == 1) || (v == 3)) {
+			nout += sf_flow_sample<EMIT>(c, v == 3, pr, out, at + nout);
+			if (c.bad) break;
+		} else {
+			const uint32_t l = sf_u32(c);
+			if (c.bad) break;
+			c.pos += l;
+		}
+	}
+	return nout;
+}
+
+__global__ void __launch_bounds__(XW_BLOCK)
+xw_sf_count_kernel(const xe_walk_in in, uint32_t *cnt, unsigned long long *total)
+{
+	const uint32_t i = blockIdx.x * XW_BLOCK + threadIdx.x;
+	uint32_t n = 0;
+
+	if ((i < in.n) && in.kinds && (in.kinds[i] == XE_KIND_SFLOW)) n = sf_walk<false>(in, i, nullptr, 0);
+	if (i < in.n) cnt[i] = n;
+	/* the batch total in 64 bits: the 32-bit prefix sums could wrap unnoticed */
+	unsigned long long s = n;
+	for (int d = 32; d; d >>= 1) s += __shfl_down(s, d, 64);
+	if (((threadIdx.x & 63) == 0) && s) atomicAdd(total, s);
+}
+
+__global__ void __launch_bounds__(XW_BLOCK)
+xw_sf_emit_kernel(const xe_walk_in in, const uint32_t *base, xe_sfrec *out)
+{
+	const uint32_t i = blockIdx.x * XW_BLOCK + threadIdx.x;
+
+	if ((i < in.n) && in.kinds && (in.kinds[i] == XE_KIND_SFLOW) && (base[i + 1] != base[i])) (void)sf_walk<true>(in, i, out, base[i]);
+}
+
+/* ------------------------------------------------------------------ Netflow v5 / v9 / IPFIX */
+static __device__ __forceinline__ bool
+tmpl_lookup(const xe_walk_in &in, uint32_t ver_tid, uint32_t src_ip, uint32_t source_id, xe_thent &e)
+{
+	if (!in.thash) return false;
+	for (uint32_t j = xe_thent_hash(ver_tid, src_ip, source_id) & in.thash_mask;; j = (j + 1) & in.thash_mask) {
+		e = in.thash[j];
+		if (!e.ver_tid) return false;
+		if ((e.ver_tid == ver_tid) && (e.src_ip == src_ip) && (e.source_id == source_id)) return true;
+	}
+}
+
+/* devices.conf: sampling rate and whether the exporter's records need no rule check */
+static __device__ __forceinline__ bool
+exporter_plain(const xe_walk_in &in, uint32_t ip, uint32_t id, uint32_t &rate)
+{
+	const int dev = dev_find(in, ip, id);
+	if (dev < 0) { rate = 1; return true; }
+	const xe_devkey d = in.devs[dev];
+	rate = d.rate | 0x80000000u;
+	return d.plain && !(d.rate & 0x80000000u);
+}
+
+__global__ void __launch_bounds__(XW_BLOCK)
+xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular)
+{
+	const uint32_t i = blockIdx.x * XW_BLOCK + threadIdx.x;
+	if (i >= in.n) return;
+	xe_dgrun r = { 0, 0, 0, 0 };
+	bool ok = false;
+
+	if (!(in.kinds && (in.kinds[i] == XE_KIND_SFLOW))) {
+		const uint64_t off = in.offs[i];
+		int64_t len64 = (int64_t)(in.offs[i + 1] - off);
+		const uint32_t len = (len64 > 65536) ? 65536u : (uint32_t)len64;
+		const uint8_t *p = in.pkt + off;
+		const uint32_t src = in.src[i];
+		if (len >= 24) {
+			const uint32_t ver = be16(p);
+			if (ver == 5) {
+				/* parse_netflow_v5(), netflow.c:727-786 */
+				const uint32_t n = be16(p + 2), sid = p[21];
+				if (n && ((24 + 48 * n) == len) && in.v5_slot_plus1 && in.twalk[in.v5_slot_plus1 - 1].fast
+					&& exporter_plain(in, src, sid, r.rate)) {
+					r.nrec = n;
+					r.tmpl = in.v5_slot_plus1 - 1;
+					r.dev_id = __builtin_bswap32(sid);
+					ok = true;
+				}
+			} else if (ver == 9) {
+				/* parse_netflow_v9() + parse_netflow_v9_flowset(), netflow.c:319-365, :246-317:
+				 * one data set that ends with the datagram, header.count complete records in it */
+				const uint32_t count = be16(p + 2), sid = ld32(p + 16), fsid = be16(p + 20), length = be16(p + 22);
+				xe_thent e;
+				if ((fsid >= 2) && ((20 + length) == len) && count
+					&& tmpl_lookup(in, (9u << 16) | p[20] | ((uint32_t)p[21] << 8), src, sid, e)
+					&& (e.slot < in.ntmpl)) {
+					const xe_twalk tw = in.twalk[e.slot];
+					if (tw.fast && (count * tw.stride <= length) && ((24 + count * tw.stride) <= len)
+						&& exporter_plain(in, src, sid, r.rate)) {
+						r.nrec = count;
+						r.tmpl = e.slot;
+						r.dev_id = __builtin_bswap32(sid);
+						ok = true;
+					}
+				}
+			} else if (ver == 10) {
+				/* parse_ipfix() + parse_ipfix_flowset(), netflow.c:628-678, :547-625 */
+				const uint32_t sid = ld32(p + 12), fsid = be16(p + 16), length = be16(p + 18);
+				xe_thent e;
+				if ((fsid > 255) && ((16 + length) == len)
+					&& tmpl_lookup(in, (10u << 16) | p[16] | ((uint32_t)p[17] << 8), src, sid, e)
+					&& (e.slot < in.ntmpl)) {
+					const xe_twalk tw = in.twalk[e.slot];
+					if (tw.fast && (e.fc == tw.nfields) && (length >= e.fc)) {
+						/* record k exists iff length - k * stride >= field count, and gets
+						 * every field iff its last field starts before `length` */
+						const uint32_t nrec = (length - e.fc) / tw.stride + 1;
+						const uint32_t nfull = (length > tw.off_last) ? (length - tw.off_last - 1) / tw.stride + 1 : 0;
+						if ((nfull >= nrec) && ((20 + nrec * tw.stride) <= len) && exporter_plain(in, src, sid, r.rate)) {
+							r.nrec = nrec;
+							r.tmpl = e.slot;
+							r.dev_id = __builtin_bswap32(sid);
+							ok = true;
+						}
+					}
+				}
+			}
+		}
+	}
+	if (!ok) r.nrec = 0;
+	runs[i] = r;
+	regular[i] = ok ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(XW_BLOCK)
+xw_nf_counts_kernel(const xe_walk_in in, const xe_dgrun *runs, const uint8_t *walked, const uint32_t *hostfirst,
+	uint32_t *cnt, uint32_t *key, uint32_t *val, uint32_t *gtotal, uint32_t *gruns, unsigned long long *total)
+{
+	const uint32_t i = blockIdx.x * XW_BLOCK + threadIdx.x;
+	uint32_t c = 0;
+	if (i < in.n) {
+		const bool w = walked[i] != 0;
+		const xe_dgrun r = runs[i];
+		c = w ? r.nrec : (hostfirst[i + 1] - hostfirst[i]);
+		cnt[i] = c;
+		key[i] = w ? r.tmpl : in.ntmpl;
+		val[i] = i;
+		if (w) {
+			atomicAdd(&gtotal[r.tmpl], r.nrec);
+			atomicAdd(&gruns[r.tmpl], 1u);
+		}
+	}
+	/* the batch total in 64 bits: the 32-bit prefix sums could wrap unnoticed */
+	unsigned long long s = c;
+	for (int d = 32; d; d >>= 1) s += __shfl_down(s, d, 64);
+	if (((threadIdx.x & 63) == 0) && s) atomicAdd(total, s);
+}
+
+__global__ void __launch_bounds__(XW_BLOCK)
+xw_nf_gather_kernel(const xe_dgrun *runs, const uint32_t *ord, uint32_t nruns, uint32_t *snrec)
+{
+	const uint32_t j = blockIdx.x * XW_BLOCK + threadIdx.x;
+	if (j < nruns) snrec[j] = runs[ord[j]].nrec;
+}
+
+__global__ void __launch_bounds__(XW_BLOCK)
+xw_nf_runs_kernel(const xe_walk_in in, const xe_dgrun *runs, const uint32_t *ord, const uint32_t *keys,
+	const uint32_t *sscan, const uint32_t *recbase, const xe_wgroup *groups, uint32_t nruns, xe_frun *out)
+{
+	const uint32_t j = blockIdx.x * XW_BLOCK + threadIdx.x;
+	if (j >= nruns) return;
+	const uint32_t i = ord[j], t = keys[j];
+	const xe_dgrun r = runs[i];
+	const xe_wgroup g = groups[t];
+	const uint8_t *p = in.pkt + in.offs[i];
+	const uint32_t ver = be16(p);
+	xe_frun f;
+	/* the first record: behind the datagram header and the set header (v5: the header) */
+	f.data_off = (uint32_t)in.offs[i] + ((ver == 10) ? 20u : 24u);
+	f.first_rec = recbase[i];
+	f.start = g.pos0 + (sscan[j] - sscan[g.run0]);
+	f.nrec = r.nrec;
+	f.stride = in.twalk[t].stride | (r.rate & 0x80000000u);
+	f.rate = r.rate & 0x7FFFFFFFu;
+	f.dev_ip = __builtin_bswap32(in.src[i]);
+	f.dev_id = r.dev_id;
+	out[j] = f;
+}
+
+/* tile k: 64 positions of one template group; listed with the batch index of
+ * its first record as the sort key */
+__global__ void __launch_bounds__(XW_BLOCK)
+xw_nf_tiles_kernel(const xe_frun *fruns, const xe_wgroup *groups, uint32_t ntmpl, uint32_t ntiles,
+	xe_ftile *tiles, uint32_t *tkey, uint32_t *tval)
+{
+	const uint32_t k = blockIdx.x * XW_BLOCK + threadIdx.x;
+	if (k >= ntiles) return;
+	/* the group: last t with tile0[t] <= k among groups that have tiles */
+	uint32_t lo = 0, hi = ntmpl;
+	while (lo + 1 < hi) {
+		const uint32_t mid = (lo + hi) / 2;
+		if (groups[mid].tile0 <= k) lo = mid; else hi = mid;
+	}
+	/* empty groups share their tile0 with the next one: the search above ends
+	 * on the last of them, which is the one that owns the tile */
+	const uint32_t t = lo;
+	const uint32_t base = groups[t].pos0 + 64 * (k - groups[t].tile0);
+	/* the run that holds position `base`: last run of the group with start <= base */
+	uint32_t a = groups[t].run0, b = groups[t + 1].run0;
+	while (a + 1 < b) {
+		const uint32_t mid = (a + b) / 2;
+		if (fruns[mid].start <= base) a = mid; else b = mid;
+	}
+	xe_ftile ft;
+	ft.first_run = a;
+	ft.tmpl = t;
+	ft.base = base;
+	ft.pad = fruns[a].first_rec + (base - fruns[a].start);
+	tiles[k] = ft;
+	tkey[k] = ft.pad;
+	tval[k] = k;
+}
+
+__global__ void __launch_bounds__(XW_BLOCK)
+xw_nf_tiles_place_kernel(const xe_ftile *tiles, const uint32_t *order, uint32_t ntiles, xe_ftile *out)
+{
+	const uint32_t k = blockIdx.x * XW_BLOCK + threadIdx.x;
+	if (k < ntiles) out[k] = tiles[order[k]];
+}
+
+/* ------------------------------------------------------------------ launches */
+static inline uint32_t
+xw_blocks(size_t n)
+{
+	return (uint32_t)((n + XW_BLOCK - 1) / XW_BLOCK);
+}
+
+static inline int
+xw_done(void)
+{
+	return (hipGetLastError() == hipSuccess) ? XE_OK : XE_EHIP;
+}
+
+extern "C" size_t
+xe_walk_temp_bytes(size_t n)
+{
+	size_t a = 0, b = 0;
+	uint32_t *z = nullptr;
+	if (!n) n = 1;
+	(void)rocprim::exclusive_scan(nullptr, a, z, z, 0u, n + 1, rocprim::plus<uint32_t>(), (hipStream_t)0);
+	(void)rocprim::radix_sort_pairs(nullptr, b, z, z, z, z, n, 0, 32, (hipStream_t)0);
+	return ((a > b) ? a : b) + 256;
+}
+
+extern "C" int
+xe_walk_scan(void *temp, size_t temp_bytes, uint32_t *in, uint32_t *out, size_t n, void *stream)
+{
+	hipStream_t st = (hipStream_t)stream;
+	if (hipMemsetAsync(in + n, 0, 4, st) != hipSuccess) return XE_EHIP;
+	if (rocprim::exclusive_scan(temp, temp_bytes, in, out, 0u, n + 1, rocprim::plus<uint32_t>(), st) != hipSuccess) return XE_EHIP;
+	return XE_OK;
+}
+
+extern "C" int
+xe_walk_sort(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
+	size_t n, unsigned bits, void *stream)
+{
+	if (!n) return XE_OK;
+	if (bits < 1) bits = 1;
+	if (rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, n, 0, bits, (hipStream_t)stream) != hipSuccess) return XE_EHIP;
+	return XE_OK;
+}
+
+extern "C" int
+xe_walk_sf_count(const struct xe_walk_in *in, uint32_t *cnt, unsigned long long *total, void *stream)
+{
+	if (!in->n) return XE_OK;
+	hipLaunchKernelGGL(xw_sf_count_kernel, dim3(xw_blocks(in->n)), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, cnt, total);
+	return xw_done();
+}
+
+extern "C" int
+xe_walk_sf_emit(const struct xe_walk_in *in, const uint32_t *base, struct xe_sfrec *out, void *stream)
+{
+	if (!in->n) return XE_OK;
+	hipLaunchKernelGGL(xw_sf_emit_kernel, dim3(xw_blocks(in->n)), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, base, out);
+	return xw_done();
+}
+
+extern "C" int
+xe_walk_nf_shape(const struct xe_walk_in *in, struct xe_dgrun *runs, uint8_t *regular, void *stream)
+{
+	if (!in->n) return XE_OK;
+	hipLaunchKernelGGL(xw_nf_shape_kernel, dim3(xw_blocks(in->n)), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, runs, regular);
+	return xw_done();
+}
+
+extern "C" int
+xe_walk_nf_counts(const struct xe_walk_in *in, const struct xe_dgrun *runs, const uint8_t *walked, const uint32_t *hostfirst,
+	uint32_t *cnt, uint32_t *key, uint32_t *val, uint32_t *gtotal, uint32_t *gruns, unsigned long long *total, void *stream)
+{
+	if (!in->n) return XE_OK;
+	hipLaunchKernelGGL(xw_nf_counts_kernel, dim3(xw_blocks(in->n)), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, runs, walked,
+		hostfirst, cnt, key, val, gtotal, gruns, total);
+	return xw_done();
+}
+
+extern "C" int
+xe_walk_nf_gather(const struct xe_dgrun *runs, const uint32_t *ord, uint32_t nruns, uint32_t *snrec, void *stream)
+{
+	if (!nruns) return XE_OK;
+	hipLaunchKernelGGL(xw_nf_gather_kernel, dim3(xw_blocks(nruns)), dim3(XW_BLOCK), 0, (hipStream_t)stream, runs, ord, nruns, snrec);
+	return xw_done();
+}
+
+extern "C" int
+xe_walk_nf_runs(const struct xe_walk_in *in, const struct xe_dgrun *runs, const uint32_t *ord, const uint32_t *keys,
+	const uint32_t *sscan, const uint32_t *recbase, const struct xe_wgroup *groups, uint32_t nruns, struct xe_frun *out, void *stream)
+{
+	if (!nruns) return XE_OK;
+	hipLaunchKernelGGL(xw_nf_runs_kernel, dim3(xw_blocks(nruns)), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, runs, ord, keys,
+		sscan, recbase, groups, nruns, out);
+	return xw_done();
+}
+
+extern "C" int
+xe_walk_nf_tiles(const struct xe_frun *fruns, const struct xe_wgroup *groups, uint32_t ntmpl, uint32_t ntiles,
+	struct xe_ftile *tiles, uint32_t *tkey, uint32_t *tval, void *stream)
+{
+	if (!ntiles) return XE_OK;
+	hipLaunchKernelGGL(xw_nf_tiles_kernel, dim3(xw_blocks(ntiles)), dim3(XW_BLOCK), 0, (hipStream_t)stream, fruns, groups, ntmpl,
+		ntiles, tiles, tkey, tval);
+	return xw_done();
+}
+
+extern "C" int
+xe_walk_nf_tiles_place(const struct xe_ftile *tiles, const uint32_t *order, uint32_t ntiles, struct xe_ftile *out, void *stream)
+{
+	if (!ntiles) return XE_OK;
+	hipLaunchKernelGGL(xw_nf_tiles_place_kernel, dim3(xw_blocks(ntiles)), dim3(XW_BLOCK), 0, (hipStream_t)stream, tiles, order,
+		ntiles, out);
+	return xw_done();
+}
