@@ -35,6 +35,7 @@ struct xe_gpu
 	uint32_t ncjgroups, ncjderived, nrgroups;
 	/* fixed-window tables: they live as long as the handle, batches add to them */
 	hipStream_t copy_stream;   /* datagrams travel on it while the host walks their headers */
+	hipStream_t walk_stream;   /* the device's header walk over a page-locked datagram buffer runs beside the copy */
 	/* device buffers of freed batches, kept for the next ones: hipMalloc and
 	 * hipFree of hundreds of MB cost about a millisecond each, and hipFree
 	 * waits for the whole device, which serialises handles that share a GPU */
@@ -81,6 +82,8 @@ struct fwm_host
 struct walk_dev
 {
 	int mode;                  /* bit 0: the sFlow datagrams were walked on the device, bit 1: Netflow ones of the usual shape */
+	hipStream_t st;            /* what the walk is enqueued on */
+	const uint8_t *hdr_src;    /* where the Netflow walk reads headers: the batch on the device, or the caller's page-locked buffer */
 	size_t n;                  /* datagrams */
 	void *arena, *tiles;       /* device allocations the pointers below are carved from */
 	uint64_t *d_offs;
@@ -206,6 +209,11 @@ xe_gpu_create(xe_gpu **out, int device)
 		return XE_EHIP;
 	}
 	h->wstage = pinned_alloc(XE_WSTAGE_BYTES);
+	if (h->wstage && (hipStreamCreateWithFlags(&h->walk_stream, hipStreamNonBlocking) != hipSuccess)) {
+		(void)hipGetLastError();
+		pinned_free(h->wstage);
+		h->wstage = NULL;
+	}
 	if (!h->wstage) {
 		(void)hipStreamDestroy(h->copy_stream);
 		xe_host_free(&h->hs);
@@ -250,6 +258,7 @@ xe_gpu_destroy(xe_gpu *h)
 	free(h->fwms);
 	if (h->d_fwmdesc) (void)hipFree(h->d_fwmdesc);
 	if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+	if (h->walk_stream) (void)hipStreamDestroy(h->walk_stream);
 	for (int i = 0; i < XE_DPOOL; i++) if (h->dpool[i].p) (void)hipFree(h->dpool[i].p);
 	if (h->stage) (void)hipHostFree(h->stage);
 	pinned_free(h->wstage);
@@ -2107,7 +2116,8 @@ walk_input(const xe_gpu *h, const xe_batch *b, struct xe_walk_in *in)
  * walk which to pass by).  Everything is enqueued on the copy stream behind
  * the datagram bytes. */
 static int
-walk_begin(xe_gpu *h, xe_batch *b, const uint64_t *offsets, const uint32_t *src, const uint8_t *kinds, size_t n, int mode)
+walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets, const uint32_t *src, const uint8_t *kinds,
+	size_t n, int mode)
 {
 	struct walk_dev *w = &b->w;
 	hipStream_t st = h->copy_stream;
@@ -2119,9 +2129,25 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint64_t *offsets, const uint32_t *src,
 
 	w->mode = mode;
 	w->n = n;
+	w->hdr_src = (const uint8_t *)b->d_pkt;
+	if (mode == 2) {
+		/* Netflow only, from page-locked memory the GPU can read in place: the
+		 * walk needs 24 bytes of every datagram, which it fetches over the link
+		 * itself while the copy of the whole buffer is under way */
+		hipPointerAttribute_t at;
+		memset(&at, 0, sizeof(at));
+		if ((hipPointerGetAttributes(&at, data) == hipSuccess) && (at.type == hipMemoryTypeHost) && at.devicePointer) {
+			w->hdr_src = (const uint8_t *)at.devicePointer;
+			st = h->walk_stream;
+		} else {
+			(void)hipGetLastError();
+		}
+	}
+	w->st = st;
 	if (mode & 2) {
 		rc = walk_tables_sync(h);
 		if (rc != XE_OK) return rc;
+		if (h->twalk_n >= (1u << 24)) return XE_EUNSUPPORTED;
 	}
 	w->temp_bytes = xe_walk_temp_bytes(n + 1);
 #define CARVE(BYTES) (off = ALIGN_UP(off, 256), off += (BYTES), off - (BYTES))
@@ -2174,6 +2200,7 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint64_t *offsets, const uint32_t *src,
 	if (!w->kinds2 || !w->h_src) return XE_ENOMEM;
 	memcpy(w->h_src, src, 4 * n);
 	if (mode & 2) {
+		in.pkt = w->hdr_src;
 		rc = xe_walk_nf_shape(&in, w->d_dgruns, w->d_walked, st);
 		if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (Netflow)");
 		w->h_walked = (uint8_t *)malloc(n ? n : 1);
@@ -2181,6 +2208,7 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint64_t *offsets, const uint32_t *src,
 		HIPCHK(h, hipMemcpyAsync(w->h_walked, w->d_walked, n, hipMemcpyDeviceToHost, st));
 	}
 	if (mode & 1) {
+		in.pkt = (const uint8_t *)b->d_pkt;
 		rc = xe_walk_sf_count(&in, w->d_sfcnt, w->d_total, st);
 		if (rc == XE_OK) rc = xe_walk_scan(w->d_temp, w->temp_bytes, w->d_sfcnt, w->d_sfbase, n, st);
 		if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (sFlow)");
@@ -2239,7 +2267,7 @@ walk_host_part(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offs
 			xe_host_undo_rollback(&h->hs);
 			xe_plan_free(&b->plan);
 			rc = xe_prepass(&h->hs, data, offsets, src, w->kinds2, n, &b->plan);
-			e = hipMemcpyAsync(w->d_walked, w->h_walked, n, hipMemcpyHostToDevice, h->copy_stream);
+			e = hipMemcpyAsync(w->d_walked, w->h_walked, n, hipMemcpyHostToDevice, w->st);
 			if ((rc == XE_OK) && (e != hipSuccess)) { xe_plan_free(&b->plan); rc = hip_fail(h, e, "hipMemcpyAsync(walked)"); }
 		}
 	}
@@ -2256,12 +2284,17 @@ walk_finish(xe_gpu *h, xe_batch *b)
 {
 	struct walk_dev *w = &b->w;
 	struct xe_plan *plan = &b->plan;
-	hipStream_t st = h->copy_stream;
+	hipStream_t st = w->st;
 	const size_t n = w->n, nt = h->twalk_n;
 	struct xe_walk_in in;
 	int rc;
 
+	const int dbg = getenv("XE_DEBUG") != NULL;
+	double tk[6] = {0, 0, 0, 0, 0, 0};
+#define WTICK(I) do { if (dbg) { struct timespec ts_; clock_gettime(CLOCK_MONOTONIC, &ts_); tk[I] = ts_.tv_sec * 1e3 + ts_.tv_nsec * 1e-6; } } while (0)
+
 	walk_input(h, b, &in);
+	WTICK(0);
 	if (w->mode & 1) {
 		unsigned long long nsf;
 		HIPCHK(h, hipStreamSynchronize(st));
@@ -2294,7 +2327,9 @@ walk_finish(xe_gpu *h, xe_batch *b)
 		HIPCHK(h, hipMemcpyAsync(cnt, w->d_gtotal, 4 * nt, hipMemcpyDeviceToHost, st));
 		HIPCHK(h, hipMemcpyAsync(cnt + nt, w->d_gruns, 4 * nt, hipMemcpyDeviceToHost, st));
 		HIPCHK(h, hipMemcpyAsync(cnt + 2 * nt + 2, w->d_total + 1, 8, hipMemcpyDeviceToHost, st));
+		WTICK(1);
 		HIPCHK(h, hipStreamSynchronize(st));
+		WTICK(2);
 		memcpy(&total, cnt + 2 * nt + 2, 8);
 		if (total + plan->nsf > 0xFFFFFFF0ull) return XE_EUNSUPPORTED;
 		/* from 2^28 records on the fast kernel is out (32-bit column offsets) */
@@ -2381,7 +2416,11 @@ walk_finish(xe_gpu *h, xe_batch *b)
 		}
 		w->nrec2 = (size_t)dev_total;
 		plan->nrec = (size_t)total;
+		WTICK(3);
+		if (dbg) fprintf(stderr, "device walk: enqueue counts / scan / sort %.2f, wait %.2f, runs and tiles enqueued %.2f ms\n",
+			tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2]);
 	}
+#undef WTICK
 	return XE_OK;
 }
 
@@ -2392,6 +2431,7 @@ xe_gpu_batch_free(xe_batch *b)
 	(void)hipSetDevice(b->h->device);
 	if (b->ran) (void)hipStreamSynchronize(b->last_stream);
 	if (b->h && b->h->copy_stream) (void)hipStreamSynchronize(b->h->copy_stream);
+	if (b->h && b->h->walk_stream && b->w.mode) (void)hipStreamSynchronize(b->h->walk_stream);
 	dev_put(b->h, b->d_pkt);
 	dev_put(b->h, b->d_sets);
 	dev_put(b->h, b->d_exps);
@@ -2749,7 +2789,7 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 		if (n >= 0x7FFFFFF0ull) walk_mode = 0;
 	}
 	if (walk_mode) {
-		rc = walk_begin(h, b, offsets, src_ip4, kinds, n, walk_mode);
+		rc = walk_begin(h, b, data, offsets, src_ip4, kinds, n, walk_mode);
 		if (rc != XE_OK) { (void)hipStreamSynchronize(h->copy_stream); xe_gpu_batch_free(b); return rc; }
 		if (walk_mode & 2) xe_host_undo_begin(&h->hs);
 		rc = walk_host_part(h, b, data, offsets, src_ip4, n);
@@ -2762,6 +2802,7 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 			(rc == XE_EUNSUPPORTED) ? " (the batch would hold more than 2^32 records: prepare fewer datagrams at a time)" : "");
 		if (walk_mode & 2) xe_host_undo_end(&h->hs);
 		(void)hipStreamSynchronize(h->copy_stream);
+		if (b->w.mode && b->w.st) (void)hipStreamSynchronize(b->w.st);
 		dev_put(h, b->d_pkt);
 		walk_free(h, &b->w);
 		free(b);
@@ -2963,6 +3004,7 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 	{
 		/* the caller's buffer is free again, and the kernels may run on any stream */
 		hipError_t e = hipStreamSynchronize(h->copy_stream);
+		if ((e == hipSuccess) && b->w.mode && (b->w.st != h->copy_stream)) e = hipStreamSynchronize(b->w.st);
 		if (e != hipSuccess) { xe_gpu_batch_free(b); return hip_fail(h, e, "hipStreamSynchronize(packets)"); }
 	}
 	XE_TICK();
@@ -3042,7 +3084,7 @@ extern "C" int
 xe_gpu_batch_kernel_ms(xe_batch *b, float ms[3])
 {
 	int rc;
-	const uint32_t launched[3] = { b ? b->kp.ntiles : 0, b ? b->kp.nslowrec : 0, b ? b->kp.nsf : 0 };
+	const uint32_t launched[3] = { b ? (b->kp.ntiles | b->kp.ntiles2) : 0, b ? b->kp.nslowrec : 0, b ? b->kp.nsf : 0 };
 
 	if (!b || !ms) return XE_EINVAL;
 	if (!b->timing) return XE_ESTATE;
@@ -3334,7 +3376,7 @@ xe_gpu_batch_flow_info(xe_batch *b, size_t first, size_t count, void *out)
 				 * rate are in its run, the exporter address came with the datagram */
 				const struct xe_dgrun *g = &b->w.h_dgruns[di];
 				const uint32_t idb = htonl(g->dev_id);
-				t = &tm[g->tmpl];
+				t = &tm[g->tmpl & 0xFFFFFFu];
 				memcpy(from_dev.dev_ip, &b->w.h_src[di], 4);
 				memcpy(from_dev.dev_id, &idb, 4);
 				from_dev.sampling_rate = g->rate & 0x7FFFFFFFu;

@@ -215,7 +215,7 @@ struct xe_twalk
 struct xe_dgrun
 {
 	uint32_t nrec;        /* 0: not walked here */
-	uint32_t tmpl;
+	uint32_t tmpl;        /* device template | bytes from the datagram start to the first record << 24 */
 	uint32_t dev_id;      /* source id / observation domain as a big-endian number */
 	uint32_t rate;        /* sampling rate | has a devices.conf entry << 31 */
 };

@@ -279,7 +279,7 @@ xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular)
 				if (n && ((24 + 48 * n) == len) && in.v5_slot_plus1 && in.twalk[in.v5_slot_plus1 - 1].fast
 					&& exporter_plain(in, src, sid, r.rate)) {
 					r.nrec = n;
-					r.tmpl = in.v5_slot_plus1 - 1;
+					r.tmpl = (in.v5_slot_plus1 - 1) | (24u << 24);
 					r.dev_id = __builtin_bswap32(sid);
 					ok = true;
 				}
@@ -295,7 +295,7 @@ xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular)
 					if (tw.fast && (count * tw.stride <= length) && ((24 + count * tw.stride) <= len)
 						&& exporter_plain(in, src, sid, r.rate)) {
 						r.nrec = count;
-						r.tmpl = e.slot;
+						r.tmpl = e.slot | (24u << 24);
 						r.dev_id = __builtin_bswap32(sid);
 						ok = true;
 					}
@@ -315,7 +315,7 @@ xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular)
 						const uint32_t nfull = (length > tw.off_last) ? (length - tw.off_last - 1) / tw.stride + 1 : 0;
 						if ((nfull >= nrec) && ((20 + nrec * tw.stride) <= len) && exporter_plain(in, src, sid, r.rate)) {
 							r.nrec = nrec;
-							r.tmpl = e.slot;
+							r.tmpl = e.slot | (20u << 24);
 							r.dev_id = __builtin_bswap32(sid);
 							ok = true;
 						}
@@ -334,17 +334,35 @@ xw_nf_counts_kernel(const xe_walk_in in, const xe_dgrun *runs, const uint8_t *wa
 	uint32_t *cnt, uint32_t *key, uint32_t *val, uint32_t *gtotal, uint32_t *gruns, unsigned long long *total)
 {
 	const uint32_t i = blockIdx.x * XW_BLOCK + threadIdx.x;
-	uint32_t c = 0;
+	uint32_t c = 0, mine = 0xFFFFFFFFu, nrec = 0;
 	if (i < in.n) {
 		const bool w = walked[i] != 0;
 		const xe_dgrun r = runs[i];
 		c = w ? r.nrec : (hostfirst[i + 1] - hostfirst[i]);
 		cnt[i] = c;
-		key[i] = w ? r.tmpl : in.ntmpl;
+		key[i] = w ? (r.tmpl & 0xFFFFFFu) : in.ntmpl;
 		val[i] = i;
-		if (w) {
-			atomicAdd(&gtotal[r.tmpl], r.nrec);
-			atomicAdd(&gruns[r.tmpl], 1u);
+		mine = w ? (r.tmpl & 0xFFFFFFu) : 0xFFFFFFFFu;
+		nrec = w ? r.nrec : 0;
+	}
+	/* per-template sums: a batch has a handful of templates, so the lanes of a
+	 * wave that share one add up among themselves and one of them does the
+	 * atomic add (155 000 adds to two addresses took over a millisecond) */
+	{
+		const uint32_t lane = threadIdx.x & 63;
+		unsigned long long todo = __ballot(mine != 0xFFFFFFFFu);
+		while (todo) {
+			const int leader = __ffsll((long long)todo) - 1;
+			const uint32_t t = __shfl(mine, leader, 64);
+			const bool same = mine == t;
+			const unsigned long long grp = __ballot(same);
+			uint32_t sum = same ? nrec : 0;
+			for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d, 64);
+			if (lane == (uint32_t)leader) {
+				atomicAdd(&gtotal[t], sum);
+				atomicAdd(&gruns[t], (uint32_t)__popcll(grp));
+			}
+			todo &= ~grp;
 		}
 	}
 	/* the batch total in 64 bits: the 32-bit prefix sums could wrap unnoticed */
@@ -369,11 +387,9 @@ xw_nf_runs_kernel(const xe_walk_in in, const xe_dgrun *runs, const uint32_t *ord
 	const uint32_t i = ord[j], t = keys[j];
 	const xe_dgrun r = runs[i];
 	const xe_wgroup g = groups[t];
-	const uint8_t *p = in.pkt + in.offs[i];
-	const uint32_t ver = be16(p);
 	xe_frun f;
 	/* the first record: behind the datagram header and the set header (v5: the header) */
-	f.data_off = (uint32_t)in.offs[i] + ((ver == 10) ? 20u : 24u);
+	f.data_off = (uint32_t)in.offs[i] + (r.tmpl >> 24);
 	f.first_rec = recbase[i];
 	f.start = g.pos0 + (sscan[j] - sscan[g.run0]);
 	f.nrec = r.nrec;
