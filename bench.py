@@ -498,6 +498,9 @@ def main():
 
             def worker(t):
                 st = torch.cuda.Stream(device=local_rank)
+                # capture threads do not run in lock step: started together they would all copy
+                # at once and then all fetch at once, leaving the link idle in between
+                time.sleep(t * t_e2e_pinned / nthr / nthr)
                 for _ in range(rounds):
                     bb = engines[t].prepare(inputs[t])
                     bb.run(st.cuda_stream)

@@ -643,7 +643,10 @@ upload_pooled(xe_gpu *h, void **dst, const void *src, size_t bytes)
 {
 	int rc = dev_get(h, dst, bytes);
 	if (rc != XE_OK) return rc;
-	if (src && bytes) HIPCHK(h, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+	/* on the handle's copy stream (prepare waits for it before it returns); the
+	 * source may be reused as soon as the call returns: pageable memory is
+	 * staged by the runtime before it does */
+	if (src && bytes) HIPCHK(h, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, h->copy_stream));
 	return XE_OK;
 }
 
@@ -3114,7 +3117,10 @@ fetch(xe_batch *b, void *dst, size_t off, size_t bytes)
 	int rc = xe_gpu_batch_sync(b);
 	if (rc != XE_OK) return rc;
 	if (!bytes) return XE_OK;
-	HIPCHK(b->h, hipMemcpy(dst, (uint8_t *)b->d_out + off, bytes, hipMemcpyDeviceToHost));
+	/* on the handle's own stream: the default stream would order this copy
+	 * against every other handle's work on the device */
+	HIPCHK(b->h, hipMemcpyAsync(dst, (uint8_t *)b->d_out + off, bytes, hipMemcpyDeviceToHost, b->h->copy_stream));
+	HIPCHK(b->h, hipStreamSynchronize(b->h->copy_stream));
 	return XE_OK;
 }
 

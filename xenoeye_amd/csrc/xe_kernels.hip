@@ -47,6 +47,25 @@ __device__ __forceinline__ val128
 pkt_be(const pkt_src &s, int32_t off, uint32_t len)
 {
 	val128 v = {0, 0};
+	if (!s.checked && len) {
+		/* every byte of the field is inside the datagram: one or two 8-byte
+		 * loads (they may run past the field, never past the batch buffer,
+		 * which ends in 64 spare bytes) instead of a load per byte */
+		uint64_t a, b;
+		__builtin_memcpy(&a, s.p + off, 8);
+		a = __builtin_bswap64(a);
+		if (len <= 8) {
+			v.lo = a >> (64 - 8 * len);
+		} else {
+			__builtin_memcpy(&b, s.p + off + 8, 8);
+			b = __builtin_bswap64(b);
+			/* the len bytes a:b as one number, right-aligned in hi:lo */
+			const uint32_t sh = 8 * (16 - len);          /* 0..56 */
+			v.lo = sh ? ((b >> sh) | (a << (64 - sh))) : b;
+			v.hi = sh ? (a >> sh) : a;
+		}
+		return v;
+	}
 	for (uint32_t i = 0; i < len; i++) {
 		v.hi = (v.hi << 8) | (v.lo >> 56);
 		v.lo = (v.lo << 8) | pkt_byte(s, off + (int32_t)i);
@@ -1845,13 +1864,24 @@ xe_nf_general_kernel(const xe_kparams kp)
 
 	rec.mark = 0;
 	rec.nparsed = 0;
-	if (active) {
-		/* the run whose work range holds this thread */
-		uint32_t lo = 0, hi = kp.nssets - 1;
-		while (lo < hi) {
-			uint32_t mid = (lo + hi + 1) >> 1;
-			if (kp.swstart[mid] <= g) lo = mid; else hi = mid - 1;
+	/* the run whose work range holds the wave's first thread: one search per
+	 * wave with scalar loads (its lanes are consecutive records, which lie in
+	 * that run or a few runs on) */
+	uint32_t wlo = 0;
+	{
+		const uint32_t g0 = __builtin_amdgcn_readfirstlane(g - (threadIdx.x & 63));
+		const XE_CONST uint32_t *sw = (const XE_CONST uint32_t *)kp.swstart;
+		uint32_t hi = kp.nssets ? kp.nssets - 1 : 0;
+		if (g0 < kp.nslowrec) {
+			while (wlo < hi) {
+				const uint32_t mid = (wlo + hi + 1) >> 1;
+				if (sw[mid] <= g0) wlo = mid; else hi = mid - 1;
+			}
 		}
+	}
+	if (active) {
+		uint32_t lo = wlo;
+		while ((lo + 1 < kp.nssets) && (kp.swstart[lo + 1] <= g)) lo++;
 		const xe_set s = kp.ssets[lo];
 		uint32_t i = g - kp.swstart[lo];
 		ridx = s.first_rec + i;
@@ -1869,7 +1899,10 @@ xe_nf_general_kernel(const xe_kparams kp)
 		/* how many template fields the reference parses for this record */
 		uint32_t nf = rec.t->nfields, np = 0;
 		int32_t pos = 0;
-		if (rec.t->mode == XE_MODE_V9) {
+		if (!(s.flags & XE_SET_PARTIAL)) {
+			/* a run of complete records: all template fields */
+			np = nf;
+		} else if (rec.t->mode == XE_MODE_V9) {
 			for (; np < nf; np++) {
 				if ((pos + (int32_t)rec.e[np].len) > avail) break;
 				pos += rec.e[np].len;
