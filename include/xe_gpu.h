@@ -161,6 +161,26 @@ long xe_gpu_fwm_export(xe_gpu *h, int fwm, int limit, uint8_t *keys, uint64_t *v
 /* end of a window: empties the table */
 int xe_gpu_fwm_clear(xe_gpu *h, int fwm);
 
+/* Databases of the filter functions asn(), asd() and continent() ... long()
+ * (geoip.c:33-88, filter.c:753-834): `image` = the bytes of the reference's own
+ * geo4.db / geo6.db (kind 0) or as4.db / as6.db (kind 1) file, family 4 or 6
+ * (an array of struct btrie_node_geo / btrie_node_as, geoip.h:43-55; the
+ * library keeps a copy; 0 bytes drops the database).  Set them before the
+ * objects and devices: a filter with such a function is then evaluated on the
+ * device - at xe_gpu_commit the database becomes an IP list per function term,
+ * with a leaf wherever the database has one whose payload meets the term's
+ * operands, so the device's list walk answers what the function's own walk
+ * answers (an absent field is looked up as zeros, as the reference reads it).
+ * Without its database an object with such a function is host-only
+ * (xe_gpu_mo_host_only).  XE_EPARSE: the image is not a tree of whole nodes.
+ * The reference re-reads the files on a signal (geoip.c:131-178); here a new
+ * image needs a new handle.  Parity of these functions is checked against the
+ * CPU oracle over synthetic databases only: the reference tree holds no
+ * database file. */
+int xe_gpu_set_geodb(xe_gpu *h, int kind, int family, const void *image, size_t bytes);
+/* the four files of `dir` that exist (geoip.c:146-149); returns how many were loaded */
+int xe_gpu_load_geodb(xe_gpu *h, const char *dir);
+
 /* Host threads xe_gpu_batch_prepare() walks datagram headers with (default 8,
  * or the environment's XE_PREPASS_THREADS; 1 = the calling thread only).
  * Datagrams of one exporter stay on one thread, in arrival order, the way the

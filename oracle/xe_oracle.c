@@ -1617,6 +1617,85 @@ match_mfreq(struct basic *fb, struct xo_flow *flow)
 	return in_ranges(fb, res);
 }
 
+/* ---- geo / AS databases (geoip.h:13-55, geoip.c:33-88, ip-btrie.h:88-115) ----
+ * A database is the array of trie nodes the reference maps from geo4.db /
+ * geo6.db / as4.db / as6.db: {uint32_t next[2]; int is_leaf; payload}, payload =
+ * struct geoip_info (8 char arrays of 3, 3, 35, 64, 51, 15, 20, 23 bytes) or
+ * struct as_info {uint32_t asn; char asd[200]}.  The lookup walks the address
+ * bits from the most significant one while a child exists and answers with
+ * the payload of the node it stops at if that node is a leaf. */
+#define XO_GEO_NODE 228   /* 12 + 214, padded to the alignment of its ints */
+#define XO_AS_NODE 216    /* 12 + 4 + 200 */
+static const int geo_off[8] = { 0, 3, 6, 41, 105, 156, 171, 191 };
+static struct { uint8_t *img; size_t nnodes; } geodb[2][2];   /* [0 geo, 1 as][0 IPv4, 1 IPv6] */
+
+int
+xo_geodb_set(int kind, int family, const void *img, size_t bytes)
+{
+	const size_t ns = kind ? XO_AS_NODE : XO_GEO_NODE;
+	const int fi = (family == 6) ? 1 : 0;
+
+	if ((kind < 0) || (kind > 1) || (bytes % ns)) return 0;
+	free(geodb[kind][fi].img);
+	geodb[kind][fi].img = NULL;
+	geodb[kind][fi].nnodes = 0;
+	if (!bytes) return 1;
+	geodb[kind][fi].img = malloc(bytes);
+	if (!geodb[kind][fi].img) return 0;
+	memcpy(geodb[kind][fi].img, img, bytes);
+	geodb[kind][fi].nnodes = bytes / ns;
+	return 1;
+}
+
+/* IP_BTRIE_LOOKUP: the payload of the deepest node on the address's path, NULL
+ * when there is no database or that node is not a leaf */
+static const uint8_t *
+geodb_lookup(int kind, const uint8_t *addr, int nbits)
+{
+	const int fi = (nbits == 128) ? 1 : 0;
+	const size_t ns = kind ? XO_AS_NODE : XO_GEO_NODE;
+	const uint8_t *db = geodb[kind][fi].img;
+	uint32_t node = 0, next;
+	int i, leaf;
+
+	if (!db) return NULL;
+	for (i = 0; i < nbits; i++) {
+		const int bit = !!(addr[i / 8] & (1 << (7 - (i % 8))));
+		memcpy(&next, db + (size_t)node * ns + 4 * bit, 4);
+		if (!next || (next >= geodb[kind][fi].nnodes)) break;
+		node = next;
+	}
+	memcpy(&leaf, db + (size_t)node * ns + 8, 4);
+	return leaf ? db + (size_t)node * ns + 12 : NULL;
+}
+
+/* filter_function_geoip() / filter_function_as(), filter.c:753-834: the field's
+ * bytes are read whether the field is present or not; only fields of 4 and 16
+ * bytes have a defined meaning */
+static int
+match_geo_as(struct basic *fb, struct xo_flow *flow)
+{
+	const uint8_t *addr = (const uint8_t *)flow + fb->a_off;
+	const uint8_t *pay;
+	size_t i;
+
+	if ((fb->a_size != 4) && (fb->a_size != 16)) return 0;
+	pay = geodb_lookup(fb->func != FN_GEO, addr, (fb->a_size == 4) ? 32 : 128);
+	if (!pay) return 0;
+	if (fb->func == FN_ASN) {
+		uint32_t asn;
+		memcpy(&asn, pay, 4);
+		return in_ranges(fb, (int32_t)asn);
+	}
+	{
+		const char *res = (fb->func == FN_ASD) ? (const char *)pay + 4 : (const char *)pay + geo_off[fb->geo_field];
+		for (i = 0; i < fb->n; i++) {
+			if (fb->data[i].str && (strcmp(fb->data[i].str, res) == 0)) return 1;
+		}
+	}
+	return 0;
+}
+
 static int
 basic_match(struct basic *fb, struct xo_flow *flow)  /* filter.c:907-958 */
 {
@@ -1625,8 +1704,8 @@ basic_match(struct basic *fb, struct xo_flow *flow)  /* filter.c:907-958 */
 	if (fb->func == FN_PPSTR) return match_ppstr(fb, flow);
 	if (fb->func == FN_MFREQ) return match_mfreq(fb, flow);
 	/* geo / AS functions: geoip_lookup4/6 and as_lookup4/6 answer 0 while no
-	 * database is loaded (geoip.c:33-88), and none can be here: no match */
-	if ((fb->func == FN_GEO) || (fb->func == FN_ASN) || (fb->func == FN_ASD)) return 0;
+	 * database is loaded (geoip.c:33-88) */
+	if ((fb->func == FN_GEO) || (fb->func == FN_ASN) || (fb->func == FN_ASD)) return match_geo_as(fb, flow);
 	if (fb->func == FN_MIN) {  /* filter.c:685-709 */
 		uint64_t a = get_nf_val((uint8_t *)flow + fb->a_off, fb->a_size);
 		uint64_t b = get_nf_val((uint8_t *)flow + fb->b_off, fb->b_size);
@@ -3074,6 +3153,7 @@ xo_reset(void)
 	size_t i, j;
 
 	xo_log_clear();
+	for (i = 0; i < 2; i++) for (j = 0; j < 2; j++) (void)xo_geodb_set((int)i, j ? 6 : 4, NULL, 0);
 	for (i = 0; i < n_mos; i++) {
 		fexpr_free(mos[i].expr);
 		free(mos[i].kids);

@@ -117,6 +117,9 @@ int xo_xdiv(uint64_t dividend, uint64_t divisor, int is_log, int k);
 void xo_set_port_names(const char *const *names);
 void xo_port_to_str(char *res, uint16_t port);
 void xo_ports_pair_to_str(char *res, uint16_t port1, uint16_t port2);
+/* geo / AS database image as the reference maps it from geo4.db / geo6.db
+ * (kind 0) or as4.db / as6.db (kind 1); family 4 or 6; 0 bytes = none */
+int xo_geodb_set(int kind, int family, const void *img, size_t bytes);
 /* text of a TCP flags byte, as tcp_flags_to_str() (utils.c:22-26) gives it */
 void xo_tcp_flags_str(uint8_t tf, char out[40]);
 

@@ -153,6 +153,11 @@ class Oracle:
         if not ok:
             raise ValueError(err.value.decode(errors="replace"))
 
+    def geodb_set(self, kind, family, image):
+        """kind 0 geo / 1 AS, family 4 / 6, image: bytes of the reference's .db file"""
+        self.L.xo_geodb_set.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+        assert self.L.xo_geodb_set(kind, family, bytes(image), len(image))
+
     def set_port_names(self, names):
         """65536 service names ('' / None = none) for portstr() / ppstr(); None removes them"""
         if names is None:

@@ -61,6 +61,8 @@ def load_library(path=LIB_PATH):
         "xe_gpu_commit": (i32, [vp]),
         "xe_gpu_set_prepass_threads": (i32, [vp, i32]),
         "xe_gpu_set_device_walk": (i32, [vp, i32]),
+        "xe_gpu_set_geodb": (i32, [vp, i32, i32, vp, sz]),
+        "xe_gpu_load_geodb": (i32, [vp, cp]),
         "xe_gpu_batch_device_walked": (i32, [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
         "xe_gpu_batch_unsupported_sets": (C.c_size_t, [vp]),
         "xe_gpu_batch_oversized_datagrams": (C.c_size_t, [vp]),
@@ -339,6 +341,14 @@ class Engine:
     def set_prepass_threads(self, n):
         """host threads that walk datagram headers in prepare() (1 = calling thread only)"""
         self._chk(self.L.xe_gpu_set_prepass_threads(self._h, int(n)))
+
+    def set_geodb(self, kind, family, image):
+        """geo (kind 0) / AS (kind 1) database, family 4 / 6: the bytes of the reference's .db file"""
+        buf = np.frombuffer(bytes(image), dtype=np.uint8)
+        self._chk(self.L.xe_gpu_set_geodb(self._h, int(kind), int(family), buf.ctypes.data if buf.size else None, buf.size))
+
+    def load_geodb(self, d):
+        return self._chk(self.L.xe_gpu_load_geodb(self._h, d.encode()))
 
     def set_device_walk(self, mode):
         """which headers the device walks itself: bit 0 sFlow, bit 1 Netflow datagrams of the usual shape"""

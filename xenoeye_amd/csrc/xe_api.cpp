@@ -274,11 +274,28 @@ xe_gpu_destroy(xe_gpu *h)
 }
 
 /* ------------------------------------------------------------------ configuration */
+/* the lists at the end of the registry that the last commit made from the
+ * geo / AS databases (and the empty ones it put in front of them) */
+static void
+drop_made_lists(xe_gpu *h)
+{
+	struct xe_iplists *reg = &h->hs.lists;
+	while (h->hs.nlists_made && reg->n) {
+		reg->n--;
+		free(reg->l[reg->n].n4);
+		free(reg->l[reg->n].n6);
+		h->hs.nlists_made--;
+	}
+	h->hs.nlists_made = 0;
+	h->hs.nlists_fn = 0;
+}
+
 extern "C" int
 xe_gpu_load_iplists(xe_gpu *h, const char *dir)
 {
 	int rc;
 	if (!h || !dir) return XE_EINVAL;
+	drop_made_lists(h);
 	rc = xe_iplist_load_dir(&h->hs.lists, dir);
 	if (rc != XE_OK) snprintf(h->err, sizeof(h->err), "cannot load IP lists from '%s'", dir);
 	h->committed = 0;
@@ -290,6 +307,7 @@ xe_gpu_add_iplist(xe_gpu *h, const char *name, const char *text, size_t len)
 {
 	if (!h || !name || (!text && len)) return XE_EINVAL;
 	h->committed = 0;
+	drop_made_lists(h);
 	return xe_iplist_load_text(&h->hs.lists, name, text, len);
 }
 
@@ -322,6 +340,13 @@ compile_checked(xe_gpu *h, const char *text, struct xe_filter *f, int *host_only
 	}
 	if (!f->device_ok) reason = f->why;
 	else if (f->needs_port_names && !h->port_names) reason = "portstr() / ppstr() without a port-name table (xe_gpu_set_port_names)";
+	else if (f->needs_geodb) {
+		for (int k = 0; k < 4; k++) {
+			if (((f->needs_geodb >> k) & 1) && !h->hs.geodb[k >> 1][k & 1].img) {
+				reason = "geo / AS function without its database (xe_gpu_set_geodb)";
+			}
+		}
+	}
 	else if (prog_depth(f) > 64) reason = "expression nests deeper than 64";
 	if (host_only) *host_only = reason != NULL;
 	if (reason) {
@@ -415,6 +440,49 @@ xe_gpu_set_port_names(xe_gpu *h, const char *const *names)
 }
 
 extern "C" int xe_gpu_mo_count(const xe_gpu *h) { return h ? (int)h->hs.nmos : XE_EINVAL; }
+
+extern "C" int
+xe_gpu_set_geodb(xe_gpu *h, int kind, int family, const void *image, size_t bytes)
+{
+	int rc;
+	if (!h) return XE_EINVAL;
+	if (h->hs.nmos || h->hs.ndevs) {
+		snprintf(h->err, sizeof(h->err), "the geo / AS databases are set before the objects and devices are added");
+		return XE_ESTATE;
+	}
+	rc = xe_geodb_set(&h->hs, kind, family, image, bytes, h->err, sizeof(h->err));
+	if (rc == XE_OK) h->committed = 0;
+	return rc;
+}
+
+extern "C" int
+xe_gpu_load_geodb(xe_gpu *h, const char *dir)
+{
+	static const char *const names[4] = { "geo4", "geo6", "as4", "as6" };   /* geoip.c:146-149 */
+	int loaded = 0;
+
+	if (!h || !dir) return XE_EINVAL;
+	for (int k = 0; k < 4; k++) {
+		char path[4200];
+		FILE *f;
+		long len;
+		void *buf;
+		int rc;
+		snprintf(path, sizeof(path), "%.4000s/%s.db", dir, names[k]);
+		f = fopen(path, "rb");
+		if (!f) continue;             /* the reference runs without a database it cannot open */
+		if ((fseek(f, 0, SEEK_END) != 0) || ((len = ftell(f)) < 0) || (fseek(f, 0, SEEK_SET) != 0)) { fclose(f); return XE_EIO; }
+		buf = malloc(len ? (size_t)len : 1);
+		if (!buf) { fclose(f); return XE_ENOMEM; }
+		if (fread(buf, 1, (size_t)len, f) != (size_t)len) { free(buf); fclose(f); return XE_EIO; }
+		fclose(f);
+		rc = xe_gpu_set_geodb(h, k >> 1, (k & 1) ? 6 : 4, buf, (size_t)len);
+		free(buf);
+		if (rc != XE_OK) return rc;
+		loaded++;
+	}
+	return loaded;
+}
 
 extern "C" const char *
 xe_gpu_mo_name(const xe_gpu *h, int mo)
@@ -820,7 +888,7 @@ make_dopnd(const struct xe_term *t, const struct xe_opnd *o)
 /* lookup bit of the (list, family, field) membership test; the probe for
  * (group of the list, family, field) is added on first use */
 static int32_t
-intern_lookup(struct xe_blob *probes, uint32_t list, int family, uint8_t field)
+intern_lookup(struct xe_blob *probes, uint32_t list, int family, uint8_t field, int zero_absent)
 {
 	struct xe_probe *have = (struct xe_probe *)probes->p;
 	struct xe_probe pr;
@@ -836,7 +904,7 @@ intern_lookup(struct xe_blob *probes, uint32_t list, int family, uint8_t field)
 	pr.group = group;
 	pr.family = (uint8_t)family;
 	pr.field = field;
-	pr.wide4 = (family == 4) && (xe_fields[field].size_max == 16);
+	pr.wide4 = (uint8_t)((((family == 4) && (xe_fields[field].size_max == 16)) ? 1 : 0) | (zero_absent ? 2 : 0));
 	pr.used = (uint8_t)(1u << l);
 	if (!xe_blob_push(probes, &pr, sizeof(pr))) return -1;
 	return (int32_t)((probes->n - 1) * XE_LIST_GROUP + l);
@@ -854,7 +922,57 @@ intern_term(struct intern_ctx *cx, const struct xe_filter *f, size_t ti, uint32_
 	int rc = XE_OK;
 
 	t.pad = 0;
-	for (uint32_t j = 0; (j < f->terms[ti].nopnd) && (rc == XE_OK); j++) {
+	if ((t.func == XE_FN_GEO) || (t.func == XE_FN_ASN) || (t.func == XE_FN_ASD)) {
+		/* geo / AS function: the database becomes an IP list whose leaves are
+		 * the nodes that meet the operands (xe_geodb.c); the term becomes
+		 * "the field is in that list", with an absent field read as zeros
+		 * (the reference reads the field's storage without asking, filter.c:763-783) */
+		const uint32_t n = f->terms[ti].nopnd;
+		const int fam = (xe_fields[t.fa].size_max == 16) ? 6 : 4;
+		int32_t *lo = (int32_t *)calloc(n ? n : 1, sizeof(int32_t)), *hi = (int32_t *)calloc(n ? n : 1, sizeof(int32_t));
+		const char **strs = (const char **)calloc(n ? n : 1, sizeof(char *));
+		struct xe_dopnd d;
+		int li = XE_ENOMEM;
+
+		if (lo && hi && strs) {
+			for (uint32_t j = 0; j < n; j++) {
+				const size_t oi = f->terms[ti].opnd_base + j;
+				const int32_t note = f->opnd_note[oi];
+				lo[j] = (int32_t)f->opnds[oi].w[0];
+				hi[j] = (int32_t)f->opnds[oi].w[1];
+				strs[j] = ((t.type == XE_BT_STRING) && (note >= 0) && ((size_t)note < f->nstrs)) ? f->strs + note : NULL;
+			}
+			/* lists made from the databases start at a group boundary: their
+			 * probes carry the "absent reads as zeros" rule for the whole group */
+			while ((cx->h->hs.lists.n % XE_LIST_GROUP) && (cx->h->hs.nlists_fn == 0)) {
+				char nm[32];
+				snprintf(nm, sizeof(nm), "\001pad%zu", cx->h->hs.lists.n);
+				if (xe_iplist_load_text(&cx->h->hs.lists, nm, "", 0) != XE_OK) break;
+				cx->h->hs.nlists_made++;
+			}
+			if (!(cx->h->hs.lists.n % XE_LIST_GROUP) || cx->h->hs.nlists_fn) {
+				li = xe_geodb_list(&cx->h->hs, t.func, t.k, fam, lo, hi, strs, n);
+				if (li >= 0) { cx->h->hs.nlists_fn++; cx->h->hs.nlists_made++; }
+			}
+		}
+		free(lo); free(hi); free(strs);
+		if (li < 0) return li;
+		memset(&d, 0, sizeof(d));
+		d.is_list = 1;
+		d.list = (uint32_t)li;
+		t.type = (uint8_t)((fam == 4) ? XE_BT_ADDR4 : XE_BT_ADDR6);
+		t.dir = XE_DIR_SRC;
+		t.fsrc = t.fa;
+		t.fdst = 0;
+		t.func = XE_FN_NONE;
+		t.fa = t.fb = 0;
+		t.k = 0;
+		t.pad = XE_TERM_ZERO_ABSENT;
+		d.low = intern_lookup(cx->lookups, d.list, fam, t.fsrc, 1);
+		d.high = -1;
+		if (!xe_blob_push(&dl, &d, sizeof(d))) rc = XE_ENOMEM;
+	}
+	for (uint32_t j = 0; (t.pad != XE_TERM_ZERO_ABSENT) && (j < f->terms[ti].nopnd) && (rc == XE_OK); j++) {
 		const size_t oi = f->terms[ti].opnd_base + j;
 		const int32_t note = f->opnd_note[oi];
 		const char *text = ((t.type == XE_BT_STRING) && (note >= 0) && ((size_t)note < f->nstrs)) ? f->strs + note : NULL;
@@ -875,8 +993,8 @@ intern_term(struct intern_ctx *cx, const struct xe_filter *f, size_t ti, uint32_
 		}
 		if (d.is_list && (t.func == XE_FN_NONE) && ((t.type == XE_BT_ADDR4) || (t.type == XE_BT_ADDR6))) {
 			int fam = (t.type == XE_BT_ADDR4) ? 4 : 6;
-			d.low = (t.dir & XE_DIR_SRC) ? intern_lookup(cx->lookups, d.list, fam, t.fsrc) : -1;
-			d.high = (t.dir & XE_DIR_DST) ? intern_lookup(cx->lookups, d.list, fam, t.fdst) : -1;
+			d.low = (t.dir & XE_DIR_SRC) ? intern_lookup(cx->lookups, d.list, fam, t.fsrc, 0) : -1;
+			d.high = (t.dir & XE_DIR_DST) ? intern_lookup(cx->lookups, d.list, fam, t.fdst, 0) : -1;
 		}
 		if (!xe_blob_push(&dl, &d, sizeof(d))) rc = XE_ENOMEM;
 	}
@@ -917,7 +1035,7 @@ intern_term(struct intern_ctx *cx, const struct xe_filter *f, size_t ti, uint32_
 	for (size_t k = 0; k < terms->n; k++) {
 		const struct xe_term *o = &have[k];
 		if ((o->type == t.type) && (o->dir == t.dir) && (o->fsrc == t.fsrc) && (o->fdst == t.fdst)
-			&& (o->func == t.func) && (o->fa == t.fa) && (o->fb == t.fb) && (o->k == t.k)
+			&& (o->func == t.func) && (o->fa == t.fa) && (o->fb == t.fb) && (o->k == t.k) && (o->pad == t.pad)
 			&& (o->nopnd == t.nopnd)
 			&& (!t.nopnd || !memcmp(hop + o->opnd_base, ops, t.nopnd * sizeof(*ops)))) {
 			*id = (uint32_t)k;
@@ -1455,6 +1573,9 @@ xe_gpu_commit(xe_gpu *h)
 	struct xe_blob progs = {0}, ops = {0}, terms = {0}, opnds = {0}, trie = {0}, rules = {0}, lookups = {0};
 	struct strpool strs = { {0}, {0} };
 	struct intern_ctx cx = { h, &terms, &opnds, &lookups, &strs };
+
+	/* the lists an earlier commit made from the geo / AS databases go: this one makes its own */
+	drop_made_lists(h);
 	int rc = XE_OK;
 
 	if (!h) return XE_EINVAL;
@@ -2955,7 +3076,7 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 				for (int w = 0; w < XE_LK_WORDS; w++) pl[t].probes[w] = ~0ull;
 				for (uint32_t pr = 0; (pr < h->nlookups) && (k < XE_MAX_PROBES); pr++) {
 					const struct xe_probe *q = &h->h_probes[pr];
-					if (q->root_off && (fld[q->field] & XE_FFLD_PRESENT)) {
+					if (q->root_off && ((fld[q->field] & XE_FFLD_PRESENT) || (q->wide4 & 2))) {
 						pl[t].probes[k >> 3] = (pl[t].probes[k >> 3] & ~(0xFFull << (8 * (k & 7))))
 							| ((uint64_t)pr << (8 * (k & 7)));
 						k++;

@@ -120,6 +120,7 @@ struct pctx
 	struct xe_blob ops, terms, opnds, notes, strs;
 	int device_ok;
 	int needs_port_names;
+	int needs_geodb;
 	char why[128];
 };
 
@@ -443,7 +444,8 @@ add_operand(struct pctx *p, int type)
 			for (k = 0; k < len; k++) if (!xe_blob_push(&p->strs, &p->lx.text[k], 1)) return;
 			if (fn == XE_FN_TFSTR) {
 				snprintf((char *)&o.w[0], sizeof(o.w), "%s", p->lx.text);
-			} else if ((fn == XE_FN_PORTSTR) || (fn == XE_FN_PPSTR)) {
+			} else if ((fn == XE_FN_PORTSTR) || (fn == XE_FN_PPSTR) || (fn == XE_FN_ASD) || (fn == XE_FN_GEO)) {
+				/* compared on the host when the term is lowered at commit */
 				if (type != XE_BT_STRING) not_on_device(p, "string operand");
 			} else {
 				not_on_device(p, "string operand");
@@ -642,9 +644,15 @@ other_func_rule(struct pctx *p)
 		if ((xe_fields[t.fa].type == XE_T_STR) || (two_args && (xe_fields[t.fb].type == XE_T_STR))) {
 			not_on_device(p, "portstr() / ppstr() over a string field");
 		}
+	} else if (which == T_MFREQ) {
+		not_on_device(p, "mfreq() keeps state between records");
+	} else if ((xe_fields[t.fa].type != XE_T_STR) && ((xe_fields[t.fa].size_max == 4) || (xe_fields[t.fa].size_max == 16))) {
+		/* a lookup of the field's 4 or 16 bytes in the geo / AS database:
+		 * lowered at commit to a list made from the database */
+		p->needs_geodb |= 1 << (2 * (which != T_GEO) + (xe_fields[t.fa].size_max == 16));
 	} else {
-		not_on_device(p, (which == T_MFREQ) ? "mfreq() keeps state between records"
-			: "geo / AS functions read the caller's databases");
+		/* the reference reads a result it never set (filter.c:769-783, :800-816) */
+		not_on_device(p, "geo / AS function over a field that is not 4 or 16 bytes long");
 	}
 	emit_term(p, &t);
 	return value_list(p, type);
@@ -821,6 +829,7 @@ xe_filter_compile(const struct xe_iplists *reg, const char *text, struct xe_filt
 	out->strs = p.strs.p;     out->nstrs = p.strs.n;
 	out->device_ok = p.device_ok;
 	out->needs_port_names = p.needs_port_names;
+	out->needs_geodb = p.needs_geodb;
 	memcpy(out->why, p.why, sizeof(out->why));
 	if (p.lx.failed) {
 		xe_filter_free(out);

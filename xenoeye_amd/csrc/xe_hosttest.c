@@ -54,6 +54,10 @@ xe_ht_filter_dump(struct xe_host *hs, const char *text, char *out, size_t outlen
 		/* no handle, no port-name table */
 		rc = XE_EUNSUPPORTED;
 		if (err && errlen) snprintf(err, errlen, "portstr() / ppstr() without a port-name table");
+	} else if (f.needs_geodb) {
+		/* no handle, no geo / AS database */
+		rc = XE_EUNSUPPORTED;
+		if (err && errlen) snprintf(err, errlen, "geo / AS function without its database");
 	}
 	xe_filter_free(&f);
 	return rc;

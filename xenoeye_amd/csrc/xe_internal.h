@@ -158,12 +158,14 @@ enum { XE_DIR_NONE = 0, XE_DIR_SRC = 1, XE_DIR_DST = 2, XE_DIR_BOTH = 3 };
 struct xe_term
 {
 	uint8_t type, dir, fsrc, fdst;   /* fsrc/fdst: field indices */
-	uint8_t func, fa, fb, pad;       /* functions: operand fields */
+	uint8_t func, fa, fb, pad;       /* functions: operand fields.  pad: on the host the keyword index (for the
+	                                    dump); on the device XE_TERM_ZERO_ABSENT or 0 */
 	int32_t k;
 	uint32_t nopnd;
 	uint32_t opnd_base;              /* index into the operand array */
 };
 
+#define XE_TERM_ZERO_ABSENT 1    /* address term made from a geo / AS function: an absent field reads as zeros */
 #define XE_OPND_WORDS 10
 struct xe_opnd
 {
@@ -238,7 +240,8 @@ struct xe_probe
 	uint32_t root_off;   /* word offset of the group's root table (this family), 0 = empty */
 	uint8_t family;      /* 4 or 6 */
 	uint8_t field;
-	uint8_t wide4;       /* IPv4 test over the first 4 bytes of a 16-byte field */
+	uint8_t wide4;       /* bit 0: IPv4 test over the first 4 bytes of a 16-byte field;
+	                        bit 1: an absent field is looked up as the zero address (lists made of geo / AS functions) */
 	uint8_t used;        /* bit l: list (8 * group + l) is tested on this field */
 	uint32_t group;
 	uint32_t nodes_off;  /* word offset of node 0 */
@@ -409,6 +412,7 @@ struct xe_filter     /* one compiled expression, host form */
 	char *strs; size_t nstrs;         /* texts of the quoted-string operands, NUL-terminated */
 	int device_ok;                    /* 0: uses something the device cannot evaluate */
 	int needs_port_names;             /* has portstr() / ppstr() terms: evaluable with a port-name table only */
+	int needs_geodb;                  /* has geo / AS function terms: bit (2 * kind + (IPv6 ? 1 : 0)) per database they read */
 	char why[128];
 };
 int xe_filter_compile(const struct xe_iplists *reg, const char *text, struct xe_filter *out,
@@ -425,6 +429,22 @@ int xe_filter_constant(const struct xe_filter *f, int *cval);
  * (int)pow(k, (int)(log(q) / log(k))) (filter.h:407-409) has one value, found
  * with this host's libm; returns the number of pieces (<= cap) or -1 */
 int xe_div_l_pieces(int k, int32_t *lo, int32_t *hi, int32_t *val, int cap);
+
+struct xe_host;
+/* geo / AS databases (xe_geodb.c) */
+/* takes a copy of the image after checking that it is a tree of nodes inside
+ * the image; bytes == 0 drops the database */
+int xe_geodb_set(struct xe_host *hs, int kind, int family, const void *img, size_t bytes, char *err, size_t errlen);
+/* A function term over a database as an IP list: the list's trie has the
+ * shape of the database's, and a node is a leaf iff the database's node is one
+ * and its payload meets the term (asn inside one of the n ranges lo[i]..hi[i];
+ * asd / the geo field `geo_field` equal to one of the n strings).  Walking that
+ * list the way iplist_match4/6 does answers exactly what
+ * filter_function_as() / filter_function_geoip() answer (filter.c:753-834).
+ * Appends the list to the registry (named so that no filter text can refer to
+ * it) and returns its index, or a negative error code. */
+int xe_geodb_list(struct xe_host *hs, int func, int geo_field, int family,
+	const int32_t *lo, const int32_t *hi, const char *const *strs, size_t n);
 
 /* devices.conf entries */
 struct xe_device
@@ -456,9 +476,20 @@ struct xe_tslot
 	uint32_t dev_slot;                /* index into the device template table */
 };
 
+/* geo / AS database: the reference's own file image (geoip.h:43-55), an array
+ * of binary-trie nodes {uint32_t next[2]; int is_leaf; payload} */
+struct xe_geodb { uint8_t *img; size_t nnodes; };
+#define XE_GEO_NODE_BYTES 228     /* 12 + struct geoip_info (214), padded to 4 */
+#define XE_AS_NODE_BYTES 216      /* 12 + struct as_info (4 + 200) */
+
 struct xe_host
 {
 	struct xe_iplists lists;
+	/* the last nlists_made lists of the registry were made at commit from the
+	 * geo / AS databases: nlists_fn of them one per function term, the others
+	 * empty lists that put the first of those at a group boundary */
+	size_t nlists_made, nlists_fn;
+	struct xe_geodb geodb[2][2];   /* [0 geo, 1 AS][0 IPv4, 1 IPv6] */
 	struct xe_mo *mos; size_t nmos;
 	struct xe_device *devs; size_t ndevs;
 	/* template store */

@@ -403,7 +403,14 @@ term_match(const xe_kparams &kp, const REC &rec, const xe_term &t, walk_cache &w
 			 * whichever side is present */
 			fval c[2];
 			int nc = 0;
-			if (t.dir == XE_DIR_SRC) { c[0] = GET(rec, t.fsrc, nullptr); if (!c[0].has) return false; nc = 1; }
+			if (t.dir == XE_DIR_SRC) {
+				c[0] = GET(rec, t.fsrc, nullptr);
+				if (!c[0].has) {
+					if (t.pad != XE_TERM_ZERO_ABSENT) return false;
+					c[0].v.hi = c[0].v.lo = 0;
+				}
+				nc = 1;
+			}
 			else if (t.dir == XE_DIR_DST) { c[0] = GET(rec, t.fdst, nullptr); if (!c[0].has) return false; nc = 1; }
 			else if (t.dir == XE_DIR_BOTH) {
 				fval s = GET(rec, t.fsrc, nullptr), d = GET(rec, t.fdst, nullptr);
@@ -760,6 +767,8 @@ fast_lookups(const xe_kparams &kp, const TT &T, const uint64_t (&plists)[LW], ui
 				need[c][r] = false;
 				if (!act[c]) continue;
 				tile_get(T, (w1 >> 8) & 0xFF, r, has, fmax, hi[c][r], lo[c][r]);
+				/* lists made of a geo / AS database: an absent field is looked up as zeros */
+				if (!has) { hi[c][r] = lo[c][r] = 0; has = ((w1 >> 17) & 1) != 0; }
 				if (bits[c] == 32) {
 					/* IPv4: the field's 4 bytes, or the first 4 of a 16-byte field */
 					const uint32_t a4 = ((w1 >> 16) & 1) ? (uint32_t)(hi[c][r] >> 32) : (uint32_t)lo[c][r];

@@ -182,6 +182,7 @@ xe_host_free(struct xe_host *hs)
 	free(hs->thash);
 	xe_host_undo_end(hs);
 	free(hs->undo.p);
+	for (i = 0; i < 4; i++) free(hs->geodb[i >> 1][i & 1].img);
 	free(hs->dev_tmpls.p);
 	free(hs->dev_tents.p);
 	walkers_free(hs);
