@@ -45,8 +45,52 @@ def _some_port(rng):
     return int(rng.integers(0, 65536))
 
 
+AS_NAMES = ["Example Net", "ACME", "x", ""]
+GEO = [("EU", "DE", "Germany", "Berlin", "Berlin", "10115", "52.5", "13.4"),
+       ("EU", "RU", "Russia", "Moscow", "Moscow", "101000", "55.7", "37.6"),
+       ("NA", "US", "United States", "California", "San Jose", "95101", "37.3", "-121.9"),
+       ("", "", "", "", "", "", "", "")]
+GEO_KW = ["continent", "country_code", "country", "state", "city", "zip", "lat", "long"]
+
+
+def _geo_atom(rng):
+    """asn() / asd() / geo function over an address field (filter.c:753-834)"""
+    fld = ["src host", "dst host", "src host6", "dst host6", "dev-ip"][int(rng.integers(0, 5))]
+    r = int(rng.integers(0, 3))
+    if r == 0:
+        return "asn(%s) %d-%d" % (fld, *sorted(int(x) for x in rng.integers(0, 12, 2)))
+    # (an empty quoted string does not lex, filter-lexer.c: the texts asked for are never empty)
+    if r == 1:
+        return "asd(%s) '%s' or '%s'" % (fld, AS_NAMES[int(rng.integers(0, 3))], AS_NAMES[int(rng.integers(0, 3))])
+    g = int(rng.integers(0, 8))
+    return "%s(%s) '%s'" % (GEO_KW[g], fld, GEO[int(rng.integers(0, 3))][g])
+
+
+def _geo_databases(rng):
+    """small databases in the reference's layout: short prefixes, so that random addresses fall into
+    them, nested ones, the zero address (what an absent field reads as) among them"""
+    from test_gpu_geo_functions import as_payload, geo_payload, build_db
+    out = {}
+    for fam, nbytes in ((4, 4), (6, 16)):
+        asl, gel = [], []
+        for k in range(int(rng.integers(1, 40))):
+            a = bytes(int(x) for x in rng.integers(0, 256, nbytes))
+            if fam == 6:
+                a = bytes([0x20 | (a[0] & 0x0f)]) + a[1:]
+            if rng.integers(0, 8) == 0:
+                a = bytes(nbytes)
+            m = int(rng.integers(0, 14 if fam == 4 else 24))
+            asl.append((a, m, as_payload(int(rng.integers(0, 12)), AS_NAMES[int(rng.integers(0, 4))])))
+            gel.append((a, int(rng.integers(0, 14 if fam == 4 else 24)), geo_payload(*GEO[int(rng.integers(0, 4))])))
+        out[(1, fam)] = build_db(asl, 216)
+        out[(0, fam)] = build_db(gel, 228)
+    return out
+
+
 def _atom(rng, nlists):
-    k = int(rng.integers(0, 20))
+    k = int(rng.integers(0, 22))
+    if k >= 20:
+        return _geo_atom(rng)
     if k == 17:
         return "div_l(octets, packets, %d) %d-%d" % (int(rng.integers(-1, 12)), *sorted(int(x) for x in rng.integers(0, 2000, 2)))
     if k == 18:
@@ -194,7 +238,7 @@ def _case(seed):
         fl = ks + vs
         rng.shuffle(fl)
         tables.append((int(rng.integers(0, nmo)), [str(x) for x in fl]))
-    return dict(batch=b, iplists=lists, mos=mos, devices=devices, tables=tables)
+    return dict(batch=b, iplists=lists, mos=mos, devices=devices, tables=tables, geodb=_geo_databases(rng))
 
 
 import os
@@ -279,6 +323,9 @@ def _configure_both(eng, orc, w, seed):
 
     eng.set_port_names(NAMES)
     orc.set_port_names(NAMES)
+    for (kind, fam), image in w["geodb"].items():
+        eng.set_geodb(kind, fam, image)
+        orc.geodb_set(kind, fam, image)
     for name, text in w["iplists"].items():
         eng.add_iplist(name, text)
         orc.iplist_add(name, text)

@@ -2910,6 +2910,8 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 		}
 		if (!has_sf) walk_mode &= ~1;
 		if (!has_nf || !h->fast_ok || ((total + 64) >= 0xFFFF0000ull) || getenv("XE_FORCE_GENERAL") || getenv("XE_FAST_R")) walk_mode &= ~2;
+		/* (the per-template counts come back through a small page-locked buffer) */
+		if ((2 * h->hs.dev_tmpls.n + 8) * 4 + 16 > XE_WSTAGE_BYTES) walk_mode &= ~2;
 		if (n >= 0x7FFFFFF0ull) walk_mode = 0;
 	}
 	if (walk_mode) {
