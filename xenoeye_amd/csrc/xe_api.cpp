@@ -62,6 +62,13 @@ struct xe_gpu
 	size_t twalk_n;
 	uint64_t walk_epoch;       /* hs.tmpl_epoch the two tables were built from (+ 1) */
 	void *wstage;              /* small page-locked buffer for counts coming back */
+	/* page-locked scratch of one prepare call (per-datagram arrays the walk
+	 * kernels read in place, small tables on their way to the device): handed
+	 * out from the front, everything is free again when the next call begins.
+	 * Copies out of ordinary memory block the calling thread inside the runtime,
+	 * and with it the other handles' threads */
+	uint8_t *pin;
+	size_t pin_cap, pin_used;
 	char err[512];
 };
 #define XE_WSTAGE_BYTES (64 * 1024)
@@ -262,6 +269,7 @@ xe_gpu_destroy(xe_gpu *h)
 	for (int i = 0; i < XE_DPOOL; i++) if (h->dpool[i].p) (void)hipFree(h->dpool[i].p);
 	if (h->stage) (void)hipHostFree(h->stage);
 	pinned_free(h->wstage);
+	pinned_free(h->pin);
 	if (h->d_devkeys) (void)hipFree(h->d_devkeys);
 	if (h->d_thash) (void)hipFree(h->d_thash);
 	if (h->d_twalk) (void)hipFree(h->d_twalk);
@@ -2138,6 +2146,29 @@ sync_templates(xe_gpu *h)
 	return XE_OK;
 }
 
+/* page-locked scratch of the current prepare call */
+static void
+pin_begin(xe_gpu *h, size_t want)
+{
+	h->pin_used = 0;
+	if (want <= h->pin_cap) return;
+	pinned_free(h->pin);
+	h->pin_cap = 0;
+	want = want * 5 / 4 + 4096;
+	h->pin = (uint8_t *)pinned_alloc(want);
+	if (h->pin) h->pin_cap = want;
+}
+
+/* NULL when the scratch is used up (the caller then takes ordinary memory) */
+static void *
+pin_get(xe_gpu *h, size_t bytes)
+{
+	const size_t at = ALIGN_UP(h->pin_used, 256);
+	if (!h->pin || (at + bytes > h->pin_cap)) return NULL;
+	h->pin_used = at + bytes;
+	return h->pin + at;
+}
+
 /* ------------------------------------------------------------------ header walk on the device */
 static int tmpl_fast(const xe_gpu *h, const struct xe_tmpl *t, const struct xe_tent *te);
 
@@ -2248,7 +2279,7 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 	const size_t nt = h->hs.dev_tmpls.n;
 	struct xe_walk_in in;
 	size_t off = 0;
-	uint8_t *base;
+	uint8_t *base, *pin_walked = NULL;
 	int rc;
 
 	w->mode = mode;
@@ -2314,9 +2345,26 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 		w->d_groups = (struct xe_wgroup *)(base + o_groups);
 		w->d_fruns2 = (struct xe_frun *)(base + o_fruns2);
 	}
-	HIPCHK(h, hipMemcpyAsync(w->d_offs, offsets, 8 * (n + 1), hipMemcpyHostToDevice, st));
-	HIPCHK(h, hipMemcpyAsync(w->d_src, src, 4 * n, hipMemcpyHostToDevice, st));
-	if (kinds) HIPCHK(h, hipMemcpyAsync(w->d_kinds, kinds, n, hipMemcpyHostToDevice, st));
+	{
+		/* the per-datagram arrays: copied into page-locked scratch, which the
+		 * walk kernels read in place (a few bytes per datagram); without
+		 * scratch they travel like everything else */
+		uint64_t *po = (uint64_t *)pin_get(h, 8 * (n + 1));
+		uint32_t *ps = (uint32_t *)pin_get(h, 4 * n + 4);
+		uint8_t *pk = kinds ? (uint8_t *)pin_get(h, n + 1) : NULL;
+		if (po && ps && (pk || !kinds)) {
+			memcpy(po, offsets, 8 * (n + 1));
+			memcpy(ps, src, 4 * n);
+			if (kinds) memcpy(pk, kinds, n);
+			w->d_offs = po;
+			w->d_src = ps;
+			w->d_kinds = pk;
+		} else {
+			HIPCHK(h, hipMemcpyAsync(w->d_offs, offsets, 8 * (n + 1), hipMemcpyHostToDevice, st));
+			HIPCHK(h, hipMemcpyAsync(w->d_src, src, 4 * n, hipMemcpyHostToDevice, st));
+			if (kinds) HIPCHK(h, hipMemcpyAsync(w->d_kinds, kinds, n, hipMemcpyHostToDevice, st));
+		}
+	}
 	HIPCHK(h, hipMemsetAsync(w->d_total, 0, 16, st));
 	walk_input(h, b, &in);
 	w->kinds2 = (uint8_t *)malloc(n ? n : 1);
@@ -2329,7 +2377,8 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 		if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (Netflow)");
 		w->h_walked = (uint8_t *)malloc(n ? n : 1);
 		if (!w->h_walked) return XE_ENOMEM;
-		HIPCHK(h, hipMemcpyAsync(w->h_walked, w->d_walked, n, hipMemcpyDeviceToHost, st));
+		pin_walked = (uint8_t *)pin_get(h, n + 1);
+		HIPCHK(h, hipMemcpyAsync(pin_walked ? pin_walked : w->h_walked, w->d_walked, n, hipMemcpyDeviceToHost, st));
 	}
 	if (mode & 1) {
 		in.pkt = (const uint8_t *)b->d_pkt;
@@ -2340,7 +2389,10 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 	}
 	/* the host walk needs the verdict on the Netflow datagrams; with only sFlow
 	 * on the device it starts at once and the device counts beside it */
-	if (mode & 2) HIPCHK(h, hipStreamSynchronize(st));
+	if (mode & 2) {
+		HIPCHK(h, hipStreamSynchronize(st));
+		if (pin_walked) memcpy(w->h_walked, pin_walked, n);
+	}
 	for (size_t i = 0; i < n; i++) {
 		uint8_t k = kinds ? kinds[i] : (uint8_t)XE_KIND_NETFLOW;
 		if (k == XE_KIND_SFLOW) { if (mode & 1) k |= XE_KIND_ON_DEVICE; }
@@ -2436,6 +2488,7 @@ walk_finish(xe_gpu *h, xe_batch *b)
 		const struct xe_tmpl *tm = (const struct xe_tmpl *)h->hs.dev_tmpls.p;
 		uint64_t total, dev_total = 0, work = 0, nruns = 0, ntiles = 0;
 		unsigned bits = 1, ngroups = 0;
+		int gr_pinned = 0;
 
 		if ((2 * nt + 4) * 4 + 16 > XE_WSTAGE_BYTES) return XE_WALK_RETRY_ON_HOST;
 		if (plan->nrec) HIPCHK(h, hipMemcpyAsync(w->d_hostfirst, plan->dg_first_nf, 4 * (n + 1), hipMemcpyHostToDevice, st));
@@ -2458,7 +2511,9 @@ walk_finish(xe_gpu *h, xe_batch *b)
 		if (total + plan->nsf > 0xFFFFFFF0ull) return XE_EUNSUPPORTED;
 		/* from 2^28 records on the fast kernel is out (32-bit column offsets) */
 		if (total + plan->nsf >= (1ull << 28)) return XE_WALK_RETRY_ON_HOST;
-		gr = (struct xe_wgroup *)malloc((nt + 2) * sizeof(*gr));
+		gr = (struct xe_wgroup *)pin_get(h, (nt + 2) * sizeof(*gr));
+		gr_pinned = gr != NULL;
+		if (!gr) gr = (struct xe_wgroup *)malloc((nt + 2) * sizeof(*gr));
 		if (!gr) return XE_ENOMEM;
 		w->maxchunk2 = 1;
 		for (size_t t = 0; t < nt; t++) {
@@ -2473,19 +2528,20 @@ walk_finish(xe_gpu *h, xe_batch *b)
 			nruns += cnt[nt + t];
 			ntiles = work / 64;
 			if (((uint32_t)tm[t].stride + 15) / 16 > w->maxchunk2) w->maxchunk2 = ((uint32_t)tm[t].stride + 15) / 16;
-			if (!xe_plan_note_template(plan, &h->hs, (uint32_t)t, cnt[t])) { free(gr); return XE_ENOMEM; }
+			if (!xe_plan_note_template(plan, &h->hs, (uint32_t)t, cnt[t])) { if (!gr_pinned) free(gr); return XE_ENOMEM; }
 		}
 		gr[nt].pos0 = (uint32_t)work;
 		gr[nt].run0 = (uint32_t)nruns;
 		gr[nt].tile0 = (uint32_t)ntiles;
 		gr[nt].pad = 0;
-		if (work > 0xFFFFFF00ull) { free(gr); return XE_WALK_RETRY_ON_HOST; }
+		if (work > 0xFFFFFF00ull) { if (!gr_pinned) free(gr); return XE_WALK_RETRY_ON_HOST; }
 		w->nfruns2 = (uint32_t)nruns;
 		w->ntiles2 = (uint32_t)ntiles;
 		if (nruns) {
 			hipError_t e = hipMemcpyAsync(w->d_groups, gr, (nt + 1) * sizeof(*gr), hipMemcpyHostToDevice, st);
-			/* (pageable source: the copy has left `gr` when the call returns) */
-			free(gr);
+			/* (ordinary memory: the copy has left `gr` when the call returns;
+			 * the scratch stays untouched until the next prepare) */
+			if (!gr_pinned) free(gr);
 			if (e != hipSuccess) return hip_fail(h, e, "hipMemcpyAsync(groups)");
 			rc = xe_walk_nf_gather(w->d_dgruns, w->d_val2, w->nfruns2, w->d_snrec, st);
 			if (rc == XE_OK) rc = xe_walk_scan(w->d_temp, w->temp_bytes, w->d_snrec, w->d_sscan, w->nfruns2, st);
@@ -2520,7 +2576,7 @@ walk_finish(xe_gpu *h, xe_batch *b)
 				}
 				if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (tiles)");
 			}
-		} else {
+		} else if (!gr_pinned) {
 			free(gr);
 		}
 		/* the host walk numbered its records among themselves: move them to
@@ -2880,6 +2936,8 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 	b = (xe_batch *)calloc(1, sizeof(*b));
 	if (!b) return XE_ENOMEM;
 	b->h = h;
+	pin_begin(h, 14 * (n + 8) + (h->hs.dev_tmpls.n + 8) * (sizeof(struct xe_fplan) + XE_NFIELDS * 4 + sizeof(struct xe_wgroup))
+		+ (h->hs.dev_tents.n + 16) * sizeof(struct xe_fop) + 16 * 256);
 	/* The datagram bytes start moving to the device before the header walk:
 	 * neither needs the other (from page-locked memory the copy runs beside
 	 * the walk; from ordinary memory the call returns when it is done).
@@ -3036,10 +3094,24 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 		const struct xe_tmpl *tm = (const struct xe_tmpl *)h->hs.dev_tmpls.p;
 		const struct xe_tent *te = (const struct xe_tent *)h->hs.dev_tents.p;
 		size_t nt = h->hs.dev_tmpls.n, ne = h->hs.dev_tents.n, nops = 0;
-		struct xe_fplan *pl = (struct xe_fplan *)calloc(nt ? nt : 1, sizeof(*pl));
-		struct xe_fop *fo = (struct xe_fop *)calloc(ne + 4, sizeof(*fo));   /* + 4: the kernel loads four at a time */
-		uint32_t *ff = (uint32_t *)calloc((nt ? nt : 1) * XE_NFIELDS, sizeof(uint32_t));
-		if (!pl || !fo || !ff) { free(pl); free(fo); free(ff); xe_gpu_batch_free(b); return XE_ENOMEM; }
+		const size_t pl_bytes = (nt ? nt : 1) * sizeof(struct xe_fplan), fo_bytes = (ne + 4) * sizeof(struct xe_fop),
+			ff_bytes = (nt ? nt : 1) * XE_NFIELDS * sizeof(uint32_t);
+		/* in page-locked scratch when there is room: the three uploads then do not block */
+		const size_t pin_mark = h->pin_used;
+		struct xe_fplan *pl = (struct xe_fplan *)pin_get(h, pl_bytes);
+		struct xe_fop *fo = (struct xe_fop *)pin_get(h, fo_bytes);   /* + 4: the kernel loads four at a time */
+		uint32_t *ff = (uint32_t *)pin_get(h, ff_bytes);
+		const int tables_pinned = pl && fo && ff;
+		if (!tables_pinned) {
+			h->pin_used = pin_mark;
+			pl = (struct xe_fplan *)malloc(pl_bytes);
+			fo = (struct xe_fop *)malloc(fo_bytes);
+			ff = (uint32_t *)malloc(ff_bytes);
+		}
+		if (!pl || !fo || !ff) { if (!tables_pinned) { free(pl); free(fo); free(ff); } xe_gpu_batch_free(b); return XE_ENOMEM; }
+		memset(pl, 0, pl_bytes);
+		memset(fo, 0, fo_bytes);
+		memset(ff, 0, ff_bytes);
 		for (size_t t = 0; t < nt; t++) {
 			uint32_t *fld = ff + t * XE_NFIELDS;
 			pl[t].op_base = (uint32_t)nops;
@@ -3089,9 +3161,11 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 		rc = upload_pooled(h, &b->d_fplans, pl, nt * sizeof(*pl));
 		if (rc == XE_OK) rc = upload_pooled(h, &b->d_fops, fo, (nops + 4) * sizeof(*fo));
 		if (rc == XE_OK) rc = upload_pooled(h, &b->d_fflds, ff, nt * XE_NFIELDS * sizeof(uint32_t));
-		free(pl);
-		free(fo);
-		free(ff);
+		if (!tables_pinned) {
+			free(pl);
+			free(fo);
+			free(ff);
+		}
 		if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
 		b->kp.fplans = (const struct xe_fplan *)b->d_fplans;
 		b->kp.fops = (const struct xe_fop *)b->d_fops;
