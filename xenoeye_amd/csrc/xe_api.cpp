@@ -2387,7 +2387,7 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 		if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (sFlow)");
 		HIPCHK(h, hipMemcpyAsync(h->wstage, w->d_total, 8, hipMemcpyDeviceToHost, st));
 	}
-	/* the host walk needs the verdict on the Netflow datagrams; with only sFlow
+	/* the host walk needs to know which Netflow datagrams are left to it; with only sFlow
 	 * on the device it starts at once and the device counts beside it */
 	if (mode & 2) {
 		HIPCHK(h, hipStreamSynchronize(st));

@@ -962,6 +962,24 @@ fast_term(const xe_kparams &kp, const TT &T, const term_s &t, uint32_t r, const 
 /* Plain copies of 2^LG wire bytes into a column (wire length == column
  * width): n micro-ops starting at fops[j0].  The next micro-op is fetched
  * while the current one is applied. */
+/* XE_NT_STORES / XE_NT_LOADS: column stores / packet loads with the streaming
+ * hint, so that what is touched once does not push the list tables out of the
+ * caches.  Measured on MI355X: stores with the hint C2 0.2353 -> 0.2303 ms, C1
+ * and C4 unchanged; loads with the hint C2 0.2715 ms, C1 0.0977 ms (the lanes
+ * of a wave read neighbouring pieces of the same lines: the hint gives those
+ * lines up too early) */
+#ifndef XE_NT_STORES
+#define XE_NT_STORES 1
+#endif
+#ifndef XE_NT_LOADS
+#define XE_NT_LOADS 0
+#endif
+#if XE_NT_STORES
+#define XE_COL_STORE(PTR, VAL) __builtin_nontemporal_store((VAL), (PTR))
+#else
+#define XE_COL_STORE(PTR, VAL) (*(PTR) = (VAL))
+#endif
+
 template <int R, int LG>
 __device__ __forceinline__ void
 copy_ops(const xe_kparams &kp, const uint32_t *stg, uint32_t j0, uint32_t n,
@@ -990,19 +1008,19 @@ copy_ops(const xe_kparams &kp, const uint32_t *stg, uint32_t j0, uint32_t n,
 				XE_GLOBAL uint8_t *dst = col + boff[r];
 				if (LG == 0) {
 					const uint32_t w0 = q[0];
-					if (live[r]) *dst = (uint8_t)__builtin_amdgcn_alignbyte(w0, w0, sh);
+					if (live[r]) XE_COL_STORE(dst, (uint8_t)__builtin_amdgcn_alignbyte(w0, w0, sh));
 				} else if (LG <= 2) {
 					const uint32_t w0 = q[0], w1 = q[R * 64];
 					const uint32_t v = __builtin_amdgcn_alignbyte(w1, w0, sh);
 					if (live[r]) {
-						if (LG == 1) *(XE_GLOBAL uint16_t *)dst = (uint16_t)v;
-						else *(XE_GLOBAL uint32_t *)dst = v;
+						if (LG == 1) XE_COL_STORE((XE_GLOBAL uint16_t *)dst, (uint16_t)v);
+						else XE_COL_STORE((XE_GLOBAL uint32_t *)dst, v);
 					}
 				} else if (LG == 3) {
 					const uint32_t w0 = q[0], w1 = q[R * 64], w2 = q[2 * R * 64];
 					const uint32_t v0 = __builtin_amdgcn_alignbyte(w1, w0, sh);
 					const uint32_t v1 = __builtin_amdgcn_alignbyte(w2, w1, sh);
-					if (live[r]) *(XE_GLOBAL uint64_t *)dst = (uint64_t)v0 | ((uint64_t)v1 << 32);
+					if (live[r]) XE_COL_STORE((XE_GLOBAL uint64_t *)dst, (uint64_t)v0 | ((uint64_t)v1 << 32));
 				} else {
 					const uint32_t w0 = q[0], w1 = q[R * 64], w2 = q[2 * R * 64], w3 = q[3 * R * 64], w4 = q[4 * R * 64];
 					u32x4 v;
@@ -1010,7 +1028,7 @@ copy_ops(const xe_kparams &kp, const uint32_t *stg, uint32_t j0, uint32_t n,
 					v.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
 					v.z = __builtin_amdgcn_alignbyte(w3, w2, sh);
 					v.w = __builtin_amdgcn_alignbyte(w4, w3, sh);
-					if (live[r]) *(XE_GLOBAL u32x4 *)dst = v;
+					if (live[r]) XE_COL_STORE((XE_GLOBAL u32x4 *)dst, v);
 				}
 			}
 		}
@@ -1167,8 +1185,14 @@ tile_issue(const xe_kparams &kp, const tile_lanes<R> &S, u32x4 (&q)[4][R])
 #pragma unroll
 		for (int r = 0; r < R; r++) {
 			q[i][r] = (u32x4){0, 0, 0, 0};
-			if (S.live[r] && ((uint32_t)i < S.nchunk) && !(kp.pad2 & 32))
+			if (S.live[r] && ((uint32_t)i < S.nchunk) && !(kp.pad2 & 32)) {
+#if XE_NT_LOADS
+				typedef u32x4 u32x4_any __attribute__((aligned(1)));
+				q[i][r] = __builtin_nontemporal_load((const XE_GLOBAL u32x4_any *)(pkt + S.voff[r] + 16 * i));
+#else
 				__builtin_memcpy(&q[i][r], (const uint8_t *)pkt + S.voff[r] + 16 * i, 16);
+#endif
+			}
 		}
 	}
 }
