@@ -55,7 +55,7 @@ def parse_args():
     ap.add_argument("--sustain-seconds", type=float, default=3.0, help="repeat the headline step this long (0 = skip)")
     ap.add_argument("--pipeline", type=int, default=4,
                     help="capture threads (one handle each) of the sustained host-inclusive measurement, 0/1 = skip")
-    ap.add_argument("--pipeline-rounds", type=int, default=6)
+    ap.add_argument("--pipeline-rounds", type=int, default=20)
     ap.add_argument("--pipeline-walkers", type=int, default=0,
                     help="header-walking threads per capture thread of the pipelined measurement (0: 16 / threads)")
     ap.add_argument("--fwm", type=int, default=1, help="also time the fixed-window table kernel (0 = skip)")
