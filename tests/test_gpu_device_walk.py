@@ -252,3 +252,37 @@ def test_devices_conf_exporters(orc):
     assert got[0] == n_data - n_marked
     dev.close()
     host.close()
+
+
+def test_batch_beyond_the_fast_kernels_reach(orc, monkeypatch):
+    """from 2^28 records on a batch goes to the per-lane kernel, and the device walk hands such a
+    batch back to the host walk with the template store as it was (here the limit is lowered so
+    that a small batch takes that road; a template change inside the batch must survive it)"""
+    fields_a = synth.TMPL_V9_C1
+    fields_b = [(12, 4), (8, 4), (11, 2), (7, 2), (4, 1), (1, 4), (2, 4), (10, 4)]
+    rng = synth.Rng(6)
+    e1 = bytes([192, 0, 2, 1])
+    w = synth.workload_c1(64)
+    dev, host = _engines(orc, w)
+    rec_a = synth.flow_columns(rng, 64 * 30, fields_a)
+    rec_b = synth.flow_columns(rng, 50 * 10, fields_b)
+    pk_a = synth.v9_data_packets(256, rec_a, 64, 77)
+    pk_b = synth.v9_data_packets(256, rec_b, 50, 77)
+    first = synth.Batch()
+    first.add(synth.v9_template_packet(256, fields_a, 77), e1)
+    first.extend(pk_a[:4], e1)
+    assert _round(dev, host, orc, first)[0] == 0
+    monkeypatch.setenv("XE_FAST_MAX_RECORDS", "1000")
+    second = synth.Batch()
+    second.extend(pk_a[4:20], e1)
+    second.add(synth.v9_template_packet(257, fields_b, 77), e1)      # a new template: logged, rolled back, learnt again
+    for p in pk_b:
+        second.add(p[:20] + struct.pack(">H", 257) + p[22:], e1)
+    second.extend(pk_a[20:], e1)
+    got = _round(dev, host, orc, second)
+    assert got[0] == 0            # nothing was listed on the device in the end
+    monkeypatch.delenv("XE_FAST_MAX_RECORDS")
+    got = _round(dev, host, orc, second)
+    assert got[0] == len(second.pkts) - 1
+    dev.close()
+    host.close()

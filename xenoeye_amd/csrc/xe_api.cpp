@@ -2146,6 +2146,18 @@ sync_templates(xe_gpu *h)
 	return XE_OK;
 }
 
+/* From this many records on a batch takes the per-lane kernel: the fast kernel
+ * addresses a column element with a 32-bit byte offset (16-byte columns: below
+ * 2^28 records).  The environment variable lets a test reach that path with a
+ * small batch. */
+static uint64_t
+fast_record_limit(void)
+{
+	const char *e = getenv("XE_FAST_MAX_RECORDS");
+	const uint64_t v = e ? strtoull(e, NULL, 0) : 0;
+	return (v && (v < (1ull << 28))) ? v : (1ull << 28);
+}
+
 /* page-locked scratch of the current prepare call */
 static void
 pin_begin(xe_gpu *h, size_t want)
@@ -2510,7 +2522,7 @@ walk_finish(xe_gpu *h, xe_batch *b)
 		memcpy(&total, cnt + 2 * nt + 2, 8);
 		if (total + plan->nsf > 0xFFFFFFF0ull) return XE_EUNSUPPORTED;
 		/* from 2^28 records on the fast kernel is out (32-bit column offsets) */
-		if (total + plan->nsf >= (1ull << 28)) return XE_WALK_RETRY_ON_HOST;
+		if (total + plan->nsf >= fast_record_limit()) return XE_WALK_RETRY_ON_HOST;
 		gr = (struct xe_wgroup *)pin_get(h, (nt + 2) * sizeof(*gr));
 		gr_pinned = gr != NULL;
 		if (!gr) gr = (struct xe_wgroup *)malloc((nt + 2) * sizeof(*gr));
@@ -2682,7 +2694,7 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 	/* the fast kernel addresses a column element with a 32-bit byte offset
 	 * (16-byte columns: below 2^28 records); larger batches take the general
 	 * kernel.  The environment variable is a diagnostic: time the general kernel */
-	const int force_general = (getenv("XE_FORCE_GENERAL") != NULL) || (b->ntot >= (1u << 28));
+	const int force_general = (getenv("XE_FORCE_GENERAL") != NULL) || (b->ntot >= fast_record_limit());
 	uint32_t maxchunk = 1, R, tilesz;
 	size_t cnt_bytes = (h->hs.nmos <= XE_MAX_LDS_COUNTER_MOS) ? h->hs.nmos * 24 : 0;
 	int rc = XE_ENOMEM;
