@@ -286,3 +286,21 @@ def test_batch_beyond_the_fast_kernels_reach(orc, monkeypatch):
     assert got[0] == len(second.pkts) - 1
     dev.close()
     host.close()
+
+
+def test_offsets_that_decrease_are_refused():
+    w = synth.workload_c1(640)
+    eng = xenoeye_amd.Engine(device=0)
+    for name, text in w["iplists"].items():
+        eng.add_iplist(name, text)
+    eng.add_mo("mo", "src net mynet", -1)
+    eng.commit()
+    data, offs, src, kinds = w["batch"].packed()
+    bad = offs.copy()
+    bad[3], bad[4] = bad[4], bad[3]
+    with pytest.raises(xenoeye_amd.XeError):
+        eng.prepare((data, bad, src, kinds))
+    b = eng.prepare((data, offs, src, kinds))
+    b.run()
+    assert b.records == 640
+    eng.close()

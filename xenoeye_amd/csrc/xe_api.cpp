@@ -2974,9 +2974,17 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 	 * while the fast kernel is in use at all (its 32-bit packet offsets, no
 	 * diagnostic override of its shape) */
 	{
-		int has_sf = 0, has_nf = 0;
+		int has_sf = 0, has_nf = 0, ordered = 1;
 		for (size_t i = 0; i < n; i++) {
 			if (kinds && (kinds[i] == XE_KIND_SFLOW)) has_sf = 1; else has_nf = 1;
+			if (offsets[i + 1] < offsets[i]) ordered = 0;
+		}
+		if (!ordered) {
+			/* the kernels trust the offsets: a datagram may not end before it starts */
+			snprintf(h->err, sizeof(h->err), "datagram offsets must not decrease");
+			(void)hipStreamSynchronize(h->copy_stream);
+			xe_gpu_batch_free(b);
+			return XE_EINVAL;
 		}
 		if (!has_sf) walk_mode &= ~1;
 		if (!has_nf || !h->fast_ok || ((total + 64) >= 0xFFFF0000ull) || getenv("XE_FORCE_GENERAL") || getenv("XE_FAST_R")) walk_mode &= ~2;

@@ -268,7 +268,7 @@ xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular)
 	if (!(in.kinds && (in.kinds[i] == XE_KIND_SFLOW))) {
 		const uint64_t off = in.offs[i];
 		int64_t len64 = (int64_t)(in.offs[i + 1] - off);
-		const uint32_t len = (len64 > 65536) ? 65536u : (uint32_t)len64;
+		const uint32_t len = (len64 > 65536) ? 65536u : (len64 < 0) ? 0u : (uint32_t)len64;
 		const uint8_t *p = in.pkt + off;
 		const uint32_t src = in.src[i];
 		if (len >= 24) {
