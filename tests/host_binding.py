@@ -77,6 +77,14 @@ class Host:
         L.xe_ht_plan_exporters.restype = C.POINTER(Exporter)
         L.xe_ht_list_mos.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
         L.xe_ht_list_devices.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        L.xe_ht_geodb_set.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+        L.xe_ht_geodb_list.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                       C.POINTER(C.c_char_p), C.c_size_t]
+        for f in ("undo_begin", "undo_rollback", "undo_end"):
+            getattr(L, "xe_ht_" + f).argtypes = [C.c_void_p]
+            getattr(L, "xe_ht_" + f).restype = None
+        L.xe_ht_undo_count.argtypes = [C.c_void_p]
+        L.xe_ht_undo_count.restype = C.c_size_t
         self.h = L.xe_ht_create()
 
     def close(self):
@@ -91,6 +99,29 @@ class Host:
 
     def load_iplists(self, d):
         return self.L.xe_ht_load_iplists(self.h, d.encode())
+
+    def geodb_set(self, kind, family, image):
+        return self.L.xe_ht_geodb_set(self.h, kind, family, bytes(image), len(image))
+
+    def geodb_list(self, func, geo_field, family, ranges=(), strs=()):
+        """index of the list made of the database for an asn (func 10) / asd (11) / geo (9) term"""
+        n = max(len(ranges), len(strs))
+        lo = (C.c_int32 * max(n, 1))(*[r[0] for r in ranges])
+        hi = (C.c_int32 * max(n, 1))(*[r[1] for r in ranges])
+        ss = (C.c_char_p * max(n, 1))(*[x.encode() for x in strs])
+        return self.L.xe_ht_geodb_list(self.h, func, geo_field, family, lo, hi, ss, n)
+
+    def undo_begin(self):
+        self.L.xe_ht_undo_begin(self.h)
+
+    def undo_count(self):
+        return self.L.xe_ht_undo_count(self.h)
+
+    def undo_rollback(self):
+        self.L.xe_ht_undo_rollback(self.h)
+
+    def undo_end(self):
+        self.L.xe_ht_undo_end(self.h)
 
     def filter_dump(self, text):
         """(rc, dump, err)"""

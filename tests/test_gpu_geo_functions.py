@@ -46,7 +46,7 @@ def build_db(entries, node_bytes):
     return bytes(out)
 
 
-def _databases(w):
+def _databases(w=None):
     """prefixes that cover part of the traffic of workload_c2, nested ones among them"""
     rng = synth.Rng(2024)
     as4, geo4, as6, geo6 = [], [], [], []

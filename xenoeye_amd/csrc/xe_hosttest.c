@@ -196,3 +196,25 @@ xe_ht_list_devices(const char *path, char *out, size_t outlen)
 	xe_host_free(&hs);
 	return rc;
 }
+
+/* geo / AS databases and the lists made of them (xe_geodb.c) */
+int
+xe_ht_geodb_set(struct xe_host *hs, int kind, int family, const void *img, size_t bytes)
+{
+	char err[256];
+	return xe_geodb_set(hs, kind, family, img, bytes, err, sizeof(err));
+}
+
+/* ranges: n pairs lo, hi (asn); strs: n texts (asd / geo field); returns the list's index */
+int
+xe_ht_geodb_list(struct xe_host *hs, int func, int geo_field, int family, const int32_t *lo, const int32_t *hi,
+	const char *const *strs, size_t n)
+{
+	return xe_geodb_list(hs, func, geo_field, family, lo, hi, strs, n);
+}
+
+/* the log of template changes (xe_prepass.c) */
+void xe_ht_undo_begin(struct xe_host *hs) { xe_host_undo_begin(hs); }
+size_t xe_ht_undo_count(struct xe_host *hs) { return xe_host_undo_count(hs); }
+void xe_ht_undo_rollback(struct xe_host *hs) { xe_host_undo_rollback(hs); }
+void xe_ht_undo_end(struct xe_host *hs) { xe_host_undo_end(hs); }
