@@ -190,6 +190,91 @@ def test_mixed_kinds_and_unusual_datagrams(orc):
     host.close()
 
 
+def _ipfix(domain, *sets):
+    body = b"".join(sets)
+    return synth.ipfix_header(16 + len(body), domain) + body
+
+
+def _set(set_id, body, length=None):
+    return struct.pack(">HH", set_id, (4 + len(body)) if length is None else length) + body
+
+
+def test_ipfix_datagrams_of_several_sets(orc):
+    """IPFIX datagrams with up to four data sets, options template sets and
+    sets of ids that mean nothing between them are listed by the device; more
+    sets than that, template sets, unknown templates, set lengths that leave
+    the datagram or stop short of the set header go to the host walk"""
+    w = synth.workload_c2(2000, prefixes=200)
+    w["mos"] = w["mos"] + [("proto 6", -1), ("src port 53 or dst port 53", -1)]
+    dev, host = _engines(orc, w)
+    rng = synth.Rng(4242)
+    exps = [bytes([10, 255, 0, e + 1]) for e in range(4)]
+
+    first = synth.Batch()
+    for e in range(4):
+        first.add(synth.ipfix_template_packet(256, synth.TMPL_IPFIX_V4, e + 1), exps[e])
+        first.add(synth.ipfix_template_packet(257, synth.TMPL_IPFIX_V6, e + 1), exps[e])
+    _round(dev, host, orc, first)
+
+    def d4(n):
+        return _set(256, synth.flow_columns(rng, n, synth.TMPL_IPFIX_V4).tobytes())
+
+    def d6(n):
+        return _set(257, synth.flow_columns(rng, n, synth.TMPL_IPFIX_V6).tobytes())
+
+    options = _set(3, struct.pack(">HHH", 300, 2, 1) + struct.pack(">HH", 149, 4) + struct.pack(">HH", 160, 8))
+    noise = _set(17, bytes(rng.bytes(12)))
+    usual, unusual = [], []
+    for j in range(300):
+        e = j % 4
+        k = j % 6
+        if k == 0:
+            usual.append((_ipfix(e + 1, d4(7), d6(5)), e))
+        elif k == 1:
+            usual.append((_ipfix(e + 1, options, d4(9)), e))
+        elif k == 2:
+            usual.append((_ipfix(e + 1, d6(3), noise, d4(4), d6(6)), e))
+        elif k == 3:
+            usual.append((_ipfix(e + 1, d4(1), d4(2), d4(3), d6(4)), e))
+        elif k == 4:
+            usual.append((_ipfix(e + 1, d4(11)), e))
+        else:
+            usual.append((_ipfix(e + 1, noise, options, d6(2), noise), e))
+    # five data sets
+    unusual.append((_ipfix(1, d4(1), d4(2), d6(3), d4(4), d6(5)), 0))
+    # a template nobody sent behind a good set: the rest of the datagram is dropped
+    unusual.append((_ipfix(2, d4(3), _set(999, bytes(rng.bytes(46))), d4(2)), 1))
+    # an (unchanged) template between two data sets
+    unusual.append((_ipfix(3, d4(3), synth.ipfix_template_set(257, synth.TMPL_IPFIX_V6), d6(2)), 2))
+    # a set length that leaves the datagram
+    unusual.append((_ipfix(4, d4(2), _set(257, synth.flow_columns(rng, 2, synth.TMPL_IPFIX_V6).tobytes(), length=400)), 3))
+    # set lengths 0 and 3
+    unusual.append((_ipfix(1, d4(2), _set(256, b"", length=0), d4(1)), 0))
+    unusual.append((_ipfix(2, d6(2), _set(17, b"", length=3) + bytes(8), d4(1)), 1))
+    # a set header cut by the end of the datagram
+    unusual.append((_ipfix(3, d4(2)) + b"\x01\x00", 2))
+    # only sets that carry no records
+    unusual.append((_ipfix(4, options, noise), 3))
+    # a data set cut inside a record
+    p = _ipfix(1, d4(2), d6(3))
+    unusual.append((p[:-20], 0))
+
+    second = synth.Batch()
+    nusual = 0
+    for j, (p, e) in enumerate(usual):
+        second.add(p, exps[e])
+        nusual += 1
+        if (j % 30 == 7) and unusual:
+            q, e2 = unusual.pop(0)
+            second.add(q, exps[e2])
+    for q, e2 in unusual:
+        second.add(q, exps[e2])
+    got = _round(dev, host, orc, second)
+    assert got[0] == nusual, (got, nusual)
+    dev.close()
+    host.close()
+
+
 def test_template_change_inside_a_batch(orc):
     """an exporter replaces its template half way through a batch whose other
     datagrams the device has already listed with the old one: that exporter is

@@ -206,20 +206,38 @@ def _case(seed):
     b = synth.Batch()
     exps = [bytes([10, e, 0, e + 1]) for e in range(4)]
     for e, addr in enumerate(exps):
+        sets = []
         for tid in (256, 257, 300):
             t = _template(rng)
             nrec = int(rng.integers(1, 120))
             rec = synth.flow_columns(srng, nrec, t)
             rl = rec.shape[1]
-            per = max(1, min(nrec, 1400 // max(rl, 1)))
             if (e + tid) % 2:
+                per = max(1, min(nrec, 1400 // max(rl, 1)))
                 b.add(synth.v9_template_packet(tid, t, e + 1), addr)
-                pk = synth.v9_data_packets(tid, rec, per, e + 1)
+                for p in synth.v9_data_packets(tid, rec, per, e + 1):
+                    b.add(_damage(rng, p), addr)
             else:
+                per = max(1, min(nrec, 400 // max(rl, 1)))
                 b.add(synth.ipfix_template_packet(tid, t, e + 1), addr)
-                pk = synth.ipfix_data_packets(tid, rec, per, e + 1)
-            for p in pk:
-                b.add(_damage(rng, p), addr)
+                sets += [p[16:] for p in synth.ipfix_data_packets(tid, rec, per, e + 1)]
+        # IPFIX: one to five sets a datagram, the data sets of the exporter's
+        # templates mixed, now and then an options template set or a set of an
+        # id that means nothing between them
+        order = rng.permutation(len(sets))
+        at = 0
+        while at < len(sets):
+            k = int(rng.integers(1, 6)) if rng.integers(0, 3) else 1
+            body = b""
+            for j in order[at:at + k]:
+                r = int(rng.integers(0, 8))
+                if r == 0:
+                    body += struct.pack(">HHHHHHH", 3, 14, 400, 1, 1, 149, 4)
+                elif r == 1:
+                    body += struct.pack(">HH", int(rng.integers(4, 256)), 8) + bytes(4)
+                body += sets[int(j)]
+            at += k
+            b.add(_damage(rng, synth.ipfix_header(16 + len(body), e + 1) + body), addr)
         if rng.integers(0, 2):
             b.add(_damage(rng, synth.v5_packet(srng, int(rng.integers(1, 20)))), addr)
     if seed % 5 == 0:

@@ -106,6 +106,7 @@ struct walk_dev
 	struct xe_frun *d_fruns2;
 	struct xe_ftile *d_ftiles2;
 	uint32_t nfruns2, ntiles2, maxchunk2;
+	uint32_t nsets;   /* the most runs a datagram of this batch has */
 	size_t nrec2;              /* records in those runs */
 	/* host side */
 	uint8_t *kinds2;           /* the kinds with XE_KIND_ON_DEVICE on what the host walk passes by */
@@ -2314,20 +2315,21 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 	if (mode & 2) {
 		rc = walk_tables_sync(h);
 		if (rc != XE_OK) return rc;
-		if (h->twalk_n >= (1u << 24)) return XE_EUNSUPPORTED;
+		if (h->twalk_n >= (1u << 16)) return XE_EUNSUPPORTED;   /* (prepare keeps such a store off this path) */
 	}
-	w->temp_bytes = xe_walk_temp_bytes(n + 1);
+	const size_t nr = (mode & 2) ? n * XE_WALK_SETS : n;   /* runs: up to XE_WALK_SETS per datagram */
+	w->temp_bytes = xe_walk_temp_bytes(nr + 1);
 #define CARVE(BYTES) (off = ALIGN_UP(off, 256), off += (BYTES), off - (BYTES))
 	const size_t o_offs = CARVE(8 * (n + 1)), o_src = CARVE(4 * n), o_kinds = CARVE(n), o_sfcnt = CARVE(4 * (n + 2)),
-		o_sfbase = CARVE(4 * (n + 2)), o_total = CARVE(16), o_temp = CARVE(w->temp_bytes);
+		o_sfbase = CARVE(4 * (n + 2)), o_total = CARVE(32), o_temp = CARVE(w->temp_bytes);
 	size_t o_dgruns = 0, o_walked = 0, o_hostfirst = 0, o_nfcnt = 0, o_recbase = 0, o_key = 0, o_val = 0, o_key2 = 0, o_val2 = 0,
 		o_gtotal = 0, o_gruns = 0, o_snrec = 0, o_sscan = 0, o_groups = 0, o_fruns2 = 0;
 	if (mode & 2) {
-		o_dgruns = CARVE(sizeof(struct xe_dgrun) * n); o_walked = CARVE(n); o_hostfirst = CARVE(4 * (n + 2));
+		o_dgruns = CARVE(sizeof(struct xe_dgrun) * nr); o_walked = CARVE(n); o_hostfirst = CARVE(4 * (n + 2));
 		o_nfcnt = CARVE(4 * (n + 2)); o_recbase = CARVE(4 * (n + 2));
-		o_key = CARVE(4 * n); o_val = CARVE(4 * n); o_key2 = CARVE(4 * n); o_val2 = CARVE(4 * n);
-		o_gtotal = CARVE(4 * (nt + 2)); o_gruns = CARVE(4 * (nt + 2)); o_snrec = CARVE(4 * (n + 2)); o_sscan = CARVE(4 * (n + 2));
-		o_groups = CARVE(sizeof(struct xe_wgroup) * (nt + 2)); o_fruns2 = CARVE(sizeof(struct xe_frun) * (n + 1));
+		o_key = CARVE(4 * nr); o_val = CARVE(4 * nr); o_key2 = CARVE(4 * nr); o_val2 = CARVE(4 * nr);
+		o_gtotal = CARVE(4 * (nt + 2)); o_gruns = CARVE(4 * (nt + 2)); o_snrec = CARVE(4 * (nr + 2)); o_sscan = CARVE(4 * (nr + 2));
+		o_groups = CARVE(sizeof(struct xe_wgroup) * (nt + 2)); o_fruns2 = CARVE(sizeof(struct xe_frun) * (nr + 1));
 	}
 #undef CARVE
 	rc = dev_get(h, &w->arena, off + 256);
@@ -2377,7 +2379,7 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 			if (kinds) HIPCHK(h, hipMemcpyAsync(w->d_kinds, kinds, n, hipMemcpyHostToDevice, st));
 		}
 	}
-	HIPCHK(h, hipMemsetAsync(w->d_total, 0, 16, st));
+	HIPCHK(h, hipMemsetAsync(w->d_total, 0, 32, st));
 	walk_input(h, b, &in);
 	w->kinds2 = (uint8_t *)malloc(n ? n : 1);
 	w->h_src = (uint32_t *)malloc((n ? n : 1) * 4);
@@ -2385,12 +2387,13 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 	memcpy(w->h_src, src, 4 * n);
 	if (mode & 2) {
 		in.pkt = w->hdr_src;
-		rc = xe_walk_nf_shape(&in, w->d_dgruns, w->d_walked, st);
+		rc = xe_walk_nf_shape(&in, w->d_dgruns, w->d_walked, (uint32_t *)(w->d_total + 2), st);
 		if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (Netflow)");
 		w->h_walked = (uint8_t *)malloc(n ? n : 1);
 		if (!w->h_walked) return XE_ENOMEM;
 		pin_walked = (uint8_t *)pin_get(h, n + 1);
 		HIPCHK(h, hipMemcpyAsync(pin_walked ? pin_walked : w->h_walked, w->d_walked, n, hipMemcpyDeviceToHost, st));
+		HIPCHK(h, hipMemcpyAsync((uint8_t *)h->wstage + 8, w->d_total + 2, 8, hipMemcpyDeviceToHost, st));
 	}
 	if (mode & 1) {
 		in.pkt = (const uint8_t *)b->d_pkt;
@@ -2404,6 +2407,9 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 	if (mode & 2) {
 		HIPCHK(h, hipStreamSynchronize(st));
 		if (pin_walked) memcpy(w->h_walked, pin_walked, n);
+		w->nsets = *(volatile uint32_t *)((uint8_t *)h->wstage + 8);
+		if (w->nsets < 1) w->nsets = 1;
+		if (w->nsets > XE_WALK_SETS) w->nsets = XE_WALK_SETS;
 	}
 	for (size_t i = 0; i < n; i++) {
 		uint8_t k = kinds ? kinds[i] : (uint8_t)XE_KIND_NETFLOW;
@@ -2507,11 +2513,11 @@ walk_finish(xe_gpu *h, xe_batch *b)
 		else HIPCHK(h, hipMemsetAsync(w->d_hostfirst, 0, 4 * (n + 1), st));
 		HIPCHK(h, hipMemsetAsync(w->d_gtotal, 0, 4 * (nt + 2), st));
 		HIPCHK(h, hipMemsetAsync(w->d_gruns, 0, 4 * (nt + 2), st));
-		rc = xe_walk_nf_counts(&in, w->d_dgruns, w->d_walked, w->d_hostfirst, w->d_nfcnt, w->d_key, w->d_val,
+		rc = xe_walk_nf_counts(&in, w->d_dgruns, w->nsets, w->d_walked, w->d_hostfirst, w->d_nfcnt, w->d_key, w->d_val,
 			w->d_gtotal, w->d_gruns, w->d_total + 1, st);
 		if (rc == XE_OK) rc = xe_walk_scan(w->d_temp, w->temp_bytes, w->d_nfcnt, w->d_recbase, n, st);
 		while ((1ull << bits) < nt + 1) bits++;
-		if (rc == XE_OK) rc = xe_walk_sort(w->d_temp, w->temp_bytes, w->d_key, w->d_key2, w->d_val, w->d_val2, n, bits, st);
+		if (rc == XE_OK) rc = xe_walk_sort(w->d_temp, w->temp_bytes, w->d_key, w->d_key2, w->d_val, w->d_val2, n * w->nsets, bits, st);
 		if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (record indices)");
 		HIPCHK(h, hipMemcpyAsync(cnt, w->d_gtotal, 4 * nt, hipMemcpyDeviceToHost, st));
 		HIPCHK(h, hipMemcpyAsync(cnt + nt, w->d_gruns, 4 * nt, hipMemcpyDeviceToHost, st));
@@ -2989,7 +2995,7 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 		if (!has_sf) walk_mode &= ~1;
 		if (!has_nf || !h->fast_ok || ((total + 64) >= 0xFFFF0000ull) || getenv("XE_FORCE_GENERAL") || getenv("XE_FAST_R")) walk_mode &= ~2;
 		/* (the per-template counts come back through a small page-locked buffer) */
-		if ((2 * h->hs.dev_tmpls.n + 8) * 4 + 16 > XE_WSTAGE_BYTES) walk_mode &= ~2;
+		if (((2 * h->hs.dev_tmpls.n + 8) * 4 + 16 > XE_WSTAGE_BYTES) || (h->hs.dev_tmpls.n >= 0xFFF0u)) walk_mode &= ~2;
 		if (n >= 0x7FFFFFF0ull) walk_mode = 0;
 	}
 	if (walk_mode) {
@@ -3410,9 +3416,10 @@ walk_fetch(xe_batch *b, int what)
 		HIPCHK(h, hipMemcpy(w->h_sfbase, w->d_sfbase, 4 * (n + 1), hipMemcpyDeviceToHost));
 	}
 	if ((what & 4) && (w->mode & 2) && !w->h_dgruns) {
-		w->h_dgruns = (struct xe_dgrun *)malloc(sizeof(struct xe_dgrun) * (n ? n : 1));
+		/* (run k of datagram i at [k * n + i]) */
+		w->h_dgruns = (struct xe_dgrun *)malloc(sizeof(struct xe_dgrun) * (n ? n : 1) * w->nsets);
 		if (!w->h_dgruns) return XE_ENOMEM;
-		HIPCHK(h, hipMemcpy(w->h_dgruns, w->d_dgruns, sizeof(struct xe_dgrun) * n, hipMemcpyDeviceToHost));
+		HIPCHK(h, hipMemcpy(w->h_dgruns, w->d_dgruns, sizeof(struct xe_dgrun) * n * w->nsets, hipMemcpyDeviceToHost));
 	}
 	return XE_OK;
 }
@@ -3598,8 +3605,13 @@ xe_gpu_batch_flow_info(xe_batch *b, size_t first, size_t count, void *out)
 				/* a datagram the device listed: template, source id and sampling
 				 * rate are in its run, the exporter address came with the datagram */
 				const struct xe_dgrun *g = &b->w.h_dgruns[di];
+				size_t within = r - b->w.h_recbase[di];
+				for (uint32_t q = 0; (q + 1 < b->w.nsets) && (within >= g->nrec); q++) {
+					within -= g->nrec;
+					g += b->w.n;
+				}
 				const uint32_t idb = htonl(g->dev_id);
-				t = &tm[g->tmpl & 0xFFFFFFu];
+				t = &tm[g->tmpl & 0xFFFFu];
 				memcpy(from_dev.dev_ip, &b->w.h_src[di], 4);
 				memcpy(from_dev.dev_id, &idb, 4);
 				from_dev.sampling_rate = g->rate & 0x7FFFFFFFu;

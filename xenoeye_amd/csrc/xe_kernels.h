@@ -211,11 +211,13 @@ struct xe_twalk
 	uint8_t mode;
 };
 
-/* a datagram the device walked: one run of complete records */
+/* a data set of a datagram the device walked: one run of complete records
+ * (v5, v9: one per datagram; IPFIX: up to XE_WALK_SETS) */
+#define XE_WALK_SETS 4
 struct xe_dgrun
 {
-	uint32_t nrec;        /* 0: not walked here */
-	uint32_t tmpl;        /* device template | bytes from the datagram start to the first record << 24 */
+	uint32_t nrec;        /* 0: no such run */
+	uint32_t tmpl;        /* device template (16 bits) | bytes from the datagram start to the first record << 16 */
 	uint32_t dev_id;      /* source id / observation domain as a big-endian number */
 	uint32_t rate;        /* sampling rate | has a devices.conf entry << 31 */
 };
@@ -253,13 +255,14 @@ int xe_walk_sf_count(const struct xe_walk_in *in, uint32_t *cnt, unsigned long l
 /* sFlow: the records of datagram i to out[base[i] ...] */
 int xe_walk_sf_emit(const struct xe_walk_in *in, const uint32_t *base, struct xe_sfrec *out, void *stream);
 
-/* Netflow: per datagram, the run it yields when its shape is the usual one
- * (runs[i].nrec > 0, regular[i] = 1), else regular[i] = 0 */
-int xe_walk_nf_shape(const struct xe_walk_in *in, struct xe_dgrun *runs, uint8_t *regular, void *stream);
-/* cnt[i] = walked[i] ? runs[i].nrec : hostfirst[i + 1] - hostfirst[i] (what the host walk made of the datagram);
- * key[i] = walked[i] ? runs[i].tmpl : ntmpl; val[i] = i; *total += the counts;
- * gtotal[t] += records, gruns[t] += 1 per walked datagram of template t */
-int xe_walk_nf_counts(const struct xe_walk_in *in, const struct xe_dgrun *runs, const uint8_t *walked, const uint32_t *hostfirst,
+/* Netflow: per datagram, the runs it yields when its shape is the usual one
+ * (runs[k * n + i], k < XE_WALK_SETS, nrec > 0 for those it has; regular[i] = 1),
+ * else regular[i] = 0; *kmax = the most runs of any datagram (atomic max) */
+int xe_walk_nf_shape(const struct xe_walk_in *in, struct xe_dgrun *runs, uint8_t *regular, uint32_t *kmax, void *stream);
+/* cnt[i] = walked[i] ? the records of runs[k * n + i], k < nsets : hostfirst[i + 1] - hostfirst[i] (what the host walk
+ * made of the datagram); key[i * nsets + k] = template of run k, or ntmpl (no run, not walked), val[...] = k * n + i;
+ * *total += the counts; gtotal[t] += records, gruns[t] += 1 per run of template t */
+int xe_walk_nf_counts(const struct xe_walk_in *in, const struct xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
 	uint32_t *cnt, uint32_t *key, uint32_t *val, uint32_t *gtotal, uint32_t *gruns, unsigned long long *total, void *stream);
 /* snrec[j] = runs[ord[j]].nrec for j < nruns (the runs in template order) */
 int xe_walk_nf_gather(const struct xe_dgrun *runs, const uint32_t *ord, uint32_t nruns, uint32_t *snrec, void *stream);

@@ -257,30 +257,35 @@ exporter_plain(const xe_walk_in &in, uint32_t ip, uint32_t id, uint32_t &rate)
 	return d.plain && !(d.rate & 0x80000000u);
 }
 
+/* A datagram of the usual shape yields up to XE_WALK_SETS runs, one per data
+ * set: runs[k * n + i] is run k of datagram i (nrec 0: none). */
 __global__ void __launch_bounds__(XW_BLOCK)
-xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular)
+xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular, uint32_t *kmax)
 {
 	const uint32_t i = blockIdx.x * XW_BLOCK + threadIdx.x;
-	if (i >= in.n) return;
-	xe_dgrun r = { 0, 0, 0, 0 };
+	const size_t n = in.n;
+	uint32_t k = 0;
 	bool ok = false;
 
-	if (!(in.kinds && (in.kinds[i] == XE_KIND_SFLOW))) {
+	if ((i < in.n) && !(in.kinds && (in.kinds[i] == XE_KIND_SFLOW))) {
 		const uint64_t off = in.offs[i];
 		int64_t len64 = (int64_t)(in.offs[i + 1] - off);
 		const uint32_t len = (len64 > 65536) ? 65536u : (len64 < 0) ? 0u : (uint32_t)len64;
 		const uint8_t *p = in.pkt + off;
 		const uint32_t src = in.src[i];
+		xe_dgrun r = { 0, 0, 0, 0 };
 		if (len >= 24) {
 			const uint32_t ver = be16(p);
 			if (ver == 5) {
 				/* parse_netflow_v5(), netflow.c:727-786 */
-				const uint32_t n = be16(p + 2), sid = p[21];
-				if (n && ((24 + 48 * n) == len) && in.v5_slot_plus1 && in.twalk[in.v5_slot_plus1 - 1].fast
+				const uint32_t nr = be16(p + 2), sid = p[21];
+				if (nr && ((24 + 48 * nr) == len) && in.v5_slot_plus1 && in.twalk[in.v5_slot_plus1 - 1].fast
 					&& exporter_plain(in, src, sid, r.rate)) {
-					r.nrec = n;
-					r.tmpl = (in.v5_slot_plus1 - 1) | (24u << 24);
+					r.nrec = nr;
+					r.tmpl = (in.v5_slot_plus1 - 1) | (24u << 16);
 					r.dev_id = __builtin_bswap32(sid);
+					runs[i] = r;
+					k = 1;
 					ok = true;
 				}
 			} else if (ver == 9) {
@@ -295,61 +300,97 @@ xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular)
 					if (tw.fast && (count * tw.stride <= length) && ((24 + count * tw.stride) <= len)
 						&& exporter_plain(in, src, sid, r.rate)) {
 						r.nrec = count;
-						r.tmpl = e.slot | (24u << 24);
+						r.tmpl = e.slot | (24u << 16);
 						r.dev_id = __builtin_bswap32(sid);
+						runs[i] = r;
+						k = 1;
 						ok = true;
 					}
 				}
 			} else if (ver == 10) {
-				/* parse_ipfix() + parse_ipfix_flowset(), netflow.c:628-678, :547-625 */
-				const uint32_t sid = ld32(p + 12), fsid = be16(p + 16), length = be16(p + 18);
-				xe_thent e;
-				if ((fsid > 255) && ((16 + length) == len)
-					&& tmpl_lookup(in, (10u << 16) | p[16] | ((uint32_t)p[17] << 8), src, sid, e)
-					&& (e.slot < in.ntmpl)) {
-					const xe_twalk tw = in.twalk[e.slot];
-					if (tw.fast && (e.fc == tw.nfields) && (length >= e.fc)) {
-						/* record k exists iff length - k * stride >= field count, and gets
-						 * every field iff its last field starts before `length` */
-						const uint32_t nrec = (length - e.fc) / tw.stride + 1;
-						const uint32_t nfull = (length > tw.off_last) ? (length - tw.off_last - 1) / tw.stride + 1 : 0;
-						if ((nfull >= nrec) && ((20 + nrec * tw.stride) <= len) && exporter_plain(in, src, sid, r.rate)) {
-							r.nrec = nrec;
-							r.tmpl = e.slot | (20u << 24);
-							r.dev_id = __builtin_bswap32(sid);
-							ok = true;
+				/* parse_ipfix() + parse_ipfix_flowset(), netflow.c:628-678, :547-625: data
+				 * sets of known templates with complete records, options template sets
+				 * (skipped there too) and set ids that mean nothing between them; a
+				 * template set, a set length below 4 or a header cut by the end of the
+				 * datagram leave the datagram to the host */
+				const uint32_t sid = ld32(p + 12);
+				uint32_t ptr = 16;
+				bool bad = false;
+				while (ptr < len) {
+					if ((ptr + 4) > len) { bad = true; break; }
+					const uint32_t fsid = be16(p + ptr), length = be16(p + ptr + 2);
+					if ((length < 4) || (fsid == 2)) { bad = true; break; }
+					if (fsid > 255) {
+						xe_thent e;
+						bad = true;
+						if ((k < XE_WALK_SETS)
+							&& tmpl_lookup(in, (10u << 16) | p[ptr] | ((uint32_t)p[ptr + 1] << 8), src, sid, e)
+							&& (e.slot < in.ntmpl)) {
+							const xe_twalk tw = in.twalk[e.slot];
+							if (tw.fast && (e.fc == tw.nfields) && (length >= e.fc)) {
+								/* record j exists iff length - j * stride >= field count, and gets
+								 * every field iff its last field starts before `length` */
+								const uint32_t nrec = (length - e.fc) / tw.stride + 1;
+								const uint32_t nfull = (length > tw.off_last) ? (length - tw.off_last - 1) / tw.stride + 1 : 0;
+								if ((nfull >= nrec) && ((ptr + 4 + nrec * tw.stride) <= len)) {
+									r.nrec = nrec;
+									r.tmpl = e.slot | ((ptr + 4) << 16);
+									r.dev_id = __builtin_bswap32(sid);
+									runs[k * n + i] = r;
+									k++;
+									bad = false;
+								}
+							}
 						}
+						if (bad) break;
 					}
+					ptr += length;
+				}
+				ok = !bad && k && exporter_plain(in, src, sid, r.rate);
+				if (ok) {
+					for (uint32_t j = 0; j < k; j++) runs[j * n + i].rate = r.rate;
 				}
 			}
 		}
 	}
-	if (!ok) r.nrec = 0;
-	runs[i] = r;
-	regular[i] = ok ? 1 : 0;
+	if (i < in.n) {
+		const xe_dgrun none = { 0, 0, 0, 0 };
+		if (!ok) k = 0;
+		for (uint32_t j = k; j < XE_WALK_SETS; j++) runs[j * n + i] = none;
+		regular[i] = ok ? 1 : 0;
+	}
+	/* the most runs any datagram has: the later steps look at that many only */
+	{
+		uint32_t m = k;
+		for (int d = 32; d; d >>= 1) { const uint32_t o = __shfl_xor(m, d, 64); m = (o > m) ? o : m; }
+		if (((threadIdx.x & 63) == 0) && m) atomicMax(kmax, m);
+	}
 }
 
+/* Per datagram: its record count (from its runs, or what the host walk made of
+ * it); per run: the sort entry at [i * nsets + k] (template, index of the run) */
 __global__ void __launch_bounds__(XW_BLOCK)
-xw_nf_counts_kernel(const xe_walk_in in, const xe_dgrun *runs, const uint8_t *walked, const uint32_t *hostfirst,
+xw_nf_counts_kernel(const xe_walk_in in, const xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
 	uint32_t *cnt, uint32_t *key, uint32_t *val, uint32_t *gtotal, uint32_t *gruns, unsigned long long *total)
 {
 	const uint32_t i = blockIdx.x * XW_BLOCK + threadIdx.x;
-	uint32_t c = 0, mine = 0xFFFFFFFFu, nrec = 0;
-	if (i < in.n) {
-		const bool w = walked[i] != 0;
-		const xe_dgrun r = runs[i];
-		c = w ? r.nrec : (hostfirst[i + 1] - hostfirst[i]);
-		cnt[i] = c;
-		key[i] = w ? (r.tmpl & 0xFFFFFFu) : in.ntmpl;
-		val[i] = i;
-		mine = w ? (r.tmpl & 0xFFFFFFu) : 0xFFFFFFFFu;
-		nrec = w ? r.nrec : 0;
-	}
-	/* per-template sums: a batch has a handful of templates, so the lanes of a
-	 * wave that share one add up among themselves and one of them does the
-	 * atomic add (155 000 adds to two addresses took over a millisecond) */
-	{
-		const uint32_t lane = threadIdx.x & 63;
+	const size_t n = in.n;
+	const uint32_t lane = threadIdx.x & 63;
+	const bool w = (i < in.n) && (walked[i] != 0);
+	uint32_t c = 0;
+
+	for (uint32_t k = 0; k < nsets; k++) {
+		uint32_t mine = 0xFFFFFFFFu, nrec = 0;
+		if (i < in.n) {
+			const xe_dgrun r = runs[k * n + i];
+			const bool use = w && r.nrec;
+			key[(size_t)i * nsets + k] = use ? (r.tmpl & 0xFFFFu) : in.ntmpl;
+			val[(size_t)i * nsets + k] = (uint32_t)(k * n + i);
+			if (use) { mine = r.tmpl & 0xFFFFu; nrec = r.nrec; c += nrec; }
+		}
+		/* per-template sums: a batch has a handful of templates, so the lanes of a
+		 * wave that share one add up among themselves and one of them does the
+		 * atomic add (155 000 adds to two addresses took over a millisecond) */
 		unsigned long long todo = __ballot(mine != 0xFFFFFFFFu);
 		while (todo) {
 			const int leader = __ffsll((long long)todo) - 1;
@@ -365,10 +406,14 @@ xw_nf_counts_kernel(const xe_walk_in in, const xe_dgrun *runs, const uint8_t *wa
 			todo &= ~grp;
 		}
 	}
+	if (i < in.n) {
+		if (!w) c = hostfirst[i + 1] - hostfirst[i];
+		cnt[i] = c;
+	}
 	/* the batch total in 64 bits: the 32-bit prefix sums could wrap unnoticed */
 	unsigned long long s = c;
 	for (int d = 32; d; d >>= 1) s += __shfl_down(s, d, 64);
-	if (((threadIdx.x & 63) == 0) && s) atomicAdd(total, s);
+	if ((lane == 0) && s) atomicAdd(total, s);
 }
 
 __global__ void __launch_bounds__(XW_BLOCK)
@@ -384,13 +429,17 @@ xw_nf_runs_kernel(const xe_walk_in in, const xe_dgrun *runs, const uint32_t *ord
 {
 	const uint32_t j = blockIdx.x * XW_BLOCK + threadIdx.x;
 	if (j >= nruns) return;
-	const uint32_t i = ord[j], t = keys[j];
-	const xe_dgrun r = runs[i];
+	const size_t n = in.n;
+	const uint32_t v = ord[j], t = keys[j];
+	const uint32_t i = (uint32_t)(v % n), k = (uint32_t)(v / n);
+	const xe_dgrun r = runs[v];
 	const xe_wgroup g = groups[t];
 	xe_frun f;
-	/* the first record: behind the datagram header and the set header (v5: the header) */
-	f.data_off = (uint32_t)in.offs[i] + (r.tmpl >> 24);
-	f.first_rec = recbase[i];
+	uint32_t before = 0;
+	/* records of the datagram's earlier sets come first */
+	for (uint32_t q = 0; q < k; q++) before += runs[q * n + i].nrec;
+	f.data_off = (uint32_t)in.offs[i] + (r.tmpl >> 16);
+	f.first_rec = recbase[i] + before;
 	f.start = g.pos0 + (sscan[j] - sscan[g.run0]);
 	f.nrec = r.nrec;
 	f.stride = in.twalk[t].stride | (r.rate & 0x80000000u);
@@ -501,19 +550,19 @@ xe_walk_sf_emit(const struct xe_walk_in *in, const uint32_t *base, struct xe_sfr
 }
 
 extern "C" int
-xe_walk_nf_shape(const struct xe_walk_in *in, struct xe_dgrun *runs, uint8_t *regular, void *stream)
+xe_walk_nf_shape(const struct xe_walk_in *in, struct xe_dgrun *runs, uint8_t *regular, uint32_t *kmax, void *stream)
 {
 	if (!in->n) return XE_OK;
-	hipLaunchKernelGGL(xw_nf_shape_kernel, dim3(xw_blocks(in->n)), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, runs, regular);
+	hipLaunchKernelGGL(xw_nf_shape_kernel, dim3(xw_blocks(in->n)), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, runs, regular, kmax);
 	return xw_done();
 }
 
 extern "C" int
-xe_walk_nf_counts(const struct xe_walk_in *in, const struct xe_dgrun *runs, const uint8_t *walked, const uint32_t *hostfirst,
+xe_walk_nf_counts(const struct xe_walk_in *in, const struct xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
 	uint32_t *cnt, uint32_t *key, uint32_t *val, uint32_t *gtotal, uint32_t *gruns, unsigned long long *total, void *stream)
 {
 	if (!in->n) return XE_OK;
-	hipLaunchKernelGGL(xw_nf_counts_kernel, dim3(xw_blocks(in->n)), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, runs, walked,
+	hipLaunchKernelGGL(xw_nf_counts_kernel, dim3(xw_blocks(in->n)), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, runs, nsets, walked,
 		hostfirst, cnt, key, val, gtotal, gruns, total);
 	return xw_done();
 }
