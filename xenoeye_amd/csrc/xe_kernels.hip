@@ -2697,33 +2697,65 @@ xe_sf_kernel(const xe_kparams kp)
 #define XE_FWM_CHUNKS 16         /* 256-record chunks a block works through */
 #endif
 
-/* one key with its sums into the table in HBM */
+/* one key with its sums into the table in HBM.
+ *
+ * A slot's state goes 0 (free) -> 1 (its key is being written) -> 2 (key
+ * valid) once per window, and its key words are written once, between the two
+ * steps, by the thread that won the slot; that thread publishes them with a
+ * release store of the state.  Readers load the state and then the key words
+ * with agent-scope atomic loads: such loads are served by the L2, the point
+ * where all CUs of the device agree (a plain load may be answered by the CU's
+ * own L1, which can hold the line as it was before the key was written), and
+ * the key loads are issued only after the state load has returned 2, that is
+ * after the L2 held the state store and therefore the key stores the release
+ * put in front of it.  An acquire load of the state would give the same order
+ * but costs an invalidation of the CU's whole L1 for every probe step of every
+ * wave: measured on MI355X, 2.1 M records into a filled table of 177 000 keys
+ * 0.449 ms with acquire loads, 0.279 ms this way; 1.47 M two-address keys 0.932
+ * against 0.251 ms. */
 __device__ __forceinline__ void
 fwm_global_add(const xe_fwm_dev &F, const uint64_t (&kw)[XE_FWM_MAX_KWORDS], uint64_t h,
 	const unsigned long long (&val)[XE_FWM_MAX_VALS], uint32_t nrecords)
 {
 	uint32_t slot = (uint32_t)h & F.cap_mask, tried = 0;
 	bool done = false;
-	while (!done) {
-		unsigned long long *S = F.slots + (size_t)slot * F.swords;
-		uint32_t st = __hip_atomic_load((uint32_t *)S, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-		if (st == 0) {
-			const uint32_t old = atomicCAS((uint32_t *)S, 0u, 1u);
-			/* lost the slot to another thread: whatever state it is in now, the
-			 * key may only be compared behind the acquire load above */
-			if (old != 0) continue;
+	/* One probe step per lane and turn, and the lanes of the wave take their turns
+	 * together (the ballot is where they meet): a lane that finds a slot in state 1
+	 * just looks again next turn.  The thread that is writing that key may be a
+	 * lane of the same wave, which gets to finish only if the waiting lane does not
+	 * spin in a loop of its own. */
+	for (;;) {
+		if (!done) {
+			unsigned long long *S = F.slots + (size_t)slot * F.swords;
+			const uint32_t st = __hip_atomic_load((uint32_t *)S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			bool mine = false;
+			if (st == 0) mine = atomicCAS((uint32_t *)S, 0u, 1u) == 0u;
+			if (mine) {
 #pragma unroll
-			for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
-				if ((uint32_t)i < F.kwords) S[1 + i] = kw[i];
+				for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
+					if ((uint32_t)i < F.kwords) __hip_atomic_store(&S[1 + i], (unsigned long long)kw[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				__hip_atomic_store((uint32_t *)S, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 			}
-			__hip_atomic_store((uint32_t *)S, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-			st = 2;
-		}
-		if (st == 2) {
-			bool eq = true;
+			/* (a slot lost to another thread, or one in state 1: whatever state it
+			 * is in next turn, it is looked at again) */
+			bool eq = mine;
+			if (st == 2) {
+				eq = true;
 #pragma unroll
-			for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
-				if ((uint32_t)i < F.kwords) eq = eq && (S[1 + i] == kw[i]);
+				for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
+					if ((uint32_t)i < F.kwords) {
+						eq = eq && (__hip_atomic_load(&S[1 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kw[i]);
+					}
+				}
+				if (!eq) {
+					slot = (slot + 1) & F.cap_mask;
+					if (++tried > F.cap_mask) {
+						/* full: the records behind this key are lost, and counted */
+						atomicAdd(F.dropped, (unsigned long long)nrecords);
+						done = true;
+					}
+				}
 			}
 			if (eq) {
 #pragma unroll
@@ -2731,16 +2763,9 @@ fwm_global_add(const xe_fwm_dev &F, const uint64_t (&kw)[XE_FWM_MAX_KWORDS], uin
 					if ((uint32_t)j < F.nval) atomicAdd(&F.vals[(size_t)slot * F.nval + j], val[j]);
 				}
 				done = true;
-			} else {
-				slot = (slot + 1) & F.cap_mask;
-				if (++tried > F.cap_mask) {
-					/* full: the records behind this key are lost, and counted */
-					atomicAdd(F.dropped, (unsigned long long)nrecords);
-					done = true;
-				}
 			}
 		}
-		/* st == 1: another thread is writing the key; look again */
+		if (!__ballot(!done)) break;
 	}
 }
 
