@@ -2703,16 +2703,20 @@ xe_sf_kernel(const xe_kparams kp)
  * valid) once per window, and its key words are written once, between the two
  * steps, by the thread that won the slot; that thread publishes them with a
  * release store of the state.  Readers load the state and then the key words
- * with agent-scope atomic loads: such loads are served by the L2, the point
- * where all CUs of the device agree (a plain load may be answered by the CU's
- * own L1, which can hold the line as it was before the key was written), and
- * the key loads are issued only after the state load has returned 2, that is
- * after the L2 held the state store and therefore the key stores the release
- * put in front of it.  An acquire load of the state would give the same order
- * but costs an invalidation of the CU's whole L1 for every probe step of every
- * wave: measured on MI355X, 2.1 M records into a filled table of 177 000 keys
- * 0.449 ms with acquire loads, 0.279 ms this way; 1.47 M two-address keys 0.932
- * against 0.251 ms. */
+ * with agent-scope atomic loads.  Such loads are answered at the point where
+ * all CUs of the device agree, never by a cache on the way that may hold the
+ * line as it was before the key was written (a plain load may be: the L1 of a
+ * CU is not kept coherent), and the key loads are issued only after the state
+ * load has returned 2: after the state store had arrived there, and with it
+ * the key stores the release put in front of it.  An acquire load of the state
+ * gives the same order but invalidates the CU's whole L1 at every probe step of
+ * every wave: measured on MI355X, 2.1 M records into a filled table of 177 000
+ * keys 0.449 ms with acquire loads, 0.279 ms this way; 1.47 M two-address keys
+ * 0.932 against 0.257 ms.
+ *
+ * State and key in one array, the sums in another: with the sums inside the
+ * slot (one line per record instead of two) the adds to a line hold up the
+ * probes of the same line - 0.820 and 0.542 ms for the two cases above. */
 __device__ __forceinline__ void
 fwm_global_add(const xe_fwm_dev &F, const uint64_t (&kw)[XE_FWM_MAX_KWORDS], uint64_t h,
 	const unsigned long long (&val)[XE_FWM_MAX_VALS], uint32_t nrecords)
