@@ -165,11 +165,11 @@ int xe_launch_trie_probe_static(int device, const uint32_t *trie, struct xe_list
  * :727-786; sflow-impl.h:68-405) for datagrams that carry no template: one
  * thread per datagram.  sFlow datagrams keep no state from one to the next, so
  * all of them are walked here.  Of the Netflow datagrams those of the usual
- * shape are (one data set that ends with the datagram, of a template the
- * handle already knows, fixed-length records, all of them complete); anything
- * else - template sets, several sets, cut-short records, unknown templates,
- * exporters with mark rules - is left to the host walk, which keeps the
- * template store. */
+ * shape are (v5; v9 with one data set that ends with the datagram; IPFIX with
+ * up to XE_WALK_SETS data sets; templates the handle already knows,
+ * fixed-length records, all of them complete); anything else - template sets,
+ * several v9 sets, cut-short records, unknown templates, exporters with mark
+ * rules - is left to the host walk, which keeps the template store. */
 
 /* devices.conf entry as device_find() tests it (devices.c:205-232) */
 struct xe_devkey
