@@ -2790,6 +2790,45 @@ fwm_lds_bytes(uint32_t kwmax, uint32_t nvmax)
 		+ XE_FWM_CACHE * (size_t)nvmax * 8;        /* c_sum */
 }
 
+/* the column elements the key and the sums of one record need, all loads in
+ * flight together (a 16-byte field takes two); a field no template of the
+ * batch carries reads as zeros */
+struct fwm_cols
+{
+	uint64_t part0[XE_FWM_MAX_KEY_FIELDS], part1[XE_FWM_MAX_KEY_FIELDS], vraw[XE_FWM_MAX_VALS];
+	uint32_t rate;
+};
+
+__device__ __forceinline__ void
+fwm_load_cols(const xe_kparams &kp, const xe_fwm_dev &F, uint32_t r, bool hit, fwm_cols &C)
+{
+#pragma unroll
+	for (int k = 0; k < XE_FWM_MAX_KEY_FIELDS; k++) {
+		C.part0[k] = C.part1[k] = 0;
+		if (!hit || ((uint32_t)k >= F.nkey)) continue;
+		const uint32_t fld = F.kfield[k], colw = c_colw[fld];
+		const uint64_t co = kp.col_off[fld];
+		if (fld == XF_dev_ip) {
+			C.part0[k] = kp.devips[r];                      /* comes from the exporter */
+		} else if (co != ~0ull) {
+			const uint8_t *p = kp.out_base + co + (size_t)r * colw;
+			if (colw == 1) C.part0[k] = *p;
+			else if (colw == 2) C.part0[k] = *(const uint16_t *)p;
+			else if (colw == 4) C.part0[k] = *(const uint32_t *)p;
+			else if (colw == 8) C.part0[k] = *(const uint64_t *)p;
+			else { C.part0[k] = ((const uint64_t *)p)[0]; C.part1[k] = ((const uint64_t *)p)[1]; }
+		}
+	}
+#pragma unroll
+	for (int j = 0; j < XE_FWM_MAX_VALS; j++) {
+		C.vraw[j] = 0;
+		if (!hit || ((uint32_t)j >= F.nval)) continue;
+		const uint64_t co = kp.col_off[F.vfield[j]];
+		if (co != ~0ull) C.vraw[j] = ((const uint64_t *)(kp.out_base + co))[r];
+	}
+	C.rate = hit ? kp.rates[r] : 0u;
+}
+
 __global__ void __launch_bounds__(XE_BLOCK)
 xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables, uint32_t kwmax, uint32_t nvmax)
 {
@@ -2830,14 +2869,28 @@ xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables, u
 		}
 		__syncthreads();
 
-		/* the mask word of a chunk is fetched while the chunk before it is worked on */
-		uint64_t mnext = (r0 + threadIdx.x < ntot) ? kp.masks[(size_t)(r0 + threadIdx.x) * kp.mask_words + (F.mo >> 6)] : 0;
+		/* Two chunks ahead the mask word of a record is fetched, one chunk ahead the
+		 * column elements its key and sums need: what a chunk waits for was asked
+		 * for while the chunk before it went through the tables */
+		fwm_cols cnext;
+		uint64_t m1, m2;
+		bool hit_next;
+		{
+			const uint32_t ra = r0 + threadIdx.x, rb = ra + XE_BLOCK;
+			const uint64_t m0 = (ra < ntot) ? kp.masks[(size_t)ra * kp.mask_words + (F.mo >> 6)] : 0;
+			m1 = (rb < ntot) ? kp.masks[(size_t)rb * kp.mask_words + (F.mo >> 6)] : 0;
+			hit_next = ((m0 >> (F.mo & 63)) & 1) != 0;
+			fwm_load_cols(kp, F, ra, hit_next, cnext);
+		}
 		for (uint32_t chunk = 0; chunk < XE_FWM_CHUNKS; chunk++) {
 			const uint32_t r = r0 + chunk * XE_BLOCK + threadIdx.x;
-			const uint64_t mword = mnext;
-			mnext = ((chunk + 1 < XE_FWM_CHUNKS) && (r + XE_BLOCK < ntot))
-				? kp.masks[(size_t)(r + XE_BLOCK) * kp.mask_words + (F.mo >> 6)] : 0;
-			const bool hit = (r < ntot) && (((mword >> (F.mo & 63)) & 1) != 0);
+			const bool hit = hit_next;
+			const fwm_cols C = cnext;
+			m2 = ((chunk + 2 < XE_FWM_CHUNKS) && (r + 2 * XE_BLOCK < ntot))
+				? kp.masks[(size_t)(r + 2 * XE_BLOCK) * kp.mask_words + (F.mo >> 6)] : 0;
+			hit_next = (chunk + 1 < XE_FWM_CHUNKS) && (((m1 >> (F.mo & 63)) & 1) != 0);
+			fwm_load_cols(kp, F, r + XE_BLOCK, hit_next, cnext);
+			m1 = m2;
 			XE_PHASE(0);
 			if (!__ballot(hit)) continue;
 
@@ -2851,35 +2904,10 @@ xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables, u
 			uint64_t h = 0xcbf29ce484222325ull;
 			if (hit) {
 				uint32_t pos = 0;
-				/* every column element the key and the sums need, all loads in
-				 * flight together (a 16-byte field takes two); a field no template
-				 * of the batch carries reads as zeros */
-				uint64_t part0[XE_FWM_MAX_KEY_FIELDS], part1[XE_FWM_MAX_KEY_FIELDS], vraw[XE_FWM_MAX_VALS];
-#pragma unroll
-				for (int k = 0; k < XE_FWM_MAX_KEY_FIELDS; k++) {
-					part0[k] = part1[k] = 0;
-					if ((uint32_t)k >= F.nkey) continue;
-					const uint32_t fld = F.kfield[k], colw = c_colw[fld];
-					const uint64_t co = kp.col_off[fld];
-					if (fld == XF_dev_ip) {
-						part0[k] = kp.devips[r];                      /* comes from the exporter */
-					} else if (co != ~0ull) {
-						const uint8_t *p = kp.out_base + co + (size_t)r * colw;
-						if (colw == 1) part0[k] = *p;
-						else if (colw == 2) part0[k] = *(const uint16_t *)p;
-						else if (colw == 4) part0[k] = *(const uint32_t *)p;
-						else if (colw == 8) part0[k] = *(const uint64_t *)p;
-						else { part0[k] = ((const uint64_t *)p)[0]; part1[k] = ((const uint64_t *)p)[1]; }
-					}
-				}
-#pragma unroll
-				for (int j = 0; j < XE_FWM_MAX_VALS; j++) {
-					vraw[j] = 0;
-					if ((uint32_t)j >= F.nval) continue;
-					const uint64_t co = kp.col_off[F.vfield[j]];
-					if (co != ~0ull) vraw[j] = ((const uint64_t *)(kp.out_base + co))[r];
-				}
-				const uint64_t rate = kp.rates[r];
+				const uint64_t (&part0)[XE_FWM_MAX_KEY_FIELDS] = C.part0;
+				const uint64_t (&part1)[XE_FWM_MAX_KEY_FIELDS] = C.part1;
+				const uint64_t (&vraw)[XE_FWM_MAX_VALS] = C.vraw;
+				const uint64_t rate = C.rate;
 				for (uint32_t i = 0; i < F.kwords; i++) s_key(wave, i, lane) = 0;
 #pragma unroll
 				for (int k = 0; k < XE_FWM_MAX_KEY_FIELDS; k++) {
