@@ -2997,6 +2997,8 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 		/* (the per-template counts come back through a small page-locked buffer) */
 		if (((2 * h->hs.dev_tmpls.n + 8) * 4 + 16 > XE_WSTAGE_BYTES) || (h->hs.dev_tmpls.n >= 0xFFF0u)) walk_mode &= ~2;
 		if (n >= 0x7FFFFFF0ull) walk_mode = 0;
+		/* (run indices, XE_WALK_SETS per datagram, are sorted as 32-bit values) */
+		if (n >= (0xFFFFFFF0ull / XE_WALK_SETS)) walk_mode &= ~2;
 	}
 	if (walk_mode) {
 		rc = walk_begin(h, b, data, offsets, src_ip4, kinds, n, walk_mode);
