@@ -473,7 +473,7 @@ def main():
     eng.set_prepass_threads(0)
 
     # sustained host-inclusive rate: `args.pipeline` capture threads, each with a handle of its own
-    # (as INTEGRATION.md describes), take turns on this GPU: while one walks headers on the host,
+    # (the arrangement a collector with several capture threads would use), take turns on this GPU: while one walks headers on the host,
     # another copies or runs.  Every thread owns a share of the exporters and a page-locked buffer.
     piped = None
     if args.pipeline > 1 and world == 1:

@@ -84,8 +84,8 @@ int xe_gpu_mo_host_gated(const xe_gpu *h, int mo);
 /* Service names of the 65536 ports, what port_to_str() / ports_pair_to_str()
  * (utils.c:28-77) put in front of "(port)": names[port] = the name, NULL or ""
  * for a port without one (the reference's table is a static array of its
- * utils.c; the binding derives the names from port_to_str(), see
- * INTEGRATION.md).  With the table set, portstr() and ppstr() filters are
+ * utils.c; a binding derives the names by calling port_to_str() for every
+ * port and cutting the text at the "(").  With the table set, portstr() and ppstr() filters are
  * lowered at commit to sets / conditions over the port values and evaluated
  * on the device; must be called before the objects that use them are added.
  * NULL removes the table. */
