@@ -273,3 +273,34 @@ def test_many_blocks_insert_the_same_new_keys(eng, orc):
         assert eng.fwm_read(ids[2])[0] == orc.fwm_read(ids[2])
         for t in ids:
             eng.fwm_clear(t)
+
+
+def test_the_key_a_one_word_table_cannot_store_among_the_others(eng, orc):
+    """tables whose key is one word keep it xor-ed with a constant, 0 meaning a free slot: the
+    one key that would be stored as 0 gets a row of its own, with the oracle's sums like any other"""
+    rng = synth.Rng(0x51)
+    n = 5000
+    fields = [(8, 4), (12, 4), (7, 2), (11, 2), (4, 1), (1, 8), (2, 8)]
+    recs = synth.flow_columns(rng, n, fields)
+    special = bytes.fromhex("157c4a7fb979379e")       # the constant's bytes in key order: src host, dst host
+    for i in range(0, n, 7):
+        recs[i, 0:8] = np.frombuffer(special, dtype=np.uint8)
+    for i in range(1, n, 7):                          # neighbours that differ in one byte
+        recs[i, 0:8] = np.frombuffer(special, dtype=np.uint8)
+        recs[i, 7] ^= 1
+    b = synth.Batch()
+    exp = bytes([192, 0, 2, 1])
+    b.add(synth.v9_template_packet(256, fields, 77), exp)
+    b.extend(synth.v9_data_packets(256, recs, 48, 77), exp)
+    w = dict(batch=b, mos=[("", -1)])
+    ids = setup(eng, orc, w, [(0, ["src host", "dst host", "packets", "octets"]), (0, ["packets"])])
+    out = eng.prepare(b)
+    for window in range(2):
+        out.run()
+        if window == 0:
+            run_oracle(orc, b, keep_flows=False)
+        same_tables(eng, orc, ids)
+        got, _ = eng.fwm_read(ids[0])
+        assert special in got and len(got) > 1400
+        for t in ids:
+            eng.fwm_clear(t)

@@ -1324,11 +1324,13 @@ xe_gpu_add_fwm(xe_gpu *h, int mo, const char *const *fields, int nfields, size_t
 	if (!tmp) return XE_ENOMEM;
 	h->fwms = tmp;
 	{
-		hipError_t e = hipMalloc((void **)&w.dev.slots, w.slots * w.dev.swords * 8);
-		if (e == hipSuccess) e = hipMalloc((void **)&w.dev.vals, w.slots * (w.dev.nval ? w.dev.nval : 1) * 8);
+		/* (one slot more than the table has: the row of the one key that the
+		 * one-word tables cannot keep among the others, see fwm_global_add()) */
+		hipError_t e = hipMalloc((void **)&w.dev.slots, (w.slots + 1) * w.dev.swords * 8);
+		if (e == hipSuccess) e = hipMalloc((void **)&w.dev.vals, (w.slots + 1) * (w.dev.nval ? w.dev.nval : 1) * 8);
 		if (e == hipSuccess) e = hipMalloc((void **)&w.dev.dropped, 8);
-		if (e == hipSuccess) e = hipMemset(w.dev.slots, 0, w.slots * w.dev.swords * 8);
-		if (e == hipSuccess) e = hipMemset(w.dev.vals, 0, w.slots * (w.dev.nval ? w.dev.nval : 1) * 8);
+		if (e == hipSuccess) e = hipMemset(w.dev.slots, 0, (w.slots + 1) * w.dev.swords * 8);
+		if (e == hipSuccess) e = hipMemset(w.dev.vals, 0, (w.slots + 1) * (w.dev.nval ? w.dev.nval : 1) * 8);
 		if (e == hipSuccess) e = hipMemset(w.dev.dropped, 0, 8);
 		if (e != hipSuccess) {
 			if (w.dev.slots) (void)hipFree(w.dev.slots);
@@ -1365,19 +1367,20 @@ xe_gpu_fwm_read(xe_gpu *h, int fwm, uint8_t *keys, uint64_t *vals, size_t max_ro
 	HIPCHK(h, hipSetDevice(h->device));
 	HIPCHK(h, hipDeviceSynchronize());
 	nv = w->dev.nval ? w->dev.nval : 1;
-	sl = (uint64_t *)malloc(w->slots * w->dev.swords * 8);
-	vl = (uint64_t *)malloc(w->slots * nv * 8);
+	sl = (uint64_t *)malloc((w->slots + 1) * w->dev.swords * 8);
+	vl = (uint64_t *)malloc((w->slots + 1) * nv * 8);
 	if (!sl || !vl) goto out;
-	if ((hipMemcpy(sl, w->dev.slots, w->slots * w->dev.swords * 8, hipMemcpyDeviceToHost) != hipSuccess)
-		|| (hipMemcpy(vl, w->dev.vals, w->slots * nv * 8, hipMemcpyDeviceToHost) != hipSuccess)
+	if ((hipMemcpy(sl, w->dev.slots, (w->slots + 1) * w->dev.swords * 8, hipMemcpyDeviceToHost) != hipSuccess)
+		|| (hipMemcpy(vl, w->dev.vals, (w->slots + 1) * nv * 8, hipMemcpyDeviceToHost) != hipSuccess)
 		|| (dropped && (hipMemcpy(dropped, w->dev.dropped, 8, hipMemcpyDeviceToHost) != hipSuccess))) {
 		rc = XE_EHIP;
 		goto out;
 	}
-	for (size_t i = 0; i < w->slots; i++) {
-		const uint64_t *S = sl + i * w->dev.swords;
+	for (size_t i = 0; i < w->slots + 1; i++) {
+		uint64_t *S = sl + i * w->dev.swords;
 		if ((uint32_t)S[0] != 2) continue;
 		if (n < max_rows) {
+			if (w->dev.kwords == 1) S[1] ^= XE_FWM_KEY_XOR;
 			if (keys) memcpy(keys + n * w->keybytes, S + 1, w->keybytes);
 			if (vals) memcpy(vals + n * w->dev.nval, vl + i * nv, (size_t)w->dev.nval * 8);
 		}
@@ -1420,21 +1423,22 @@ fwm_rows(xe_gpu *h, struct fwm_host *w, uint8_t **keys, uint64_t **vals)
 	*vals = NULL;
 	HIPCHK(h, hipSetDevice(h->device));
 	HIPCHK(h, hipDeviceSynchronize());
-	sl = (uint64_t *)malloc(w->slots * w->dev.swords * 8);
-	vl = (uint64_t *)malloc(w->slots * nv * 8);
+	sl = (uint64_t *)malloc((w->slots + 1) * w->dev.swords * 8);
+	vl = (uint64_t *)malloc((w->slots + 1) * nv * 8);
 	if (!sl || !vl) goto out;
-	if ((hipMemcpy(sl, w->dev.slots, w->slots * w->dev.swords * 8, hipMemcpyDeviceToHost) != hipSuccess)
-		|| (hipMemcpy(vl, w->dev.vals, w->slots * nv * 8, hipMemcpyDeviceToHost) != hipSuccess)) {
+	if ((hipMemcpy(sl, w->dev.slots, (w->slots + 1) * w->dev.swords * 8, hipMemcpyDeviceToHost) != hipSuccess)
+		|| (hipMemcpy(vl, w->dev.vals, (w->slots + 1) * nv * 8, hipMemcpyDeviceToHost) != hipSuccess)) {
 		rc = hip_fail(h, hipGetLastError(), "hipMemcpy(fixed-window table)");
 		goto out;
 	}
-	for (size_t i = 0; i < w->slots; i++) if ((uint32_t)sl[i * w->dev.swords] == 2) n++;
+	for (size_t i = 0; i < w->slots + 1; i++) if ((uint32_t)sl[i * w->dev.swords] == 2) n++;
 	*keys = (uint8_t *)malloc((n ? n : 1) * (size_t)(w->keybytes ? w->keybytes : 1));
 	*vals = (uint64_t *)malloc((n ? n : 1) * nv * 8);
 	if (!*keys || !*vals) goto out;
-	for (size_t i = 0; i < w->slots; i++) {
-		const uint64_t *S = sl + i * w->dev.swords;
+	for (size_t i = 0; i < w->slots + 1; i++) {
+		uint64_t *S = sl + i * w->dev.swords;
 		if ((uint32_t)S[0] != 2) continue;
+		if (w->dev.kwords == 1) S[1] ^= XE_FWM_KEY_XOR;
 		memcpy(*keys + k * w->keybytes, S + 1, w->keybytes);
 		memcpy(*vals + k * w->dev.nval, vl + i * nv, (size_t)w->dev.nval * 8);
 		k++;
@@ -1529,8 +1533,8 @@ xe_gpu_fwm_clear(xe_gpu *h, int fwm)
 	w = &h->fwms[fwm];
 	HIPCHK(h, hipSetDevice(h->device));
 	HIPCHK(h, hipDeviceSynchronize());
-	HIPCHK(h, hipMemset(w->dev.slots, 0, w->slots * w->dev.swords * 8));
-	HIPCHK(h, hipMemset(w->dev.vals, 0, w->slots * (w->dev.nval ? w->dev.nval : 1) * 8));
+	HIPCHK(h, hipMemset(w->dev.slots, 0, (w->slots + 1) * w->dev.swords * 8));
+	HIPCHK(h, hipMemset(w->dev.vals, 0, (w->slots + 1) * (w->dev.nval ? w->dev.nval : 1) * 8));
 	HIPCHK(h, hipMemset(w->dev.dropped, 0, 8));
 	return XE_OK;
 }

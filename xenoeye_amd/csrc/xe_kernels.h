@@ -136,6 +136,8 @@ int xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events);
 #define XE_FWM_MAX_KEY_FIELDS 8
 #define XE_FWM_MAX_VALS 4
 #define XE_FWM_MAX_KWORDS 8
+/* tables whose key is one word keep it as key ^ XE_FWM_KEY_XOR, 0 = free slot */
+#define XE_FWM_KEY_XOR 0x9E3779B97F4A7C15ull
 struct xe_fwm_dev
 {
 	uint32_t mo, nkey, nval, kwords;

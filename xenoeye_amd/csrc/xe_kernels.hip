@@ -2723,6 +2723,43 @@ fwm_global_add(const xe_fwm_dev &F, const uint64_t (&kw)[XE_FWM_MAX_KWORDS], uin
 {
 	uint32_t slot = (uint32_t)h & F.cap_mask, tried = 0;
 	bool done = false;
+	if (F.kwords == 1) {
+		/* A key of one word is its own publication: the word holds key ^
+		 * XE_FWM_KEY_XOR, 0 while the slot is free, and is claimed with one
+		 * compare-and-swap that hands back whatever key got there first - no
+		 * state to wait for, nothing to order.  (The state word is still set, for
+		 * the host that reads the table after the kernel.)  The one key that
+		 * would be stored as 0 has a row of its own behind the table. */
+		const unsigned long long x = kw[0] ^ XE_FWM_KEY_XOR;
+		if (x == 0) {
+			slot = F.cap_mask + 1;
+			__hip_atomic_store((uint32_t *)(F.slots + (size_t)slot * F.swords), 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		} else {
+			for (;;) {
+				unsigned long long *S = F.slots + (size_t)slot * F.swords;
+				unsigned long long cur = __hip_atomic_load(&S[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (cur == 0) {
+					cur = atomicCAS(&S[1], 0ull, x);
+					if (cur == 0) {
+						__hip_atomic_store((uint32_t *)S, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						cur = x;
+					}
+				}
+				if (cur == x) break;
+				slot = (slot + 1) & F.cap_mask;
+				if (++tried > F.cap_mask) {
+					/* full: the records behind this key are lost, and counted */
+					atomicAdd(F.dropped, (unsigned long long)nrecords);
+					return;
+				}
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < XE_FWM_MAX_VALS; j++) {
+			if ((uint32_t)j < F.nval) atomicAdd(&F.vals[(size_t)slot * F.nval + j], val[j]);
+		}
+		return;
+	}
 	/* One probe step per lane and turn, and the lanes of the wave take their turns
 	 * together (the ballot is where they meet): a lane that finds a slot in state 1
 	 * just looks again next turn.  The thread that is writing that key may be a
