@@ -1773,7 +1773,9 @@ xe_nf_fast_kernel(const xe_kparams kp)
 		XE_PHASE(3);
 		/* decode: the template's micro-ops, sorted by kind.  The stores come
 		 * after the list walks so that no gather waits behind them (the vector
-		 * memory counter retires in order) */
+		 * memory counter retires in order).  Issued behind the first root
+		 * gathers instead, to fill that wait: C2 0.2135 against 0.2019 ms, C1
+		 * 0.0890 against 0.0856 ms - the later gathers then wait for them. */
 		if (!(kp.pad2 & 16)) {
 			uint32_t j = op_base;
 			copy_ops<R, 0>(kp, stg, j, PL[1], ridx, T.live); j += PL[1];
