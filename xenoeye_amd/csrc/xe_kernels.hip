@@ -515,9 +515,11 @@ wave_sum(unsigned long long v)
 	return v;
 }
 
-/* column stores of the per-lane kernels: XE_NT_LANE = with the streaming hint */
+/* column stores of the per-lane kernels: XE_NT_LANE = with the streaming hint
+ * (measured on MI355X: per-lane Netflow kernel 0.634 -> 0.612 ms, sFlow kernel
+ * 0.408 -> 0.403 ms) */
 #ifndef XE_NT_LANE
-#define XE_NT_LANE 0
+#define XE_NT_LANE 1
 #endif
 #if XE_NT_LANE
 #define XE_LANE_STORE(PTR, VAL) __builtin_nontemporal_store((VAL), (PTR))
