@@ -2021,7 +2021,7 @@ xe_nf_general_kernel(const xe_kparams kp)
 			}
 		}
 		rec.nparsed = np;
-		kp.nparsed[ridx] = (uint8_t)np;
+		XE_LANE_STORE(&kp.nparsed[ridx], (uint8_t)np);
 
 		/* decode into the columns */
 		for (uint32_t j = 0; j < np; j++) {
@@ -2690,8 +2690,8 @@ xe_sf_kernel(const xe_kparams kp)
 		}
 		deliver = state >= 2;   /* sflow.c:164-168 */
 		XE_PHASE(0);
-		kp.nparsed[ridx] = (uint8_t)(state | (deliver ? 0 : XE_SF_SKIPPED));
-		kp.sf_has[g] = rec.has;
+		XE_LANE_STORE(&kp.nparsed[ridx], (uint8_t)(state | (deliver ? 0 : XE_SF_SKIPPED)));
+		XE_LANE_STORE(&kp.sf_has[g], rec.has);
 		uint64_t rate = own.b.y;
 		if (kp.rates) kp.rates[ridx] = (uint32_t)rate;
 		if (kp.devips) {
