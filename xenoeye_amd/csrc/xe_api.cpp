@@ -2891,7 +2891,17 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 		b->kp.motab_lds = (h->motab_words * 8 <= 8192 + 64) ? 1u : 0u;
 		b->kp.probes = (const struct xe_probe *)h->d_lookups;
 		b->kp.nprobes = h->nlookups;
-		b->kp.lds_counters = (h->hs.nmos <= XE_MAX_LDS_COUNTER_MOS) ? 1u : 0u;
+		/* copies of the counters per block: as many as 3 KB of LDS hold, 16 at most */
+		b->kp.lds_counters = 0;
+		if (h->hs.nmos <= XE_MAX_LDS_COUNTER_MOS) {
+			uint32_t copies = 1;
+			while ((copies < 16) && ((size_t)h->hs.nmos * 24 * copies * 2 <= 3072)) copies *= 2;
+			if (getenv("XE_COUNTER_COPIES")) {       /* diagnostic */
+				const int want = atoi(getenv("XE_COUNTER_COPIES"));
+				if ((want == 1) || (want == 2) || (want == 4) || (want == 8) || (want == 16)) copies = (uint32_t)want;
+			}
+			b->kp.lds_counters = copies;
+		}
 	}
 out:
 	free(tfast); free(is_fast); free(gcount); free(gpos);

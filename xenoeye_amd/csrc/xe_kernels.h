@@ -102,7 +102,7 @@ struct xe_kparams
 	uint32_t ntneed, pad4;
 	const struct xe_probe *probes;
 	uint32_t nprobes, pad2;
-	uint32_t lds_counters;       /* per-block counter staging fits in LDS */
+	uint32_t lds_counters;       /* copies of the counters a block keeps in LDS (a power of two; 0: none, adds go to memory) */
 	uint32_t port_named_off;     /* word offset in `trie` of the 65536-bit set of ports with a service name, 0 = none */
 	/* a second run / tile table pair for the fast kernel: what the header walk
 	 * on the device listed (the first pair is the host walk's) */

@@ -1614,9 +1614,13 @@ classify_objects(const xe_kparams &kp, const bool (&live)[R], const uint64_t (&l
 					const uint32_t m = m0 + (uint32_t)__builtin_ctzll(x);
 					x &= x - 1;
 					if (kp.lds_counters) {
-						__hip_atomic_fetch_add(lcnt + 3 * m + 0, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-						__hip_atomic_fetch_add(lcnt + 3 * m + 1, bxr[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-						__hip_atomic_fetch_add(lcnt + 3 * m + 2, pxr[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						/* the block keeps lds_counters copies of the counters (a power of
+						 * two), a lane adds to the copy of its number: lanes that matched
+						 * the same object take their turns at one address otherwise */
+						lds_u64 *mine = lcnt + (size_t)(threadIdx.x & (kp.lds_counters - 1)) * kp.nmo * 3;
+						__hip_atomic_fetch_add(mine + 3 * m + 0, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						__hip_atomic_fetch_add(mine + 3 * m + 1, bxr[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						__hip_atomic_fetch_add(mine + 3 * m + 2, pxr[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					} else {
 						atomicAdd(kp.counters + 3 * m + 0, 1ull);
 						atomicAdd(kp.counters + 3 * m + 1, bxr[r]);
@@ -1648,12 +1652,12 @@ xe_nf_fast_kernel(const xe_kparams kp)
 	 * the block's counters and its copy of the atom table */
 	uint32_t *stg = lds32 + (size_t)wave * kp.fast_dwords * R * 64 + lane;
 	lds_u64 *lcnt = (lds_u64 *)(lds32 + (size_t)(XE_BLOCK / 64) * kp.fast_dwords * R * 64);
-	lds_u64 *lmt = lcnt + (kp.lds_counters ? (size_t)kp.nmo * 3 : 0);
+	lds_u64 *lmt = lcnt + (size_t)kp.lds_counters * kp.nmo * 3;
 	const bool want_dev = kp.fast_want_dev != 0;
 	const XE_GLOBAL uint8_t *pkt = (const XE_GLOBAL uint8_t *)kp.pkt;
 
 	if (kp.lds_counters) {
-		for (uint32_t i = threadIdx.x; i < kp.nmo * 3; i += XE_BLOCK) lcnt[i] = 0;
+		for (uint32_t i = threadIdx.x; i < kp.nmo * 3 * kp.lds_counters; i += XE_BLOCK) lcnt[i] = 0;
 	}
 	if (kp.motab_lds) {
 		for (uint32_t i = threadIdx.x; i < kp.motab_words; i += XE_BLOCK) lmt[i] = kp.motab[i];
@@ -1796,7 +1800,8 @@ xe_nf_fast_kernel(const xe_kparams kp)
 	if (kp.lds_counters) {
 		__syncthreads();
 		for (uint32_t i = threadIdx.x; i < kp.nmo * 3; i += XE_BLOCK) {
-			unsigned long long v = lcnt[i];
+			unsigned long long v = 0;
+			for (uint32_t c = 0; c < kp.lds_counters; c++) v += lcnt[(size_t)c * kp.nmo * 3 + i];
 			if (v) atomicAdd(kp.counters + i, v);
 		}
 	}
@@ -1916,9 +1921,9 @@ __device__ __forceinline__ void
 lane_kernel_lds(const xe_kparams &kp, uint64_t *lds, lds_u64 *&lcnt, lds_u64 *&lmt)
 {
 	lcnt = (lds_u64 *)lds;
-	lmt = lcnt + (kp.lds_counters ? (size_t)kp.nmo * 3 : 0);
+	lmt = lcnt + (size_t)kp.lds_counters * kp.nmo * 3;
 	if (kp.lds_counters) {
-		for (uint32_t i = threadIdx.x; i < kp.nmo * 3; i += XE_BLOCK) lcnt[i] = 0;
+		for (uint32_t i = threadIdx.x; i < kp.nmo * 3 * kp.lds_counters; i += XE_BLOCK) lcnt[i] = 0;
 	}
 	if (kp.motab_lds) {
 		for (uint32_t i = threadIdx.x; i < kp.motab_words; i += XE_BLOCK) lmt[i] = kp.motab[i];
@@ -1932,7 +1937,8 @@ lane_kernel_flush(const xe_kparams &kp, const lds_u64 *lcnt)
 	if (!kp.lds_counters) return;
 	__syncthreads();
 	for (uint32_t i = threadIdx.x; i < kp.nmo * 3; i += XE_BLOCK) {
-		unsigned long long v = lcnt[i];
+		unsigned long long v = 0;
+		for (uint32_t c = 0; c < kp.lds_counters; c++) v += lcnt[(size_t)c * kp.nmo * 3 + i];
 		if (v) atomicAdd(kp.counters + i, v);
 	}
 }
@@ -2661,7 +2667,7 @@ xe_sf_kernel(const xe_kparams kp)
 	rec.mark = 0;
 	rec.q = kp.sfrecs;
 	/* the staging columns follow the counters and the atom-table copy */
-	rec.stg = (const uint32_t *)(lane_lds + (kp.lds_counters ? (size_t)kp.nmo * 3 : 0)
+	rec.stg = (const uint32_t *)(lane_lds + (size_t)kp.lds_counters * kp.nmo * 3
 		+ (kp.motab_lds ? (size_t)kp.motab_words : 0)) + threadIdx.x;
 	rec.p = kp.pkt;
 	rec.left = 0;
@@ -3280,7 +3286,7 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 		uint32_t per_block = XE_BLOCK / 64;
 		uint32_t blocks = (kq->ntiles + per_block - 1) / per_block;
 		size_t shmem = (size_t)per_block * kq->fast_dwords * kq->fast_r * 64 * 4
-			+ (kq->lds_counters ? (size_t)kq->nmo * 24 : 0)
+			+ (size_t)kq->lds_counters * kq->nmo * 24
 			+ (kq->motab_lds ? (size_t)kq->motab_words * 8 : 0);
 		if (blocks > 4096) blocks = 4096;
 		if (getenv("XE_FAST_BLOCKS")) {          /* diagnostic: grid size of the fast kernel */
@@ -3311,7 +3317,7 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 		}
 	}
 	if (ev && fast_started) (void)hipEventRecord(ev[1], st);
-	const size_t lane_lds = (kp->lds_counters ? (size_t)kp->nmo * 24 : 0)
+	const size_t lane_lds = (size_t)kp->lds_counters * kp->nmo * 24
 		+ (kp->motab_lds ? (size_t)kp->motab_words * 8 : 0) + 16;
 	if (kp->nslowrec) {
 		uint32_t blocks = (kp->nslowrec + XE_BLOCK - 1) / XE_BLOCK;
@@ -3328,9 +3334,9 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 			/* many objects: their counters go to memory directly, the staging
 			 * columns keep the LDS */
 			ksf = *kp;
+			sf_lds -= (size_t)kp->lds_counters * kp->nmo * 24;
 			ksf.lds_counters = 0;
 			kp = &ksf;
-			sf_lds -= (size_t)kp->nmo * 24;
 		}
 		if (ev) (void)hipEventRecord(ev[4], st);
 		hipLaunchKernelGGL(xe_sf_kernel, dim3(blocks), dim3(XE_BLOCK), sf_lds, st, *kp);
