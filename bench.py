@@ -64,6 +64,11 @@ def parse_args():
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch from a rocprofv3 --pmc pass (reported as roofline.traffic)")
+    ap.add_argument("--walk-reps", type=int, default=4,
+                    help="prepare() calls the device header walk is timed over (0 = skip)")
+    ap.add_argument("--spawn-check", action="store_true",
+                    help="ranks only join the process group, add up their ranks and report (no GPU work): "
+                         "rehearsal of the --gpus N launch path")
     ap.add_argument("--quick", action="store_true",
                     help="the headline measurement only (no CPU legs, other configurations, sustained / pipelined / table legs)")
     a = ap.parse_args()
@@ -326,11 +331,13 @@ def measure_other(torch, name, args, device, stream):
     batch.timing(True)
     dt, step_ms, kms = time_steps(torch, batch, stream, args.other_steps, 3)
     n = batch.records
+    walk_ms = measure_walk(eng, packed, args.walk_reps)
     out = {"workload": wl_name, "records_per_step": n, "steps": args.other_steps,
            "headers_walked_on_device": dict(zip(("netflow_datagrams", "netflow_records", "sflow_records"), batch.device_walked())),
            "ms_per_step": dt / args.other_steps * 1e3, "records_per_s": n * args.other_steps / dt,
            "payload_GBps": batch.payload_bytes * args.other_steps / dt / 1e9,
            "roofline": roofline_of(batch, kms, name, n)}
+    out["device_path"] = device_path(out["roofline"], walk_ms, n)
     if name == "c4":
         out["list_table_bytes"] = tb = list_table_bytes(w)
         out["random_gathers_per_s"] = gather_rate(torch, device, tb)
@@ -356,8 +363,132 @@ def list_table_bytes(w):
         return 0
 
 
+def measure_walk(eng, packed, reps):
+    """mean device time (ms) of the header walk of a prepare() over `packed`: every launch that
+    turns datagram bytes resident in HBM into the run / tile tables (Netflow) or the per-datagram
+    sample tables (sFlow) the decode kernels start from; HIP events on the walk's stream"""
+    if reps <= 0:
+        return None
+    eng.set_walk_timing(True)
+    ms = []
+    try:
+        for _ in range(reps):
+            b = eng.prepare(packed)
+            t = b.walk_ms()
+            b.free()
+            if t >= 0:
+                ms.append(t)
+    finally:
+        eng.set_walk_timing(False)
+    return float(sum(ms) / len(ms)) if ms else None
+
+
+def device_path(roof, walk_ms, nrec):
+    """the whole device path of one batch: header walk + dominant decode / classify kernel"""
+    if walk_ms is None:
+        return None
+    ms = walk_ms + roof["kernel_ms"]
+    ach = roof["algorithmic_bytes_per_launch"] / (ms * 1e-3) / 1e9
+    return {"walk_ms": walk_ms, "kernel_ms": roof["kernel_ms"], "device_path_ms": ms,
+            "records_per_s_device_path": nrec / (ms * 1e-3), "achieved": ach, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBPS}
+
+
+def launch_ranks(n):
+    """`bench.py --gpus N` from a plain shell: start one child process per GPU (the reference
+    starts one worker thread per capture entry, xenoeye.c:584-625), each with the rank variables
+    torch.distributed reads; rank 0's line is this process's output.  The parent never touches
+    the GPU and replaces no process image."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out.decode(errors="replace"))
+    sys.stdout.flush()
+    return rc
+
+
+def spawn_check(args):
+    """every rank joins the group and adds up the ranks: what --gpus N starts, without GPU work"""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        dist.all_reduce(t)
+        dist.barrier()
+        dist.destroy_process_group()
+        total = int(t.item())
+    else:
+        total = 1
+    if rank == 0:
+        print(json.dumps({"spawn_check": True, "n_gpus": world, "sum_of_ranks_plus_1": total,
+                          "asked": args.gpus}), flush=True)
+
+
+def c5_sharded(torch, dist, args, rank, world, device, stream, dev):
+    """the 512-exporter replay cut by exporter hash over the ranks: every rank generates and runs its
+    share, the per-object counters merge by wrapping addition, and rank 0 checks the merged table
+    against its own run of the whole replay (same seeds)"""
+    from xenoeye_amd import shard, synth
+    total = 1 << 21
+    w = synth.workload_c5(total, rank=rank, world=world)
+    eng = make_engine(w, device)
+    packed = w["batch"].packed()
+    eng.prepare(packed).free()
+    batch = eng.prepare(packed)
+    batch.timing(True)
+    steps = max(10, args.other_steps // 2)
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt, step_ms, kms = time_steps(torch, batch, stream, steps, 3, barrier)
+    ctr = shard.merge_counters(batch.counters(), dist, dev)
+    dt_all, tot = shard.reduce_scalars([dt, batch.records], ["max", "sum"], dist, dev)
+    out = None
+    if rank == 0:
+        whole = synth.workload_c5(total)
+        e1 = make_engine(whole, device)
+        p1 = whole["batch"].packed()
+        e1.prepare(p1).free()
+        b1 = e1.prepare(p1)
+        b1.run(stream)
+        c1 = b1.counters()
+        out = {"workload": "C5 sharded replay, 512 exporters cut by exporter hash over %d ranks" % world,
+               "records_all_ranks_per_step": int(tot), "records_one_rank_whole_replay": int(b1.records),
+               "steps": steps, "ms_per_step": dt_all / steps * 1e3, "records_per_s": tot * steps / dt_all,
+               "merged_counters_equal_one_rank": bool(int(tot) == int(b1.records) and (ctr == c1).all())}
+        b1.free()
+        e1.close()
+    batch.free()
+    eng.close()
+    return out
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+    if args.spawn_check:
+        spawn_check(args)
+        return
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -419,6 +550,8 @@ def main():
         torch.cuda.synchronize()
 
     dt, step_ms, kms = time_steps(torch, batch, stream, args.steps, args.warmup, barrier)
+    # the header walk that built this batch's run / tile tables, from datagram bytes resident in HBM
+    walk_ms = measure_walk(eng, packed, args.walk_reps) if rank == 0 else None
 
     # the headline step repeated for seconds: the K timed steps above last milliseconds, which no
     # activity sampler sees; same batch, same launches
@@ -582,10 +715,17 @@ def main():
     # per-object counters of the shards merge by wrapping u64 addition
     ctr = shard.merge_counters(c, dist if world > 1 else None, dev)
     value = tot * args.steps / dt_all
+    c5n = None
+    if world > 1 and args.others:
+        try:
+            c5n = c5_sharded(torch, dist, args, rank, world, local_rank, stream, dev)
+        except Exception as ex:
+            c5n = {"error": repr(ex)}
 
     if rank == 0:
         roof = roofline_of(batch, kms, args.workload, nrec, args.traffic)
         roof["step_ms_events"] = step_ms
+        dpath = device_path(roof, walk_ms, nrec)
         # second denominator: what a plain device copy reaches on this box, measured now
         try:
             roof["peak_measured"] = copy_bandwidth(torch, torch.device("cuda", local_rank))
@@ -623,6 +763,7 @@ def main():
             "merged_records_per_object": [int(x) for x in ctr[:, 0]] if len(ctr) else [],
             "records_all_steps": int(tot) * args.steps,
             "roofline": roof,
+            "device_path": dpath,
             "sustained": sustained,
             "host_inclusive": {"prepare_s": t_prep, "prepare_run_fetch_s": t_e2e,
                                "records_per_s": nrec / t_e2e,
@@ -645,6 +786,8 @@ def main():
                 except Exception as ex:
                     others[name] = {"error": repr(ex)}
             out["workloads"] = others
+        if c5n is not None:
+            out["workloads"] = {"c5": c5n}
         out.update(cpu)
         out["bench_wall_s"] = time.perf_counter() - t_start
         print(json.dumps(out), flush=True)

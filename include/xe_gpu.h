@@ -241,6 +241,14 @@ int xe_gpu_batch_sync(xe_batch *b);
 int xe_gpu_batch_timing(xe_batch *b, int enable);
 int xe_gpu_batch_kernel_ms(xe_batch *b, float ms[3]);
 int xe_gpu_batch_fwm_ms(xe_batch *b, float *ms);   /* the fixed-window kernel, -1 without tables */
+/* the header walk on the device: with walk timing enabled on the handle every
+ * xe_gpu_batch_prepare() records HIP events around the walk's launches (the
+ * device side of netflow.c:319-365, :628-678, sflow-impl.h:293-405: shape,
+ * counts, prefix sums, run and tile tables), xe_gpu_batch_walk_ms() gives
+ * their summed duration in milliseconds, host waits in between left out
+ * (-1: the batch was walked by the host or timing was off) */
+int xe_gpu_set_walk_timing(xe_gpu *h, int enable);
+int xe_gpu_batch_walk_ms(xe_batch *b, float *ms);
 
 /* data sets left out because their template has more elements than this
  * library's device form of a template holds (254 within the first 64 KiB of a

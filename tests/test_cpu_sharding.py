@@ -124,3 +124,17 @@ def test_two_ranks_equal_one_process():
     assert res[0][1] > 0 and res[1][1] > 0
     assert res[0][3] == res[1][3] == ctr.tolist()
     assert res[0][5] == 2.0
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_n_starts_n_ranks():
+    """`bench.py --gpus 2` from a plain shell starts two ranks that find each other
+    (the rehearsal mode stops before any GPU work) and prints one line for the job"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--spawn-check"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.startswith("{")]
+    assert lines == [{"spawn_check": True, "n_gpus": 2, "sum_of_ranks_plus_1": 3, "asked": 2}]

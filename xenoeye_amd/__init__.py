@@ -85,6 +85,8 @@ def load_library(path=LIB_PATH):
         "xe_gpu_batch_sync": (i32, [vp]),
         "xe_gpu_batch_timing": (i32, [vp, i32]),
         "xe_gpu_batch_kernel_ms": (i32, [vp, C.POINTER(C.c_float)]),
+        "xe_gpu_set_walk_timing": (i32, [vp, i32]),
+        "xe_gpu_batch_walk_ms": (i32, [vp, C.POINTER(C.c_float)]),
         "xe_gpu_batch_records": (sz, [vp]),
         "xe_gpu_batch_mask_words": (sz, [vp]),
         "xe_gpu_batch_payload_bytes": (sz, [vp]),
@@ -354,6 +356,10 @@ class Engine:
         """which headers the device walks itself: bit 0 sFlow, bit 1 Netflow datagrams of the usual shape"""
         self._chk(self.L.xe_gpu_set_device_walk(self._h, int(mode)))
 
+    def set_walk_timing(self, enable=True):
+        """record HIP events around the device header walk of every prepare()"""
+        self._chk(self.L.xe_gpu_set_walk_timing(self._h, int(enable)))
+
     def commit(self):
         self._chk(self.L.xe_gpu_commit(self._h))
 
@@ -457,6 +463,12 @@ class PreparedBatch:
         ms = (C.c_float * 3)()
         self.eng._chk(self.L.xe_gpu_batch_kernel_ms(self._b, ms))
         return tuple(ms)
+
+    def walk_ms(self):
+        """device time of the header walk of this batch's prepare(), -1 = not timed / walked by the host"""
+        ms = C.c_float()
+        self.eng._chk(self.L.xe_gpu_batch_walk_ms(self._b, C.byref(ms)))
+        return float(ms.value)
 
     def masks(self, out=None):
         if out is None:

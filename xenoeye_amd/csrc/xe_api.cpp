@@ -56,6 +56,7 @@ struct xe_gpu
 	uint32_t port_named_off;   /* word offset in the list tables of the "port has a name" set, 0 = none */
 	/* header walk on the device (xe_walk.hip): bit 0 sFlow, bit 1 Netflow */
 	int device_walk;
+	int walk_timing;           /* record HIP events around the walk's launches of every prepare */
 	void *d_devkeys;           /* struct xe_devkey per devices.conf entry */
 	void *d_thash, *d_twalk;   /* the template store and the device templates as the walk reads them */
 	uint32_t thash_mask;
@@ -85,6 +86,7 @@ struct fwm_host
 	struct { uint8_t aggr, descending; uint16_t size; } order[XE_FWM_MAX_KEY_FIELDS + XE_FWM_MAX_VALS];
 };
 
+#define XE_WALK_EVENTS 16
 /* what the header walk on the device leaves for one batch */
 struct walk_dev
 {
@@ -112,6 +114,10 @@ struct walk_dev
 	uint8_t *kinds2;           /* the kinds with XE_KIND_ON_DEVICE on what the host walk passes by */
 	uint8_t *h_walked;         /* per datagram: its Netflow records were listed on the device */
 	uint32_t *h_src;           /* exporter addresses (the caller's array is gone after prepare) */
+	/* instrumentation: event pairs (start, stop) around every stretch of walk
+	 * launches that is enqueued without the host waiting in between */
+	hipEvent_t wev[XE_WALK_EVENTS];
+	int nwev;
 	/* fetched when somebody asks for them */
 	uint32_t *h_recbase, *h_sfbase;
 	struct xe_dgrun *h_dgruns;
@@ -144,6 +150,16 @@ hip_fail(struct xe_gpu *h, hipError_t e, const char *what)
 }
 
 #define HIPCHK(H, CALL) do { hipError_t e_ = (CALL); if (e_ != hipSuccess) return hip_fail((H), e_, #CALL); } while (0)
+
+/* instrumentation: marks the start or the end of a stretch of walk launches */
+static void
+walk_mark(struct xe_gpu *h, struct walk_dev *w, hipStream_t st)
+{
+	if (!h->walk_timing || (w->nwev >= XE_WALK_EVENTS)) return;
+	if (hipEventCreate(&w->wev[w->nwev]) != hipSuccess) { (void)hipGetLastError(); return; }
+	if (hipEventRecord(w->wev[w->nwev], st) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(w->wev[w->nwev]); return; }
+	w->nwev++;
+}
 
 extern "C" const char *
 xe_gpu_strerror(int code)
@@ -2254,6 +2270,7 @@ walk_free(xe_gpu *h, struct walk_dev *w)
 {
 	dev_put(h, w->arena);
 	dev_put(h, w->tiles);
+	for (int i = 0; i < w->nwev; i++) (void)hipEventDestroy(w->wev[i]);
 	free(w->kinds2);
 	free(w->h_walked);
 	free(w->h_src);
@@ -2383,6 +2400,7 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 			if (kinds) HIPCHK(h, hipMemcpyAsync(w->d_kinds, kinds, n, hipMemcpyHostToDevice, st));
 		}
 	}
+	walk_mark(h, w, st);
 	HIPCHK(h, hipMemsetAsync(w->d_total, 0, 32, st));
 	walk_input(h, b, &in);
 	w->kinds2 = (uint8_t *)malloc(n ? n : 1);
@@ -2406,6 +2424,7 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 		if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (sFlow)");
 		HIPCHK(h, hipMemcpyAsync(h->wstage, w->d_total, 8, hipMemcpyDeviceToHost, st));
 	}
+	walk_mark(h, w, st);
 	/* the host walk needs to know which Netflow datagrams are left to it; with only sFlow
 	 * on the device it starts at once and the device counts beside it */
 	if (mode & 2) {
@@ -2500,7 +2519,9 @@ walk_finish(xe_gpu *h, xe_batch *b)
 		if (nsf + plan->nrec > 0xFFFFFFF0ull) return XE_EUNSUPPORTED;
 		rc = dev_get(h, &b->d_sfrecs, (size_t)nsf * sizeof(struct xe_sfrec));
 		if (rc != XE_OK) return rc;
+		walk_mark(h, w, st);
 		rc = xe_walk_sf_emit(&in, w->d_sfbase, (struct xe_sfrec *)b->d_sfrecs, st);
+		walk_mark(h, w, st);
 		if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (sFlow elements)");
 		plan->nsf = (size_t)nsf;
 	}
@@ -2513,6 +2534,7 @@ walk_finish(xe_gpu *h, xe_batch *b)
 		int gr_pinned = 0;
 
 		if ((2 * nt + 4) * 4 + 16 > XE_WSTAGE_BYTES) return XE_WALK_RETRY_ON_HOST;
+		walk_mark(h, w, st);
 		if (plan->nrec) HIPCHK(h, hipMemcpyAsync(w->d_hostfirst, plan->dg_first_nf, 4 * (n + 1), hipMemcpyHostToDevice, st));
 		else HIPCHK(h, hipMemsetAsync(w->d_hostfirst, 0, 4 * (n + 1), st));
 		HIPCHK(h, hipMemsetAsync(w->d_gtotal, 0, 4 * (nt + 2), st));
@@ -2526,6 +2548,7 @@ walk_finish(xe_gpu *h, xe_batch *b)
 		HIPCHK(h, hipMemcpyAsync(cnt, w->d_gtotal, 4 * nt, hipMemcpyDeviceToHost, st));
 		HIPCHK(h, hipMemcpyAsync(cnt + nt, w->d_gruns, 4 * nt, hipMemcpyDeviceToHost, st));
 		HIPCHK(h, hipMemcpyAsync(cnt + 2 * nt + 2, w->d_total + 1, 8, hipMemcpyDeviceToHost, st));
+		walk_mark(h, w, st);
 		WTICK(1);
 		HIPCHK(h, hipStreamSynchronize(st));
 		WTICK(2);
@@ -2560,6 +2583,7 @@ walk_finish(xe_gpu *h, xe_batch *b)
 		w->nfruns2 = (uint32_t)nruns;
 		w->ntiles2 = (uint32_t)ntiles;
 		if (nruns) {
+			walk_mark(h, w, st);
 			hipError_t e = hipMemcpyAsync(w->d_groups, gr, (nt + 1) * sizeof(*gr), hipMemcpyHostToDevice, st);
 			/* (ordinary memory: the copy has left `gr` when the call returns;
 			 * the scratch stays untouched until the next prepare) */
@@ -2598,6 +2622,7 @@ walk_finish(xe_gpu *h, xe_batch *b)
 				}
 				if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (tiles)");
 			}
+			walk_mark(h, w, st);
 		} else if (!gr_pinned) {
 			free(gr);
 		}
@@ -2942,6 +2967,32 @@ xe_gpu_set_device_walk(xe_gpu *h, int mode)
 {
 	if (!h || (mode < 0) || (mode > 3)) return XE_EINVAL;
 	h->device_walk = mode;
+	return XE_OK;
+}
+
+extern "C" int
+xe_gpu_set_walk_timing(xe_gpu *h, int enable)
+{
+	if (!h) return XE_EINVAL;
+	h->walk_timing = enable ? 1 : 0;
+	return XE_OK;
+}
+
+extern "C" int
+xe_gpu_batch_walk_ms(xe_batch *b, float *ms)
+{
+	float sum = 0.0f;
+	if (!b || !ms) return XE_EINVAL;
+	*ms = -1.0f;
+	if (!b->w.nwev) return XE_OK;
+	HIPCHK(b->h, hipSetDevice(b->h->device));
+	for (int i = 0; i + 1 < b->w.nwev; i += 2) {
+		float t = 0.0f;
+		HIPCHK(b->h, hipEventSynchronize(b->w.wev[i + 1]));
+		HIPCHK(b->h, hipEventElapsedTime(&t, b->w.wev[i], b->w.wev[i + 1]));
+		sum += t;
+	}
+	*ms = sum;
 	return XE_OK;
 }
 
