@@ -57,6 +57,9 @@ struct xe_gpu
 	/* header walk on the device (xe_walk.hip): bit 0 sFlow, bit 1 Netflow */
 	int device_walk;
 	int walk_timing;           /* record HIP events around the walk's launches of every prepare */
+	/* read from the environment once, when the handle is made */
+	int dbg;                   /* XE_DEBUG: timers of prepare on stderr */
+	int diag_force_general, diag_fast_r, diag_counter_copies;   /* diagnostic builds (-DXE_DIAG) only, else 0 */
 	void *d_devkeys;           /* struct xe_devkey per devices.conf entry */
 	void *d_thash, *d_twalk;   /* the template store and the device templates as the walk reads them */
 	uint32_t thash_mask;
@@ -99,6 +102,8 @@ struct walk_dev
 	uint32_t *d_src;
 	uint8_t *d_kinds;
 	uint32_t *d_sfcnt, *d_sfbase;
+	struct xe_sfdg *d_sfdg;    /* per datagram: what the sFlow decode kernel needs of it */
+	void *d_rec2dg;            /* per sFlow record: its datagram (an allocation of its own: sized after the count) */
 	unsigned long long *d_total;   /* [0] sFlow records, [1] Netflow records */
 	void *d_temp; size_t temp_bytes;
 	struct xe_dgrun *d_dgruns;
@@ -130,7 +135,7 @@ struct xe_batch
 	size_t ntot, payload_bytes;
 	void *d_pkt, *d_sets, *d_exps, *d_sfrecs, *d_out;
 	void *d_fruns, *d_ftiles, *d_ssets, *d_swstart, *d_fplans, *d_fops, *d_fflds;
-	size_t out_bytes, masks_off, nparsed_off, marks_off, counters_off, sfhas_off, rates_off, devips_off;
+	size_t out_bytes, masks_off, nparsed_off, marks_off, counters_off, sfhas_off, sfrate_off, rates_off, devips_off;
 	struct xe_kparams kp;
 	hipStream_t last_stream;
 	int ran;
@@ -245,7 +250,13 @@ xe_gpu_create(xe_gpu **out, int device)
 		return XE_EHIP;
 	}
 	h->device_walk = 3;
-	if (getenv("XE_DEVICE_WALK")) h->device_walk = atoi(getenv("XE_DEVICE_WALK")) & 3;   /* diagnostic */
+	if (getenv("XE_DEVICE_WALK")) h->device_walk = atoi(getenv("XE_DEVICE_WALK")) & 3;
+	h->dbg = getenv("XE_DEBUG") != NULL;
+#ifdef XE_DIAG
+	h->diag_force_general = getenv("XE_FORCE_GENERAL") != NULL;
+	if (getenv("XE_FAST_R")) h->diag_fast_r = atoi(getenv("XE_FAST_R"));
+	if (getenv("XE_COUNTER_COPIES")) h->diag_counter_copies = atoi(getenv("XE_COUNTER_COPIES"));
+#endif
 	*out = h;
 	return XE_OK;
 }
@@ -1945,7 +1956,7 @@ xe_gpu_commit(xe_gpu *h)
 				}
 				free(tab);
 			}
-			if (getenv("XE_DEBUG")) {
+			if (h->dbg) {
 				fprintf(stderr, "xe_gpu_commit: %zu objects, %u terms, %u lookups, %zu listed programs, "
 					"%zu need/forbid rows in %u byte tables, %zu derived atoms\n", h->hs.nmos, h->nterms, h->nlookups, nb, nrows, h->ncjgroups, nder);
 			}
@@ -2067,7 +2078,7 @@ xe_gpu_commit(xe_gpu *h)
 				rc = upload(h, &h->d_rgroups, rg, (size_t)nrg * sizeof(rg[0]));
 				if (rc == XE_OK) rc = upload(h, &h->d_rgdata, rgd.p, rgd.n * 4);
 			}
-			if (getenv("XE_DEBUG")) fprintf(stderr, "xe_gpu_commit: %u range groups, %zu table bytes\n", h->nrgroups, rgd.n * 4);
+			if (h->dbg) fprintf(stderr, "xe_gpu_commit: %u range groups, %zu table bytes\n", h->nrgroups, rgd.n * 4);
 			free(rgd.p);
 		}
 		if (rc == XE_OK) rc = upload(h, &h->d_fterms, ft, (size_t)h->nterms * sizeof(*ft));
@@ -2082,7 +2093,7 @@ xe_gpu_commit(xe_gpu *h)
 				if (t >= XE_MAX_FAST_TERMS) h->fast_ok = 0;
 			}
 			h->ntneed = n;
-			if (getenv("XE_DEBUG")) fprintf(stderr, "xe_gpu_commit: %u terms evaluated per record\n", n);
+			if (h->dbg) fprintf(stderr, "xe_gpu_commit: %u terms evaluated per record\n", n);
 			if (rc == XE_OK) rc = upload(h, &h->d_tneed, need, (size_t)n * sizeof(uint32_t));
 			free(need);
 		}
@@ -2169,13 +2180,14 @@ sync_templates(xe_gpu *h)
 
 /* From this many records on a batch takes the per-lane kernel: the fast kernel
  * addresses a column element with a 32-bit byte offset (16-byte columns: below
- * 2^28 records).  The environment variable lets a test reach that path with a
- * small batch. */
+ * 2^28 records).  (XE_FAST_MAX_RECORDS in the environment lets a test reach
+ * that path with a small batch.) */
 static uint64_t
-fast_record_limit(void)
+fast_record_limit(const xe_gpu *h)
 {
-	const char *e = getenv("XE_FAST_MAX_RECORDS");
+	const char *e = getenv("XE_FAST_MAX_RECORDS");   /* once per prepared batch, never per launch */
 	const uint64_t v = e ? strtoull(e, NULL, 0) : 0;
+	(void)h;
 	return (v && (v < (1ull << 28))) ? v : (1ull << 28);
 }
 
@@ -2270,6 +2282,7 @@ walk_free(xe_gpu *h, struct walk_dev *w)
 {
 	dev_put(h, w->arena);
 	dev_put(h, w->tiles);
+	dev_put(h, w->d_rec2dg);
 	for (int i = 0; i < w->nwev; i++) (void)hipEventDestroy(w->wev[i]);
 	free(w->kinds2);
 	free(w->h_walked);
@@ -2342,7 +2355,8 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 	w->temp_bytes = xe_walk_temp_bytes(nr + 1);
 #define CARVE(BYTES) (off = ALIGN_UP(off, 256), off += (BYTES), off - (BYTES))
 	const size_t o_offs = CARVE(8 * (n + 1)), o_src = CARVE(4 * n), o_kinds = CARVE(n), o_sfcnt = CARVE(4 * (n + 2)),
-		o_sfbase = CARVE(4 * (n + 2)), o_total = CARVE(32), o_temp = CARVE(w->temp_bytes);
+		o_sfbase = CARVE(4 * (n + 2)), o_total = CARVE(32), o_temp = CARVE(w->temp_bytes),
+		o_sfdg = CARVE((mode & 1) ? sizeof(struct xe_sfdg) * (n + 1) : 0);
 	size_t o_dgruns = 0, o_walked = 0, o_hostfirst = 0, o_nfcnt = 0, o_recbase = 0, o_key = 0, o_val = 0, o_key2 = 0, o_val2 = 0,
 		o_gtotal = 0, o_gruns = 0, o_snrec = 0, o_sscan = 0, o_groups = 0, o_fruns2 = 0;
 	if (mode & 2) {
@@ -2361,6 +2375,7 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 	w->d_kinds = kinds ? base + o_kinds : NULL;
 	w->d_sfcnt = (uint32_t *)(base + o_sfcnt);
 	w->d_sfbase = (uint32_t *)(base + o_sfbase);
+	w->d_sfdg = (struct xe_sfdg *)(base + o_sfdg);
 	w->d_total = (unsigned long long *)(base + o_total);
 	w->d_temp = base + o_temp;
 	if (mode & 2) {
@@ -2419,7 +2434,7 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 	}
 	if (mode & 1) {
 		in.pkt = (const uint8_t *)b->d_pkt;
-		rc = xe_walk_sf_count(&in, w->d_sfcnt, w->d_total, st);
+		rc = xe_walk_sf_count(&in, w->d_sfcnt, w->d_sfdg, w->d_total, st);
 		if (rc == XE_OK) rc = xe_walk_scan(w->d_temp, w->temp_bytes, w->d_sfcnt, w->d_sfbase, n, st);
 		if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (sFlow)");
 		HIPCHK(h, hipMemcpyAsync(h->wstage, w->d_total, 8, hipMemcpyDeviceToHost, st));
@@ -2506,7 +2521,7 @@ walk_finish(xe_gpu *h, xe_batch *b)
 	struct xe_walk_in in;
 	int rc;
 
-	const int dbg = getenv("XE_DEBUG") != NULL;
+	const int dbg = h->dbg;
 	double tk[6] = {0, 0, 0, 0, 0, 0};
 #define WTICK(I) do { if (dbg) { struct timespec ts_; clock_gettime(CLOCK_MONOTONIC, &ts_); tk[I] = ts_.tv_sec * 1e3 + ts_.tv_nsec * 1e-6; } } while (0)
 
@@ -2517,12 +2532,12 @@ walk_finish(xe_gpu *h, xe_batch *b)
 		HIPCHK(h, hipStreamSynchronize(st));
 		nsf = *(volatile unsigned long long *)h->wstage;
 		if (nsf + plan->nrec > 0xFFFFFFF0ull) return XE_EUNSUPPORTED;
-		rc = dev_get(h, &b->d_sfrecs, (size_t)nsf * sizeof(struct xe_sfrec));
+		rc = dev_get(h, &w->d_rec2dg, (size_t)nsf * 4 + 4);
 		if (rc != XE_OK) return rc;
 		walk_mark(h, w, st);
-		rc = xe_walk_sf_emit(&in, w->d_sfbase, (struct xe_sfrec *)b->d_sfrecs, st);
+		rc = xe_walk_sf_place((uint32_t)n, w->d_sfbase, (uint32_t *)w->d_rec2dg, st);
 		walk_mark(h, w, st);
-		if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (sFlow elements)");
+		if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (sFlow records)");
 		plan->nsf = (size_t)nsf;
 	}
 	if (w->mode & 2) {
@@ -2555,7 +2570,7 @@ walk_finish(xe_gpu *h, xe_batch *b)
 		memcpy(&total, cnt + 2 * nt + 2, 8);
 		if (total + plan->nsf > 0xFFFFFFF0ull) return XE_EUNSUPPORTED;
 		/* from 2^28 records on the fast kernel is out (32-bit column offsets) */
-		if (total + plan->nsf >= fast_record_limit()) return XE_WALK_RETRY_ON_HOST;
+		if (total + plan->nsf >= fast_record_limit(h)) return XE_WALK_RETRY_ON_HOST;
 		gr = (struct xe_wgroup *)pin_get(h, (nt + 2) * sizeof(*gr));
 		gr_pinned = gr != NULL;
 		if (!gr) gr = (struct xe_wgroup *)malloc((nt + 2) * sizeof(*gr));
@@ -2729,7 +2744,7 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 	/* the fast kernel addresses a column element with a 32-bit byte offset
 	 * (16-byte columns: below 2^28 records); larger batches take the general
 	 * kernel.  The environment variable is a diagnostic: time the general kernel */
-	const int force_general = (getenv("XE_FORCE_GENERAL") != NULL) || (b->ntot >= fast_record_limit());
+	const int force_general = h->diag_force_general || (b->ntot >= fast_record_limit(h));
 	uint32_t maxchunk = 1, R, tilesz;
 	size_t cnt_bytes = (h->hs.nmos <= XE_MAX_LDS_COUNTER_MOS) ? h->hs.nmos * 24 : 0;
 	int rc = XE_ENOMEM;
@@ -2761,8 +2776,8 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 	 * stay available while they fit the LDS budget (4 waves x R x 64 records
 	 * x 16 * maxchunk bytes) */
 	R = 1;
-	if (getenv("XE_FAST_R")) {
-		int want = atoi(getenv("XE_FAST_R"));   /* diagnostic override */
+	if (h->diag_fast_r) {
+		int want = h->diag_fast_r;   /* diagnostic override */
 		if ((want == 1) || (want == 2) || (want == 4)) R = (uint32_t)want;
 		while ((R > 1) && ((size_t)4 * R * 64 * 4 * (4 * maxchunk + 1) + cnt_bytes + 8192 > XE_FAST_LDS_BUDGET)) R >>= 1;
 	}
@@ -2921,8 +2936,8 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 		if (h->hs.nmos <= XE_MAX_LDS_COUNTER_MOS) {
 			uint32_t copies = 1;
 			while ((copies < 16) && ((size_t)h->hs.nmos * 24 * copies * 2 <= 3072)) copies *= 2;
-			if (getenv("XE_COUNTER_COPIES")) {       /* diagnostic */
-				const int want = atoi(getenv("XE_COUNTER_COPIES"));
+			if (h->diag_counter_copies) {       /* diagnostic */
+				const int want = h->diag_counter_copies;
 				if ((want == 1) || (want == 2) || (want == 4) || (want == 8) || (want == 16)) copies = (uint32_t)want;
 			}
 			b->kp.lds_counters = copies;
@@ -3003,7 +3018,7 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 	xe_batch *b;
 	int rc;
 	size_t total, off, f;
-	const int dbg = getenv("XE_DEBUG") != NULL;
+	const int dbg = h ? h->dbg : 0;
 	double tm_[8];
 	int ntm_ = 0;
 #define XE_TICK() do { if (dbg && (ntm_ < 8)) { struct timespec ts_; clock_gettime(CLOCK_MONOTONIC, &ts_); \
@@ -3058,7 +3073,7 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 			return XE_EINVAL;
 		}
 		if (!has_sf) walk_mode &= ~1;
-		if (!has_nf || !h->fast_ok || ((total + 64) >= 0xFFFF0000ull) || getenv("XE_FORCE_GENERAL") || getenv("XE_FAST_R")) walk_mode &= ~2;
+		if (!has_nf || !h->fast_ok || ((total + 64) >= 0xFFFF0000ull) || h->diag_force_general || h->diag_fast_r) walk_mode &= ~2;
 		/* (the per-template counts come back through a small page-locked buffer) */
 		if (((2 * h->hs.dev_tmpls.n + 8) * 4 + 16 > XE_WSTAGE_BYTES) || (h->hs.dev_tmpls.n >= 0xFFF0u)) walk_mode &= ~2;
 		if (n >= 0x7FFFFFF0ull) walk_mode = 0;
@@ -3124,6 +3139,7 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 	b->marks_off = off;    if (h->hs.ndevs) off = ALIGN_UP(off + b->ntot * 4, 256);
 	b->counters_off = off; off = ALIGN_UP(off + (size_t)(h->nmo ? h->nmo : 1) * 24, 256);
 	b->sfhas_off = off;    off = ALIGN_UP(off + b->plan.nsf * 4, 256);
+	b->sfrate_off = off;   if (b->w.mode & 1) off = ALIGN_UP(off + b->plan.nsf * 4, 256);
 	b->rates_off = off;    if (h->nfwm) off = ALIGN_UP(off + b->ntot * 4, 256);
 	b->devips_off = off;   if (h->fwm_devip) off = ALIGN_UP(off + b->ntot * 4, 256);
 	for (f = 0; f < XE_NFIELDS; f++) {
@@ -3291,6 +3307,14 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 	b->kp.marks = h->hs.ndevs ? (uint32_t *)((uint8_t *)b->d_out + b->marks_off) : NULL;
 	b->kp.counters = (unsigned long long *)((uint8_t *)b->d_out + b->counters_off);
 	b->kp.sf_has = (uint32_t *)((uint8_t *)b->d_out + b->sfhas_off);
+	if (b->w.mode & 1) {
+		/* the device walked the sFlow datagrams: no element descriptors, the kernel
+		 * finds every record's sample through its datagram's entry */
+		b->kp.sfdg = b->w.d_sfdg;
+		b->kp.sfbase = b->w.d_sfbase;
+		b->kp.sf_rec2dg = (const uint32_t *)b->w.d_rec2dg;
+		b->kp.sf_rate = (uint32_t *)((uint8_t *)b->d_out + b->sfrate_off);
+	}
 	b->kp.rates = h->nfwm ? (uint32_t *)((uint8_t *)b->d_out + b->rates_off) : NULL;
 	b->kp.devips = h->fwm_devip ? (uint32_t *)((uint8_t *)b->d_out + b->devips_off) : NULL;
 	XE_TICK();
@@ -3575,6 +3599,66 @@ sf_field_size(int f)
 	}
 }
 
+/* sFlow records [first, first + count) of a batch whose datagrams the device
+ * walked: descriptors with the per-datagram fields (agent address, sub-agent
+ * id) and the sampling rate filled in, for the re-creation of struct flow_info */
+static int
+sf_meta_fetch(xe_batch *b, size_t first, size_t count, struct xe_sfrec **out)
+{
+	xe_gpu *h = b->h;
+	struct xe_sfrec *sl = (struct xe_sfrec *)calloc(count + 1, sizeof(*sl));
+	uint32_t *r2d = (uint32_t *)malloc((count + 1) * 4), *rate = (uint32_t *)malloc((count + 1) * 4);
+	struct xe_sfdg *dg = NULL;
+	uint8_t *hdr = NULL;
+	int rc = XE_ENOMEM;
+
+	*out = NULL;
+	if (!sl || !r2d || !rate) goto out;
+	rc = xe_gpu_batch_sync(b);
+	if (rc != XE_OK) goto out;
+	rc = XE_EHIP;
+	if (hipMemcpy(r2d, (const uint32_t *)b->w.d_rec2dg + first, count * 4, hipMemcpyDeviceToHost) != hipSuccess) goto hipfail;
+	if (hipMemcpy(rate, (const uint8_t *)b->d_out + b->sfrate_off + first * 4, count * 4, hipMemcpyDeviceToHost) != hipSuccess) goto hipfail;
+	{
+		const uint32_t d0 = r2d[0], d1 = r2d[count - 1];
+		const size_t nd = (size_t)d1 - d0 + 1;
+		uint64_t lo, hi;
+		rc = XE_ENOMEM;
+		dg = (struct xe_sfdg *)malloc(nd * sizeof(*dg));
+		if (!dg) goto out;
+		rc = XE_EHIP;
+		if (hipMemcpy(dg, b->w.d_sfdg + d0, nd * sizeof(*dg), hipMemcpyDeviceToHost) != hipSuccess) goto hipfail;
+		/* header bytes of the datagrams in between: one copy of the stretch of the
+		 * batch buffer from the first to the header of the last */
+		lo = dg[0].off;
+		hi = dg[nd - 1].off + 48;
+		if (hi > b->payload_bytes + 64) hi = b->payload_bytes + 64;
+		rc = XE_ENOMEM;
+		hdr = (uint8_t *)malloc((size_t)(hi - lo) + 64);
+		if (!hdr) goto out;
+		rc = XE_EHIP;
+		if (hipMemcpy(hdr, (const uint8_t *)b->d_pkt + lo, (size_t)(hi - lo), hipMemcpyDeviceToHost) != hipSuccess) goto hipfail;
+		for (size_t k = 0; k < count; k++) {
+			const struct xe_sfdg *g = &dg[r2d[k] - d0];
+			const uint8_t *p = hdr + (g->off - lo);
+			const int v6 = (g->len & XE_SFDG_AGENT6) != 0;
+			sl[k].agent_ver = v6 ? 6 : 4;
+			memcpy(sl[k].agent, p + 8, v6 ? 16 : 4);
+			memcpy(sl[k].dev_id, p + 8 + (v6 ? 16 : 4), 4);
+			sl[k].sampling_rate = rate[k];
+		}
+	}
+	rc = XE_OK;
+	*out = sl;
+	sl = NULL;
+	goto out;
+hipfail:
+	rc = hip_fail(h, hipGetLastError(), "hipMemcpy(sFlow datagram headers)");
+out:
+	free(sl); free(r2d); free(rate); free(dg); free(hdr);
+	return rc;
+}
+
 extern "C" int
 xe_gpu_batch_flow_info(xe_batch *b, size_t first, size_t count, void *out)
 {
@@ -3616,10 +3700,11 @@ xe_gpu_batch_flow_info(xe_batch *b, size_t first, size_t count, void *out)
 		rc = fetch(b, s.sfhas + (b->plan.nrec + sf_first - first), b->sfhas_off + sf_first * 4, sf_count * 4);
 		if (rc != XE_OK) goto done;
 		if (b->w.mode & 1) {
-			sf_slice = (struct xe_sfrec *)malloc((sf_count + 1) * sizeof(struct xe_sfrec));
-			if (!sf_slice) { rc = XE_ENOMEM; goto done; }
-			if (hipMemcpy(sf_slice, (const struct xe_sfrec *)b->d_sfrecs + sf_first, sf_count * sizeof(struct xe_sfrec),
-				hipMemcpyDeviceToHost) != hipSuccess) { rc = hip_fail(h, hipGetLastError(), "hipMemcpy(sFlow elements)"); goto done; }
+			/* the device walked these datagrams: what sflow_reset() sets per datagram
+			 * (sflow-impl.h:274-291) is read back from the datagram headers in the batch
+			 * buffer, the sampling rate from the column the kernel wrote */
+			rc = sf_meta_fetch(b, sf_first, sf_count, &sf_slice);
+			if (rc != XE_OK) goto done;
 			sf_slice_first = sf_first;
 		}
 	}

@@ -109,6 +109,12 @@ struct xe_kparams
 	const struct xe_frun *fruns2;
 	const struct xe_ftile *ftiles2;
 	uint32_t nfruns2, ntiles2;
+	/* sFlow records whose datagrams the device walked (sfrecs is NULL then): per
+	 * datagram its entry and the index of its first record, per record its datagram */
+	const struct xe_sfdg *sfdg;
+	const uint32_t *sfbase;
+	const uint32_t *sf_rec2dg;
+	uint32_t *sf_rate;           /* per sFlow record: the sampling rate of its sample */
 };
 
 #define XE_MAX_FAST_TERMS 256
@@ -224,6 +230,19 @@ struct xe_dgrun
 	uint32_t rate;        /* sampling rate | has a devices.conf entry << 31 */
 };
 
+/* what the sFlow walk leaves per datagram for the decode kernel */
+#define XE_SFDG_POS 8
+#define XE_SFDG_WALK 0x80000000u     /* len: not of the usual shape, the decode kernel walks the datagram itself */
+#define XE_SFDG_AGENT6 0x40000000u   /* len: the agent address is an IPv6 one */
+#define XE_SFDG_LEN 0x0001FFFFu
+struct xe_sfdg
+{
+	uint64_t off;                 /* the datagram in the batch buffer */
+	uint32_t len;                 /* min(its length, 65536) | XE_SFDG_*; 0 = yields nothing */
+	uint32_t dev;                 /* devices.conf entry + 1, 0 = none */
+	uint16_t pos[XE_SFDG_POS];    /* usual shape: byte offset of the sample (its type word) of record k */
+};
+
 struct xe_walk_in
 {
 	const uint8_t *pkt;
@@ -252,10 +271,11 @@ int xe_walk_scan(void *temp, size_t temp_bytes, uint32_t *in, uint32_t *out, siz
 int xe_walk_sort(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
 	size_t n, unsigned bits, void *stream);
 
-/* sFlow: cnt[i] = records datagram i yields (0 for other kinds); *total += their sum */
-int xe_walk_sf_count(const struct xe_walk_in *in, uint32_t *cnt, unsigned long long *total, void *stream);
-/* sFlow: the records of datagram i to out[base[i] ...] */
-int xe_walk_sf_emit(const struct xe_walk_in *in, const uint32_t *base, struct xe_sfrec *out, void *stream);
+/* sFlow: cnt[i] = records datagram i yields (0 for other kinds), dgs[i] = what the decode kernel
+ * needs of the datagram; *total += the counts */
+int xe_walk_sf_count(const struct xe_walk_in *in, uint32_t *cnt, struct xe_sfdg *dgs, unsigned long long *total, void *stream);
+/* sFlow: rec2dg[r] = i for the records r in [base[i], base[i + 1]) of datagram i < n */
+int xe_walk_sf_place(uint32_t n, const uint32_t *base, uint32_t *rec2dg, void *stream);
 
 /* Netflow: per datagram, the runs it yields when its shape is the usual one
  * (runs[k * n + i], k < XE_WALK_SETS, nrec > 0 for those it has; regular[i] = 1),

@@ -22,6 +22,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "xe_kernels.h"
+#include "xe_sfwalk.h"
 
 #define XE_BLOCK 256
 
@@ -715,9 +716,22 @@ tile_get(const lane_tile<REC, GET> &T, uint32_t field, uint32_t r, bool &has, ui
 
 /* diagnostic phase timing (XE_ABLATE bit 6): wave-clock cycles per phase, summed
  * over the waves' tiles into xe_fast_phase_cycles[] */
+#ifdef XE_DIAG
 __device__ unsigned long long xe_fast_phase_cycles[8];
-#define XE_PHASE(N) do { if (kp.pad2 & 64) { const uint64_t now_ = __builtin_readcyclecounter(); \
+#endif
+#ifdef XE_DIAG
+/* diagnostic build only (tools/build_variant.sh -DXE_DIAG): phases of the kernels can be
+ * switched off through XE_ABLATE (wrong results, timing only) and wave cycles per phase
+ * collected; the product library is compiled without any of it */
+#define XE_ABL(BIT) (kp.pad2 & (BIT))
+#define XE_PHASE_DECL uint64_t tprev = __builtin_readcyclecounter()
+#define XE_PHASE(N) do { if XE_ABL(64) { const uint64_t now_ = __builtin_readcyclecounter(); \
 	if (lane == 0) atomicAdd(&xe_fast_phase_cycles[N], (unsigned long long)(now_ - tprev)); tprev = now_; } } while (0)
+#else
+#define XE_ABL(BIT) (0)
+#define XE_PHASE_DECL do { } while (0)
+#define XE_PHASE(N) do { (void)lane; } while (0)
+#endif
 
 /*
  * All IP-list membership tests of a tile.  Per probe (one field against one
@@ -842,11 +856,11 @@ fast_lookups(const xe_kparams &kp, const TT &T, const uint64_t (&plists)[LW], ui
 					if (walk[c][r]) {
 						if (e[c][r] & XE_TRIE_CHAIN) {
 							const XE_CONST uint32_t *cp = (const XE_CONST uint32_t *)(kp.trie + chains[c])
-								+ (size_t)((e[c][r] & ~XE_TRIE_CHAIN) & ((kp.pad2 & 128) ? 63u : ~0u)) * XE_CHAIN_WORDS;
+								+ (size_t)((e[c][r] & ~XE_TRIE_CHAIN) & (XE_ABL(128) ? 63u : ~0u)) * XE_CHAIN_WORDS;
 							ca[c][r] = XE_GATHER_LOAD((const XE_CONST u32x4 *)cp);
 							cb[c][r] = XE_GATHER_LOAD((const XE_CONST u32x2 *)(cp + 4));
 						} else {
-							nx[c][r] = XE_GATHER_LOAD(&((const XE_CONST uint32_t *)(kp.trie + nodes[c]))[(size_t)(e[c][r] & ((kp.pad2 & 128) ? 15u : ~0u)) * XE_NODE_WORDS
+							nx[c][r] = XE_GATHER_LOAD(&((const XE_CONST uint32_t *)(kp.trie + nodes[c]))[(size_t)(e[c][r] & (XE_ABL(128) ? 15u : ~0u)) * XE_NODE_WORDS
 								+ addr_byte(hi[c][r], lo[c][r], depth)]);
 						}
 					}
@@ -1231,7 +1245,7 @@ tile_issue(const xe_kparams &kp, const tile_lanes<R> &S, u32x4 (&q)[4][R])
 #pragma unroll
 		for (int r = 0; r < R; r++) {
 			q[i][r] = (u32x4){0, 0, 0, 0};
-			if (S.live[r] && ((uint32_t)i < S.nchunk) && !(kp.pad2 & 32)) {
+			if (S.live[r] && ((uint32_t)i < S.nchunk) && !XE_ABL(32)) {
 #if XE_NT_LOADS
 				typedef u32x4 u32x4_any __attribute__((aligned(1)));
 				q[i][r] = __builtin_nontemporal_load((const XE_GLOBAL u32x4_any *)(pkt + S.voff[r] + 16 * i));
@@ -1361,27 +1375,27 @@ template <int R, bool LEAN, int LW, typename TT, int RGC = XE_RG_STEP, int PC = 
 __device__ __forceinline__ void
 classify_atoms(const xe_kparams &kp, const TT &T, const uint64_t (&plist)[LW], uint64_t (&lk)[R][LW], uint64_t (&tb)[R][4])
 {
-		if (kp.pad2 & 1) {
+		if XE_ABL(1) {
 #pragma unroll
 			for (int r = 0; r < R; r++) {
 #pragma unroll
 				for (int w = 0; w < LW; w++) lk[r][w] = 0;
 			}
 		} else {
-			uint64_t tprev = (kp.pad2 & 64) ? __builtin_readcyclecounter() : 0;
+			XE_PHASE_DECL;
 			const uint32_t lane = threadIdx.x & 63;
 			fast_lookups<R, LW, TT, PC>(kp, T, plist, lk);
 			XE_PHASE(6);
 		}
 #pragma unroll
 		for (int r = 0; r < R; r++) tb[r][0] = tb[r][1] = tb[r][2] = tb[r][3] = 0;
-		if (!LEAN && !(kp.pad2 & 2)) {
-			uint64_t tprev = (kp.pad2 & 64) ? __builtin_readcyclecounter() : 0;
+		if (!LEAN && !XE_ABL(2)) {
+			XE_PHASE_DECL;
 			const uint32_t lane = threadIdx.x & 63;
 			range_groups<R, TT, RGC>(kp, T, tb);
 			XE_PHASE(7);
 		}
-		for (uint32_t ti = 0; (ti < kp.ntneed) && !(kp.pad2 & 2); ti++) {
+		for (uint32_t ti = 0; (ti < kp.ntneed) && !XE_ABL(2); ti++) {
 			const uint32_t t = ((cu32)kp.tneed)[ti];
 			cu64 fq = (cu64)(kp.fterms + t);
 			const uint64_t fkind = fq[0];
@@ -1423,7 +1437,7 @@ classify_objects(const xe_kparams &kp, const bool (&live)[R], const uint64_t (&l
 		uint64_t dbits[R];
 #pragma unroll
 		for (int r = 0; r < R; r++) dbits[r] = 0;
-		for (uint32_t j = 0; !LEAN && (j < kp.ncjderived) && !(kp.pad2 & 8); j++) {
+		for (uint32_t j = 0; !LEAN && (j < kp.ncjderived) && !XE_ABL(8); j++) {
 			/* xe_cjderived: pos_lk[4], neg_lk[4], pos_tb, neg_tb */
 			cu64 dq = (cu64)(kp.cjderived + j);
 			const uint64_t pt = dq[8], nt = dq[9];
@@ -1441,7 +1455,7 @@ classify_objects(const xe_kparams &kp, const bool (&live)[R], const uint64_t (&l
 		 * give the failing objects.  A table row holds all mask words side by
 		 * side: up to four of them are fetched per visit, for all words at once */
 		uint64_t failw[R][4];
-		const bool cj_rows = !LEAN && kp.ncjgroups && (kp.mask_words <= 4) && !(kp.pad2 & 8);
+		const bool cj_rows = !LEAN && kp.ncjgroups && (kp.mask_words <= 4) && !XE_ABL(8);
 #pragma unroll
 		for (int r = 0; r < R; r++) failw[r][0] = failw[r][1] = failw[r][2] = failw[r][3] = 0;
 		if (cj_rows) {
@@ -1497,7 +1511,7 @@ classify_objects(const xe_kparams &kp, const bool (&live)[R], const uint64_t (&l
 		/* object programs: the atom table first, then the conjunctive objects
 		 * (need / forbid rows), then the listed objects */
 		uint32_t bi = 0;
-		for (uint32_t w = 0; (w < kp.mask_words) && !(kp.pad2 & 8); w++) {
+		for (uint32_t w = 0; (w < kp.mask_words) && !XE_ABL(8); w++) {
 			uint64_t bits[R];
 			const uint32_t m0 = w * 64, m1 = (m0 + 64 < kp.nmo) ? m0 + 64 : kp.nmo;
 			/* atoms whose row for this word is not empty */
@@ -1609,7 +1623,7 @@ classify_objects(const xe_kparams &kp, const bool (&live)[R], const uint64_t (&l
 				if (XE_NT_MASKS && (kp.mask_words == 1)) nt_store_u64(mp, bits[r]);
 				else *mp = bits[r];
 				/* counters: every lane adds for each object it matched */
-				uint64_t x = (kp.pad2 & 4) ? 0 : bits[r];
+				uint64_t x = XE_ABL(4) ? 0 : bits[r];
 				while (x) {
 					const uint32_t m = m0 + (uint32_t)__builtin_ctzll(x);
 					x &= x - 1;
@@ -1645,7 +1659,7 @@ __attribute__((amdgpu_waves_per_eu((R == 1 && LW == 1) ? XE_FAST_WAVES : 1)))
 #endif
 xe_nf_fast_kernel(const xe_kparams kp)
 {
-	uint64_t tprev = __builtin_readcyclecounter();
+	XE_PHASE_DECL;
 	extern __shared__ uint32_t lds32[];
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	/* staging: kp.fast_dwords dwords per record, [wave][dword][r][lane]; then
@@ -1725,7 +1739,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 #pragma unroll
 			for (int r = 0; r < R; r++) {
 				u32x4 x = {0, 0, 0, 0};
-				if (C.live[r] && !(kp.pad2 & 32)) __builtin_memcpy(&x, (const uint8_t *)pkt + C.voff[r] + 16 * k, 16);
+				if (C.live[r] && !XE_ABL(32)) __builtin_memcpy(&x, (const uint8_t *)pkt + C.voff[r] + 16 * k, 16);
 				uint32_t *d = stg + ((4 * k) * R + r) * 64;
 				d[0] = x.x;
 				d[R * 64] = x.y;
@@ -1782,7 +1796,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 		 * memory counter retires in order).  Issued behind the first root
 		 * gathers instead, to fill that wait: C2 0.2135 against 0.2019 ms, C1
 		 * 0.0890 against 0.0856 ms - the later gathers then wait for them. */
-		if (!(kp.pad2 & 16)) {
+		if (!XE_ABL(16)) {
 			uint32_t j = op_base;
 			copy_ops<R, 0>(kp, stg, j, PL[1], ridx, T.live); j += PL[1];
 			copy_ops<R, 1>(kp, stg, j, PL[2], ridx, T.live); j += PL[2];
@@ -1896,7 +1910,7 @@ classify(const xe_kparams &kp, REC &rec, int32_t device, uint32_t ridx, bool act
 	if (kp.lw == 1) {
 		uint64_t lk[1][1];
 		const uint64_t pl[1] = { kp.all_probes[0] };
-		uint64_t tprev = __builtin_readcyclecounter();
+		XE_PHASE_DECL;
 		const uint32_t lane = threadIdx.x & 63;
 		/* per-lane kernels have registers to spare: four range groups at a time */
 		classify_atoms<1, false, 1, lane_tile<REC, GET>, 4, XE_LANE_PC>(kp, T, pl, lk, tb);
@@ -2163,13 +2177,21 @@ sf_slot_of(int i)
  * sFlow decoder never sets it */
 __constant__ uint16_t c_sf_slot[XE_NFIELDS];
 
+/* where the fields sflow_reset() sets per datagram come from (sflow-impl.h:274-291):
+ * the agent address (4 or 16 bytes) and the sub-agent id, bytes as on the wire */
+struct sf_meta
+{
+	const uint8_t *agent, *dev_id;
+	uint32_t agent_ver;       /* 4 or 6 */
+};
+
 struct sf_rec
 {
 	uint64_t v[SF_NFIELDS];   /* field bytes 0-7 */
 	uint64_t v6hi[2];         /* bytes 8-15 of ip6_src / ip6_dst */
 	uint32_t has;
 	uint32_t mark;
-	const xe_sfrec *q;
+	sf_meta q;
 	/* the sampled header / IPv4 structure: its first SF_STAGE_BYTES bytes staged
 	 * in LDS (dword d of this thread at stg[d * XE_BLOCK]), the rest, if a
 	 * header ever reaches that far, read from the datagram at p */
@@ -2511,18 +2533,18 @@ sf_get(const sf_rec &r, uint32_t f, uint32_t *size_out)
 	out.v.hi = out.v.lo = 0;
 	(void)size_out;
 	if (f == XF_dev_id) {
-		const uint8_t *b = r.q->dev_id;
+		const uint8_t *b = r.q.dev_id;
 		out.has = true;
 		out.v.lo = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3];
 		return out;
 	}
 	if ((f == XF_dev_ip) || (f == XF_dev_ip6)) {
-		bool v4 = r.q->agent_ver == 4;
+		bool v4 = r.q.agent_ver == 4;
 		if ((f == XF_dev_ip) != v4) return out;
 		out.has = true;
 		for (int i = 0; i < (v4 ? 4 : 16); i++) {
 			out.v.hi = (out.v.hi << 8) | (out.v.lo >> 56);
-			out.v.lo = (out.v.lo << 8) | r.q->agent[i];
+			out.v.lo = (out.v.lo << 8) | r.q.agent[i];
 		}
 		return out;
 	}
@@ -2541,7 +2563,7 @@ struct sf_img
 	const uint32_t *img;      /* word w of this thread at img[w * XE_BLOCK] */
 	uint32_t has;
 	uint32_t mark;
-	const xe_sfrec *q;
+	sf_meta q;
 };
 
 template <int FI>
@@ -2573,18 +2595,18 @@ sf_img_get(const sf_img &r, uint32_t f, uint32_t *size_out)
 	out.v.hi = out.v.lo = 0;
 	(void)size_out;
 	if (f == XF_dev_id) {
-		const uint8_t *b = r.q->dev_id;
+		const uint8_t *b = r.q.dev_id;
 		out.has = true;
 		out.v.lo = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | b[3];
 		return out;
 	}
 	if ((f == XF_dev_ip) || (f == XF_dev_ip6)) {
-		bool v4 = r.q->agent_ver == 4;
+		bool v4 = r.q.agent_ver == 4;
 		if ((f == XF_dev_ip) != v4) return out;
 		out.has = true;
 		for (int i = 0; i < (v4 ? 4 : 16); i++) {
 			out.v.hi = (out.v.hi << 8) | (out.v.lo >> 56);
-			out.v.lo = (out.v.lo << 8) | r.q->agent[i];
+			out.v.lo = (out.v.lo << 8) | r.q.agent[i];
 		}
 		return out;
 	}
@@ -2637,9 +2659,35 @@ sf_store_all(const xe_kparams &kp, const uint32_t *img, uint32_t has, uint32_t r
 	(sf_store<FI>(kp, img, has, ridx), ...);
 }
 
+/* the slow way to an element: the word-by-word walk, kept out of line (datagrams
+ * of unusual shape only) */
+__device__ __attribute__((noinline)) bool
+sf_next_slow(xe_sfiter &c, xe_sfel &d)
+{
+	return xsf_next<false>(c, d);
+}
+
+__device__ __forceinline__ sf_elem
+sf_elem_of(const xe_sfel &e, uint64_t dgram_off, uint32_t dgram_len)
+{
+	sf_elem q;
+	q.hdr_off = dgram_off + e.hdr_pos;
+	q.header_len = e.header_len;
+	q.frame_len_be = e.frame_len_be;
+	q.kind = e.kind;
+	q.rp_type = e.rp_type;
+	q.left = (int32_t)(dgram_len - e.hdr_pos);
+	return q;
+}
+
 #ifndef XE_SF_WAVES
 #define XE_SF_WAVES 4      /* measured on MI355X (3.2 M samples): 4 waves 0.430 ms; 5 waves spill and take 0.526 ms */
 #endif
+/* SELFWALK: the datagrams were walked on the device (kp.sfdg, kp.sfbase,
+ * kp.sf_rec2dg): a lane finds its sample through the datagram's entry and reads
+ * the sample and element headers itself; else every record has a descriptor
+ * the host walk wrote (kp.sfrecs) */
+template <bool SELFWALK>
 __global__ void __launch_bounds__(XE_BLOCK)
 #if XE_SF_WAVES
 __attribute__((amdgpu_waves_per_eu(XE_SF_WAVES, XE_SF_WAVES)))
@@ -2650,7 +2698,7 @@ xe_sf_kernel(const xe_kparams kp)
 	lds_u64 *lcnt;
 	lds_u64 *lmt;
 	lane_kernel_lds(kp, lane_lds, lcnt, lmt);
-	uint64_t tprev = __builtin_readcyclecounter();
+	XE_PHASE_DECL;
 	const uint32_t lane = threadIdx.x & 63;
 	uint32_t g = blockIdx.x * XE_BLOCK + threadIdx.x;
 	bool active = g < kp.nsf;
@@ -2665,7 +2713,8 @@ xe_sf_kernel(const xe_kparams kp)
 	rec.v6hi[0] = rec.v6hi[1] = 0;
 	rec.has = 0;
 	rec.mark = 0;
-	rec.q = kp.sfrecs;
+	rec.q.agent = rec.q.dev_id = kp.pkt;
+	rec.q.agent_ver = 4;
 	/* the staging columns follow the counters and the atom-table copy */
 	rec.stg = (const uint32_t *)(lane_lds + (size_t)kp.lds_counters * kp.nmo * 3
 		+ (kp.motab_lds ? (size_t)kp.motab_words : 0)) + threadIdx.x;
@@ -2673,40 +2722,110 @@ xe_sf_kernel(const xe_kparams kp)
 	rec.left = 0;
 	rec.lim = 0;
 	if (active) {
-		rec.q = kp.sfrecs + g;
-		const sf_desc own = sf_desc_load(rec.q);
-		/* elements of one sample share the flow: replay the earlier ones */
-		uint32_t first = g;
-		if ((own.c.x >> 24) & 0xFF) {
-			first = g - 1;
-			while ((first > 0) && kp.sfrecs[first].chained) first--;
+		uint32_t rate = 0, in_if_be = 0, out_if_be = 0;
+		int state = 4;
+		if (SELFWALK) {
+			const uint32_t dgi = kp.sf_rec2dg[g];
+			const u32x4 *gq = (const u32x4 *)(kp.sfdg + dgi);
+			const u32x4 ga = gq[0], gb = gq[1];
+			const uint32_t k = g - kp.sfbase[dgi];
+			const uint64_t dgoff = (uint64_t)ga.x | ((uint64_t)ga.y << 32);
+			const uint32_t dglen = ga.z & XE_SFDG_LEN;
+			const uint8_t *dg = kp.pkt + dgoff;
+			xe_sfel el;
+			xe_sfiter it;
+			bool replay = false, found = true;
+
+			rec.q.agent_ver = (ga.z & XE_SFDG_AGENT6) ? 6 : 4;
+			rec.q.agent = dg + XE_SF_AGENT_POS;
+			rec.q.dev_id = rec.q.agent + ((ga.z & XE_SFDG_AGENT6) ? 16 : 4);
+			device = (int32_t)ga.w - 1;
+			if (!(ga.z & XE_SFDG_WALK)) {
+				/* the usual shape: the record is the first element of the sample at pos[k] */
+				const uint32_t pw = (k < 2) ? gb.x : (k < 4) ? gb.y : (k < 6) ? gb.z : gb.w;
+				const uint32_t sp = (pw >> (16 * (k & 1))) & 0xFFFFu;
+				xe_sfwin W;
+				uint32_t nel;
+				bool is_raw, bad = false;
+				xsf_window_load(W, dg + sp);
+				const bool expanded = __builtin_bswap32(W.w[0]) == 3;
+				xsf_window_sample(W, expanded, el.rate, el.in_if_be, el.out_if_be, nel);
+				found = xsf_window_first(W, expanded, sp, el, is_raw, bad);
+			} else {
+				/* any other shape: walk the datagram to the record; when earlier
+				 * elements of its sample yielded records too, the flow carries over
+				 * (sflow-impl.h:145-270 never resets it between elements): replay the
+				 * sample from its start */
+				uint32_t av, idx = 0;
+				found = xsf_begin(it, dg, (int64_t)dglen, av);
+				while (found && (found = sf_next_slow(it, el)) && (idx < k)) idx++;
+				if (found && el.chained) {
+					replay = true;
+					it.pos = el.sample_pos;
+					it.ns_left = 1;
+					it.nel_left = 0;
+					it.bad = false;
+					it.chained = false;
+				}
+			}
+			if (found) {
+				rate = el.rate;
+				in_if_be = el.in_if_be;
+				out_if_be = el.out_if_be;
+				for (;;) {
+					xe_sfel e = el;
+					bool last = true;
+					if (replay) {
+						if (!sf_next_slow(it, e)) break;
+						last = e.hdr_pos >= el.hdr_pos;
+					}
+					state = sf_apply(kp, rec, sf_elem_of(e, dgoff, dglen));
+					if (last) break;
+				}
+			} else {
+				state = 0;   /* (the count pass and this walk disagree: cannot happen; the record stays empty) */
+			}
+		} else {
+			const xe_sfrec *q = kp.sfrecs + g;
+			const sf_desc own = sf_desc_load(q);
+			rec.q.agent = q->agent;
+			rec.q.dev_id = q->dev_id;
+			rec.q.agent_ver = (own.c.x >> 16) & 0xFF;
+			/* elements of one sample share the flow: replay the earlier ones */
+			uint32_t first = g;
+			if ((own.c.x >> 24) & 0xFF) {
+				first = g - 1;
+				while ((first > 0) && kp.sfrecs[first].chained) first--;
+			}
+			rate = own.b.y;
+			in_if_be = own.b.z;
+			out_if_be = own.b.w;
+			device = kp.exps[own.d.z].device;
+			for (uint32_t k = first; k <= g; k++) {
+				sf_desc x = own;
+				if (k != g) x = sf_desc_load(kp.sfrecs + k);
+				state = sf_apply(kp, rec, sf_elem_of(x));
+			}
 		}
 		/* sf5_flow(), sflow-impl.h:106-143: interface indices, bytes as stored */
-		rec.v[SFI_input_snmp] = own.b.z;
-		rec.v[SFI_output_snmp] = own.b.w;
+		rec.v[SFI_input_snmp] = in_if_be;
+		rec.v[SFI_output_snmp] = out_if_be;
 		rec.has |= (1u << SFI_input_snmp) | (1u << SFI_output_snmp);
-		/* element descriptors the device walk wrote name the devices.conf entry
-		 * itself (top bit set: entry + 1), the host walk's name the exporter */
-		device = (own.d.z & 0x80000000u) ? (int32_t)(own.d.z & 0x7FFFFFFFu) - 1 : kp.exps[own.d.z].device;
-		int state = 4;
-		for (uint32_t k = first; k <= g; k++) {
-			sf_desc x = own;
-			if (k != g) x = sf_desc_load(kp.sfrecs + k);
-			state = sf_apply(kp, rec, sf_elem_of(x));
-		}
 		deliver = state >= 2;   /* sflow.c:164-168 */
 		XE_PHASE(0);
 		XE_LANE_STORE(&kp.nparsed[ridx], (uint8_t)(state | (deliver ? 0 : XE_SF_SKIPPED)));
 		XE_LANE_STORE(&kp.sf_has[g], rec.has);
-		uint64_t rate = own.b.y;
-		if (kp.rates) kp.rates[ridx] = (uint32_t)rate;
+		if (kp.sf_rate) XE_LANE_STORE(&kp.sf_rate[g], rate);
+		if (kp.rates) kp.rates[ridx] = rate;
 		if (kp.devips) {
 			/* dev_ip = the agent's address when it is an IPv4 one (sflow-impl.h:330-345):
 			 * its four bytes in memory order */
-			kp.devips[ridx] = (((own.c.x >> 16) & 0xFF) == 4) ? own.c.z : 0u;
+			uint32_t a4 = 0;
+			if (rec.q.agent_ver == 4) __builtin_memcpy(&a4, rec.q.agent, 4);
+			kp.devips[ridx] = a4;
 		}
-		bxr = sf_get(rec, XF_in_bytes, nullptr).v.lo * rate;
-		pxr = sf_get(rec, XF_in_pkts, nullptr).v.lo * rate;
+		bxr = sf_get(rec, XF_in_bytes, nullptr).v.lo * (uint64_t)rate;
+		pxr = sf_get(rec, XF_in_pkts, nullptr).v.lo * (uint64_t)rate;
 		if (!deliver && kp.marks) kp.marks[ridx] = 0;
 	}
 	/* the fields move to the thread's LDS column for the filter code */
@@ -2944,7 +3063,7 @@ xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables, u
 	const uint32_t ntot = kp.nrec + kp.nsf;
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint32_t r0 = blockIdx.x * (XE_BLOCK * XE_FWM_CHUNKS);
-	uint64_t tprev = __builtin_readcyclecounter();
+	XE_PHASE_DECL;
 
 	for (uint32_t f = 0; f < ntables; f++) {
 		const xe_fwm_dev F = tables[f];
@@ -3144,16 +3263,19 @@ xe_launch_fwm(const struct xe_kparams *kp, const struct xe_fwm_dev *tables, uint
 
 	if (!ntables || !ntot) return XE_OK;
 	if (!kwmax || (kwmax > XE_FWM_MAX_KWORDS) || !nvmax || (nvmax > XE_FWM_MAX_VALS)) return XE_EINVAL;
+#ifdef XE_DIAG
 	struct xe_kparams kcopy;
 	if (getenv("XE_ABLATE")) {      /* diagnostic switches, as in xe_launch_batch() */
 		kcopy = *kp;
 		kcopy.pad2 = (uint32_t)atoi(getenv("XE_ABLATE"));
 		kp = &kcopy;
 	}
+#endif
 	if (ev) (void)hipEventRecord(ev[0], st);
 	hipLaunchKernelGGL(xe_fwm_kernel, dim3((ntot + per_block - 1) / per_block), dim3(XE_BLOCK), fwm_lds_bytes(kwmax, nvmax), st,
 		*kp, tables, ntables, kwmax, nvmax);
 	if (ev) (void)hipEventRecord(ev[1], st);
+#ifdef XE_DIAG
 	if (kp->pad2 & 64) {
 		/* diagnostic: print and reset the per-phase wave cycles */
 		unsigned long long pc[8], z[8] = {0};
@@ -3164,6 +3286,7 @@ xe_launch_fwm(const struct xe_kparams *kp, const struct xe_fwm_dev *tables, uint
 		fprintf(stderr, "table kernel phase cycles per wave: mask %.0f key %.0f election %.0f block table %.0f global %.0f flush %.0f\n",
 			(double)pc[0] / nw, (double)pc[1] / nw, (double)pc[2] / nw, (double)pc[3] / nw, (double)pc[4] / nw, (double)pc[5] / nw);
 	}
+#endif
 	return (hipGetLastError() == hipSuccess) ? XE_OK : XE_EHIP;
 }
 
@@ -3249,18 +3372,20 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 {
 	hipStream_t st = (hipStream_t)stream;
 	hipEvent_t *ev = (hipEvent_t *)events;   /* NULL or 3 start/stop pairs */
-	struct xe_kparams kcopy;
 	bool fast_started = false;
 
 	if (!g_tables_ready) return XE_ESTATE;
-	/* XE_ABLATE (diagnostic): bit 0 skip list lookups, 1 terms, 2 counters,
+#ifdef XE_DIAG
+	/* XE_ABLATE (diagnostic build only): bit 0 skip list lookups, 1 terms, 2 counters,
 	 * 3 programs, 4 column stores, 5 packet loads.  Results are wrong with
 	 * any bit set. */
+	struct xe_kparams kcopy;
 	if (getenv("XE_ABLATE")) {
 		kcopy = *kp;
 		kcopy.pad2 = (uint32_t)atoi(getenv("XE_ABLATE"));
 		kp = &kcopy;
 	}
+#endif
 	if (kp->nmo) {
 		if (hipMemsetAsync(kp->counters, 0, (size_t)kp->nmo * 3 * sizeof(unsigned long long), st) != hipSuccess) {
 			return XE_EHIP;
@@ -3289,10 +3414,12 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 			+ (size_t)kq->lds_counters * kq->nmo * 24
 			+ (kq->motab_lds ? (size_t)kq->motab_words * 8 : 0);
 		if (blocks > 4096) blocks = 4096;
+#ifdef XE_DIAG
 		if (getenv("XE_FAST_BLOCKS")) {          /* diagnostic: grid size of the fast kernel */
 			uint32_t want = (uint32_t)atoi(getenv("XE_FAST_BLOCKS"));
 			if ((want >= 8) && (want < blocks)) blocks = want;
 		}
+#endif
 		/* the kernel deals the tile list to 8 groups of blocks (blockIdx % 8):
 		 * every group needs at least one block */
 		if (blocks < 8) blocks = 8;
@@ -3305,6 +3432,7 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 		else if (lean) hipLaunchKernelGGL((xe_nf_fast_kernel<1, true, 1>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kq);
 		else hipLaunchKernelGGL((xe_nf_fast_kernel<1, false, 1>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kq);
 		if (hipGetLastError() != hipSuccess) return XE_EHIP;
+#ifdef XE_DIAG
 		if (kq->pad2 & 64) {
 			/* diagnostic: print and reset the per-phase wave cycles */
 			unsigned long long pc[8], z[8] = {0};
@@ -3315,6 +3443,7 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 				(double)pc[0] / kq->ntiles, (double)pc[1] / kq->ntiles, (double)pc[2] / kq->ntiles,
 				(double)pc[3] / kq->ntiles, (double)pc[4] / kq->ntiles, (double)pc[5] / kq->ntiles);
 		}
+#endif
 	}
 	if (ev && fast_started) (void)hipEventRecord(ev[1], st);
 	const size_t lane_lds = (size_t)kp->lds_counters * kp->nmo * 24
@@ -3339,9 +3468,11 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 			kp = &ksf;
 		}
 		if (ev) (void)hipEventRecord(ev[4], st);
-		hipLaunchKernelGGL(xe_sf_kernel, dim3(blocks), dim3(XE_BLOCK), sf_lds, st, *kp);
+		if (kp->sfdg) hipLaunchKernelGGL(xe_sf_kernel<true>, dim3(blocks), dim3(XE_BLOCK), sf_lds, st, *kp);
+		else hipLaunchKernelGGL(xe_sf_kernel<false>, dim3(blocks), dim3(XE_BLOCK), sf_lds, st, *kp);
 		if (ev) (void)hipEventRecord(ev[5], st);
 		if (hipGetLastError() != hipSuccess) return XE_EHIP;
+#ifdef XE_DIAG
 		if (kp->pad2 & 64) {
 			/* diagnostic: print and reset the per-phase wave cycles */
 			unsigned long long pc[8], z[8] = {0};
@@ -3352,6 +3483,7 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 			fprintf(stderr, "sflow phase cycles per wave: load+parse %.0f stores+image %.0f atoms %.0f (lookups %.0f range groups %.0f) objects %.0f\n",
 				(double)pc[0] / nw, (double)pc[1] / nw, (double)pc[2] / nw, (double)pc[6] / nw, (double)pc[7] / nw, (double)pc[3] / nw);
 		}
+#endif
 	}
 	return XE_OK;
 }

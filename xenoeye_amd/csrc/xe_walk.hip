@@ -18,6 +18,7 @@
 #include <rocprim/rocprim.hpp>
 #include <stdint.h>
 #include "xe_kernels.h"
+#include "xe_sfwalk.h"
 
 #define XW_BLOCK 256
 
@@ -54,184 +55,71 @@ dev_find(const xe_walk_in &in, uint32_t ip, uint32_t id)
 }
 
 /* ------------------------------------------------------------------ sFlow v5 */
-struct sfcur { const uint8_t *p; int64_t pos, len; bool bad; };
-
-/* READ_SF_BYTES / READ32_H, sflow-impl.h:51-65 */
-static __device__ __forceinline__ uint32_t
-sf_raw32(sfcur &c)
-{
-	if (c.bad || ((c.pos + 4) > c.len)) { c.bad = true; return 0; }
-	const uint32_t v = ld32(c.p + c.pos);
-	c.pos += 4;
-	return v;
-}
-
-static __device__ __forceinline__ uint32_t
-sf_u32(sfcur &c)
-{
-	return __builtin_bswap32(sf_raw32(c));
-}
-
-struct sfproto
-{
-	uint32_t agent_ver, agent[4], dev_id, exporter;
-	uint64_t base;
-};
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-template <bool EMIT>
-static __device__ __forceinline__ void
-sf_put(xe_sfrec *out, uint32_t at, const sfproto &pr, const sfcur &c, uint32_t header_len, uint32_t frame_len_be,
-	uint32_t rate, uint32_t in_if_be, uint32_t out_if_be, uint32_t kind, uint32_t rp_type, uint32_t chained)
-{
-	if (!EMIT) return;
-	const uint64_t hdr_off = pr.base + (uint64_t)c.pos;
-	u32x4 *q = (u32x4 *)(out + at);
-	q[0] = (u32x4){ (uint32_t)hdr_off, (uint32_t)(hdr_off >> 32), header_len, (uint32_t)(int32_t)(c.len - c.pos) };
-	q[1] = (u32x4){ frame_len_be, rate, in_if_be, out_if_be };
-	q[2] = (u32x4){ kind | (rp_type << 8) | (pr.agent_ver << 16) | (chained << 24), pr.dev_id, pr.agent[0], pr.agent[1] };
-	q[3] = (u32x4){ pr.agent[2], pr.agent[3], pr.exporter, 0u };
-}
-
-/* sf5_flow(), sflow-impl.h:68-272: one flow sample; returns the records it yields */
-template <bool EMIT>
-static __device__ uint32_t
-sf_flow_sample(sfcur &c, bool expanded, const sfproto &pr, xe_sfrec *out, uint32_t at)
-{
-	uint32_t nout = 0, v, nel, rate, in_if_be, out_if_be, frame_len_be = 0, kind = 0, rp_type = 0, chained = 0;
-
-	sf_u32(c);                       /* length */
-	sf_u32(c);                       /* sequence */
-	sf_u32(c);                       /* source id (or class) */
-	if (expanded) sf_u32(c);         /* source index */
-	rate = sf_u32(c);
-	sf_u32(c);                       /* pool */
-	sf_u32(c);                       /* drops */
-	if (expanded) sf_u32(c);         /* input format */
-	v = sf_u32(c);
-	if (!expanded) v &= 0x3fffffff;
-	in_if_be = __builtin_bswap32(v);
-	if (expanded) sf_u32(c);         /* output format */
-	v = sf_u32(c);
-	if (!expanded) v &= 0x3fffffff;
-	out_if_be = __builtin_bswap32(v);
-	nel = sf_u32(c);
-	if (c.bad) return 0;
-
-	for (uint32_t j = 0; j < nel; j++) {
-		const uint32_t tag = sf_u32(c), ell = sf_u32(c);
-		if (c.bad) return nout;
-		if (tag == 1) {
-			const uint32_t hp = sf_u32(c);
-			frame_len_be = sf_raw32(c);
-			sf_u32(c);               /* stripped */
-			const uint32_t hl = sf_u32(c);
-			if (c.bad) return nout;
-			if (hp == 1) rp_type = 0;
-			else if (hp == 11) rp_type = 1;
-			else if (hp == 12) rp_type = 2;
-			else { c.bad = true; return nout; }
-			kind = 1;
-			sf_put<EMIT>(out, at + nout, pr, c, hl, frame_len_be, rate, in_if_be, out_if_be, kind, rp_type, chained);
-			nout++;
-			chained = 1;
-			c.pos += (hl % 4) ? (int64_t)hl + (4 - (hl % 4)) : (int64_t)hl;
-		} else if (tag == 1001) {
-			sf_u32(c); sf_u32(c); sf_u32(c); sf_u32(c);
-		} else if (tag == 3) {
-			frame_len_be = sf_raw32(c);
-			if (c.bad) return nout;
-			/* the 7 words after the length are read one by one and a short
-			 * datagram aborts before the record is delivered */
-			if ((c.pos + 28) > c.len) { c.bad = true; return nout; }
-			kind = 3;
-			sf_put<EMIT>(out, at + nout, pr, c, 28, frame_len_be, rate, in_if_be, out_if_be, kind, rp_type, chained);
-			nout++;
-			chained = 1;
-			c.pos += 28;
-		} else {
-			c.pos += ell;
-		}
-	}
-	return nout;
-}
-
-/* sflow_process(), sflow-impl.h:293-405 */
-template <bool EMIT>
-static __device__ uint32_t
-sf_walk(const xe_walk_in &in, uint32_t i, xe_sfrec *out, uint32_t at)
-{
-	const uint64_t off = in.offs[i];
-	int64_t len = (int64_t)(in.offs[i + 1] - off);
-	if (len > 65536) len = 65536;
-	sfcur c = { in.pkt + off, 0, len, false };
-	sfproto pr;
-	uint32_t v, n, nout = 0;
-
-	pr.base = off;
-	pr.agent[0] = pr.agent[1] = pr.agent[2] = pr.agent[3] = 0;
-	if (sf_u32(c) != 5) return 0;
-	v = sf_u32(c);
-	if (c.bad) return 0;
-	if (v == 1) {
-		pr.agent_ver = 4;
-		if ((c.pos + 4) > len) return 0;
-		pr.agent[0] = ld32(c.p + c.pos);
-		c.pos += 4;
-	} else if (v == 2) {
-		pr.agent_ver = 6;
-		if ((c.pos + 16) > len) return 0;
-		for (int k = 0; k < 4; k++) pr.agent[k] = ld32(c.p + c.pos + 4 * k);
-		c.pos += 16;
-	} else {
-		return 0;
-	}
-	pr.dev_id = sf_raw32(c);
-	sf_u32(c);
-	sf_u32(c);
-	n = sf_u32(c);
-	if (c.bad) return 0;
-	/* device rules use the UDP source and the packet's source_id field, which
-	 * sflow_process() never sets: 0.  The decode kernel takes the devices.conf
-	 * entry from the top bit form of `exporter` */
-	pr.exporter = 0x80000000u | (uint32_t)(dev_find(in, in.src[i], 0) + 1);
-
-	for (uint32_t s = 0; s < n; s++) {
-		v = sf_u32(c);
-		if (c.bad) break;
-		if ((v == 1) || (v == 3)) {
-			nout += sf_flow_sample<EMIT>(c, v == 3, pr, out, at + nout);
-			if (c.bad) break;
-		} else {
-			const uint32_t l = sf_u32(c);
-			if (c.bad) break;
-			c.pos += l;
-		}
-	}
-	return nout;
-}
-
+/* sFlow datagrams carry no state from one to the next.  One pass, one thread
+ * per datagram, walks sample and element headers (xe_sfwalk.h) and leaves per
+ * datagram: the number of records it yields and a 32-byte entry with where it
+ * lies, its devices.conf entry and - for datagrams of the usual shape, up to
+ * XE_SFDG_POS records, each from the first element of its sample - where each
+ * record's sample starts.  After the prefix sum over the counts a second,
+ * trivial pass notes the datagram of every record.  The decode kernel reads a
+ * record's sample header itself (one window load); only for datagrams of any
+ * other shape it walks the datagram again up to its record. */
 __global__ void __launch_bounds__(XW_BLOCK)
-xw_sf_count_kernel(const xe_walk_in in, uint32_t *cnt, unsigned long long *total)
+xw_sf_count_kernel(const xe_walk_in in, uint32_t *cnt, xe_sfdg *dgs, unsigned long long *total)
 {
 	const uint32_t i = blockIdx.x * XW_BLOCK + threadIdx.x;
 	uint32_t n = 0;
 
-	if ((i < in.n) && in.kinds && (in.kinds[i] == XE_KIND_SFLOW)) n = sf_walk<false>(in, i, nullptr, 0);
-	if (i < in.n) cnt[i] = n;
+	if (i < in.n) {
+		xe_sfdg g;
+		g.off = 0;
+		g.len = 0;
+		g.dev = 0;
+#pragma unroll
+		for (int k = 0; k < XE_SFDG_POS; k++) g.pos[k] = 0;
+		if (in.kinds && (in.kinds[i] == XE_KIND_SFLOW)) {
+			const uint64_t off = in.offs[i];
+			const int64_t len = (int64_t)(in.offs[i + 1] - off);
+			xe_sfiter it;
+			xe_sfel d;
+			uint32_t agent_ver;
+			bool usual = true;
+			if (xsf_begin(it, in.pkt + off, len, agent_ver)) {
+				while (xsf_next<true>(it, d)) {
+					if (!d.first) usual = false;
+					if (n < XE_SFDG_POS) {
+						/* (the index is a loop counter, not a constant: spelled out so
+						 * that the array stays in registers) */
+#pragma unroll
+						for (int k = 0; k < XE_SFDG_POS; k++) if (n == (uint32_t)k) g.pos[k] = (uint16_t)d.sample_pos;
+					}
+					n++;
+				}
+				if (n > XE_SFDG_POS) usual = false;
+				g.off = off;
+				g.len = (uint32_t)it.len | (usual ? 0u : XE_SFDG_WALK) | ((agent_ver == 6) ? XE_SFDG_AGENT6 : 0u);
+				/* device rules use the UDP source and the packet's source_id field, which
+				 * sflow_process() never sets: 0 */
+				g.dev = (uint32_t)(dev_find(in, in.src[i], 0) + 1);
+			}
+		}
+		cnt[i] = n;
+		dgs[i] = g;
+	}
 	/* the batch total in 64 bits: the 32-bit prefix sums could wrap unnoticed */
 	unsigned long long s = n;
 	for (int d = 32; d; d >>= 1) s += __shfl_down(s, d, 64);
 	if (((threadIdx.x & 63) == 0) && s) atomicAdd(total, s);
 }
 
+/* rec2dg[r] = the datagram record r comes from */
 __global__ void __launch_bounds__(XW_BLOCK)
-xw_sf_emit_kernel(const xe_walk_in in, const uint32_t *base, xe_sfrec *out)
+xw_sf_place_kernel(uint32_t n, const uint32_t *base, uint32_t *rec2dg)
 {
 	const uint32_t i = blockIdx.x * XW_BLOCK + threadIdx.x;
-
-	if ((i < in.n) && in.kinds && (in.kinds[i] == XE_KIND_SFLOW) && (base[i + 1] != base[i])) (void)sf_walk<true>(in, i, out, base[i]);
+	if (i >= n) return;
+	const uint32_t b0 = base[i], b1 = base[i + 1];
+	for (uint32_t r = b0; r < b1; r++) rec2dg[r] = i;
 }
 
 /* ------------------------------------------------------------------ Netflow v5 / v9 / IPFIX */
@@ -534,18 +422,18 @@ xe_walk_sort(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout,
 }
 
 extern "C" int
-xe_walk_sf_count(const struct xe_walk_in *in, uint32_t *cnt, unsigned long long *total, void *stream)
+xe_walk_sf_count(const struct xe_walk_in *in, uint32_t *cnt, struct xe_sfdg *dgs, unsigned long long *total, void *stream)
 {
 	if (!in->n) return XE_OK;
-	hipLaunchKernelGGL(xw_sf_count_kernel, dim3(xw_blocks(in->n)), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, cnt, total);
+	hipLaunchKernelGGL(xw_sf_count_kernel, dim3(xw_blocks(in->n)), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, cnt, dgs, total);
 	return xw_done();
 }
 
 extern "C" int
-xe_walk_sf_emit(const struct xe_walk_in *in, const uint32_t *base, struct xe_sfrec *out, void *stream)
+xe_walk_sf_place(uint32_t n, const uint32_t *base, uint32_t *rec2dg, void *stream)
 {
-	if (!in->n) return XE_OK;
-	hipLaunchKernelGGL(xw_sf_emit_kernel, dim3(xw_blocks(in->n)), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, base, out);
+	if (!n) return XE_OK;
+	hipLaunchKernelGGL(xw_sf_place_kernel, dim3(xw_blocks(n)), dim3(XW_BLOCK), 0, (hipStream_t)stream, n, base, rec2dg);
 	return xw_done();
 }
 
