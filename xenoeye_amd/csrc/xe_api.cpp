@@ -103,7 +103,7 @@ struct walk_dev
 	uint8_t *d_kinds;
 	uint32_t *d_sfcnt, *d_sfbase;
 	struct xe_sfdg *d_sfdg;    /* per datagram: what the sFlow decode kernel needs of it */
-	void *d_rec2dg;            /* per sFlow record: its datagram (an allocation of its own: sized after the count) */
+	void *d_rec2dg;            /* struct xe_sfrd per sFlow record (an allocation of its own: sized after the count) */
 	unsigned long long *d_total;   /* [0] sFlow records, [1] Netflow records */
 	void *d_temp; size_t temp_bytes;
 	struct xe_dgrun *d_dgruns;
@@ -2395,28 +2395,27 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 		w->d_groups = (struct xe_wgroup *)(base + o_groups);
 		w->d_fruns2 = (struct xe_frun *)(base + o_fruns2);
 	}
+	/* (cleared ahead of the copies below, which it then runs beside) */
+	HIPCHK(h, hipMemsetAsync(w->d_total, 0, 32, st));
 	{
-		/* the per-datagram arrays: copied into page-locked scratch, which the
-		 * walk kernels read in place (a few bytes per datagram); without
-		 * scratch they travel like everything else */
+		/* the per-datagram arrays go through page-locked scratch (a copy out of
+		 * ordinary memory blocks the calling thread inside the runtime, and with it
+		 * the other handles' threads) into the arena: the walk kernels, and later
+		 * the decode kernels, read them from device memory */
 		uint64_t *po = (uint64_t *)pin_get(h, 8 * (n + 1));
 		uint32_t *ps = (uint32_t *)pin_get(h, 4 * n + 4);
 		uint8_t *pk = kinds ? (uint8_t *)pin_get(h, n + 1) : NULL;
-		if (po && ps && (pk || !kinds)) {
+		const int pinned = po && ps && (pk || !kinds);
+		if (pinned) {
 			memcpy(po, offsets, 8 * (n + 1));
 			memcpy(ps, src, 4 * n);
 			if (kinds) memcpy(pk, kinds, n);
-			w->d_offs = po;
-			w->d_src = ps;
-			w->d_kinds = pk;
-		} else {
-			HIPCHK(h, hipMemcpyAsync(w->d_offs, offsets, 8 * (n + 1), hipMemcpyHostToDevice, st));
-			HIPCHK(h, hipMemcpyAsync(w->d_src, src, 4 * n, hipMemcpyHostToDevice, st));
-			if (kinds) HIPCHK(h, hipMemcpyAsync(w->d_kinds, kinds, n, hipMemcpyHostToDevice, st));
 		}
+		HIPCHK(h, hipMemcpyAsync(w->d_offs, pinned ? po : offsets, 8 * (n + 1), hipMemcpyHostToDevice, st));
+		HIPCHK(h, hipMemcpyAsync(w->d_src, pinned ? ps : src, 4 * n, hipMemcpyHostToDevice, st));
+		if (kinds) HIPCHK(h, hipMemcpyAsync(w->d_kinds, pinned ? pk : kinds, n, hipMemcpyHostToDevice, st));
 	}
 	walk_mark(h, w, st);
-	HIPCHK(h, hipMemsetAsync(w->d_total, 0, 32, st));
 	walk_input(h, b, &in);
 	w->kinds2 = (uint8_t *)malloc(n ? n : 1);
 	w->h_src = (uint32_t *)malloc((n ? n : 1) * 4);
@@ -2532,10 +2531,10 @@ walk_finish(xe_gpu *h, xe_batch *b)
 		HIPCHK(h, hipStreamSynchronize(st));
 		nsf = *(volatile unsigned long long *)h->wstage;
 		if (nsf + plan->nrec > 0xFFFFFFF0ull) return XE_EUNSUPPORTED;
-		rc = dev_get(h, &w->d_rec2dg, (size_t)nsf * 4 + 4);
+		rc = dev_get(h, &w->d_rec2dg, ((size_t)nsf + 1) * sizeof(struct xe_sfrd));
 		if (rc != XE_OK) return rc;
 		walk_mark(h, w, st);
-		rc = xe_walk_sf_place((uint32_t)n, w->d_sfbase, (uint32_t *)w->d_rec2dg, st);
+		rc = xe_walk_sf_place((uint32_t)n, w->d_sfbase, w->d_sfdg, (struct xe_sfrd *)w->d_rec2dg, st);
 		walk_mark(h, w, st);
 		if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (sFlow records)");
 		plan->nsf = (size_t)nsf;
@@ -3072,7 +3071,7 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 			xe_gpu_batch_free(b);
 			return XE_EINVAL;
 		}
-		if (!has_sf) walk_mode &= ~1;
+		if (!has_sf || (h->hs.ndevs >= 0xFFFFu)) walk_mode &= ~1;   /* (a record's entry names its devices.conf entry in 16 bits) */
 		if (!has_nf || !h->fast_ok || ((total + 64) >= 0xFFFF0000ull) || h->diag_force_general || h->diag_fast_r) walk_mode &= ~2;
 		/* (the per-template counts come back through a small page-locked buffer) */
 		if (((2 * h->hs.dev_tmpls.n + 8) * 4 + 16 > XE_WSTAGE_BYTES) || (h->hs.dev_tmpls.n >= 0xFFF0u)) walk_mode &= ~2;
@@ -3312,7 +3311,7 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 		 * finds every record's sample through its datagram's entry */
 		b->kp.sfdg = b->w.d_sfdg;
 		b->kp.sfbase = b->w.d_sfbase;
-		b->kp.sf_rec2dg = (const uint32_t *)b->w.d_rec2dg;
+		b->kp.sfrd = (const struct xe_sfrd *)b->w.d_rec2dg;
 		b->kp.sf_rate = (uint32_t *)((uint8_t *)b->d_out + b->sfrate_off);
 	}
 	b->kp.rates = h->nfwm ? (uint32_t *)((uint8_t *)b->d_out + b->rates_off) : NULL;
@@ -3607,7 +3606,8 @@ sf_meta_fetch(xe_batch *b, size_t first, size_t count, struct xe_sfrec **out)
 {
 	xe_gpu *h = b->h;
 	struct xe_sfrec *sl = (struct xe_sfrec *)calloc(count + 1, sizeof(*sl));
-	uint32_t *r2d = (uint32_t *)malloc((count + 1) * 4), *rate = (uint32_t *)malloc((count + 1) * 4);
+	struct xe_sfrd *r2d = (struct xe_sfrd *)malloc((count + 1) * sizeof(*r2d));
+	uint32_t *rate = (uint32_t *)malloc((count + 1) * 4);
 	struct xe_sfdg *dg = NULL;
 	uint8_t *hdr = NULL;
 	int rc = XE_ENOMEM;
@@ -3617,10 +3617,10 @@ sf_meta_fetch(xe_batch *b, size_t first, size_t count, struct xe_sfrec **out)
 	rc = xe_gpu_batch_sync(b);
 	if (rc != XE_OK) goto out;
 	rc = XE_EHIP;
-	if (hipMemcpy(r2d, (const uint32_t *)b->w.d_rec2dg + first, count * 4, hipMemcpyDeviceToHost) != hipSuccess) goto hipfail;
+	if (hipMemcpy(r2d, (const struct xe_sfrd *)b->w.d_rec2dg + first, count * sizeof(*r2d), hipMemcpyDeviceToHost) != hipSuccess) goto hipfail;
 	if (hipMemcpy(rate, (const uint8_t *)b->d_out + b->sfrate_off + first * 4, count * 4, hipMemcpyDeviceToHost) != hipSuccess) goto hipfail;
 	{
-		const uint32_t d0 = r2d[0], d1 = r2d[count - 1];
+		const uint32_t d0 = r2d[0].dgram, d1 = r2d[count - 1].dgram;
 		const size_t nd = (size_t)d1 - d0 + 1;
 		uint64_t lo, hi;
 		rc = XE_ENOMEM;
@@ -3639,7 +3639,7 @@ sf_meta_fetch(xe_batch *b, size_t first, size_t count, struct xe_sfrec **out)
 		rc = XE_EHIP;
 		if (hipMemcpy(hdr, (const uint8_t *)b->d_pkt + lo, (size_t)(hi - lo), hipMemcpyDeviceToHost) != hipSuccess) goto hipfail;
 		for (size_t k = 0; k < count; k++) {
-			const struct xe_sfdg *g = &dg[r2d[k] - d0];
+			const struct xe_sfdg *g = &dg[r2d[k].dgram - d0];
 			const uint8_t *p = hdr + (g->off - lo);
 			const int v6 = (g->len & XE_SFDG_AGENT6) != 0;
 			sl[k].agent_ver = v6 ? 6 : 4;

@@ -113,7 +113,7 @@ struct xe_kparams
 	 * datagram its entry and the index of its first record, per record its datagram */
 	const struct xe_sfdg *sfdg;
 	const uint32_t *sfbase;
-	const uint32_t *sf_rec2dg;
+	const struct xe_sfrd *sfrd;
 	uint32_t *sf_rate;           /* per sFlow record: the sampling rate of its sample */
 };
 
@@ -230,7 +230,7 @@ struct xe_dgrun
 	uint32_t rate;        /* sampling rate | has a devices.conf entry << 31 */
 };
 
-/* what the sFlow walk leaves per datagram for the decode kernel */
+/* what the sFlow walk leaves per datagram */
 #define XE_SFDG_POS 8
 #define XE_SFDG_WALK 0x80000000u     /* len: not of the usual shape, the decode kernel walks the datagram itself */
 #define XE_SFDG_AGENT6 0x40000000u   /* len: the agent address is an IPv6 one */
@@ -239,8 +239,20 @@ struct xe_sfdg
 {
 	uint64_t off;                 /* the datagram in the batch buffer */
 	uint32_t len;                 /* min(its length, 65536) | XE_SFDG_*; 0 = yields nothing */
-	uint32_t dev;                 /* devices.conf entry + 1, 0 = none */
-	uint16_t pos[XE_SFDG_POS];    /* usual shape: byte offset of the sample (its type word) of record k */
+	uint32_t dev;                 /* bits 0-15: devices.conf entry + 1, 0 = none; bit 16 + k: record k comes from an
+	                                 expanded flow sample (usual shape) */
+	uint16_t pos[XE_SFDG_POS];    /* usual shape: byte offset of the sampled header of record k */
+};
+/* ... and per record (16 bytes, written once the prefix sums over the datagrams' counts are known) */
+#define XE_SFRD_EXPANDED 0x100u
+#define XE_SFRD_WALK 0x200u
+#define XE_SFRD_AGENT6 0x400u
+struct xe_sfrd
+{
+	uint32_t hdr_lo;              /* usual shape: the sampled header in the batch buffer, bits 0-31 */
+	uint32_t hi;                  /* bits 0-7: bits 32-39 of that offset; XE_SFRD_*; bits 16-31: devices.conf entry + 1 */
+	int32_t left;                 /* usual shape: bytes from the sampled header to the end of the datagram */
+	uint32_t dgram;               /* the record's datagram */
 };
 
 struct xe_walk_in
@@ -274,8 +286,8 @@ int xe_walk_sort(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *k
 /* sFlow: cnt[i] = records datagram i yields (0 for other kinds), dgs[i] = what the decode kernel
  * needs of the datagram; *total += the counts */
 int xe_walk_sf_count(const struct xe_walk_in *in, uint32_t *cnt, struct xe_sfdg *dgs, unsigned long long *total, void *stream);
-/* sFlow: rec2dg[r] = i for the records r in [base[i], base[i + 1]) of datagram i < n */
-int xe_walk_sf_place(uint32_t n, const uint32_t *base, uint32_t *rec2dg, void *stream);
+/* sFlow: recs[r] for the records r in [base[i], base[i + 1]) of datagram i < n */
+int xe_walk_sf_place(uint32_t n, const uint32_t *base, const struct xe_sfdg *dgs, struct xe_sfrd *recs, void *stream);
 
 /* Netflow: per datagram, the runs it yields when its shape is the usual one
  * (runs[k * n + i], k < XE_WALK_SETS, nrec > 0 for those it has; regular[i] = 1),

@@ -2725,39 +2725,59 @@ xe_sf_kernel(const xe_kparams kp)
 		uint32_t rate = 0, in_if_be = 0, out_if_be = 0;
 		int state = 4;
 		if (SELFWALK) {
-			const uint32_t dgi = kp.sf_rec2dg[g];
-			const u32x4 *gq = (const u32x4 *)(kp.sfdg + dgi);
-			const u32x4 ga = gq[0], gb = gq[1];
-			const uint32_t k = g - kp.sfbase[dgi];
-			const uint64_t dgoff = (uint64_t)ga.x | ((uint64_t)ga.y << 32);
-			const uint32_t dglen = ga.z & XE_SFDG_LEN;
-			const uint8_t *dg = kp.pkt + dgoff;
+			const u32x4 rd = *(const u32x4 *)(kp.sfrd + g);
+			const uint32_t dgi = rd.w;
+			uint64_t dgoff = 0;
+			uint32_t dglen = 0;
 			xe_sfel el;
 			xe_sfiter it;
 			bool replay = false, found = true;
 
-			rec.q.agent_ver = (ga.z & XE_SFDG_AGENT6) ? 6 : 4;
-			rec.q.agent = dg + XE_SF_AGENT_POS;
-			rec.q.dev_id = rec.q.agent + ((ga.z & XE_SFDG_AGENT6) ? 16 : 4);
-			device = (int32_t)ga.w - 1;
-			if (!(ga.z & XE_SFDG_WALK)) {
-				/* the usual shape: the record is the first element of the sample at pos[k] */
-				const uint32_t pw = (k < 2) ? gb.x : (k < 4) ? gb.y : (k < 6) ? gb.z : gb.w;
-				const uint32_t sp = (pw >> (16 * (k & 1))) & 0xFFFFu;
-				xe_sfwin W;
-				uint32_t nel;
-				bool is_raw, bad = false;
-				xsf_window_load(W, dg + sp);
-				const bool expanded = __builtin_bswap32(W.w[0]) == 3;
-				xsf_window_sample(W, expanded, el.rate, el.in_if_be, el.out_if_be, nel);
-				found = xsf_window_first(W, expanded, sp, el, is_raw, bad);
+			rec.q.agent_ver = (rd.y & XE_SFRD_AGENT6) ? 6 : 4;
+			device = (int32_t)(rd.y >> 16) - 1;
+			if ((rd.y & XE_SFRD_WALK) || kp.fast_want_dev || kp.devips || kp.ndevrules) {
+				/* the datagram's entry: for the walk below, and when something reads
+				 * what sflow_reset() sets per datagram (sflow-impl.h:274-291) */
+				const u32x4 ga = *(const u32x4 *)(kp.sfdg + dgi);
+				dgoff = (uint64_t)ga.x | ((uint64_t)ga.y << 32);
+				dglen = ga.z & XE_SFDG_LEN;
+				rec.q.agent = kp.pkt + dgoff + XE_SF_AGENT_POS;
+				rec.q.dev_id = rec.q.agent + ((rd.y & XE_SFRD_AGENT6) ? 16 : 4);
+			}
+			if (!(rd.y & XE_SFRD_WALK)) {
+				/* the usual shape: the record is the first element of its sample, a
+				 * sampled header; the 64 bytes before that header hold the element header
+				 * (6 words) and, in front of it, the sample header: 10 words of a compact
+				 * sample (type word included), the last 10 of 13 of an expanded one */
+				const uint64_t hoff = (uint64_t)rd.x | ((uint64_t)(rd.y & 0xFFu) << 32);
+				const bool expanded = (rd.y & XE_SFRD_EXPANDED) != 0;
+				const uint8_t *hp = kp.pkt + hoff;
+				u32x4 u[4];
+#pragma unroll
+				for (int i = 0; i < 4; i++) u[i] = *(const XE_GLOBAL u32x4 *)(hp - 64 + 16 * i);
+				/* the element is described relative to the sampled header itself */
+				dgoff = hoff;
+				dglen = (uint32_t)rd.z;
+				el.hdr_pos = 0;
+				el.sample_pos = 0;
+				el.kind = 1;
+				el.chained = 0;
+				el.first = 1;
+				el.rate = __builtin_bswap32(expanded ? u[0].z : u[1].x);
+				el.in_if_be = expanded ? u[1].z : (u[1].w & __builtin_bswap32(0x3fffffffu));
+				el.out_if_be = expanded ? u[2].x : (u[2].x & __builtin_bswap32(0x3fffffffu));
+				const uint32_t hproto = __builtin_bswap32(u[3].x);
+				el.rp_type = (hproto == 11) ? 1 : (hproto == 12) ? 2 : 0;
+				el.frame_len_be = u[3].y;
+				el.header_len = __builtin_bswap32(u[3].w);
 			} else {
 				/* any other shape: walk the datagram to the record; when earlier
 				 * elements of its sample yielded records too, the flow carries over
 				 * (sflow-impl.h:145-270 never resets it between elements): replay the
 				 * sample from its start */
+				const uint32_t k = g - kp.sfbase[dgi];
 				uint32_t av, idx = 0;
-				found = xsf_begin(it, dg, (int64_t)dglen, av);
+				found = xsf_begin(it, kp.pkt + dgoff, (int64_t)dglen, av);
 				while (found && (found = sf_next_slow(it, el)) && (idx < k)) idx++;
 				if (found && el.chained) {
 					replay = true;

@@ -21,6 +21,7 @@
 #include "xe_sfwalk.h"
 
 #define XW_BLOCK 256
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 static __device__ __forceinline__ uint32_t
 ld32(const uint8_t *p)
@@ -91,7 +92,8 @@ xw_sf_count_kernel(const xe_walk_in in, uint32_t *cnt, xe_sfdg *dgs, unsigned lo
 						/* (the index is a loop counter, not a constant: spelled out so
 						 * that the array stays in registers) */
 #pragma unroll
-						for (int k = 0; k < XE_SFDG_POS; k++) if (n == (uint32_t)k) g.pos[k] = (uint16_t)d.sample_pos;
+						for (int k = 0; k < XE_SFDG_POS; k++) if (n == (uint32_t)k) g.pos[k] = (uint16_t)d.hdr_pos;
+						if (d.hdr_pos - d.sample_pos == 76) g.dev |= 0x10000u << n;
 					}
 					n++;
 				}
@@ -100,7 +102,7 @@ xw_sf_count_kernel(const xe_walk_in in, uint32_t *cnt, xe_sfdg *dgs, unsigned lo
 				g.len = (uint32_t)it.len | (usual ? 0u : XE_SFDG_WALK) | ((agent_ver == 6) ? XE_SFDG_AGENT6 : 0u);
 				/* device rules use the UDP source and the packet's source_id field, which
 				 * sflow_process() never sets: 0 */
-				g.dev = (uint32_t)(dev_find(in, in.src[i], 0) + 1);
+				g.dev |= (uint32_t)(dev_find(in, in.src[i], 0) + 1) & 0xFFFFu;
 			}
 		}
 		cnt[i] = n;
@@ -112,14 +114,32 @@ xw_sf_count_kernel(const xe_walk_in in, uint32_t *cnt, xe_sfdg *dgs, unsigned lo
 	if (((threadIdx.x & 63) == 0) && s) atomicAdd(total, s);
 }
 
-/* rec2dg[r] = the datagram record r comes from */
+/* the 16-byte entry of every record, at its place in arrival order */
 __global__ void __launch_bounds__(XW_BLOCK)
-xw_sf_place_kernel(uint32_t n, const uint32_t *base, uint32_t *rec2dg)
+xw_sf_place_kernel(uint32_t n, const uint32_t *base, const xe_sfdg *dgs, xe_sfrd *recs)
 {
 	const uint32_t i = blockIdx.x * XW_BLOCK + threadIdx.x;
 	if (i >= n) return;
 	const uint32_t b0 = base[i], b1 = base[i + 1];
-	for (uint32_t r = b0; r < b1; r++) rec2dg[r] = i;
+	if (b0 == b1) return;
+	const u32x4 *gq = (const u32x4 *)(dgs + i);
+	const u32x4 ga = gq[0], gb = gq[1];
+	const uint64_t off = (uint64_t)ga.x | ((uint64_t)ga.y << 32);
+	const uint32_t len = ga.z & XE_SFDG_LEN;
+	const uint32_t common = ((ga.w & 0xFFFFu) << 16) | ((ga.z & XE_SFDG_AGENT6) ? XE_SFRD_AGENT6 : 0u);
+	if (ga.z & XE_SFDG_WALK) {
+		const u32x4 r = { 0u, common | XE_SFRD_WALK, 0u, i };
+		for (uint32_t q = b0; q < b1; q++) ((u32x4 *)recs)[q] = r;
+		return;
+	}
+	for (uint32_t k = 0; k < b1 - b0; k++) {
+		const uint32_t pw = (k < 2) ? gb.x : (k < 4) ? gb.y : (k < 6) ? gb.z : gb.w;
+		const uint32_t hp = (pw >> (16 * (k & 1))) & 0xFFFFu;
+		const uint64_t h = off + hp;
+		const u32x4 r = { (uint32_t)h, (uint32_t)((h >> 32) & 0xFFu) | common | (((ga.w >> (16 + k)) & 1u) ? XE_SFRD_EXPANDED : 0u),
+			len - hp, i };
+		((u32x4 *)recs)[b0 + k] = r;
+	}
 }
 
 /* ------------------------------------------------------------------ Netflow v5 / v9 / IPFIX */
@@ -430,10 +450,10 @@ xe_walk_sf_count(const struct xe_walk_in *in, uint32_t *cnt, struct xe_sfdg *dgs
 }
 
 extern "C" int
-xe_walk_sf_place(uint32_t n, const uint32_t *base, uint32_t *rec2dg, void *stream)
+xe_walk_sf_place(uint32_t n, const uint32_t *base, const struct xe_sfdg *dgs, struct xe_sfrd *recs, void *stream)
 {
 	if (!n) return XE_OK;
-	hipLaunchKernelGGL(xw_sf_place_kernel, dim3(xw_blocks(n)), dim3(XW_BLOCK), 0, (hipStream_t)stream, n, base, rec2dg);
+	hipLaunchKernelGGL(xw_sf_place_kernel, dim3(xw_blocks(n)), dim3(XW_BLOCK), 0, (hipStream_t)stream, n, base, dgs, recs);
 	return xw_done();
 }
 
