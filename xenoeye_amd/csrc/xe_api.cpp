@@ -108,7 +108,7 @@ struct walk_dev
 	void *d_temp; size_t temp_bytes;
 	struct xe_dgrun *d_dgruns;
 	uint8_t *d_walked;
-	uint32_t *d_hostfirst, *d_nfcnt, *d_recbase, *d_key, *d_val, *d_key2, *d_val2, *d_gtotal, *d_gruns, *d_snrec, *d_sscan;
+	uint32_t *d_hostfirst, *d_recbase, *d_gtotal, *d_gruns;
 	struct xe_wgroup *d_groups;
 	struct xe_frun *d_fruns2;
 	struct xe_ftile *d_ftiles2;
@@ -2352,19 +2352,17 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 		if (h->twalk_n >= (1u << 16)) return XE_EUNSUPPORTED;   /* (prepare keeps such a store off this path) */
 	}
 	const size_t nr = (mode & 2) ? n * XE_WALK_SETS : n;   /* runs: up to XE_WALK_SETS per datagram */
-	w->temp_bytes = xe_walk_temp_bytes(nr + 1);
+	w->temp_bytes = xe_walk_temp_bytes(n + 1);
 #define CARVE(BYTES) (off = ALIGN_UP(off, 256), off += (BYTES), off - (BYTES))
 	const size_t o_offs = CARVE(8 * (n + 1)), o_src = CARVE(4 * n), o_kinds = CARVE(n), o_sfcnt = CARVE(4 * (n + 2)),
-		o_sfbase = CARVE(4 * (n + 2)), o_total = CARVE(32), o_temp = CARVE(w->temp_bytes),
+		o_sfbase = CARVE(4 * (n + 2)), o_total = CARVE(32), o_temp = CARVE((mode & 1) ? w->temp_bytes : 0),
 		o_sfdg = CARVE((mode & 1) ? sizeof(struct xe_sfdg) * (n + 1) : 0);
-	size_t o_dgruns = 0, o_walked = 0, o_hostfirst = 0, o_nfcnt = 0, o_recbase = 0, o_key = 0, o_val = 0, o_key2 = 0, o_val2 = 0,
-		o_gtotal = 0, o_gruns = 0, o_snrec = 0, o_sscan = 0, o_groups = 0, o_fruns2 = 0;
+	size_t o_dgruns = 0, o_walked = 0, o_hostfirst = 0, o_recbase = 0, o_gtotal = 0, o_gruns = 0, o_groups = 0;
 	if (mode & 2) {
 		o_dgruns = CARVE(sizeof(struct xe_dgrun) * nr); o_walked = CARVE(n); o_hostfirst = CARVE(4 * (n + 2));
-		o_nfcnt = CARVE(4 * (n + 2)); o_recbase = CARVE(4 * (n + 2));
-		o_key = CARVE(4 * nr); o_val = CARVE(4 * nr); o_key2 = CARVE(4 * nr); o_val2 = CARVE(4 * nr);
-		o_gtotal = CARVE(4 * (nt + 2)); o_gruns = CARVE(4 * (nt + 2)); o_snrec = CARVE(4 * (nr + 2)); o_sscan = CARVE(4 * (nr + 2));
-		o_groups = CARVE(sizeof(struct xe_wgroup) * (nt + 2)); o_fruns2 = CARVE(sizeof(struct xe_frun) * (nr + 1));
+		o_recbase = CARVE(4 * (n + 2));
+		o_gtotal = CARVE(4 * (nt + 2)); o_gruns = CARVE(4 * (nt + 2));
+		o_groups = CARVE(sizeof(struct xe_wgroup) * (nt + 2));
 	}
 #undef CARVE
 	rc = dev_get(h, &w->arena, off + 256);
@@ -2382,18 +2380,10 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 		w->d_dgruns = (struct xe_dgrun *)(base + o_dgruns);
 		w->d_walked = base + o_walked;
 		w->d_hostfirst = (uint32_t *)(base + o_hostfirst);
-		w->d_nfcnt = (uint32_t *)(base + o_nfcnt);
 		w->d_recbase = (uint32_t *)(base + o_recbase);
-		w->d_key = (uint32_t *)(base + o_key);
-		w->d_val = (uint32_t *)(base + o_val);
-		w->d_key2 = (uint32_t *)(base + o_key2);
-		w->d_val2 = (uint32_t *)(base + o_val2);
 		w->d_gtotal = (uint32_t *)(base + o_gtotal);
 		w->d_gruns = (uint32_t *)(base + o_gruns);
-		w->d_snrec = (uint32_t *)(base + o_snrec);
-		w->d_sscan = (uint32_t *)(base + o_sscan);
 		w->d_groups = (struct xe_wgroup *)(base + o_groups);
-		w->d_fruns2 = (struct xe_frun *)(base + o_fruns2);
 	}
 	/* (cleared ahead of the copies below, which it then runs beside) */
 	HIPCHK(h, hipMemsetAsync(w->d_total, 0, 32, st));
@@ -2542,10 +2532,12 @@ walk_finish(xe_gpu *h, xe_batch *b)
 	if (w->mode & 2) {
 		uint32_t *cnt = (uint32_t *)h->wstage;   /* [0, nt) records, [nt, 2 nt) runs per template, then the total */
 		struct xe_wgroup *gr;
+		uint8_t *tmap;
 		const struct xe_tmpl *tm = (const struct xe_tmpl *)h->hs.dev_tmpls.p;
 		uint64_t total, dev_total = 0, work = 0, nruns = 0, ntiles = 0;
-		unsigned bits = 1, ngroups = 0;
-		int gr_pinned = 0;
+		const size_t nslots = n * w->nsets;
+		size_t nactive = 0, npass, off = 0;
+		uint8_t *fbase;
 
 		if ((2 * nt + 4) * 4 + 16 > XE_WSTAGE_BYTES) return XE_WALK_RETRY_ON_HOST;
 		walk_mark(h, w, st);
@@ -2553,12 +2545,8 @@ walk_finish(xe_gpu *h, xe_batch *b)
 		else HIPCHK(h, hipMemsetAsync(w->d_hostfirst, 0, 4 * (n + 1), st));
 		HIPCHK(h, hipMemsetAsync(w->d_gtotal, 0, 4 * (nt + 2), st));
 		HIPCHK(h, hipMemsetAsync(w->d_gruns, 0, 4 * (nt + 2), st));
-		rc = xe_walk_nf_counts(&in, w->d_dgruns, w->nsets, w->d_walked, w->d_hostfirst, w->d_nfcnt, w->d_key, w->d_val,
-			w->d_gtotal, w->d_gruns, w->d_total + 1, st);
-		if (rc == XE_OK) rc = xe_walk_scan(w->d_temp, w->temp_bytes, w->d_nfcnt, w->d_recbase, n, st);
-		while ((1ull << bits) < nt + 1) bits++;
-		if (rc == XE_OK) rc = xe_walk_sort(w->d_temp, w->temp_bytes, w->d_key, w->d_key2, w->d_val, w->d_val2, n * w->nsets, bits, st);
-		if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (record indices)");
+		rc = xe_walk_nf_totals(&in, w->d_dgruns, w->nsets, w->d_walked, w->d_hostfirst, w->d_gtotal, w->d_gruns, w->d_total + 1, st);
+		if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (totals)");
 		HIPCHK(h, hipMemcpyAsync(cnt, w->d_gtotal, 4 * nt, hipMemcpyDeviceToHost, st));
 		HIPCHK(h, hipMemcpyAsync(cnt + nt, w->d_gruns, 4 * nt, hipMemcpyDeviceToHost, st));
 		HIPCHK(h, hipMemcpyAsync(cnt + 2 * nt + 2, w->d_total + 1, 8, hipMemcpyDeviceToHost, st));
@@ -2570,75 +2558,70 @@ walk_finish(xe_gpu *h, xe_batch *b)
 		if (total + plan->nsf > 0xFFFFFFF0ull) return XE_EUNSUPPORTED;
 		/* from 2^28 records on the fast kernel is out (32-bit column offsets) */
 		if (total + plan->nsf >= fast_record_limit(h)) return XE_WALK_RETRY_ON_HOST;
+		for (size_t t = 0; t < nt; t++) if (cnt[nt + t]) nactive++;
+		/* the prefix sums of XE_WTUPLE templates are scanned together; a batch with
+		 * more distinct templates than a few passes cover goes to the host walk */
+		npass = (nactive + XE_WTUPLE - 1) / XE_WTUPLE;
+		if (npass > 8) return XE_WALK_RETRY_ON_HOST;
+		if (!npass) npass = 1;
 		gr = (struct xe_wgroup *)pin_get(h, (nt + 2) * sizeof(*gr));
-		gr_pinned = gr != NULL;
-		if (!gr) gr = (struct xe_wgroup *)malloc((nt + 2) * sizeof(*gr));
-		if (!gr) return XE_ENOMEM;
+		tmap = (uint8_t *)pin_get(h, npass * (nt + 1));
+		if (!gr || !tmap) return XE_WALK_RETRY_ON_HOST;   /* (the scratch is sized for them in xe_gpu_batch_prepare) */
+		memset(tmap, 0xFF, npass * (nt + 1));
 		w->maxchunk2 = 1;
+		nactive = 0;
 		for (size_t t = 0; t < nt; t++) {
 			gr[t].pos0 = (uint32_t)work;
 			gr[t].run0 = (uint32_t)nruns;
 			gr[t].tile0 = (uint32_t)ntiles;
 			gr[t].pad = 0;
 			if (!cnt[nt + t]) continue;
-			ngroups++;
+			tmap[(nactive / XE_WTUPLE) * (nt + 1) + t] = (uint8_t)(nactive % XE_WTUPLE);
+			nactive++;
 			dev_total += cnt[t];
 			work += ((uint64_t)cnt[t] + 63) / 64 * 64;
 			nruns += cnt[nt + t];
 			ntiles = work / 64;
 			if (((uint32_t)tm[t].stride + 15) / 16 > w->maxchunk2) w->maxchunk2 = ((uint32_t)tm[t].stride + 15) / 16;
-			if (!xe_plan_note_template(plan, &h->hs, (uint32_t)t, cnt[t])) { if (!gr_pinned) free(gr); return XE_ENOMEM; }
+			if (!xe_plan_note_template(plan, &h->hs, (uint32_t)t, cnt[t])) return XE_ENOMEM;
 		}
 		gr[nt].pos0 = (uint32_t)work;
 		gr[nt].run0 = (uint32_t)nruns;
 		gr[nt].tile0 = (uint32_t)ntiles;
 		gr[nt].pad = 0;
-		if (work > 0xFFFFFF00ull) { if (!gr_pinned) free(gr); return XE_WALK_RETRY_ON_HOST; }
+		if (work > 0xFFFFFF00ull) return XE_WALK_RETRY_ON_HOST;
 		w->nfruns2 = (uint32_t)nruns;
 		w->ntiles2 = (uint32_t)ntiles;
-		if (nruns) {
+		{
+			/* what the second half works in: the tuple scan's output, each run's two
+			 * prefix sums, the values of the second scan and their sums, the maps,
+			 * and the two tables the fast kernel reads */
+			const size_t tb = xe_walk_temp_bytes(nslots + 1);
+#define CARVE(BYTES) (off = ALIGN_UP(off, 256), off += (BYTES), off - (BYTES))
+			const size_t o_scan = CARVE((nslots + 1) * XE_WTUPLE_BYTES), o_pos = CARVE((nslots + 1) * 8), o_val = CARVE((nslots + 2) * 8),
+				o_vscan = CARVE((nslots + 2) * 8), o_tmap = CARVE(npass * (nt + 1)), o_fruns = CARVE((nruns + 1) * sizeof(struct xe_frun)),
+				o_tiles = CARVE((ntiles + 1) * sizeof(struct xe_ftile)), o_temp = CARVE(tb);
+#undef CARVE
+			rc = dev_get(h, &w->tiles, off + 256);
+			if (rc != XE_OK) return rc;
+			fbase = (uint8_t *)w->tiles;
+			w->d_fruns2 = (struct xe_frun *)(fbase + o_fruns);
+			w->d_ftiles2 = (struct xe_ftile *)(fbase + o_tiles);
 			walk_mark(h, w, st);
-			hipError_t e = hipMemcpyAsync(w->d_groups, gr, (nt + 1) * sizeof(*gr), hipMemcpyHostToDevice, st);
-			/* (ordinary memory: the copy has left `gr` when the call returns;
-			 * the scratch stays untouched until the next prepare) */
-			if (!gr_pinned) free(gr);
-			if (e != hipSuccess) return hip_fail(h, e, "hipMemcpyAsync(groups)");
-			rc = xe_walk_nf_gather(w->d_dgruns, w->d_val2, w->nfruns2, w->d_snrec, st);
-			if (rc == XE_OK) rc = xe_walk_scan(w->d_temp, w->temp_bytes, w->d_snrec, w->d_sscan, w->nfruns2, st);
-			if (rc == XE_OK) rc = xe_walk_nf_runs(&in, w->d_dgruns, w->d_val2, w->d_key2, w->d_sscan, w->d_recbase, w->d_groups,
-				w->nfruns2, w->d_fruns2, st);
-			if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (runs)");
-			{
-				/* tiles, then (several templates) the tile list in the order of the
-				 * batch index of each tile's first record */
-				const size_t nti = w->ntiles2, tb = xe_walk_temp_bytes(nti);
-				size_t off = 0;
-				uint8_t *tbase;
-				const size_t o_a = off; off += ALIGN_UP(16 * nti, 256);
-				const size_t o_b = off; off += ALIGN_UP(16 * nti, 256);
-				const size_t o_k = off; off += ALIGN_UP(4 * nti, 256);
-				const size_t o_v = off; off += ALIGN_UP(4 * nti, 256);
-				const size_t o_k2 = off; off += ALIGN_UP(4 * nti, 256);
-				const size_t o_v2 = off; off += ALIGN_UP(4 * nti, 256);
-				const size_t o_t = off; off += tb;
-				rc = dev_get(h, &w->tiles, off);
-				if (rc != XE_OK) return rc;
-				tbase = (uint8_t *)w->tiles;
-				rc = xe_walk_nf_tiles(w->d_fruns2, w->d_groups, (uint32_t)nt, w->ntiles2, (struct xe_ftile *)(tbase + o_a),
-					(uint32_t *)(tbase + o_k), (uint32_t *)(tbase + o_v), st);
-				w->d_ftiles2 = (struct xe_ftile *)(tbase + o_a);
-				if ((rc == XE_OK) && (ngroups > 1)) {
-					rc = xe_walk_sort(tbase + o_t, tb, (uint32_t *)(tbase + o_k), (uint32_t *)(tbase + o_k2),
-						(uint32_t *)(tbase + o_v), (uint32_t *)(tbase + o_v2), nti, 32, st);
-					if (rc == XE_OK) rc = xe_walk_nf_tiles_place((struct xe_ftile *)(tbase + o_a), (uint32_t *)(tbase + o_v2),
-						w->ntiles2, (struct xe_ftile *)(tbase + o_b), st);
-					w->d_ftiles2 = (struct xe_ftile *)(tbase + o_b);
-				}
-				if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (tiles)");
+			HIPCHK(h, hipMemcpyAsync(w->d_groups, gr, (nt + 1) * sizeof(*gr), hipMemcpyHostToDevice, st));
+			HIPCHK(h, hipMemcpyAsync(fbase + o_tmap, tmap, npass * (nt + 1), hipMemcpyHostToDevice, st));
+			for (size_t p = 0; (p < npass) && (rc == XE_OK); p++) {
+				const uint8_t *d_tmap = fbase + o_tmap + p * (nt + 1);
+				rc = xe_walk_nf_tuple_scan(fbase + o_temp, tb, &in, w->d_dgruns, w->nsets, w->d_walked, d_tmap, fbase + o_scan, st);
+				if (rc == XE_OK) rc = xe_walk_nf_extract(&in, w->d_dgruns, w->nsets, w->d_walked, w->d_hostfirst, d_tmap, fbase + o_scan,
+					p == 0, fbase + o_pos, (unsigned long long *)(fbase + o_val), st);
 			}
+			if (rc == XE_OK) rc = xe_walk_scan64(fbase + o_temp, tb, (unsigned long long *)(fbase + o_val),
+				(unsigned long long *)(fbase + o_vscan), nslots, st);
+			if (rc == XE_OK) rc = xe_walk_nf_runs(&in, w->d_dgruns, w->nsets, w->d_walked, fbase + o_pos,
+				(const unsigned long long *)(fbase + o_vscan), w->d_groups, w->d_fruns2, w->d_ftiles2, w->d_recbase, st);
 			walk_mark(h, w, st);
-		} else if (!gr_pinned) {
-			free(gr);
+			if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (runs and tiles)");
 		}
 		/* the host walk numbered its records among themselves: move them to
 		 * their places in arrival order over all datagrams */
@@ -2647,7 +2630,8 @@ walk_finish(xe_gpu *h, xe_batch *b)
 			size_t k = 0;
 			w->h_recbase = (uint32_t *)malloc(4 * (n + 1));
 			if (!w->h_recbase) return XE_ENOMEM;
-			HIPCHK(h, hipMemcpy(w->h_recbase, w->d_recbase, 4 * (n + 1), hipMemcpyDeviceToHost));
+			HIPCHK(h, hipMemcpyAsync(w->h_recbase, w->d_recbase, 4 * (n + 1), hipMemcpyDeviceToHost, st));
+			HIPCHK(h, hipStreamSynchronize(st));
 			for (size_t i = 0; (i < n) && (k < plan->sets.n); i++) {
 				while ((k < plan->sets.n) && (sets[k].first_rec < plan->dg_first_nf[i + 1])) {
 					sets[k].first_rec = w->h_recbase[i] + (sets[k].first_rec - plan->dg_first_nf[i]);
@@ -2658,7 +2642,7 @@ walk_finish(xe_gpu *h, xe_batch *b)
 		w->nrec2 = (size_t)dev_total;
 		plan->nrec = (size_t)total;
 		WTICK(3);
-		if (dbg) fprintf(stderr, "device walk: enqueue counts / scan / sort %.2f, wait %.2f, runs and tiles enqueued %.2f ms\n",
+		if (dbg) fprintf(stderr, "device walk: totals enqueued %.2f, wait %.2f, scans / runs / tiles enqueued %.2f ms\n",
 			tk[1] - tk[0], tk[2] - tk[1], tk[3] - tk[2]);
 	}
 #undef WTICK
@@ -3033,7 +3017,7 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 	b = (xe_batch *)calloc(1, sizeof(*b));
 	if (!b) return XE_ENOMEM;
 	b->h = h;
-	pin_begin(h, 14 * (n + 8) + (h->hs.dev_tmpls.n + 8) * (sizeof(struct xe_fplan) + XE_NFIELDS * 4 + sizeof(struct xe_wgroup))
+	pin_begin(h, 14 * (n + 8) + (h->hs.dev_tmpls.n + 8) * (sizeof(struct xe_fplan) + XE_NFIELDS * 4 + sizeof(struct xe_wgroup) + 8 + 256)
 		+ (h->hs.dev_tents.n + 16) * sizeof(struct xe_fop) + 16 * 256);
 	/* The datagram bytes start moving to the device before the header walk:
 	 * neither needs the other (from page-locked memory the copy runs beside

@@ -279,9 +279,6 @@ extern "C" {
 size_t xe_walk_temp_bytes(size_t n);
 /* out[0..n] = exclusive prefix sums of in[0..n) (out[n] = the total); in must have n + 1 entries, in[n] is overwritten with 0 */
 int xe_walk_scan(void *temp, size_t temp_bytes, uint32_t *in, uint32_t *out, size_t n, void *stream);
-/* stable sort of (key, value) pairs by the low `bits` bits of the key */
-int xe_walk_sort(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
-	size_t n, unsigned bits, void *stream);
 
 /* sFlow: cnt[i] = records datagram i yields (0 for other kinds), dgs[i] = what the decode kernel
  * needs of the datagram; *total += the counts */
@@ -293,20 +290,31 @@ int xe_walk_sf_place(uint32_t n, const uint32_t *base, const struct xe_sfdg *dgs
  * (runs[k * n + i], k < XE_WALK_SETS, nrec > 0 for those it has; regular[i] = 1),
  * else regular[i] = 0; *kmax = the most runs of any datagram (atomic max) */
 int xe_walk_nf_shape(const struct xe_walk_in *in, struct xe_dgrun *runs, uint8_t *regular, uint32_t *kmax, void *stream);
-/* cnt[i] = walked[i] ? the records of runs[k * n + i], k < nsets : hostfirst[i + 1] - hostfirst[i] (what the host walk
- * made of the datagram); key[i * nsets + k] = template of run k, or ntmpl (no run, not walked), val[...] = k * n + i;
- * *total += the counts; gtotal[t] += records, gruns[t] += 1 per run of template t */
-int xe_walk_nf_counts(const struct xe_walk_in *in, const struct xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
-	uint32_t *cnt, uint32_t *key, uint32_t *val, uint32_t *gtotal, uint32_t *gruns, unsigned long long *total, void *stream);
-/* snrec[j] = runs[ord[j]].nrec for j < nruns (the runs in template order) */
-int xe_walk_nf_gather(const struct xe_dgrun *runs, const uint32_t *ord, uint32_t nruns, uint32_t *snrec, void *stream);
-/* per template group t: first position, first run, first tile (ntmpl + 1 entries each) */
+/* gtotal[t] += records, gruns[t] += runs of template t in the datagrams the device listed (walked[i] != 0, runs
+ * runs[k * n + i], k < nsets); *total += the records of all datagrams (hostfirst[i + 1] - hostfirst[i] for those the host
+ * walked) */
+int xe_walk_nf_totals(const struct xe_walk_in *in, const struct xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
+	uint32_t *gtotal, uint32_t *gruns, unsigned long long *total, void *stream);
+/* per template group t: first position, first run (ntmpl + 1 entries each) */
 struct xe_wgroup { uint32_t pos0, run0, tile0, pad; };
-int xe_walk_nf_runs(const struct xe_walk_in *in, const struct xe_dgrun *runs, const uint32_t *ord, const uint32_t *keys,
-	const uint32_t *sscan, const uint32_t *recbase, const struct xe_wgroup *groups, uint32_t nruns, struct xe_frun *out, void *stream);
-int xe_walk_nf_tiles(const struct xe_frun *fruns, const struct xe_wgroup *groups, uint32_t ntmpl, uint32_t ntiles,
-	struct xe_ftile *tiles, uint32_t *tkey, uint32_t *tval, void *stream);
-int xe_walk_nf_tiles_place(const struct xe_ftile *tiles, const uint32_t *order, uint32_t ntiles, struct xe_ftile *out, void *stream);
+/* Run slots are numbered in arrival order, slot j = datagram * nsets + set.
+ * One pass of the tuple scan: scan[j] = per template of the pass (tmap[template] = 0..XE_WTUPLE-1, 0xFF = not in this
+ * pass) the records and runs of that template in the slots before j (XE_WTUPLE_BYTES per slot) */
+#define XE_WTUPLE 8
+#define XE_WTUPLE_BYTES (8 * XE_WTUPLE)
+int xe_walk_nf_tuple_scan(void *temp, size_t temp_bytes, const struct xe_walk_in *in, const struct xe_dgrun *runs, uint32_t nsets,
+	const uint8_t *walked, const uint8_t *tmap, void *scan, void *stream);
+/* after a pass: pos[j] = {records, runs of its template before slot j} (8 bytes per slot) for the runs of the pass's
+ * templates, val[j] = tiles that start in the run | its records << 32; in the first pass also val[j] of the slots
+ * without a run (the host walk's records of the datagram in its first slot) */
+int xe_walk_nf_extract(const struct xe_walk_in *in, const struct xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
+	const uint8_t *tmap, const void *scan, int first_pass, void *pos, unsigned long long *val, void *stream);
+/* out[0..n] = exclusive prefix sums of in[0..n) (in[n] is overwritten with 0) */
+int xe_walk_scan64(void *temp, size_t temp_bytes, unsigned long long *in, unsigned long long *out, size_t n, void *stream);
+/* the run table, the tile list and recbase[0..n] from the prefix sums vscan of val */
+int xe_walk_nf_runs(const struct xe_walk_in *in, const struct xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const void *pos,
+	const unsigned long long *vscan, const struct xe_wgroup *groups, struct xe_frun *out, struct xe_ftile *tiles, uint32_t *recbase,
+	void *stream);
 #ifdef __cplusplus
 }
 #endif

@@ -275,127 +275,196 @@ xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular, uint32
 	}
 }
 
-/* Per datagram: its record count (from its runs, or what the host walk made of
- * it); per run: the sort entry at [i * nsets + k] (template, index of the run) */
-__global__ void __launch_bounds__(XW_BLOCK)
-xw_nf_counts_kernel(const xe_walk_in in, const xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
-	uint32_t *cnt, uint32_t *key, uint32_t *val, uint32_t *gtotal, uint32_t *gruns, unsigned long long *total)
+/* ---- from the datagrams' runs to the fast kernel's run and tile tables ----
+ *
+ * The fast kernel wants the runs grouped by template (a wave decodes 64 records
+ * of ONE template), in arrival order inside a group, and the tiles of all groups
+ * listed in the order of the batch index of their first record.  With the run
+ * slots in arrival order (slot j = datagram * nsets + set) that is:
+ *   position of a run inside its group = records of the same template in the
+ *       slots before it  -> a prefix sum per template.  Batches carry a handful
+ *       of distinct templates, so the sums of up to XE_WTUPLE templates are
+ *       scanned together as one 64-byte value (one pass of the scan per
+ *       XE_WTUPLE templates a batch uses);
+ *   batch index of a run's first record = records of any template in the slots
+ *       before it, and place of a tile in the tile list = tiles that start in the
+ *       slots before it (a tile starts wherever a group position is a multiple
+ *       of 64): one more scan, over both numbers packed in 64 bits.
+ * No sort is involved. */
+struct xe_wtuple { uint32_t recs[XE_WTUPLE], runs[XE_WTUPLE]; };
+
+struct wtuple_plus
 {
-	const uint32_t i = blockIdx.x * XW_BLOCK + threadIdx.x;
+	__device__ __host__ xe_wtuple operator()(const xe_wtuple &a, const xe_wtuple &b) const
+	{
+		xe_wtuple r;
+#pragma unroll
+		for (int i = 0; i < XE_WTUPLE; i++) { r.recs[i] = a.recs[i] + b.recs[i]; r.runs[i] = a.runs[i] + b.runs[i]; }
+		return r;
+	}
+};
+
+/* the value of run slot j for one pass: its record count under its template's
+ * place in the tuple (tmap[template]: 0..XE_WTUPLE-1, 0xFF = not in this pass) */
+struct wtuple_in
+{
+	const xe_dgrun *runs;
+	const uint8_t *walked, *tmap;
+	uint32_t n, nsets;
+	__device__ xe_wtuple operator()(uint32_t j) const
+	{
+		xe_wtuple v;
+#pragma unroll
+		for (int i = 0; i < XE_WTUPLE; i++) v.recs[i] = v.runs[i] = 0;
+		const uint32_t i = j / nsets, k = j - i * nsets;
+		if ((i < n) && walked[i]) {
+			const xe_dgrun r = runs[(size_t)k * n + i];
+			if (r.nrec) {
+				const uint32_t a = tmap[r.tmpl & 0xFFFFu];
+#pragma unroll
+				for (int q = 0; q < XE_WTUPLE; q++) if (a == (uint32_t)q) { v.recs[q] = r.nrec; v.runs[q] = 1; }
+			}
+		}
+		return v;
+	}
+};
+
+/* Per template: records and runs of the datagrams the device listed (a block
+ * adds up in LDS first: a batch has a handful of templates, and a hundred
+ * thousand atomic adds to two addresses take longer than everything else here);
+ * *total += the records of all datagrams, the host-walked ones included */
+#define XW_TCACHE 32
+__global__ void __launch_bounds__(XW_BLOCK)
+xw_nf_totals_kernel(const xe_walk_in in, const xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
+	uint32_t *gtotal, uint32_t *gruns, unsigned long long *total)
+{
+	__shared__ uint32_t c_t[XW_TCACHE], c_rec[XW_TCACHE], c_run[XW_TCACHE];
+	__shared__ unsigned long long c_all;
 	const size_t n = in.n;
 	const uint32_t lane = threadIdx.x & 63;
-	const bool w = (i < in.n) && (walked[i] != 0);
-	uint32_t c = 0;
+	unsigned long long all = 0;
 
-	for (uint32_t k = 0; k < nsets; k++) {
-		uint32_t mine = 0xFFFFFFFFu, nrec = 0;
-		if (i < in.n) {
-			const xe_dgrun r = runs[k * n + i];
-			const bool use = w && r.nrec;
-			key[(size_t)i * nsets + k] = use ? (r.tmpl & 0xFFFFu) : in.ntmpl;
-			val[(size_t)i * nsets + k] = (uint32_t)(k * n + i);
-			if (use) { mine = r.tmpl & 0xFFFFu; nrec = r.nrec; c += nrec; }
-		}
-		/* per-template sums: a batch has a handful of templates, so the lanes of a
-		 * wave that share one add up among themselves and one of them does the
-		 * atomic add (155 000 adds to two addresses took over a millisecond) */
-		unsigned long long todo = __ballot(mine != 0xFFFFFFFFu);
-		while (todo) {
-			const int leader = __ffsll((long long)todo) - 1;
-			const uint32_t t = __shfl(mine, leader, 64);
-			const bool same = mine == t;
-			const unsigned long long grp = __ballot(same);
-			uint32_t sum = same ? nrec : 0;
-			for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d, 64);
-			if (lane == (uint32_t)leader) {
-				atomicAdd(&gtotal[t], sum);
-				atomicAdd(&gruns[t], (uint32_t)__popcll(grp));
+	if (threadIdx.x < XW_TCACHE) { c_t[threadIdx.x] = 0xFFFFFFFFu; c_rec[threadIdx.x] = c_run[threadIdx.x] = 0; }
+	if (threadIdx.x == 0) c_all = 0;
+	__syncthreads();
+	for (size_t i0 = (size_t)blockIdx.x * XW_BLOCK; i0 < n; i0 += (size_t)gridDim.x * XW_BLOCK) {
+		const size_t i = i0 + threadIdx.x;
+		const bool w = (i < n) && (walked[i] != 0);
+		if ((i < n) && !w) all += hostfirst[i + 1] - hostfirst[i];
+		for (uint32_t k = 0; k < nsets; k++) {
+			uint32_t mine = 0xFFFFFFFFu, nrec = 0;
+			if (w) {
+				const xe_dgrun r = runs[k * n + i];
+				if (r.nrec) { mine = r.tmpl & 0xFFFFu; nrec = r.nrec; all += nrec; }
 			}
-			todo &= ~grp;
+			unsigned long long todo = __ballot(mine != 0xFFFFFFFFu);
+			while (todo) {
+				const int leader = __ffsll((long long)todo) - 1;
+				const uint32_t t = __shfl(mine, leader, 64);
+				const bool same = mine == t;
+				const unsigned long long grp = __ballot(same);
+				uint32_t sum = same ? nrec : 0;
+				for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d, 64);
+				if (lane == (uint32_t)leader) {
+					/* the block's entry of this template, or memory when the block has met more than it holds */
+					uint32_t e = t % XW_TCACHE, tries = 0;
+					for (; tries < XW_TCACHE; tries++, e = (e + 1) % XW_TCACHE) {
+						const uint32_t was = atomicCAS(&c_t[e], 0xFFFFFFFFu, t);
+						if ((was == 0xFFFFFFFFu) || (was == t)) break;
+					}
+					if (tries < XW_TCACHE) {
+						atomicAdd(&c_rec[e], sum);
+						atomicAdd(&c_run[e], (uint32_t)__popcll(grp));
+					} else {
+						atomicAdd(&gtotal[t], sum);
+						atomicAdd(&gruns[t], (uint32_t)__popcll(grp));
+					}
+				}
+				todo &= ~grp;
+			}
 		}
 	}
-	if (i < in.n) {
-		if (!w) c = hostfirst[i + 1] - hostfirst[i];
-		cnt[i] = c;
+	for (int d = 32; d; d >>= 1) all += __shfl_down(all, d, 64);
+	if ((lane == 0) && all) atomicAdd(&c_all, all);
+	__syncthreads();
+	if ((threadIdx.x < XW_TCACHE) && (c_t[threadIdx.x] != 0xFFFFFFFFu)) {
+		atomicAdd(&gtotal[c_t[threadIdx.x]], c_rec[threadIdx.x]);
+		atomicAdd(&gruns[c_t[threadIdx.x]], c_run[threadIdx.x]);
 	}
-	/* the batch total in 64 bits: the 32-bit prefix sums could wrap unnoticed */
-	unsigned long long s = c;
-	for (int d = 32; d; d >>= 1) s += __shfl_down(s, d, 64);
-	if ((lane == 0) && s) atomicAdd(total, s);
+	if ((threadIdx.x == 0) && c_all) atomicAdd(total, c_all);
 }
 
+/* After a pass of the tuple scan: every run whose template was in the pass takes
+ * its two prefix sums out of the 64-byte value (pos[j] = {records, runs of its
+ * template before it}) and notes what the second scan adds up: the tiles that
+ * start inside it (low word) and its records (high word).  Slots without a run
+ * note theirs in the first pass: nothing, or - first slot of a datagram the
+ * host walked - the records the host walk made of it. */
 __global__ void __launch_bounds__(XW_BLOCK)
-xw_nf_gather_kernel(const xe_dgrun *runs, const uint32_t *ord, uint32_t nruns, uint32_t *snrec)
+xw_nf_extract_kernel(const xe_walk_in in, const xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
+	const uint8_t *tmap, const xe_wtuple *scan, int first_pass, uint2 *pos, unsigned long long *val)
 {
-	const uint32_t j = blockIdx.x * XW_BLOCK + threadIdx.x;
-	if (j < nruns) snrec[j] = runs[ord[j]].nrec;
-}
-
-__global__ void __launch_bounds__(XW_BLOCK)
-xw_nf_runs_kernel(const xe_walk_in in, const xe_dgrun *runs, const uint32_t *ord, const uint32_t *keys,
-	const uint32_t *sscan, const uint32_t *recbase, const xe_wgroup *groups, uint32_t nruns, xe_frun *out)
-{
-	const uint32_t j = blockIdx.x * XW_BLOCK + threadIdx.x;
-	if (j >= nruns) return;
+	const size_t j = (size_t)blockIdx.x * XW_BLOCK + threadIdx.x;
 	const size_t n = in.n;
-	const uint32_t v = ord[j], t = keys[j];
-	const uint32_t i = (uint32_t)(v % n), k = (uint32_t)(v / n);
-	const xe_dgrun r = runs[v];
+	if (j >= n * nsets) return;
+	const size_t i = j / nsets;
+	const uint32_t k = (uint32_t)(j - i * nsets);
+	const bool w = walked[i] != 0;
+	xe_dgrun r = { 0, 0, 0, 0 };
+	if (w) r = runs[k * n + i];
+	if (!w || !r.nrec) {
+		if (first_pass) val[j] = (!w && (k == 0)) ? ((unsigned long long)(hostfirst[i + 1] - hostfirst[i]) << 32) : 0ull;
+		return;
+	}
+	const uint32_t a = tmap[r.tmpl & 0xFFFFu];
+	if (a == 0xFFu) return;
+	const uint32_t s = scan[j].recs[a];
+	pos[j] = make_uint2(s, scan[j].runs[a]);
+	val[j] = (unsigned long long)((s + r.nrec + 63) / 64 - (s + 63) / 64) | ((unsigned long long)r.nrec << 32);
+}
+
+/* The run table (grouped by template, arrival order inside a group) and the
+ * tile list (in the order of the batch index of each tile's first record);
+ * recbase[i] = batch index of datagram i's first record */
+__global__ void __launch_bounds__(XW_BLOCK)
+xw_nf_runs_kernel(const xe_walk_in in, const xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint2 *pos,
+	const unsigned long long *vscan, const xe_wgroup *groups, xe_frun *out, xe_ftile *tiles, uint32_t *recbase)
+{
+	const size_t j = (size_t)blockIdx.x * XW_BLOCK + threadIdx.x;
+	const size_t n = in.n;
+	if (j > n * nsets) return;
+	if (j == n * nsets) { recbase[n] = (uint32_t)(vscan[j] >> 32); return; }
+	const size_t i = j / nsets;
+	const uint32_t k = (uint32_t)(j - i * nsets);
+	const unsigned long long x = vscan[j];
+	const uint32_t first_rec = (uint32_t)(x >> 32);
+	if (k == 0) recbase[i] = first_rec;
+	if (!walked[i]) return;
+	const xe_dgrun r = runs[k * n + i];
+	if (!r.nrec) return;
+	const uint32_t t = r.tmpl & 0xFFFFu;
 	const xe_wgroup g = groups[t];
+	const uint2 p = pos[j];
 	xe_frun f;
-	uint32_t before = 0;
-	/* records of the datagram's earlier sets come first */
-	for (uint32_t q = 0; q < k; q++) before += runs[q * n + i].nrec;
 	f.data_off = (uint32_t)in.offs[i] + (r.tmpl >> 16);
-	f.first_rec = recbase[i] + before;
-	f.start = g.pos0 + (sscan[j] - sscan[g.run0]);
+	f.first_rec = first_rec;
+	f.start = g.pos0 + p.x;
 	f.nrec = r.nrec;
 	f.stride = in.twalk[t].stride | (r.rate & 0x80000000u);
 	f.rate = r.rate & 0x7FFFFFFFu;
 	f.dev_ip = __builtin_bswap32(in.src[i]);
 	f.dev_id = r.dev_id;
-	out[j] = f;
-}
-
-/* tile k: 64 positions of one template group; listed with the batch index of
- * its first record as the sort key */
-__global__ void __launch_bounds__(XW_BLOCK)
-xw_nf_tiles_kernel(const xe_frun *fruns, const xe_wgroup *groups, uint32_t ntmpl, uint32_t ntiles,
-	xe_ftile *tiles, uint32_t *tkey, uint32_t *tval)
-{
-	const uint32_t k = blockIdx.x * XW_BLOCK + threadIdx.x;
-	if (k >= ntiles) return;
-	/* the group: last t with tile0[t] <= k among groups that have tiles */
-	uint32_t lo = 0, hi = ntmpl;
-	while (lo + 1 < hi) {
-		const uint32_t mid = (lo + hi) / 2;
-		if (groups[mid].tile0 <= k) lo = mid; else hi = mid;
+	out[g.run0 + p.y] = f;
+	/* the tiles that start inside this run */
+	uint32_t at = (uint32_t)x;
+	for (uint32_t q = (p.x + 63) / 64; (uint64_t)q * 64 < (uint64_t)p.x + r.nrec; q++, at++) {
+		xe_ftile ft;
+		ft.first_run = g.run0 + p.y;
+		ft.tmpl = t;
+		ft.base = g.pos0 + 64 * q;
+		ft.pad = first_rec + (64 * q - p.x);
+		tiles[at] = ft;
 	}
-	/* empty groups share their tile0 with the next one: the search above ends
-	 * on the last of them, which is the one that owns the tile */
-	const uint32_t t = lo;
-	const uint32_t base = groups[t].pos0 + 64 * (k - groups[t].tile0);
-	/* the run that holds position `base`: last run of the group with start <= base */
-	uint32_t a = groups[t].run0, b = groups[t + 1].run0;
-	while (a + 1 < b) {
-		const uint32_t mid = (a + b) / 2;
-		if (fruns[mid].start <= base) a = mid; else b = mid;
-	}
-	xe_ftile ft;
-	ft.first_run = a;
-	ft.tmpl = t;
-	ft.base = base;
-	ft.pad = fruns[a].first_rec + (base - fruns[a].start);
-	tiles[k] = ft;
-	tkey[k] = ft.pad;
-	tval[k] = k;
-}
-
-__global__ void __launch_bounds__(XW_BLOCK)
-xw_nf_tiles_place_kernel(const xe_ftile *tiles, const uint32_t *order, uint32_t ntiles, xe_ftile *out)
-{
-	const uint32_t k = blockIdx.x * XW_BLOCK + threadIdx.x;
-	if (k < ntiles) out[k] = tiles[order[k]];
 }
 
 /* ------------------------------------------------------------------ launches */
@@ -414,12 +483,21 @@ xw_done(void)
 extern "C" size_t
 xe_walk_temp_bytes(size_t n)
 {
-	size_t a = 0, b = 0;
+	size_t a = 0, b = 0, c = 0;
 	uint32_t *z = nullptr;
+	unsigned long long *z8 = nullptr;
+	xe_wtuple *zt = nullptr;
+	xe_wtuple zero;
+	wtuple_in src = { nullptr, nullptr, nullptr, 0, 1 };
+	memset(&zero, 0, sizeof(zero));
 	if (!n) n = 1;
 	(void)rocprim::exclusive_scan(nullptr, a, z, z, 0u, n + 1, rocprim::plus<uint32_t>(), (hipStream_t)0);
-	(void)rocprim::radix_sort_pairs(nullptr, b, z, z, z, z, n, 0, 32, (hipStream_t)0);
-	return ((a > b) ? a : b) + 256;
+	(void)rocprim::exclusive_scan(nullptr, b, z8, z8, 0ull, n + 1, rocprim::plus<unsigned long long>(), (hipStream_t)0);
+	(void)rocprim::exclusive_scan(nullptr, c, rocprim::make_transform_iterator(rocprim::make_counting_iterator(0u), src), zt, zero, n + 1,
+		wtuple_plus(), (hipStream_t)0);
+	if (b > a) a = b;
+	if (c > a) a = c;
+	return a + 256;
 }
 
 extern "C" int
@@ -432,12 +510,25 @@ xe_walk_scan(void *temp, size_t temp_bytes, uint32_t *in, uint32_t *out, size_t 
 }
 
 extern "C" int
-xe_walk_sort(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
-	size_t n, unsigned bits, void *stream)
+xe_walk_scan64(void *temp, size_t temp_bytes, unsigned long long *in, unsigned long long *out, size_t n, void *stream)
 {
-	if (!n) return XE_OK;
-	if (bits < 1) bits = 1;
-	if (rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, n, 0, bits, (hipStream_t)stream) != hipSuccess) return XE_EHIP;
+	hipStream_t st = (hipStream_t)stream;
+	if (hipMemsetAsync(in + n, 0, 8, st) != hipSuccess) return XE_EHIP;
+	if (rocprim::exclusive_scan(temp, temp_bytes, in, out, 0ull, n + 1, rocprim::plus<unsigned long long>(), st) != hipSuccess) return XE_EHIP;
+	return XE_OK;
+}
+
+extern "C" int
+xe_walk_nf_tuple_scan(void *temp, size_t temp_bytes, const struct xe_walk_in *in, const struct xe_dgrun *runs, uint32_t nsets,
+	const uint8_t *walked, const uint8_t *tmap, void *scan, void *stream)
+{
+	const size_t nslots = (size_t)in->n * nsets;
+	wtuple_in src = { runs, walked, tmap, in->n, nsets };
+	xe_wtuple zero;
+	memset(&zero, 0, sizeof(zero));
+	if (!nslots) return XE_OK;
+	if (rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator(rocprim::make_counting_iterator(0u), src),
+		(xe_wtuple *)scan, zero, nslots, wtuple_plus(), (hipStream_t)stream) != hipSuccess) return XE_EHIP;
 	return XE_OK;
 }
 
@@ -466,48 +557,36 @@ xe_walk_nf_shape(const struct xe_walk_in *in, struct xe_dgrun *runs, uint8_t *re
 }
 
 extern "C" int
-xe_walk_nf_counts(const struct xe_walk_in *in, const struct xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
-	uint32_t *cnt, uint32_t *key, uint32_t *val, uint32_t *gtotal, uint32_t *gruns, unsigned long long *total, void *stream)
+xe_walk_nf_totals(const struct xe_walk_in *in, const struct xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
+	uint32_t *gtotal, uint32_t *gruns, unsigned long long *total, void *stream)
 {
+	uint32_t blocks = xw_blocks(in->n);
 	if (!in->n) return XE_OK;
-	hipLaunchKernelGGL(xw_nf_counts_kernel, dim3(xw_blocks(in->n)), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, runs, nsets, walked,
-		hostfirst, cnt, key, val, gtotal, gruns, total);
+	if (blocks > 512) blocks = 512;
+	hipLaunchKernelGGL(xw_nf_totals_kernel, dim3(blocks), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, runs, nsets, walked, hostfirst,
+		gtotal, gruns, total);
 	return xw_done();
 }
 
 extern "C" int
-xe_walk_nf_gather(const struct xe_dgrun *runs, const uint32_t *ord, uint32_t nruns, uint32_t *snrec, void *stream)
+xe_walk_nf_extract(const struct xe_walk_in *in, const struct xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
+	const uint8_t *tmap, const void *scan, int first_pass, void *pos, unsigned long long *val, void *stream)
 {
-	if (!nruns) return XE_OK;
-	hipLaunchKernelGGL(xw_nf_gather_kernel, dim3(xw_blocks(nruns)), dim3(XW_BLOCK), 0, (hipStream_t)stream, runs, ord, nruns, snrec);
+	const size_t nslots = (size_t)in->n * nsets;
+	if (!nslots) return XE_OK;
+	hipLaunchKernelGGL(xw_nf_extract_kernel, dim3(xw_blocks(nslots)), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, runs, nsets, walked,
+		hostfirst, tmap, (const xe_wtuple *)scan, first_pass, (uint2 *)pos, val);
 	return xw_done();
 }
 
 extern "C" int
-xe_walk_nf_runs(const struct xe_walk_in *in, const struct xe_dgrun *runs, const uint32_t *ord, const uint32_t *keys,
-	const uint32_t *sscan, const uint32_t *recbase, const struct xe_wgroup *groups, uint32_t nruns, struct xe_frun *out, void *stream)
+xe_walk_nf_runs(const struct xe_walk_in *in, const struct xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const void *pos,
+	const unsigned long long *vscan, const struct xe_wgroup *groups, struct xe_frun *out, struct xe_ftile *tiles, uint32_t *recbase,
+	void *stream)
 {
-	if (!nruns) return XE_OK;
-	hipLaunchKernelGGL(xw_nf_runs_kernel, dim3(xw_blocks(nruns)), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, runs, ord, keys,
-		sscan, recbase, groups, nruns, out);
-	return xw_done();
-}
-
-extern "C" int
-xe_walk_nf_tiles(const struct xe_frun *fruns, const struct xe_wgroup *groups, uint32_t ntmpl, uint32_t ntiles,
-	struct xe_ftile *tiles, uint32_t *tkey, uint32_t *tval, void *stream)
-{
-	if (!ntiles) return XE_OK;
-	hipLaunchKernelGGL(xw_nf_tiles_kernel, dim3(xw_blocks(ntiles)), dim3(XW_BLOCK), 0, (hipStream_t)stream, fruns, groups, ntmpl,
-		ntiles, tiles, tkey, tval);
-	return xw_done();
-}
-
-extern "C" int
-xe_walk_nf_tiles_place(const struct xe_ftile *tiles, const uint32_t *order, uint32_t ntiles, struct xe_ftile *out, void *stream)
-{
-	if (!ntiles) return XE_OK;
-	hipLaunchKernelGGL(xw_nf_tiles_place_kernel, dim3(xw_blocks(ntiles)), dim3(XW_BLOCK), 0, (hipStream_t)stream, tiles, order,
-		ntiles, out);
+	const size_t nslots = (size_t)in->n * nsets;
+	if (!in->n) return XE_OK;
+	hipLaunchKernelGGL(xw_nf_runs_kernel, dim3(xw_blocks(nslots + 1)), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, runs, nsets, walked,
+		(const uint2 *)pos, vscan, groups, out, tiles, recbase);
 	return xw_done();
 }
