@@ -76,6 +76,10 @@ struct xe_gpu
 	char err[512];
 };
 #define XE_WSTAGE_BYTES (64 * 1024)
+/* device words the walk adds up into, cleared once per batch: 32 bytes of
+ * totals ([0] sFlow records, [1] Netflow records, [2] u32 most runs of a
+ * datagram + u32 datagrams left to the host), then per template records and runs */
+#define XE_WZERO_BYTES(NT) (32 + 8 * ((NT) + 2))
 
 struct fwm_host
 {
@@ -2323,10 +2327,9 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 {
 	struct walk_dev *w = &b->w;
 	hipStream_t st = h->copy_stream;
-	const size_t nt = h->hs.dev_tmpls.n;
 	struct xe_walk_in in;
 	size_t off = 0;
-	uint8_t *base, *pin_walked = NULL;
+	uint8_t *base;
 	int rc;
 
 	w->mode = mode;
@@ -2352,17 +2355,16 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 		if (h->twalk_n >= (1u << 16)) return XE_EUNSUPPORTED;   /* (prepare keeps such a store off this path) */
 	}
 	const size_t nr = (mode & 2) ? n * XE_WALK_SETS : n;   /* runs: up to XE_WALK_SETS per datagram */
+	const size_t nt = (mode & 2) ? h->twalk_n : 0;         /* device templates as the walk tables hold them */
 	w->temp_bytes = xe_walk_temp_bytes(n + 1);
 #define CARVE(BYTES) (off = ALIGN_UP(off, 256), off += (BYTES), off - (BYTES))
 	const size_t o_offs = CARVE(8 * (n + 1)), o_src = CARVE(4 * n), o_kinds = CARVE(n), o_sfcnt = CARVE(4 * (n + 2)),
-		o_sfbase = CARVE(4 * (n + 2)), o_total = CARVE(32), o_temp = CARVE((mode & 1) ? w->temp_bytes : 0),
+		o_sfbase = CARVE(4 * (n + 2)), o_total = CARVE(XE_WZERO_BYTES(nt)), o_temp = CARVE((mode & 1) ? w->temp_bytes : 0),
 		o_sfdg = CARVE((mode & 1) ? sizeof(struct xe_sfdg) * (n + 1) : 0);
-	size_t o_dgruns = 0, o_walked = 0, o_hostfirst = 0, o_recbase = 0, o_gtotal = 0, o_gruns = 0, o_groups = 0;
+	size_t o_dgruns = 0, o_walked = 0, o_hostfirst = 0, o_recbase = 0;
 	if (mode & 2) {
 		o_dgruns = CARVE(sizeof(struct xe_dgrun) * nr); o_walked = CARVE(n); o_hostfirst = CARVE(4 * (n + 2));
 		o_recbase = CARVE(4 * (n + 2));
-		o_gtotal = CARVE(4 * (nt + 2)); o_gruns = CARVE(4 * (nt + 2));
-		o_groups = CARVE(sizeof(struct xe_wgroup) * (nt + 2));
 	}
 #undef CARVE
 	rc = dev_get(h, &w->arena, off + 256);
@@ -2381,12 +2383,12 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 		w->d_walked = base + o_walked;
 		w->d_hostfirst = (uint32_t *)(base + o_hostfirst);
 		w->d_recbase = (uint32_t *)(base + o_recbase);
-		w->d_gtotal = (uint32_t *)(base + o_gtotal);
-		w->d_gruns = (uint32_t *)(base + o_gruns);
-		w->d_groups = (struct xe_wgroup *)(base + o_groups);
+		/* the per-template sums lie behind the totals: one clear, one copy back */
+		w->d_gtotal = (uint32_t *)(base + o_total + 32);
+		w->d_gruns = w->d_gtotal + (nt + 2);
 	}
 	/* (cleared ahead of the copies below, which it then runs beside) */
-	HIPCHK(h, hipMemsetAsync(w->d_total, 0, 32, st));
+	HIPCHK(h, hipMemsetAsync(w->d_total, 0, (mode & 2) ? XE_WZERO_BYTES(nt) : 32, st));
 	{
 		/* the per-datagram arrays go through page-locked scratch (a copy out of
 		 * ordinary memory blocks the calling thread inside the runtime, and with it
@@ -2417,9 +2419,7 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 		if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (Netflow)");
 		w->h_walked = (uint8_t *)malloc(n ? n : 1);
 		if (!w->h_walked) return XE_ENOMEM;
-		pin_walked = (uint8_t *)pin_get(h, n + 1);
-		HIPCHK(h, hipMemcpyAsync(pin_walked ? pin_walked : w->h_walked, w->d_walked, n, hipMemcpyDeviceToHost, st));
-		HIPCHK(h, hipMemcpyAsync((uint8_t *)h->wstage + 8, w->d_total + 2, 8, hipMemcpyDeviceToHost, st));
+		HIPCHK(h, hipMemcpyAsync((uint8_t *)h->wstage + 16, w->d_total + 2, 8, hipMemcpyDeviceToHost, st));
 	}
 	if (mode & 1) {
 		in.pkt = (const uint8_t *)b->d_pkt;
@@ -2433,10 +2433,18 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 	 * on the device it starts at once and the device counts beside it */
 	if (mode & 2) {
 		HIPCHK(h, hipStreamSynchronize(st));
-		if (pin_walked) memcpy(w->h_walked, pin_walked, n);
-		w->nsets = *(volatile uint32_t *)((uint8_t *)h->wstage + 8);
+		w->nsets = *(volatile uint32_t *)((uint8_t *)h->wstage + 16);
 		if (w->nsets < 1) w->nsets = 1;
 		if (w->nsets > XE_WALK_SETS) w->nsets = XE_WALK_SETS;
+		if (*(volatile uint32_t *)((uint8_t *)h->wstage + 20) == 0) {
+			/* every Netflow datagram is of the usual shape */
+			for (size_t i = 0; i < n; i++) w->h_walked[i] = !(kinds && (kinds[i] == XE_KIND_SFLOW));
+		} else {
+			uint8_t *pin_walked = (uint8_t *)pin_get(h, n + 1);
+			HIPCHK(h, hipMemcpyAsync(pin_walked ? pin_walked : w->h_walked, w->d_walked, n, hipMemcpyDeviceToHost, st));
+			HIPCHK(h, hipStreamSynchronize(st));
+			if (pin_walked) memcpy(w->h_walked, pin_walked, n);
+		}
 	}
 	for (size_t i = 0; i < n; i++) {
 		uint8_t k = kinds ? kinds[i] : (uint8_t)XE_KIND_NETFLOW;
@@ -2530,43 +2538,43 @@ walk_finish(xe_gpu *h, xe_batch *b)
 		plan->nsf = (size_t)nsf;
 	}
 	if (w->mode & 2) {
-		uint32_t *cnt = (uint32_t *)h->wstage;   /* [0, nt) records, [nt, 2 nt) runs per template, then the total */
+		/* the words the device added up, as they lie in its arena (XE_WZERO_BYTES):
+		 * cnt[0, nt + 2) records, cnt[nt + 2, ...) runs per template */
+		const uint8_t *back = (const uint8_t *)h->wstage;
+		const uint32_t *cnt = (const uint32_t *)(back + 32), *cntruns = cnt + (nt + 2);
 		struct xe_wgroup *gr;
 		uint8_t *tmap;
 		const struct xe_tmpl *tm = (const struct xe_tmpl *)h->hs.dev_tmpls.p;
 		uint64_t total, dev_total = 0, work = 0, nruns = 0, ntiles = 0;
-		const size_t nslots = n * w->nsets;
 		size_t nactive = 0, npass, off = 0;
+		const uint32_t *d_hostfirst = plan->nrec ? w->d_hostfirst : NULL;
 		uint8_t *fbase;
 
-		if ((2 * nt + 4) * 4 + 16 > XE_WSTAGE_BYTES) return XE_WALK_RETRY_ON_HOST;
+		if (XE_WZERO_BYTES(nt) > XE_WSTAGE_BYTES) return XE_WALK_RETRY_ON_HOST;
 		walk_mark(h, w, st);
 		if (plan->nrec) HIPCHK(h, hipMemcpyAsync(w->d_hostfirst, plan->dg_first_nf, 4 * (n + 1), hipMemcpyHostToDevice, st));
-		else HIPCHK(h, hipMemsetAsync(w->d_hostfirst, 0, 4 * (n + 1), st));
-		HIPCHK(h, hipMemsetAsync(w->d_gtotal, 0, 4 * (nt + 2), st));
-		HIPCHK(h, hipMemsetAsync(w->d_gruns, 0, 4 * (nt + 2), st));
-		rc = xe_walk_nf_totals(&in, w->d_dgruns, w->nsets, w->d_walked, w->d_hostfirst, w->d_gtotal, w->d_gruns, w->d_total + 1, st);
+		rc = xe_walk_nf_totals(&in, w->d_dgruns, w->nsets, w->d_walked, d_hostfirst, w->d_gtotal, w->d_gruns, w->d_total + 1, st);
 		if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (totals)");
-		HIPCHK(h, hipMemcpyAsync(cnt, w->d_gtotal, 4 * nt, hipMemcpyDeviceToHost, st));
-		HIPCHK(h, hipMemcpyAsync(cnt + nt, w->d_gruns, 4 * nt, hipMemcpyDeviceToHost, st));
-		HIPCHK(h, hipMemcpyAsync(cnt + 2 * nt + 2, w->d_total + 1, 8, hipMemcpyDeviceToHost, st));
+		HIPCHK(h, hipMemcpyAsync((uint8_t *)h->wstage + 8, w->d_total + 1, XE_WZERO_BYTES(nt) - 8, hipMemcpyDeviceToHost, st));
 		walk_mark(h, w, st);
 		WTICK(1);
 		HIPCHK(h, hipStreamSynchronize(st));
 		WTICK(2);
-		memcpy(&total, cnt + 2 * nt + 2, 8);
+		memcpy(&total, back + 8, 8);
 		if (total + plan->nsf > 0xFFFFFFF0ull) return XE_EUNSUPPORTED;
 		/* from 2^28 records on the fast kernel is out (32-bit column offsets) */
 		if (total + plan->nsf >= fast_record_limit(h)) return XE_WALK_RETRY_ON_HOST;
-		for (size_t t = 0; t < nt; t++) if (cnt[nt + t]) nactive++;
+		for (size_t t = 0; t < nt; t++) if (cntruns[t]) nactive++;
 		/* the prefix sums of XE_WTUPLE templates are scanned together; a batch with
 		 * more distinct templates than a few passes cover goes to the host walk */
 		npass = (nactive + XE_WTUPLE - 1) / XE_WTUPLE;
 		if (npass > 8) return XE_WALK_RETRY_ON_HOST;
 		if (!npass) npass = 1;
-		gr = (struct xe_wgroup *)pin_get(h, (nt + 2) * sizeof(*gr));
-		tmap = (uint8_t *)pin_get(h, npass * (nt + 1));
-		if (!gr || !tmap) return XE_WALK_RETRY_ON_HOST;   /* (the scratch is sized for them in xe_gpu_batch_prepare) */
+		/* group table and template maps, side by side: one copy */
+		const size_t gr_bytes = ALIGN_UP((nt + 2) * sizeof(*gr), 256), up_bytes = gr_bytes + npass * (nt + 1);
+		gr = (struct xe_wgroup *)pin_get(h, up_bytes);
+		if (!gr) return XE_WALK_RETRY_ON_HOST;   /* (the scratch is sized for them in xe_gpu_batch_prepare) */
+		tmap = (uint8_t *)gr + gr_bytes;
 		memset(tmap, 0xFF, npass * (nt + 1));
 		w->maxchunk2 = 1;
 		nactive = 0;
@@ -2575,12 +2583,12 @@ walk_finish(xe_gpu *h, xe_batch *b)
 			gr[t].run0 = (uint32_t)nruns;
 			gr[t].tile0 = (uint32_t)ntiles;
 			gr[t].pad = 0;
-			if (!cnt[nt + t]) continue;
+			if (!cntruns[t]) continue;
 			tmap[(nactive / XE_WTUPLE) * (nt + 1) + t] = (uint8_t)(nactive % XE_WTUPLE);
 			nactive++;
 			dev_total += cnt[t];
 			work += ((uint64_t)cnt[t] + 63) / 64 * 64;
-			nruns += cnt[nt + t];
+			nruns += cntruns[t];
 			ntiles = work / 64;
 			if (((uint32_t)tm[t].stride + 15) / 16 > w->maxchunk2) w->maxchunk2 = ((uint32_t)tm[t].stride + 15) / 16;
 			if (!xe_plan_note_template(plan, &h->hs, (uint32_t)t, cnt[t])) return XE_ENOMEM;
@@ -2593,33 +2601,23 @@ walk_finish(xe_gpu *h, xe_batch *b)
 		w->nfruns2 = (uint32_t)nruns;
 		w->ntiles2 = (uint32_t)ntiles;
 		{
-			/* what the second half works in: the tuple scan's output, each run's two
-			 * prefix sums, the values of the second scan and their sums, the maps,
-			 * and the two tables the fast kernel reads */
-			const size_t tb = xe_walk_temp_bytes(nslots + 1);
+			/* the two tables the fast kernel reads, the group table with the maps,
+			 * and the scratch of the scans */
+			const size_t wb = xe_walk_nf_work_bytes(n, w->nsets);
 #define CARVE(BYTES) (off = ALIGN_UP(off, 256), off += (BYTES), off - (BYTES))
-			const size_t o_scan = CARVE((nslots + 1) * XE_WTUPLE_BYTES), o_pos = CARVE((nslots + 1) * 8), o_val = CARVE((nslots + 2) * 8),
-				o_vscan = CARVE((nslots + 2) * 8), o_tmap = CARVE(npass * (nt + 1)), o_fruns = CARVE((nruns + 1) * sizeof(struct xe_frun)),
-				o_tiles = CARVE((ntiles + 1) * sizeof(struct xe_ftile)), o_temp = CARVE(tb);
+			const size_t o_fruns = CARVE((nruns + 1) * sizeof(struct xe_frun)), o_tiles = CARVE((ntiles + 1) * sizeof(struct xe_ftile)),
+				o_up = CARVE(up_bytes), o_work = CARVE(wb);
 #undef CARVE
 			rc = dev_get(h, &w->tiles, off + 256);
 			if (rc != XE_OK) return rc;
 			fbase = (uint8_t *)w->tiles;
 			w->d_fruns2 = (struct xe_frun *)(fbase + o_fruns);
 			w->d_ftiles2 = (struct xe_ftile *)(fbase + o_tiles);
+			w->d_groups = (struct xe_wgroup *)(fbase + o_up);
 			walk_mark(h, w, st);
-			HIPCHK(h, hipMemcpyAsync(w->d_groups, gr, (nt + 1) * sizeof(*gr), hipMemcpyHostToDevice, st));
-			HIPCHK(h, hipMemcpyAsync(fbase + o_tmap, tmap, npass * (nt + 1), hipMemcpyHostToDevice, st));
-			for (size_t p = 0; (p < npass) && (rc == XE_OK); p++) {
-				const uint8_t *d_tmap = fbase + o_tmap + p * (nt + 1);
-				rc = xe_walk_nf_tuple_scan(fbase + o_temp, tb, &in, w->d_dgruns, w->nsets, w->d_walked, d_tmap, fbase + o_scan, st);
-				if (rc == XE_OK) rc = xe_walk_nf_extract(&in, w->d_dgruns, w->nsets, w->d_walked, w->d_hostfirst, d_tmap, fbase + o_scan,
-					p == 0, fbase + o_pos, (unsigned long long *)(fbase + o_val), st);
-			}
-			if (rc == XE_OK) rc = xe_walk_scan64(fbase + o_temp, tb, (unsigned long long *)(fbase + o_val),
-				(unsigned long long *)(fbase + o_vscan), nslots, st);
-			if (rc == XE_OK) rc = xe_walk_nf_runs(&in, w->d_dgruns, w->nsets, w->d_walked, fbase + o_pos,
-				(const unsigned long long *)(fbase + o_vscan), w->d_groups, w->d_fruns2, w->d_ftiles2, w->d_recbase, st);
+			HIPCHK(h, hipMemcpyAsync(fbase + o_up, gr, up_bytes, hipMemcpyHostToDevice, st));
+			rc = xe_walk_nf_tables(&in, w->d_dgruns, w->nsets, w->d_walked, d_hostfirst, fbase + o_up + gr_bytes, (uint32_t)npass,
+				(uint32_t)nactive, w->d_groups, fbase + o_work, w->d_fruns2, w->d_ftiles2, w->d_recbase, st);
 			walk_mark(h, w, st);
 			if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (runs and tiles)");
 		}
@@ -3058,7 +3056,7 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 		if (!has_sf || (h->hs.ndevs >= 0xFFFFu)) walk_mode &= ~1;   /* (a record's entry names its devices.conf entry in 16 bits) */
 		if (!has_nf || !h->fast_ok || ((total + 64) >= 0xFFFF0000ull) || h->diag_force_general || h->diag_fast_r) walk_mode &= ~2;
 		/* (the per-template counts come back through a small page-locked buffer) */
-		if (((2 * h->hs.dev_tmpls.n + 8) * 4 + 16 > XE_WSTAGE_BYTES) || (h->hs.dev_tmpls.n >= 0xFFF0u)) walk_mode &= ~2;
+		if ((XE_WZERO_BYTES(h->hs.dev_tmpls.n) > XE_WSTAGE_BYTES) || (h->hs.dev_tmpls.n >= 0xFFF0u)) walk_mode &= ~2;
 		if (n >= 0x7FFFFFF0ull) walk_mode = 0;
 		/* (run indices, XE_WALK_SETS per datagram, are sorted as 32-bit values) */
 		if (n >= (0xFFFFFFF0ull / XE_WALK_SETS)) walk_mode &= ~2;

@@ -288,7 +288,7 @@ int xe_walk_sf_place(uint32_t n, const uint32_t *base, const struct xe_sfdg *dgs
 
 /* Netflow: per datagram, the runs it yields when its shape is the usual one
  * (runs[k * n + i], k < XE_WALK_SETS, nrec > 0 for those it has; regular[i] = 1),
- * else regular[i] = 0; *kmax = the most runs of any datagram (atomic max) */
+ * else regular[i] = 0; kmax[0] = the most runs of any datagram (atomic max), kmax[1] += Netflow datagrams that are not regular */
 int xe_walk_nf_shape(const struct xe_walk_in *in, struct xe_dgrun *runs, uint8_t *regular, uint32_t *kmax, void *stream);
 /* gtotal[t] += records, gruns[t] += runs of template t in the datagrams the device listed (walked[i] != 0, runs
  * runs[k * n + i], k < nsets); *total += the records of all datagrams (hostfirst[i + 1] - hostfirst[i] for those the host
@@ -297,24 +297,17 @@ int xe_walk_nf_totals(const struct xe_walk_in *in, const struct xe_dgrun *runs, 
 	uint32_t *gtotal, uint32_t *gruns, unsigned long long *total, void *stream);
 /* per template group t: first position, first run (ntmpl + 1 entries each) */
 struct xe_wgroup { uint32_t pos0, run0, tile0, pad; };
-/* Run slots are numbered in arrival order, slot j = datagram * nsets + set.
- * One pass of the tuple scan: scan[j] = per template of the pass (tmap[template] = 0..XE_WTUPLE-1, 0xFF = not in this
- * pass) the records and runs of that template in the slots before j (XE_WTUPLE_BYTES per slot) */
+/* Run slots are numbered in arrival order, slot j = datagram * nsets + set.  From the runs to the fast kernel's
+ * tables: tmaps[p * (ntmpl + 1) + template] = the template's place among the XE_WTUPLE templates of pass p (0xFF = another
+ * pass), nactive = templates with runs in this batch; out[groups[t].run0 + ...] the runs of template t in arrival order,
+ * tiles[] the tile list in the order of the batch index of each tile's first record, recbase[0..n] the batch index of
+ * every datagram's first record (hostfirst: what the host walk made of the datagrams it walked, NULL = it walked none);
+ * work = xe_walk_nf_work_bytes() bytes of device scratch */
 #define XE_WTUPLE 8
-#define XE_WTUPLE_BYTES (8 * XE_WTUPLE)
-int xe_walk_nf_tuple_scan(void *temp, size_t temp_bytes, const struct xe_walk_in *in, const struct xe_dgrun *runs, uint32_t nsets,
-	const uint8_t *walked, const uint8_t *tmap, void *scan, void *stream);
-/* after a pass: pos[j] = {records, runs of its template before slot j} (8 bytes per slot) for the runs of the pass's
- * templates, val[j] = tiles that start in the run | its records << 32; in the first pass also val[j] of the slots
- * without a run (the host walk's records of the datagram in its first slot) */
-int xe_walk_nf_extract(const struct xe_walk_in *in, const struct xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
-	const uint8_t *tmap, const void *scan, int first_pass, void *pos, unsigned long long *val, void *stream);
-/* out[0..n] = exclusive prefix sums of in[0..n) (in[n] is overwritten with 0) */
-int xe_walk_scan64(void *temp, size_t temp_bytes, unsigned long long *in, unsigned long long *out, size_t n, void *stream);
-/* the run table, the tile list and recbase[0..n] from the prefix sums vscan of val */
-int xe_walk_nf_runs(const struct xe_walk_in *in, const struct xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const void *pos,
-	const unsigned long long *vscan, const struct xe_wgroup *groups, struct xe_frun *out, struct xe_ftile *tiles, uint32_t *recbase,
-	void *stream);
+size_t xe_walk_nf_work_bytes(size_t n, uint32_t nsets);
+int xe_walk_nf_tables(const struct xe_walk_in *in, const struct xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
+	const uint8_t *tmaps, uint32_t npass, uint32_t nactive, const struct xe_wgroup *groups, void *work,
+	struct xe_frun *out, struct xe_ftile *tiles, uint32_t *recbase, void *stream);
 #ifdef __cplusplus
 }
 #endif

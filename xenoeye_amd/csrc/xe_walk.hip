@@ -267,11 +267,18 @@ xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular, uint32
 		for (uint32_t j = k; j < XE_WALK_SETS; j++) runs[j * n + i] = none;
 		regular[i] = ok ? 1 : 0;
 	}
-	/* the most runs any datagram has: the later steps look at that many only */
+	/* the most runs any datagram has: the later steps look at that many only;
+	 * and how many Netflow datagrams are left to the host (none, on a collector
+	 * whose exporters' templates are known: the per-datagram flags then need not
+	 * travel) */
 	{
 		uint32_t m = k;
+		const unsigned long long left = __ballot((i < in.n) && !ok && !(in.kinds && (in.kinds[i] == XE_KIND_SFLOW)));
 		for (int d = 32; d; d >>= 1) { const uint32_t o = __shfl_xor(m, d, 64); m = (o > m) ? o : m; }
-		if (((threadIdx.x & 63) == 0) && m) atomicMax(kmax, m);
+		if ((threadIdx.x & 63) == 0) {
+			if (m) atomicMax(kmax, m);
+			if (left) atomicAdd(kmax + 1, (uint32_t)__popcll(left));
+		}
 	}
 }
 
@@ -284,55 +291,70 @@ xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular, uint32
  *   position of a run inside its group = records of the same template in the
  *       slots before it  -> a prefix sum per template.  Batches carry a handful
  *       of distinct templates, so the sums of up to XE_WTUPLE templates are
- *       scanned together as one 64-byte value (one pass of the scan per
- *       XE_WTUPLE templates a batch uses);
+ *       scanned together (one pass per XE_WTUPLE templates a batch uses);
  *   batch index of a run's first record = records of any template in the slots
  *       before it, and place of a tile in the tile list = tiles that start in the
  *       slots before it (a tile starts wherever a group position is a multiple
  *       of 64): one more scan, over both numbers packed in 64 bits.
- * No sort is involved. */
-struct xe_wtuple { uint32_t recs[XE_WTUPLE], runs[XE_WTUPLE]; };
+ * No sort is involved.  Both scans have the same three steps - sums of chunks of
+ * XW_CHUNK slots, prefix sums over the chunks (one small block), prefix sums
+ * inside every chunk - and the step that finishes one scan prepares the next:
+ * five short kernels from runs to tables. */
+#define XW_ITEMS 4
+#define XW_CHUNK (XW_BLOCK * XW_ITEMS)
 
-struct wtuple_plus
-{
-	__device__ __host__ xe_wtuple operator()(const xe_wtuple &a, const xe_wtuple &b) const
-	{
-		xe_wtuple r;
-#pragma unroll
-		for (int i = 0; i < XE_WTUPLE; i++) { r.recs[i] = a.recs[i] + b.recs[i]; r.runs[i] = a.runs[i] + b.runs[i]; }
-		return r;
-	}
-};
+/* what run slot j holds: its template's place in this pass's tuple (0xFF = no
+ * run, or a template of another pass) and its record count */
+struct wslot { uint32_t a, nrec, tmpl; bool walked, run; };
 
-/* the value of run slot j for one pass: its record count under its template's
- * place in the tuple (tmap[template]: 0..XE_WTUPLE-1, 0xFF = not in this pass) */
-struct wtuple_in
+static __device__ __forceinline__ wslot
+slot_of(const xe_walk_in &in, const xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint8_t *tmap, size_t j, xe_dgrun &r)
 {
-	const xe_dgrun *runs;
-	const uint8_t *walked, *tmap;
-	uint32_t n, nsets;
-	__device__ xe_wtuple operator()(uint32_t j) const
-	{
-		xe_wtuple v;
-#pragma unroll
-		for (int i = 0; i < XE_WTUPLE; i++) v.recs[i] = v.runs[i] = 0;
-		const uint32_t i = j / nsets, k = j - i * nsets;
-		if ((i < n) && walked[i]) {
-			const xe_dgrun r = runs[(size_t)k * n + i];
-			if (r.nrec) {
-				const uint32_t a = tmap[r.tmpl & 0xFFFFu];
-#pragma unroll
-				for (int q = 0; q < XE_WTUPLE; q++) if (a == (uint32_t)q) { v.recs[q] = r.nrec; v.runs[q] = 1; }
-			}
-		}
-		return v;
+	wslot s = { 0xFFu, 0, 0, false, false };
+	const size_t n = in.n;
+	r = (xe_dgrun){ 0, 0, 0, 0 };
+	if (j >= n * nsets) return s;
+	const size_t i = j / nsets;
+	const uint32_t k = (uint32_t)(j - i * nsets);
+	s.walked = walked[i] != 0;
+	if (!s.walked) return s;
+	r = runs[k * n + i];
+	if (!r.nrec) return s;
+	s.run = true;
+	s.nrec = r.nrec;
+	s.tmpl = r.tmpl & 0xFFFFu;
+	s.a = tmap[s.tmpl];
+	return s;
+}
+
+/* exclusive prefix sum of v over the block's threads; *total = the block's sum */
+static __device__ __forceinline__ unsigned long long
+block_scan64(unsigned long long v, unsigned long long *wsum, unsigned long long *total)
+{
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	unsigned long long x = v;
+	for (int d = 1; d < 64; d <<= 1) {
+		const unsigned long long y = __shfl_up(x, d, 64);
+		if (lane >= (uint32_t)d) x += y;
 	}
-};
+	__syncthreads();                      /* (wsum may still be read from the scan before) */
+	if (lane == 63) wsum[wave] = x;
+	__syncthreads();
+	unsigned long long before = 0, all = 0;
+	for (uint32_t w = 0; w < XW_BLOCK / 64; w++) {
+		const unsigned long long t = wsum[w];
+		if (w < wave) before += t;
+		all += t;
+	}
+	*total = all;
+	return before + x - v;
+}
 
 /* Per template: records and runs of the datagrams the device listed (a block
  * adds up in LDS first: a batch has a handful of templates, and a hundred
  * thousand atomic adds to two addresses take longer than everything else here);
- * *total += the records of all datagrams, the host-walked ones included */
+ * *total += the records of all datagrams, the host-walked ones included
+ * (hostfirst NULL: the host walked none) */
 #define XW_TCACHE 32
 __global__ void __launch_bounds__(XW_BLOCK)
 xw_nf_totals_kernel(const xe_walk_in in, const xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
@@ -350,7 +372,7 @@ xw_nf_totals_kernel(const xe_walk_in in, const xe_dgrun *runs, uint32_t nsets, c
 	for (size_t i0 = (size_t)blockIdx.x * XW_BLOCK; i0 < n; i0 += (size_t)gridDim.x * XW_BLOCK) {
 		const size_t i = i0 + threadIdx.x;
 		const bool w = (i < n) && (walked[i] != 0);
-		if ((i < n) && !w) all += hostfirst[i + 1] - hostfirst[i];
+		if ((i < n) && !w && hostfirst) all += hostfirst[i + 1] - hostfirst[i];
 		for (uint32_t k = 0; k < nsets; k++) {
 			uint32_t mine = 0xFFFFFFFFu, nrec = 0;
 			if (w) {
@@ -394,76 +416,181 @@ xw_nf_totals_kernel(const xe_walk_in in, const xe_dgrun *runs, uint32_t nsets, c
 	if ((threadIdx.x == 0) && c_all) atomicAdd(total, c_all);
 }
 
-/* After a pass of the tuple scan: every run whose template was in the pass takes
- * its two prefix sums out of the 64-byte value (pos[j] = {records, runs of its
- * template before it}) and notes what the second scan adds up: the tiles that
- * start inside it (low word) and its records (high word).  Slots without a run
- * note theirs in the first pass: nothing, or - first slot of a datagram the
- * host walked - the records the host walk made of it. */
+/* step 1 of the tuple scan: per chunk and template of the pass, runs << 32 | records */
 __global__ void __launch_bounds__(XW_BLOCK)
-xw_nf_extract_kernel(const xe_walk_in in, const xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
-	const uint8_t *tmap, const xe_wtuple *scan, int first_pass, uint2 *pos, unsigned long long *val)
+xw_nf_tuple_sums_kernel(const xe_walk_in in, const xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint8_t *tmap,
+	unsigned long long *csum)
 {
-	const size_t j = (size_t)blockIdx.x * XW_BLOCK + threadIdx.x;
-	const size_t n = in.n;
-	if (j >= n * nsets) return;
-	const size_t i = j / nsets;
-	const uint32_t k = (uint32_t)(j - i * nsets);
-	const bool w = walked[i] != 0;
-	xe_dgrun r = { 0, 0, 0, 0 };
-	if (w) r = runs[k * n + i];
-	if (!w || !r.nrec) {
-		if (first_pass) val[j] = (!w && (k == 0)) ? ((unsigned long long)(hostfirst[i + 1] - hostfirst[i]) << 32) : 0ull;
-		return;
+	__shared__ unsigned long long acc[XE_WTUPLE];
+	const uint32_t lane = threadIdx.x & 63;
+	const size_t j0 = (size_t)blockIdx.x * XW_CHUNK + (size_t)threadIdx.x * XW_ITEMS;
+
+	if (threadIdx.x < XE_WTUPLE) acc[threadIdx.x] = 0;
+	__syncthreads();
+	for (int q = 0; q < XW_ITEMS; q++) {
+		xe_dgrun r;
+		const wslot s = slot_of(in, runs, nsets, walked, tmap, j0 + q, r);
+		unsigned long long todo = __ballot(s.a != 0xFFu);
+		while (todo) {
+			const int leader = __ffsll((long long)todo) - 1;
+			const uint32_t a = __shfl(s.a, leader, 64);
+			const bool same = s.a == a;
+			const unsigned long long grp = __ballot(same);
+			uint32_t sum = same ? s.nrec : 0;
+			for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d, 64);
+			if (lane == (uint32_t)leader) atomicAdd(&acc[a], ((unsigned long long)__popcll(grp) << 32) | sum);
+			todo &= ~grp;
+		}
 	}
-	const uint32_t a = tmap[r.tmpl & 0xFFFFu];
-	if (a == 0xFFu) return;
-	const uint32_t s = scan[j].recs[a];
-	pos[j] = make_uint2(s, scan[j].runs[a]);
-	val[j] = (unsigned long long)((s + r.nrec + 63) / 64 - (s + 63) / 64) | ((unsigned long long)r.nrec << 32);
+	__syncthreads();
+	if (threadIdx.x < XE_WTUPLE) csum[(size_t)blockIdx.x * XE_WTUPLE + threadIdx.x] = acc[threadIdx.x];
 }
 
-/* The run table (grouped by template, arrival order inside a group) and the
- * tile list (in the order of the batch index of each tile's first record);
- * recbase[i] = batch index of datagram i's first record */
+/* step 2 of either scan: exclusive prefix sums over the chunks, column by
+ * column (one wave per column of `width` columns; the halves of a value are
+ * summed apart: neither carries into the other) */
+__global__ void __launch_bounds__(64 * XE_WTUPLE)
+xw_chunk_scan_kernel(const unsigned long long *csum, unsigned long long *cpre, uint32_t nchunks, uint32_t width)
+{
+	const uint32_t lane = threadIdx.x & 63, col = threadIdx.x >> 6;
+	unsigned long long carry = 0;
+	if (col >= width) return;
+	for (uint32_t c0 = 0; c0 < nchunks; c0 += 64) {
+		const uint32_t c = c0 + lane;
+		const unsigned long long v = (c < nchunks) ? csum[(size_t)c * width + col] : 0;
+		unsigned long long x = v;
+		for (int d = 1; d < 64; d <<= 1) {
+			const unsigned long long y = __shfl_up(x, d, 64);
+			if (lane >= (uint32_t)d) x += y;
+		}
+		if (c < nchunks) cpre[(size_t)c * width + col] = carry + x - v;
+		carry += __shfl(x, 63, 64);
+	}
+}
+
+/* step 3 of the tuple scan: every run whose template is in the pass gets its
+ * two prefix sums (pos[j] = {records, runs of its template before it}) and
+ * notes what the second scan adds up: the tiles that start inside it (low
+ * word) and its records (high word).  Slots without a run note theirs in the
+ * first pass: nothing, or - first slot of a datagram the host walked - the
+ * records the host walk made of it.  With one pass the sums of the chunks for
+ * the second scan are taken here as well (vsum). */
+__global__ void __launch_bounds__(XW_BLOCK)
+xw_nf_tuple_apply_kernel(const xe_walk_in in, const xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
+	const uint8_t *tmap, const unsigned long long *cpre, uint32_t nact, int first_pass, uint2 *pos, unsigned long long *val,
+	unsigned long long *vsum)
+{
+	__shared__ unsigned long long wsum[XW_BLOCK / 64];
+	const size_t n = in.n, nslots = n * nsets;
+	const size_t j0 = (size_t)blockIdx.x * XW_CHUNK + (size_t)threadIdx.x * XW_ITEMS;
+	wslot s[XW_ITEMS];
+	unsigned long long myval = 0;
+	uint32_t px[XW_ITEMS], py[XW_ITEMS];
+
+	for (int q = 0; q < XW_ITEMS; q++) {
+		xe_dgrun r;
+		s[q] = slot_of(in, runs, nsets, walked, tmap, j0 + q, r);
+		px[q] = py[q] = 0;
+	}
+	for (uint32_t a = 0; a < nact; a++) {
+		unsigned long long x[XW_ITEMS], t = 0, all;
+		for (int q = 0; q < XW_ITEMS; q++) {
+			x[q] = (s[q].a == a) ? ((1ull << 32) | s[q].nrec) : 0;
+			t += x[q];
+		}
+		unsigned long long before = cpre[(size_t)blockIdx.x * XE_WTUPLE + a] + block_scan64(t, wsum, &all);
+		for (int q = 0; q < XW_ITEMS; q++) {
+			if (s[q].a == a) { px[q] = (uint32_t)before; py[q] = (uint32_t)(before >> 32); }
+			before += x[q];
+		}
+	}
+	for (int q = 0; q < XW_ITEMS; q++) {
+		const size_t j = j0 + q;
+		if (j >= nslots) continue;
+		if (s[q].a != 0xFFu) {
+			const unsigned long long v = (unsigned long long)((px[q] + s[q].nrec + 63) / 64 - (px[q] + 63) / 64) | ((unsigned long long)s[q].nrec << 32);
+			pos[j] = make_uint2(px[q], py[q]);
+			val[j] = v;
+			myval += v;
+		} else if (first_pass && !s[q].run) {
+			const size_t i = j / nsets;
+			const unsigned long long v = (!s[q].walked && hostfirst && (j == i * nsets)) ? ((unsigned long long)(hostfirst[i + 1] - hostfirst[i]) << 32) : 0ull;
+			val[j] = v;
+			myval += v;
+		}
+	}
+	if (vsum) {
+		unsigned long long all;
+		(void)block_scan64(myval, wsum, &all);
+		if (threadIdx.x == 0) vsum[blockIdx.x] = all;
+	}
+}
+
+/* step 1 of the second scan when the tuple scan took several passes */
+__global__ void __launch_bounds__(XW_BLOCK)
+xw_val_sums_kernel(const unsigned long long *val, size_t nslots, unsigned long long *vsum)
+{
+	__shared__ unsigned long long wsum[XW_BLOCK / 64];
+	const size_t j0 = (size_t)blockIdx.x * XW_CHUNK + (size_t)threadIdx.x * XW_ITEMS;
+	unsigned long long t = 0, all;
+	for (int q = 0; q < XW_ITEMS; q++) if (j0 + q < nslots) t += val[j0 + q];
+	(void)block_scan64(t, wsum, &all);
+	if (threadIdx.x == 0) vsum[blockIdx.x] = all;
+}
+
+/* step 3 of the second scan, and what it was for: the run table (grouped by
+ * template, arrival order inside a group), the tile list (in the order of the
+ * batch index of each tile's first record) and recbase[i] = batch index of
+ * datagram i's first record */
 __global__ void __launch_bounds__(XW_BLOCK)
 xw_nf_runs_kernel(const xe_walk_in in, const xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint2 *pos,
-	const unsigned long long *vscan, const xe_wgroup *groups, xe_frun *out, xe_ftile *tiles, uint32_t *recbase)
+	const unsigned long long *val, const unsigned long long *vpre, const xe_wgroup *groups, xe_frun *out, xe_ftile *tiles,
+	uint32_t *recbase)
 {
-	const size_t j = (size_t)blockIdx.x * XW_BLOCK + threadIdx.x;
-	const size_t n = in.n;
-	if (j > n * nsets) return;
-	if (j == n * nsets) { recbase[n] = (uint32_t)(vscan[j] >> 32); return; }
-	const size_t i = j / nsets;
-	const uint32_t k = (uint32_t)(j - i * nsets);
-	const unsigned long long x = vscan[j];
-	const uint32_t first_rec = (uint32_t)(x >> 32);
-	if (k == 0) recbase[i] = first_rec;
-	if (!walked[i]) return;
-	const xe_dgrun r = runs[k * n + i];
-	if (!r.nrec) return;
-	const uint32_t t = r.tmpl & 0xFFFFu;
-	const xe_wgroup g = groups[t];
-	const uint2 p = pos[j];
-	xe_frun f;
-	f.data_off = (uint32_t)in.offs[i] + (r.tmpl >> 16);
-	f.first_rec = first_rec;
-	f.start = g.pos0 + p.x;
-	f.nrec = r.nrec;
-	f.stride = in.twalk[t].stride | (r.rate & 0x80000000u);
-	f.rate = r.rate & 0x7FFFFFFFu;
-	f.dev_ip = __builtin_bswap32(in.src[i]);
-	f.dev_id = r.dev_id;
-	out[g.run0 + p.y] = f;
-	/* the tiles that start inside this run */
-	uint32_t at = (uint32_t)x;
-	for (uint32_t q = (p.x + 63) / 64; (uint64_t)q * 64 < (uint64_t)p.x + r.nrec; q++, at++) {
-		xe_ftile ft;
-		ft.first_run = g.run0 + p.y;
-		ft.tmpl = t;
-		ft.base = g.pos0 + 64 * q;
-		ft.pad = first_rec + (64 * q - p.x);
-		tiles[at] = ft;
+	__shared__ unsigned long long wsum[XW_BLOCK / 64];
+	const size_t n = in.n, nslots = n * nsets;
+	const size_t j0 = (size_t)blockIdx.x * XW_CHUNK + (size_t)threadIdx.x * XW_ITEMS;
+	unsigned long long v[XW_ITEMS], t = 0, all;
+
+	for (int q = 0; q < XW_ITEMS; q++) {
+		v[q] = (j0 + q < nslots) ? val[j0 + q] : 0;
+		t += v[q];
+	}
+	unsigned long long x = vpre[blockIdx.x] + block_scan64(t, wsum, &all);
+	for (int q = 0; q < XW_ITEMS; q++, x += v[q - 1]) {
+		const size_t j = j0 + q;
+		if (j > nslots) break;
+		const uint32_t first_rec = (uint32_t)(x >> 32);
+		if (j == nslots) { recbase[n] = first_rec; break; }
+		const size_t i = j / nsets;
+		const uint32_t k = (uint32_t)(j - i * nsets);
+		if (k == 0) recbase[i] = first_rec;
+		if (!walked[i]) continue;
+		const xe_dgrun r = runs[k * n + i];
+		if (!r.nrec) continue;
+		const uint32_t tm = r.tmpl & 0xFFFFu;
+		const xe_wgroup g = groups[tm];
+		const uint2 p = pos[j];
+		xe_frun f;
+		f.data_off = (uint32_t)in.offs[i] + (r.tmpl >> 16);
+		f.first_rec = first_rec;
+		f.start = g.pos0 + p.x;
+		f.nrec = r.nrec;
+		f.stride = in.twalk[tm].stride | (r.rate & 0x80000000u);
+		f.rate = r.rate & 0x7FFFFFFFu;
+		f.dev_ip = __builtin_bswap32(in.src[i]);
+		f.dev_id = r.dev_id;
+		out[g.run0 + p.y] = f;
+		/* the tiles that start inside this run */
+		uint32_t at = (uint32_t)x;
+		for (uint32_t tq = (p.x + 63) / 64; (uint64_t)tq * 64 < (uint64_t)p.x + r.nrec; tq++, at++) {
+			xe_ftile ft;
+			ft.first_run = g.run0 + p.y;
+			ft.tmpl = tm;
+			ft.base = g.pos0 + 64 * tq;
+			ft.pad = first_rec + (64 * tq - p.x);
+			tiles[at] = ft;
+		}
 	}
 }
 
@@ -483,20 +610,10 @@ xw_done(void)
 extern "C" size_t
 xe_walk_temp_bytes(size_t n)
 {
-	size_t a = 0, b = 0, c = 0;
+	size_t a = 0;
 	uint32_t *z = nullptr;
-	unsigned long long *z8 = nullptr;
-	xe_wtuple *zt = nullptr;
-	xe_wtuple zero;
-	wtuple_in src = { nullptr, nullptr, nullptr, 0, 1 };
-	memset(&zero, 0, sizeof(zero));
 	if (!n) n = 1;
 	(void)rocprim::exclusive_scan(nullptr, a, z, z, 0u, n + 1, rocprim::plus<uint32_t>(), (hipStream_t)0);
-	(void)rocprim::exclusive_scan(nullptr, b, z8, z8, 0ull, n + 1, rocprim::plus<unsigned long long>(), (hipStream_t)0);
-	(void)rocprim::exclusive_scan(nullptr, c, rocprim::make_transform_iterator(rocprim::make_counting_iterator(0u), src), zt, zero, n + 1,
-		wtuple_plus(), (hipStream_t)0);
-	if (b > a) a = b;
-	if (c > a) a = c;
 	return a + 256;
 }
 
@@ -506,29 +623,6 @@ xe_walk_scan(void *temp, size_t temp_bytes, uint32_t *in, uint32_t *out, size_t 
 	hipStream_t st = (hipStream_t)stream;
 	if (hipMemsetAsync(in + n, 0, 4, st) != hipSuccess) return XE_EHIP;
 	if (rocprim::exclusive_scan(temp, temp_bytes, in, out, 0u, n + 1, rocprim::plus<uint32_t>(), st) != hipSuccess) return XE_EHIP;
-	return XE_OK;
-}
-
-extern "C" int
-xe_walk_scan64(void *temp, size_t temp_bytes, unsigned long long *in, unsigned long long *out, size_t n, void *stream)
-{
-	hipStream_t st = (hipStream_t)stream;
-	if (hipMemsetAsync(in + n, 0, 8, st) != hipSuccess) return XE_EHIP;
-	if (rocprim::exclusive_scan(temp, temp_bytes, in, out, 0ull, n + 1, rocprim::plus<unsigned long long>(), st) != hipSuccess) return XE_EHIP;
-	return XE_OK;
-}
-
-extern "C" int
-xe_walk_nf_tuple_scan(void *temp, size_t temp_bytes, const struct xe_walk_in *in, const struct xe_dgrun *runs, uint32_t nsets,
-	const uint8_t *walked, const uint8_t *tmap, void *scan, void *stream)
-{
-	const size_t nslots = (size_t)in->n * nsets;
-	wtuple_in src = { runs, walked, tmap, in->n, nsets };
-	xe_wtuple zero;
-	memset(&zero, 0, sizeof(zero));
-	if (!nslots) return XE_OK;
-	if (rocprim::exclusive_scan(temp, temp_bytes, rocprim::make_transform_iterator(rocprim::make_counting_iterator(0u), src),
-		(xe_wtuple *)scan, zero, nslots, wtuple_plus(), (hipStream_t)stream) != hipSuccess) return XE_EHIP;
 	return XE_OK;
 }
 
@@ -568,25 +662,48 @@ xe_walk_nf_totals(const struct xe_walk_in *in, const struct xe_dgrun *runs, uint
 	return xw_done();
 }
 
-extern "C" int
-xe_walk_nf_extract(const struct xe_walk_in *in, const struct xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
-	const uint8_t *tmap, const void *scan, int first_pass, void *pos, unsigned long long *val, void *stream)
+extern "C" size_t
+xe_walk_nf_chunks(size_t n, uint32_t nsets)
 {
-	const size_t nslots = (size_t)in->n * nsets;
-	if (!nslots) return XE_OK;
-	hipLaunchKernelGGL(xw_nf_extract_kernel, dim3(xw_blocks(nslots)), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, runs, nsets, walked,
-		hostfirst, tmap, (const xe_wtuple *)scan, first_pass, (uint2 *)pos, val);
-	return xw_done();
+	return (n * nsets + 1 + XW_CHUNK - 1) / XW_CHUNK;
 }
 
 extern "C" int
-xe_walk_nf_runs(const struct xe_walk_in *in, const struct xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const void *pos,
-	const unsigned long long *vscan, const struct xe_wgroup *groups, struct xe_frun *out, struct xe_ftile *tiles, uint32_t *recbase,
-	void *stream)
+xe_walk_nf_tables(const struct xe_walk_in *in, const struct xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
+	const uint8_t *tmaps, uint32_t npass, uint32_t nactive, const struct xe_wgroup *groups, void *work,
+	struct xe_frun *out, struct xe_ftile *tiles, uint32_t *recbase, void *stream)
 {
+	hipStream_t st = (hipStream_t)stream;
 	const size_t nslots = (size_t)in->n * nsets;
+	const uint32_t nchunks = (uint32_t)xe_walk_nf_chunks(in->n, nsets);
+	uint8_t *wk = (uint8_t *)work;
+	/* the layout xe_walk_nf_work_bytes() sizes */
+	unsigned long long *csum = (unsigned long long *)wk; wk += (size_t)nchunks * XE_WTUPLE * 8;
+	unsigned long long *cpre = (unsigned long long *)wk; wk += (size_t)nchunks * XE_WTUPLE * 8;
+	unsigned long long *vsum = (unsigned long long *)wk; wk += (size_t)nchunks * 8;
+	unsigned long long *vpre = (unsigned long long *)wk; wk += (size_t)nchunks * 8;
+	uint2 *pos = (uint2 *)wk; wk += (nslots + 1) * 8;
+	unsigned long long *val = (unsigned long long *)wk;
+
 	if (!in->n) return XE_OK;
-	hipLaunchKernelGGL(xw_nf_runs_kernel, dim3(xw_blocks(nslots + 1)), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, runs, nsets, walked,
-		(const uint2 *)pos, vscan, groups, out, tiles, recbase);
+	for (uint32_t p = 0; p < npass; p++) {
+		const uint8_t *tmap = tmaps + (size_t)p * (in->ntmpl + 1);
+		const uint32_t nact = (nactive > p * XE_WTUPLE) ? ((nactive - p * XE_WTUPLE > XE_WTUPLE) ? XE_WTUPLE : nactive - p * XE_WTUPLE) : 0;
+		hipLaunchKernelGGL(xw_nf_tuple_sums_kernel, dim3(nchunks), dim3(XW_BLOCK), 0, st, *in, runs, nsets, walked, tmap, csum);
+		hipLaunchKernelGGL(xw_chunk_scan_kernel, dim3(1), dim3(64 * XE_WTUPLE), 0, st, csum, cpre, nchunks, (uint32_t)XE_WTUPLE);
+		hipLaunchKernelGGL(xw_nf_tuple_apply_kernel, dim3(nchunks), dim3(XW_BLOCK), 0, st, *in, runs, nsets, walked, hostfirst, tmap, cpre,
+			nact, (int)(p == 0), pos, val, (npass == 1) ? vsum : (unsigned long long *)nullptr);
+	}
+	if (npass != 1) hipLaunchKernelGGL(xw_val_sums_kernel, dim3(nchunks), dim3(XW_BLOCK), 0, st, val, nslots, vsum);
+	hipLaunchKernelGGL(xw_chunk_scan_kernel, dim3(1), dim3(64 * XE_WTUPLE), 0, st, vsum, vpre, nchunks, 1u);
+	hipLaunchKernelGGL(xw_nf_runs_kernel, dim3(nchunks), dim3(XW_BLOCK), 0, st, *in, runs, nsets, walked, pos, val, vpre, groups, out, tiles,
+		recbase);
 	return xw_done();
+}
+
+extern "C" size_t
+xe_walk_nf_work_bytes(size_t n, uint32_t nsets)
+{
+	const size_t nchunks = xe_walk_nf_chunks(n, nsets);
+	return nchunks * XE_WTUPLE * 8 * 2 + nchunks * 8 * 2 + (n * nsets + 1) * 8 * 2 + 256;
 }
