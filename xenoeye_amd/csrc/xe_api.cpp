@@ -76,10 +76,6 @@ struct xe_gpu
 	char err[512];
 };
 #define XE_WSTAGE_BYTES (64 * 1024)
-/* device words the walk adds up into, cleared once per batch: 32 bytes of
- * totals ([0] sFlow records, [1] Netflow records, [2] u32 most runs of a
- * datagram + u32 datagrams left to the host), then per template records and runs */
-#define XE_WZERO_BYTES(NT) (32 + 8 * ((NT) + 2))
 
 struct fwm_host
 {
@@ -112,7 +108,8 @@ struct walk_dev
 	void *d_temp; size_t temp_bytes;
 	struct xe_dgrun *d_dgruns;
 	uint8_t *d_walked;
-	uint32_t *d_hostfirst, *d_recbase, *d_gtotal, *d_gruns;
+	uint32_t *d_hostfirst, *d_recbase;
+	int sums_valid;            /* the shape kernel's per-template sums hold (no datagram was left to the host) */
 	struct xe_wgroup *d_groups;
 	struct xe_frun *d_fruns2;
 	struct xe_ftile *d_ftiles2;
@@ -2383,9 +2380,6 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 		w->d_walked = base + o_walked;
 		w->d_hostfirst = (uint32_t *)(base + o_hostfirst);
 		w->d_recbase = (uint32_t *)(base + o_recbase);
-		/* the per-template sums lie behind the totals: one clear, one copy back */
-		w->d_gtotal = (uint32_t *)(base + o_total + 32);
-		w->d_gruns = w->d_gtotal + (nt + 2);
 	}
 	/* (cleared ahead of the copies below, which it then runs beside) */
 	HIPCHK(h, hipMemsetAsync(w->d_total, 0, (mode & 2) ? XE_WZERO_BYTES(nt) : 32, st));
@@ -2415,11 +2409,11 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 	memcpy(w->h_src, src, 4 * n);
 	if (mode & 2) {
 		in.pkt = w->hdr_src;
-		rc = xe_walk_nf_shape(&in, w->d_dgruns, w->d_walked, (uint32_t *)(w->d_total + 2), st);
+		rc = xe_walk_nf_shape(&in, w->d_dgruns, w->d_walked, w->d_total, st);
 		if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (Netflow)");
 		w->h_walked = (uint8_t *)malloc(n ? n : 1);
 		if (!w->h_walked) return XE_ENOMEM;
-		HIPCHK(h, hipMemcpyAsync((uint8_t *)h->wstage + 16, w->d_total + 2, 8, hipMemcpyDeviceToHost, st));
+		HIPCHK(h, hipMemcpyAsync((uint8_t *)h->wstage + 16, w->d_total + 2, XE_WZERO_BYTES(nt) - 16, hipMemcpyDeviceToHost, st));
 	}
 	if (mode & 1) {
 		in.pkt = (const uint8_t *)b->d_pkt;
@@ -2436,7 +2430,8 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 		w->nsets = *(volatile uint32_t *)((uint8_t *)h->wstage + 16);
 		if (w->nsets < 1) w->nsets = 1;
 		if (w->nsets > XE_WALK_SETS) w->nsets = XE_WALK_SETS;
-		if (*(volatile uint32_t *)((uint8_t *)h->wstage + 20) == 0) {
+		w->sums_valid = *(volatile uint32_t *)((uint8_t *)h->wstage + 20) == 0;
+		if (w->sums_valid) {
 			/* every Netflow datagram is of the usual shape */
 			for (size_t i = 0; i < n; i++) w->h_walked[i] = !(kinds && (kinds[i] == XE_KIND_SFLOW));
 		} else {
@@ -2540,8 +2535,8 @@ walk_finish(xe_gpu *h, xe_batch *b)
 	if (w->mode & 2) {
 		/* the words the device added up, as they lie in its arena (XE_WZERO_BYTES):
 		 * cnt[0, nt + 2) records, cnt[nt + 2, ...) runs per template */
-		const uint8_t *back = (const uint8_t *)h->wstage;
-		const uint32_t *cnt = (const uint32_t *)(back + 32), *cntruns = cnt + (nt + 2);
+		uint8_t *back = (uint8_t *)h->wstage;
+		uint32_t *cnt = (uint32_t *)(back + 32 + 8), *cntruns = cnt + (nt + 2);
 		struct xe_wgroup *gr;
 		uint8_t *tmap;
 		const struct xe_tmpl *tm = (const struct xe_tmpl *)h->hs.dev_tmpls.p;
@@ -2551,16 +2546,31 @@ walk_finish(xe_gpu *h, xe_batch *b)
 		uint8_t *fbase;
 
 		if (XE_WZERO_BYTES(nt) > XE_WSTAGE_BYTES) return XE_WALK_RETRY_ON_HOST;
-		walk_mark(h, w, st);
 		if (plan->nrec) HIPCHK(h, hipMemcpyAsync(w->d_hostfirst, plan->dg_first_nf, 4 * (n + 1), hipMemcpyHostToDevice, st));
-		rc = xe_walk_nf_totals(&in, w->d_dgruns, w->nsets, w->d_walked, d_hostfirst, w->d_gtotal, w->d_gruns, w->d_total + 1, st);
-		if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (totals)");
-		HIPCHK(h, hipMemcpyAsync((uint8_t *)h->wstage + 8, w->d_total + 1, XE_WZERO_BYTES(nt) - 8, hipMemcpyDeviceToHost, st));
-		walk_mark(h, w, st);
-		WTICK(1);
-		HIPCHK(h, hipStreamSynchronize(st));
-		WTICK(2);
-		memcpy(&total, back + 8, 8);
+		if (!w->sums_valid || xe_host_undo_count(&h->hs)) {
+			/* the host walked some datagrams (and may have taken exporters back from
+			 * the device): the sums once more, over what is still listed here */
+			walk_mark(h, w, st);
+			HIPCHK(h, hipMemsetAsync((uint8_t *)w->d_total + 32, 0, XE_WZERO_BYTES(nt) - 32, st));
+			rc = xe_walk_nf_totals(&in, w->d_dgruns, w->nsets, w->d_walked, d_hostfirst, w->d_total, st);
+			if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (totals)");
+			HIPCHK(h, hipMemcpyAsync(back + 32, (uint8_t *)w->d_total + 32, XE_WZERO_BYTES(nt) - 32, hipMemcpyDeviceToHost, st));
+			walk_mark(h, w, st);
+			WTICK(1);
+			HIPCHK(h, hipStreamSynchronize(st));
+			WTICK(2);
+		}
+		/* the copies add up in the first */
+		for (size_t c = 1; c < XE_WCOPIES; c++) {
+			const uint8_t *src = back + 32 + c * XE_WCOPY_BYTES(nt);
+			uint64_t a, bsum;
+			memcpy(&a, back + 32, 8);
+			memcpy(&bsum, src, 8);
+			a += bsum;
+			memcpy(back + 32, &a, 8);
+			for (size_t t = 0; t < 2 * (nt + 2); t++) cnt[t] += ((const uint32_t *)(src + 8))[t];
+		}
+		memcpy(&total, back + 32, 8);
 		if (total + plan->nsf > 0xFFFFFFF0ull) return XE_EUNSUPPORTED;
 		/* from 2^28 records on the fast kernel is out (32-bit column offsets) */
 		if (total + plan->nsf >= fast_record_limit(h)) return XE_WALK_RETRY_ON_HOST;

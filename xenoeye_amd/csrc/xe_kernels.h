@@ -230,6 +230,16 @@ struct xe_dgrun
 	uint32_t rate;        /* sampling rate | has a devices.conf entry << 31 */
 };
 
+/* Device words the Netflow walk adds up into, cleared once per batch: 32 bytes
+ * ([0] u64 sFlow records of the batch, [2] u32 most runs of a datagram + u32
+ * Netflow datagrams left to the host), then XE_WCOPIES copies (a block adds to
+ * copy blockIdx % XE_WCOPIES: adds to one address from all over the chip queue
+ * up) of { u64 records of all datagrams; u32 records[nt + 2]; u32 runs[nt + 2] }
+ * per device template */
+#define XE_WCOPIES 8
+#define XE_WCOPY_BYTES(NT) (8 + 8 * ((size_t)(NT) + 2))
+#define XE_WZERO_BYTES(NT) (32 + XE_WCOPIES * XE_WCOPY_BYTES(NT))
+
 /* what the sFlow walk leaves per datagram */
 #define XE_SFDG_POS 8
 #define XE_SFDG_WALK 0x80000000u     /* len: not of the usual shape, the decode kernel walks the datagram itself */
@@ -288,13 +298,13 @@ int xe_walk_sf_place(uint32_t n, const uint32_t *base, const struct xe_sfdg *dgs
 
 /* Netflow: per datagram, the runs it yields when its shape is the usual one
  * (runs[k * n + i], k < XE_WALK_SETS, nrec > 0 for those it has; regular[i] = 1),
- * else regular[i] = 0; kmax[0] = the most runs of any datagram (atomic max), kmax[1] += Netflow datagrams that are not regular */
-int xe_walk_nf_shape(const struct xe_walk_in *in, struct xe_dgrun *runs, uint8_t *regular, uint32_t *kmax, void *stream);
-/* gtotal[t] += records, gruns[t] += runs of template t in the datagrams the device listed (walked[i] != 0, runs
- * runs[k * n + i], k < nsets); *total += the records of all datagrams (hostfirst[i + 1] - hostfirst[i] for those the host
- * walked) */
+ * else regular[i] = 0.  sums = the XE_WZERO_BYTES(in->ntmpl) words above: most runs of a datagram (atomic max), Netflow
+ * datagrams that are not regular, and - valid when there are none of those - per template the records and runs listed */
+int xe_walk_nf_shape(const struct xe_walk_in *in, struct xe_dgrun *runs, uint8_t *regular, void *sums, void *stream);
+/* the same sums (the copies of `sums` must have been cleared) after the host walk has had its say: over the datagrams
+ * with walked[i] != 0, plus hostfirst[i + 1] - hostfirst[i] records for each of the others (hostfirst NULL: none) */
 int xe_walk_nf_totals(const struct xe_walk_in *in, const struct xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
-	uint32_t *gtotal, uint32_t *gruns, unsigned long long *total, void *stream);
+	void *sums, void *stream);
 /* per template group t: first position, first run (ntmpl + 1 entries each) */
 struct xe_wgroup { uint32_t pos0, run0, tile0, pad; };
 /* Run slots are numbered in arrival order, slot j = datagram * nsets + set.  From the runs to the fast kernel's

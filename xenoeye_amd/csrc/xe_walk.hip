@@ -165,15 +165,88 @@ exporter_plain(const xe_walk_in &in, uint32_t ip, uint32_t id, uint32_t &rate)
 	return d.plain && !(d.rate & 0x80000000u);
 }
 
+/* Per template: records and runs, added up per block in LDS first (a batch has
+ * a handful of templates, and a hundred thousand atomic adds to two addresses
+ * take longer than everything else here), then into one of the copies */
+#define XW_TCACHE 32
+struct wtotals { uint32_t t[XW_TCACHE], rec[XW_TCACHE], run[XW_TCACHE]; unsigned long long all; };
+
+static __device__ __forceinline__ uint8_t *
+wtotals_copy(void *sums, uint32_t nt)
+{
+	return (uint8_t *)sums + 32 + (size_t)(blockIdx.x % XE_WCOPIES) * XE_WCOPY_BYTES(nt);
+}
+
+static __device__ __forceinline__ void
+wtotals_init(wtotals &T)
+{
+	if (threadIdx.x < XW_TCACHE) { T.t[threadIdx.x] = 0xFFFFFFFFu; T.rec[threadIdx.x] = T.run[threadIdx.x] = 0; }
+	if (threadIdx.x == 0) T.all = 0;
+	__syncthreads();
+}
+
+/* all lanes of the wave call this together; mine = template or 0xFFFFFFFF */
+static __device__ __forceinline__ void
+wtotals_add(wtotals &T, uint32_t mine, uint32_t nrec, void *sums, uint32_t nt)
+{
+	const uint32_t lane = threadIdx.x & 63;
+	unsigned long long todo = __ballot(mine != 0xFFFFFFFFu);
+	while (todo) {
+		const int leader = __ffsll((long long)todo) - 1;
+		const uint32_t t = __shfl(mine, leader, 64);
+		const bool same = mine == t;
+		const unsigned long long grp = __ballot(same);
+		uint32_t sum = same ? nrec : 0;
+		for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d, 64);
+		if (lane == (uint32_t)leader) {
+			/* the block's entry of this template, or memory when the block has met more than it holds */
+			uint32_t e = t % XW_TCACHE, tries = 0;
+			for (; tries < XW_TCACHE; tries++, e = (e + 1) % XW_TCACHE) {
+				const uint32_t was = atomicCAS(&T.t[e], 0xFFFFFFFFu, t);
+				if ((was == 0xFFFFFFFFu) || (was == t)) break;
+			}
+			if (tries < XW_TCACHE) {
+				atomicAdd(&T.rec[e], sum);
+				atomicAdd(&T.run[e], (uint32_t)__popcll(grp));
+			} else {
+				uint32_t *g = (uint32_t *)(wtotals_copy(sums, nt) + 8);
+				atomicAdd(&g[t], sum);
+				atomicAdd(&g[nt + 2 + t], (uint32_t)__popcll(grp));
+			}
+		}
+		todo &= ~grp;
+	}
+}
+
+/* all threads of the block; `all` = this thread's records of any template */
+static __device__ __forceinline__ void
+wtotals_flush(wtotals &T, unsigned long long all, void *sums, uint32_t nt)
+{
+	uint8_t *c = wtotals_copy(sums, nt);
+	uint32_t *g = (uint32_t *)(c + 8);
+	for (int d = 32; d; d >>= 1) all += __shfl_down(all, d, 64);
+	if (((threadIdx.x & 63) == 0) && all) atomicAdd(&T.all, all);
+	__syncthreads();
+	if ((threadIdx.x < XW_TCACHE) && (T.t[threadIdx.x] != 0xFFFFFFFFu)) {
+		atomicAdd(&g[T.t[threadIdx.x]], T.rec[threadIdx.x]);
+		atomicAdd(&g[nt + 2 + T.t[threadIdx.x]], T.run[threadIdx.x]);
+	}
+	if ((threadIdx.x == 0) && T.all) atomicAdd((unsigned long long *)c, T.all);
+}
+
 /* A datagram of the usual shape yields up to XE_WALK_SETS runs, one per data
  * set: runs[k * n + i] is run k of datagram i (nrec 0: none). */
 __global__ void __launch_bounds__(XW_BLOCK)
-xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular, uint32_t *kmax)
+xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular, void *sums)
 {
+	__shared__ wtotals T;
 	const uint32_t i = blockIdx.x * XW_BLOCK + threadIdx.x;
 	const size_t n = in.n;
+	uint32_t *kmax = (uint32_t *)sums + 4;
 	uint32_t k = 0;
 	bool ok = false;
+
+	wtotals_init(T);
 
 	if ((i < in.n) && !(in.kinds && (in.kinds[i] == XE_KIND_SFLOW))) {
 		const uint64_t off = in.offs[i];
@@ -268,17 +341,30 @@ xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular, uint32
 		regular[i] = ok ? 1 : 0;
 	}
 	/* the most runs any datagram has: the later steps look at that many only;
-	 * and how many Netflow datagrams are left to the host (none, on a collector
+	 * how many Netflow datagrams are left to the host (none, on a collector
 	 * whose exporters' templates are known: the per-datagram flags then need not
-	 * travel) */
+	 * travel); and the per-template sums of what was listed, which hold when
+	 * nothing is left to the host */
 	{
 		uint32_t m = k;
+		unsigned long long all = 0;
 		const unsigned long long left = __ballot((i < in.n) && !ok && !(in.kinds && (in.kinds[i] == XE_KIND_SFLOW)));
 		for (int d = 32; d; d >>= 1) { const uint32_t o = __shfl_xor(m, d, 64); m = (o > m) ? o : m; }
 		if ((threadIdx.x & 63) == 0) {
 			if (m) atomicMax(kmax, m);
 			if (left) atomicAdd(kmax + 1, (uint32_t)__popcll(left));
 		}
+		for (uint32_t q = 0; q < m; q++) {
+			uint32_t mine = 0xFFFFFFFFu, nrec = 0;
+			if (q < k) {
+				const xe_dgrun r = runs[q * n + i];   /* (this thread's own store) */
+				mine = r.tmpl & 0xFFFFu;
+				nrec = r.nrec;
+				all += nrec;
+			}
+			wtotals_add(T, mine, nrec, sums, in.ntmpl);
+		}
+		wtotals_flush(T, all, sums, in.ntmpl);
 	}
 }
 
@@ -350,25 +436,17 @@ block_scan64(unsigned long long v, unsigned long long *wsum, unsigned long long 
 	return before + x - v;
 }
 
-/* Per template: records and runs of the datagrams the device listed (a block
- * adds up in LDS first: a batch has a handful of templates, and a hundred
- * thousand atomic adds to two addresses take longer than everything else here);
- * *total += the records of all datagrams, the host-walked ones included
- * (hostfirst NULL: the host walked none) */
-#define XW_TCACHE 32
+/* the sums of the shape kernel once more, after the host walk: over the
+ * datagrams still listed here, plus what the host made of the others */
 __global__ void __launch_bounds__(XW_BLOCK)
 xw_nf_totals_kernel(const xe_walk_in in, const xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
-	uint32_t *gtotal, uint32_t *gruns, unsigned long long *total)
+	void *sums)
 {
-	__shared__ uint32_t c_t[XW_TCACHE], c_rec[XW_TCACHE], c_run[XW_TCACHE];
-	__shared__ unsigned long long c_all;
+	__shared__ wtotals T;
 	const size_t n = in.n;
-	const uint32_t lane = threadIdx.x & 63;
 	unsigned long long all = 0;
 
-	if (threadIdx.x < XW_TCACHE) { c_t[threadIdx.x] = 0xFFFFFFFFu; c_rec[threadIdx.x] = c_run[threadIdx.x] = 0; }
-	if (threadIdx.x == 0) c_all = 0;
-	__syncthreads();
+	wtotals_init(T);
 	for (size_t i0 = (size_t)blockIdx.x * XW_BLOCK; i0 < n; i0 += (size_t)gridDim.x * XW_BLOCK) {
 		const size_t i = i0 + threadIdx.x;
 		const bool w = (i < n) && (walked[i] != 0);
@@ -379,41 +457,10 @@ xw_nf_totals_kernel(const xe_walk_in in, const xe_dgrun *runs, uint32_t nsets, c
 				const xe_dgrun r = runs[k * n + i];
 				if (r.nrec) { mine = r.tmpl & 0xFFFFu; nrec = r.nrec; all += nrec; }
 			}
-			unsigned long long todo = __ballot(mine != 0xFFFFFFFFu);
-			while (todo) {
-				const int leader = __ffsll((long long)todo) - 1;
-				const uint32_t t = __shfl(mine, leader, 64);
-				const bool same = mine == t;
-				const unsigned long long grp = __ballot(same);
-				uint32_t sum = same ? nrec : 0;
-				for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d, 64);
-				if (lane == (uint32_t)leader) {
-					/* the block's entry of this template, or memory when the block has met more than it holds */
-					uint32_t e = t % XW_TCACHE, tries = 0;
-					for (; tries < XW_TCACHE; tries++, e = (e + 1) % XW_TCACHE) {
-						const uint32_t was = atomicCAS(&c_t[e], 0xFFFFFFFFu, t);
-						if ((was == 0xFFFFFFFFu) || (was == t)) break;
-					}
-					if (tries < XW_TCACHE) {
-						atomicAdd(&c_rec[e], sum);
-						atomicAdd(&c_run[e], (uint32_t)__popcll(grp));
-					} else {
-						atomicAdd(&gtotal[t], sum);
-						atomicAdd(&gruns[t], (uint32_t)__popcll(grp));
-					}
-				}
-				todo &= ~grp;
-			}
+			wtotals_add(T, mine, nrec, sums, in.ntmpl);
 		}
 	}
-	for (int d = 32; d; d >>= 1) all += __shfl_down(all, d, 64);
-	if ((lane == 0) && all) atomicAdd(&c_all, all);
-	__syncthreads();
-	if ((threadIdx.x < XW_TCACHE) && (c_t[threadIdx.x] != 0xFFFFFFFFu)) {
-		atomicAdd(&gtotal[c_t[threadIdx.x]], c_rec[threadIdx.x]);
-		atomicAdd(&gruns[c_t[threadIdx.x]], c_run[threadIdx.x]);
-	}
-	if ((threadIdx.x == 0) && c_all) atomicAdd(total, c_all);
+	wtotals_flush(T, all, sums, in.ntmpl);
 }
 
 /* step 1 of the tuple scan: per chunk and template of the pass, runs << 32 | records */
@@ -643,22 +690,21 @@ xe_walk_sf_place(uint32_t n, const uint32_t *base, const struct xe_sfdg *dgs, st
 }
 
 extern "C" int
-xe_walk_nf_shape(const struct xe_walk_in *in, struct xe_dgrun *runs, uint8_t *regular, uint32_t *kmax, void *stream)
+xe_walk_nf_shape(const struct xe_walk_in *in, struct xe_dgrun *runs, uint8_t *regular, void *sums, void *stream)
 {
 	if (!in->n) return XE_OK;
-	hipLaunchKernelGGL(xw_nf_shape_kernel, dim3(xw_blocks(in->n)), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, runs, regular, kmax);
+	hipLaunchKernelGGL(xw_nf_shape_kernel, dim3(xw_blocks(in->n)), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, runs, regular, sums);
 	return xw_done();
 }
 
 extern "C" int
 xe_walk_nf_totals(const struct xe_walk_in *in, const struct xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
-	uint32_t *gtotal, uint32_t *gruns, unsigned long long *total, void *stream)
+	void *sums, void *stream)
 {
 	uint32_t blocks = xw_blocks(in->n);
 	if (!in->n) return XE_OK;
-	if (blocks > 512) blocks = 512;
-	hipLaunchKernelGGL(xw_nf_totals_kernel, dim3(blocks), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, runs, nsets, walked, hostfirst,
-		gtotal, gruns, total);
+	if (blocks > 256) blocks = 256;
+	hipLaunchKernelGGL(xw_nf_totals_kernel, dim3(blocks), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, runs, nsets, walked, hostfirst, sums);
 	return xw_done();
 }
 
