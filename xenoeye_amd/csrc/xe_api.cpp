@@ -2413,7 +2413,7 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 		if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (Netflow)");
 		w->h_walked = (uint8_t *)malloc(n ? n : 1);
 		if (!w->h_walked) return XE_ENOMEM;
-		HIPCHK(h, hipMemcpyAsync((uint8_t *)h->wstage + 16, w->d_total + 2, XE_WZERO_BYTES(nt) - 16, hipMemcpyDeviceToHost, st));
+		HIPCHK(h, hipMemcpyAsync((uint8_t *)h->wstage + 32, w->d_total + 4, XE_WZERO_BYTES(nt) - 32, hipMemcpyDeviceToHost, st));
 	}
 	if (mode & 1) {
 		in.pkt = (const uint8_t *)b->d_pkt;
@@ -2427,10 +2427,19 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 	 * on the device it starts at once and the device counts beside it */
 	if (mode & 2) {
 		HIPCHK(h, hipStreamSynchronize(st));
-		w->nsets = *(volatile uint32_t *)((uint8_t *)h->wstage + 16);
+		{
+			/* most runs of a datagram, datagrams left to the host: over the copies */
+			uint32_t kmax = 0, left = 0;
+			for (size_t c = 0; c < XE_WCOPIES; c++) {
+				const volatile uint32_t *q = (const volatile uint32_t *)((uint8_t *)h->wstage + 32 + c * XE_WCOPY_BYTES(nt) + 8);
+				if (q[0] > kmax) kmax = q[0];
+				left += q[1];
+			}
+			w->nsets = kmax;
+			w->sums_valid = left == 0;
+		}
 		if (w->nsets < 1) w->nsets = 1;
 		if (w->nsets > XE_WALK_SETS) w->nsets = XE_WALK_SETS;
-		w->sums_valid = *(volatile uint32_t *)((uint8_t *)h->wstage + 20) == 0;
 		if (w->sums_valid) {
 			/* every Netflow datagram is of the usual shape */
 			for (size_t i = 0; i < n; i++) w->h_walked[i] = !(kinds && (kinds[i] == XE_KIND_SFLOW));
@@ -2536,7 +2545,7 @@ walk_finish(xe_gpu *h, xe_batch *b)
 		/* the words the device added up, as they lie in its arena (XE_WZERO_BYTES):
 		 * cnt[0, nt + 2) records, cnt[nt + 2, ...) runs per template */
 		uint8_t *back = (uint8_t *)h->wstage;
-		uint32_t *cnt = (uint32_t *)(back + 32 + 8), *cntruns = cnt + (nt + 2);
+		uint32_t *cnt = (uint32_t *)(back + 32 + 16), *cntruns = cnt + (nt + 2);
 		struct xe_wgroup *gr;
 		uint8_t *tmap;
 		const struct xe_tmpl *tm = (const struct xe_tmpl *)h->hs.dev_tmpls.p;
@@ -2568,7 +2577,7 @@ walk_finish(xe_gpu *h, xe_batch *b)
 			memcpy(&bsum, src, 8);
 			a += bsum;
 			memcpy(back + 32, &a, 8);
-			for (size_t t = 0; t < 2 * (nt + 2); t++) cnt[t] += ((const uint32_t *)(src + 8))[t];
+			for (size_t t = 0; t < 2 * (nt + 2); t++) cnt[t] += ((const uint32_t *)(src + 16))[t];
 		}
 		memcpy(&total, back + 32, 8);
 		if (total + plan->nsf > 0xFFFFFFF0ull) return XE_EUNSUPPORTED;

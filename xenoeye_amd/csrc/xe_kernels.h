@@ -230,14 +230,14 @@ struct xe_dgrun
 	uint32_t rate;        /* sampling rate | has a devices.conf entry << 31 */
 };
 
-/* Device words the Netflow walk adds up into, cleared once per batch: 32 bytes
- * ([0] u64 sFlow records of the batch, [2] u32 most runs of a datagram + u32
- * Netflow datagrams left to the host), then XE_WCOPIES copies (a block adds to
- * copy blockIdx % XE_WCOPIES: adds to one address from all over the chip queue
- * up) of { u64 records of all datagrams; u32 records[nt + 2]; u32 runs[nt + 2] }
- * per device template */
+/* Device words the walk adds up into, cleared once per batch: 32 bytes ([0] u64
+ * sFlow records of the batch), then XE_WCOPIES copies (a block adds to copy
+ * blockIdx % XE_WCOPIES: adds to one address from all over the chip queue up)
+ * of { u64 records of all datagrams; u32 most runs of a datagram; u32 Netflow
+ * datagrams left to the host; u32 records[nt + 2]; u32 runs[nt + 2] } per
+ * device template */
 #define XE_WCOPIES 8
-#define XE_WCOPY_BYTES(NT) (8 + 8 * ((size_t)(NT) + 2))
+#define XE_WCOPY_BYTES(NT) (16 + 8 * ((size_t)(NT) + 2))
 #define XE_WZERO_BYTES(NT) (32 + XE_WCOPIES * XE_WCOPY_BYTES(NT))
 
 /* what the sFlow walk leaves per datagram */

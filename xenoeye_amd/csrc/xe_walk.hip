@@ -169,7 +169,7 @@ exporter_plain(const xe_walk_in &in, uint32_t ip, uint32_t id, uint32_t &rate)
  * a handful of templates, and a hundred thousand atomic adds to two addresses
  * take longer than everything else here), then into one of the copies */
 #define XW_TCACHE 32
-struct wtotals { uint32_t t[XW_TCACHE], rec[XW_TCACHE], run[XW_TCACHE]; unsigned long long all; };
+struct wtotals { uint32_t t[XW_TCACHE], rec[XW_TCACHE], run[XW_TCACHE]; unsigned long long all; uint32_t kmax, left; };
 
 static __device__ __forceinline__ uint8_t *
 wtotals_copy(void *sums, uint32_t nt)
@@ -181,7 +181,7 @@ static __device__ __forceinline__ void
 wtotals_init(wtotals &T)
 {
 	if (threadIdx.x < XW_TCACHE) { T.t[threadIdx.x] = 0xFFFFFFFFu; T.rec[threadIdx.x] = T.run[threadIdx.x] = 0; }
-	if (threadIdx.x == 0) T.all = 0;
+	if (threadIdx.x == 0) { T.all = 0; T.kmax = T.left = 0; }
 	__syncthreads();
 }
 
@@ -209,7 +209,7 @@ wtotals_add(wtotals &T, uint32_t mine, uint32_t nrec, void *sums, uint32_t nt)
 				atomicAdd(&T.rec[e], sum);
 				atomicAdd(&T.run[e], (uint32_t)__popcll(grp));
 			} else {
-				uint32_t *g = (uint32_t *)(wtotals_copy(sums, nt) + 8);
+				uint32_t *g = (uint32_t *)(wtotals_copy(sums, nt) + 16);
 				atomicAdd(&g[t], sum);
 				atomicAdd(&g[nt + 2 + t], (uint32_t)__popcll(grp));
 			}
@@ -223,7 +223,7 @@ static __device__ __forceinline__ void
 wtotals_flush(wtotals &T, unsigned long long all, void *sums, uint32_t nt)
 {
 	uint8_t *c = wtotals_copy(sums, nt);
-	uint32_t *g = (uint32_t *)(c + 8);
+	uint32_t *g = (uint32_t *)(c + 16);
 	for (int d = 32; d; d >>= 1) all += __shfl_down(all, d, 64);
 	if (((threadIdx.x & 63) == 0) && all) atomicAdd(&T.all, all);
 	__syncthreads();
@@ -231,7 +231,11 @@ wtotals_flush(wtotals &T, unsigned long long all, void *sums, uint32_t nt)
 		atomicAdd(&g[T.t[threadIdx.x]], T.rec[threadIdx.x]);
 		atomicAdd(&g[nt + 2 + T.t[threadIdx.x]], T.run[threadIdx.x]);
 	}
-	if ((threadIdx.x == 0) && T.all) atomicAdd((unsigned long long *)c, T.all);
+	if (threadIdx.x == 0) {
+		if (T.all) atomicAdd((unsigned long long *)c, T.all);
+		if (T.kmax) atomicMax((uint32_t *)(c + 8), T.kmax);
+		if (T.left) atomicAdd((uint32_t *)(c + 12), T.left);
+	}
 }
 
 /* A datagram of the usual shape yields up to XE_WALK_SETS runs, one per data
@@ -242,7 +246,6 @@ xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular, void *
 	__shared__ wtotals T;
 	const uint32_t i = blockIdx.x * XW_BLOCK + threadIdx.x;
 	const size_t n = in.n;
-	uint32_t *kmax = (uint32_t *)sums + 4;
 	uint32_t k = 0;
 	bool ok = false;
 
@@ -351,8 +354,8 @@ xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular, void *
 		const unsigned long long left = __ballot((i < in.n) && !ok && !(in.kinds && (in.kinds[i] == XE_KIND_SFLOW)));
 		for (int d = 32; d; d >>= 1) { const uint32_t o = __shfl_xor(m, d, 64); m = (o > m) ? o : m; }
 		if ((threadIdx.x & 63) == 0) {
-			if (m) atomicMax(kmax, m);
-			if (left) atomicAdd(kmax + 1, (uint32_t)__popcll(left));
+			if (m) atomicMax(&T.kmax, m);
+			if (left) atomicAdd(&T.left, (uint32_t)__popcll(left));
 		}
 		for (uint32_t q = 0; q < m; q++) {
 			uint32_t mine = 0xFFFFFFFFu, nrec = 0;
@@ -515,6 +518,17 @@ xw_chunk_scan_kernel(const unsigned long long *csum, unsigned long long *cpre, u
 	}
 }
 
+/* step 2 done by the consumer itself (few chunks): the sum of column `col` of
+ * the chunks before this block's; all threads of the block call it */
+static __device__ __forceinline__ unsigned long long
+chunk_prefix(const unsigned long long *csum, uint32_t width, uint32_t col, unsigned long long *wsum)
+{
+	unsigned long long t = 0, all;
+	for (uint32_t c = threadIdx.x; c < blockIdx.x; c += XW_BLOCK) t += csum[(size_t)c * width + col];
+	(void)block_scan64(t, wsum, &all);
+	return all;
+}
+
 /* step 3 of the tuple scan: every run whose template is in the pass gets its
  * two prefix sums (pos[j] = {records, runs of its template before it}) and
  * notes what the second scan adds up: the tiles that start inside it (low
@@ -524,8 +538,8 @@ xw_chunk_scan_kernel(const unsigned long long *csum, unsigned long long *cpre, u
  * the second scan are taken here as well (vsum). */
 __global__ void __launch_bounds__(XW_BLOCK)
 xw_nf_tuple_apply_kernel(const xe_walk_in in, const xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
-	const uint8_t *tmap, const unsigned long long *cpre, uint32_t nact, int first_pass, uint2 *pos, unsigned long long *val,
-	unsigned long long *vsum)
+	const uint8_t *tmap, const unsigned long long *cpre, int inline_prefix, uint32_t nact, int first_pass, uint2 *pos,
+	unsigned long long *val, unsigned long long *vsum)
 {
 	__shared__ unsigned long long wsum[XW_BLOCK / 64];
 	const size_t n = in.n, nslots = n * nsets;
@@ -545,7 +559,9 @@ xw_nf_tuple_apply_kernel(const xe_walk_in in, const xe_dgrun *runs, uint32_t nse
 			x[q] = (s[q].a == a) ? ((1ull << 32) | s[q].nrec) : 0;
 			t += x[q];
 		}
-		unsigned long long before = cpre[(size_t)blockIdx.x * XE_WTUPLE + a] + block_scan64(t, wsum, &all);
+		/* (cpre: the chunks' sums themselves when this block adds up those before it) */
+		unsigned long long before = inline_prefix ? chunk_prefix(cpre, XE_WTUPLE, a, wsum) : cpre[(size_t)blockIdx.x * XE_WTUPLE + a];
+		before += block_scan64(t, wsum, &all);
 		for (int q = 0; q < XW_ITEMS; q++) {
 			if (s[q].a == a) { px[q] = (uint32_t)before; py[q] = (uint32_t)(before >> 32); }
 			before += x[q];
@@ -591,8 +607,8 @@ xw_val_sums_kernel(const unsigned long long *val, size_t nslots, unsigned long l
  * datagram i's first record */
 __global__ void __launch_bounds__(XW_BLOCK)
 xw_nf_runs_kernel(const xe_walk_in in, const xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint2 *pos,
-	const unsigned long long *val, const unsigned long long *vpre, const xe_wgroup *groups, xe_frun *out, xe_ftile *tiles,
-	uint32_t *recbase)
+	const unsigned long long *val, const unsigned long long *vpre, int inline_prefix, const xe_wgroup *groups, xe_frun *out,
+	xe_ftile *tiles, uint32_t *recbase)
 {
 	__shared__ unsigned long long wsum[XW_BLOCK / 64];
 	const size_t n = in.n, nslots = n * nsets;
@@ -603,7 +619,8 @@ xw_nf_runs_kernel(const xe_walk_in in, const xe_dgrun *runs, uint32_t nsets, con
 		v[q] = (j0 + q < nslots) ? val[j0 + q] : 0;
 		t += v[q];
 	}
-	unsigned long long x = vpre[blockIdx.x] + block_scan64(t, wsum, &all);
+	unsigned long long x = inline_prefix ? chunk_prefix(vpre, 1, 0, wsum) : vpre[blockIdx.x];
+	x += block_scan64(t, wsum, &all);
 	for (int q = 0; q < XW_ITEMS; q++, x += v[q - 1]) {
 		const size_t j = j0 + q;
 		if (j > nslots) break;
@@ -732,18 +749,21 @@ xe_walk_nf_tables(const struct xe_walk_in *in, const struct xe_dgrun *runs, uint
 	unsigned long long *val = (unsigned long long *)wk;
 
 	if (!in->n) return XE_OK;
+	/* few chunks: the kernels that need the sums of the chunks before theirs add them up
+	 * themselves (a launch costs more than reading a few hundred numbers per block) */
+	const int inl = nchunks <= 2048;
 	for (uint32_t p = 0; p < npass; p++) {
 		const uint8_t *tmap = tmaps + (size_t)p * (in->ntmpl + 1);
 		const uint32_t nact = (nactive > p * XE_WTUPLE) ? ((nactive - p * XE_WTUPLE > XE_WTUPLE) ? XE_WTUPLE : nactive - p * XE_WTUPLE) : 0;
 		hipLaunchKernelGGL(xw_nf_tuple_sums_kernel, dim3(nchunks), dim3(XW_BLOCK), 0, st, *in, runs, nsets, walked, tmap, csum);
-		hipLaunchKernelGGL(xw_chunk_scan_kernel, dim3(1), dim3(64 * XE_WTUPLE), 0, st, csum, cpre, nchunks, (uint32_t)XE_WTUPLE);
-		hipLaunchKernelGGL(xw_nf_tuple_apply_kernel, dim3(nchunks), dim3(XW_BLOCK), 0, st, *in, runs, nsets, walked, hostfirst, tmap, cpre,
-			nact, (int)(p == 0), pos, val, (npass == 1) ? vsum : (unsigned long long *)nullptr);
+		if (!inl) hipLaunchKernelGGL(xw_chunk_scan_kernel, dim3(1), dim3(64 * XE_WTUPLE), 0, st, csum, cpre, nchunks, (uint32_t)XE_WTUPLE);
+		hipLaunchKernelGGL(xw_nf_tuple_apply_kernel, dim3(nchunks), dim3(XW_BLOCK), 0, st, *in, runs, nsets, walked, hostfirst, tmap,
+			inl ? csum : cpre, inl, nact, (int)(p == 0), pos, val, (npass == 1) ? vsum : (unsigned long long *)nullptr);
 	}
 	if (npass != 1) hipLaunchKernelGGL(xw_val_sums_kernel, dim3(nchunks), dim3(XW_BLOCK), 0, st, val, nslots, vsum);
-	hipLaunchKernelGGL(xw_chunk_scan_kernel, dim3(1), dim3(64 * XE_WTUPLE), 0, st, vsum, vpre, nchunks, 1u);
-	hipLaunchKernelGGL(xw_nf_runs_kernel, dim3(nchunks), dim3(XW_BLOCK), 0, st, *in, runs, nsets, walked, pos, val, vpre, groups, out, tiles,
-		recbase);
+	if (!inl) hipLaunchKernelGGL(xw_chunk_scan_kernel, dim3(1), dim3(64 * XE_WTUPLE), 0, st, vsum, vpre, nchunks, 1u);
+	hipLaunchKernelGGL(xw_nf_runs_kernel, dim3(nchunks), dim3(XW_BLOCK), 0, st, *in, runs, nsets, walked, pos, val, inl ? vsum : vpre, inl,
+		groups, out, tiles, recbase);
 	return xw_done();
 }
 
