@@ -62,6 +62,7 @@ struct xe_gpu
 	int diag_force_general, diag_fast_r, diag_counter_copies;   /* diagnostic builds (-DXE_DIAG) only, else 0 */
 	void *d_devkeys;           /* struct xe_devkey per devices.conf entry */
 	void *d_thash, *d_twalk;   /* the template store and the device templates as the walk reads them */
+	void *d_traw;              /* the stored templates' bytes, for the walk's "same template again?" test */
 	uint32_t thash_mask;
 	size_t twalk_n;
 	uint64_t walk_epoch;       /* hs.tmpl_epoch the two tables were built from (+ 1) */
@@ -302,6 +303,7 @@ xe_gpu_destroy(xe_gpu *h)
 	if (h->d_devkeys) (void)hipFree(h->d_devkeys);
 	if (h->d_thash) (void)hipFree(h->d_thash);
 	if (h->d_twalk) (void)hipFree(h->d_twalk);
+	if (h->d_traw) (void)hipFree(h->d_traw);
 	if (h->port_names) {
 		for (int i = 0; i < 65536; i++) free(h->port_names[i]);
 		free(h->port_names);
@@ -2229,14 +2231,18 @@ walk_tables_sync(xe_gpu *h)
 	size_t nt = hs->dev_tmpls.n, cap = 16, live = 0;
 	struct xe_twalk *tw;
 	struct xe_thent *th;
+	uint8_t *rawb;
+	size_t rawn = 0, rawat = 0;
 	int rc;
 
 	if (h->walk_epoch == hs->tmpl_epoch + 1) return XE_OK;
 	for (size_t i = 0; i < hs->ntslots; i++) if (hs->tslots[i].raw && (hs->tslots[i].dev_slot != XE_TMPL_UNSUPPORTED)) live++;
 	while (cap < 2 * live + 2) cap <<= 1;
+	for (size_t i = 0; i < hs->ntslots; i++) if (hs->tslots[i].raw) rawn += hs->tslots[i].raw_len;
 	tw = (struct xe_twalk *)calloc(nt ? nt : 1, sizeof(*tw));
 	th = (struct xe_thent *)calloc(cap, sizeof(*th));
-	if (!tw || !th) { free(tw); free(th); return XE_ENOMEM; }
+	rawb = (uint8_t *)malloc(rawn + 16);
+	if (!tw || !th || !rawb || (rawn > 0xFFFF0000ull)) { free(tw); free(th); free(rawb); return XE_ENOMEM; }
 	for (size_t t = 0; t < nt; t++) {
 		tw[t].stride = tm[t].stride;
 		tw[t].nfields = tm[t].nfields;
@@ -2255,20 +2261,28 @@ walk_tables_sync(xe_gpu *h)
 		e.source_id = ts->key.source_id;
 		e.slot = ts->dev_slot;
 		e.fc = ((uint32_t)ts->raw[2] << 8) | ts->raw[3];
+		e.raw_off = (uint32_t)rawat;
+		e.raw_len = (uint32_t)ts->raw_len;
+		memcpy(rawb + rawat, ts->raw, ts->raw_len);
+		rawat += ts->raw_len;
 		for (j = xe_thent_hash(e.ver_tid, e.src_ip, e.source_id) & (cap - 1); th[j].ver_tid; j = (j + 1) & (cap - 1)) {}
 		th[j] = e;
 	}
 	if (h->d_thash) (void)hipFree(h->d_thash);
 	if (h->d_twalk) (void)hipFree(h->d_twalk);
-	h->d_thash = h->d_twalk = NULL;
+	if (h->d_traw) (void)hipFree(h->d_traw);
+	h->d_thash = h->d_twalk = h->d_traw = NULL;
 	rc = upload(h, &h->d_thash, th, cap * sizeof(*th));
 	if (rc == XE_OK) rc = upload(h, &h->d_twalk, tw, nt * sizeof(*tw));
+	if (rc == XE_OK) rc = upload(h, &h->d_traw, rawb, rawat + 16);
 	free(tw);
 	free(th);
+	free(rawb);
 	if (rc != XE_OK) {
 		if (h->d_thash) (void)hipFree(h->d_thash);
 		if (h->d_twalk) (void)hipFree(h->d_twalk);
-		h->d_thash = h->d_twalk = NULL;
+		if (h->d_traw) (void)hipFree(h->d_traw);
+		h->d_thash = h->d_twalk = h->d_traw = NULL;
 		h->walk_epoch = 0;
 		return rc;
 	}
@@ -2310,6 +2324,7 @@ walk_input(const xe_gpu *h, const xe_batch *b, struct xe_walk_in *in)
 	in->thash_mask = h->thash_mask;
 	in->v5_slot_plus1 = h->hs.v5_slot_plus1;
 	in->twalk = (const struct xe_twalk *)h->d_twalk;
+	in->traw = (const uint8_t *)h->d_traw;
 	in->ntmpl = (uint32_t)h->twalk_n;
 }
 

@@ -196,7 +196,8 @@ struct xe_thent
 	uint32_t src_ip, source_id;
 	uint32_t slot;        /* device template */
 	uint32_t fc;          /* field count the template set announced */
-	uint32_t pad[3];
+	uint32_t raw_off, raw_len;   /* the template as the reference stores it: bytes in xe_walk_in.traw */
+	uint32_t pad;
 };
 
 #ifdef __HIPCC__
@@ -280,6 +281,7 @@ struct xe_walk_in
 	const struct xe_twalk *twalk;  /* per device template */
 	uint32_t ntmpl;
 	uint32_t pad;
+	const uint8_t *traw;           /* the stored templates' bytes (xe_thent.raw_off) */
 };
 
 #ifdef __cplusplus

@@ -154,6 +154,44 @@ tmpl_lookup(const xe_walk_in &in, uint32_t ver_tid, uint32_t src_ip, uint32_t so
 	}
 }
 
+/* is the template at `t` (tsize bytes: id, field count, (type, length) pairs -
+ * what the reference stores of a v9 template, netflow.c:160-172) the one held? */
+static __device__ bool
+tmpl_same(const xe_walk_in &in, const xe_thent &e, const uint8_t *t, uint32_t tsize)
+{
+	if (!in.traw || (e.raw_len != tsize)) return false;
+	const uint8_t *h = in.traw + e.raw_off;
+	for (uint32_t j = 0; j < tsize; j++) if (h[j] != t[j]) return false;
+	return true;
+}
+
+/* the same for the first template of an IPFIX template set at p + at (`avail`
+ * bytes of set behind the set header): the reference stores the template header
+ * and 8 bytes per element - id with the enterprise bit cleared, length,
+ * enterprise number or zeros (ipfix_template_convert(), netflow.c:389-433) - and
+ * gives up on the datagram when an element passes the end of the set */
+static __device__ bool
+tmpl_same_ipfix(const xe_walk_in &in, const xe_thent &e, const uint8_t *p, uint32_t at, uint32_t avail, uint32_t len)
+{
+	if (!in.traw || (e.raw_len < 4)) return false;
+	const uint8_t *h = in.traw + e.raw_off;
+	const uint32_t fc = be16(p + at + 2);
+	if ((fc < 1) || (e.raw_len != 4 + 8 * fc)) return false;
+	for (uint32_t j = 0; j < 4; j++) if (h[j] != p[at + j]) return false;
+	uint32_t q = at + 4;
+	for (uint32_t i = 0; i < fc; i++) {
+		const uint8_t *s = h + 4 + 8 * i;
+		if ((q + 4) > len) return false;
+		const bool ent = (p[q] & 0x80) != 0;
+		const uint32_t sz = ent ? 8 : 4;
+		if (((q - at + sz) > avail) || ((q + sz) > len)) return false;
+		if (((p[q] & 0x7F) != s[0]) || (p[q + 1] != s[1]) || (p[q + 2] != s[2]) || (p[q + 3] != s[3])) return false;
+		for (uint32_t j = 4; j < 8; j++) if (s[j] != (ent ? p[q + j] : 0)) return false;
+		q += sz;
+	}
+	return true;
+}
+
 /* devices.conf: sampling rate and whether the exporter's records need no rule check */
 static __device__ __forceinline__ bool
 exporter_plain(const xe_walk_in &in, uint32_t ip, uint32_t id, uint32_t &rate)
@@ -274,37 +312,72 @@ xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular, void *
 				}
 			} else if (ver == 9) {
 				/* parse_netflow_v9() + parse_netflow_v9_flowset(), netflow.c:319-365, :246-317:
-				 * one data set that ends with the datagram, header.count complete records in it */
-				const uint32_t count = be16(p + 2), sid = ld32(p + 16), fsid = be16(p + 20), length = be16(p + 22);
-				xe_thent e;
-				if ((fsid >= 2) && ((20 + length) == len) && count
-					&& tmpl_lookup(in, (9u << 16) | p[20] | ((uint32_t)p[21] << 8), src, sid, e)
-					&& (e.slot < in.ntmpl)) {
-					const xe_twalk tw = in.twalk[e.slot];
-					if (tw.fast && (count * tw.stride <= length) && ((24 + count * tw.stride) <= len)
-						&& exporter_plain(in, src, sid, r.rate)) {
-						r.nrec = count;
-						r.tmpl = e.slot | (24u << 16);
-						r.dev_id = __builtin_bswap32(sid);
-						runs[i] = r;
-						k = 1;
-						ok = true;
+				 * template flowsets that repeat, byte for byte, the template the handle holds
+				 * (parse_netflow_v9_template(), netflow.c:147-186: the first template of the
+				 * flowset is compared, the cursor moves on by its size), then at most one data
+				 * set, which ends with the datagram and holds header.count complete records.
+				 * Whatever else (new or changed templates, flowset headers or templates cut by
+				 * the end of the datagram, a second data set - which the reference misreads)
+				 * is the host's */
+				const uint32_t count = be16(p + 2), sid = ld32(p + 16);
+				uint32_t ptr = 20;
+				bool bad = false;
+				while (ptr < len) {
+					if ((ptr + 4) > len) { bad = true; break; }
+					const uint32_t fsid = be16(p + ptr), length = be16(p + ptr + 2);
+					if (fsid == 0) {
+						xe_thent e;
+						if ((ptr + 8) > len) { bad = true; break; }
+						const uint32_t tsize = 4 + 4 * be16(p + ptr + 6);
+						if ((tsize > length) || ((ptr + 4 + tsize) > len)
+							|| !tmpl_lookup(in, (9u << 16) | p[ptr + 4] | ((uint32_t)p[ptr + 5] << 8), src, sid, e)
+							|| !tmpl_same(in, e, p + ptr + 4, tsize)) { bad = true; break; }
+						ptr += 4 + tsize;
+						continue;
+					}
+					if (fsid == 1) break;
+					{
+						xe_thent e;
+						bad = true;
+						if (((ptr + length) == len) && count
+							&& tmpl_lookup(in, (9u << 16) | p[ptr] | ((uint32_t)p[ptr + 1] << 8), src, sid, e)
+							&& (e.slot < in.ntmpl)) {
+							const xe_twalk tw = in.twalk[e.slot];
+							if (tw.fast && (count * tw.stride <= length) && ((ptr + 4 + count * tw.stride) <= len)
+								&& exporter_plain(in, src, sid, r.rate)) {
+								r.nrec = count;
+								r.tmpl = e.slot | ((ptr + 4) << 16);
+								r.dev_id = __builtin_bswap32(sid);
+								runs[i] = r;
+								k = 1;
+								bad = false;
+							}
+						}
+						break;
 					}
 				}
+				ok = !bad;
 			} else if (ver == 10) {
 				/* parse_ipfix() + parse_ipfix_flowset(), netflow.c:628-678, :547-625: data
-				 * sets of known templates with complete records, options template sets
-				 * (skipped there too) and set ids that mean nothing between them; a
-				 * template set, a set length below 4 or a header cut by the end of the
-				 * datagram leave the datagram to the host */
+				 * sets of known templates with complete records, template sets whose first
+				 * template (the one parse_ipfix_template() looks at, netflow.c:435-485) is
+				 * the one the handle holds, options template sets (skipped there too) and set
+				 * ids that mean nothing between them; a new or changed template, a set
+				 * length below 4 or a header cut by the end of the datagram leave the
+				 * datagram to the host */
 				const uint32_t sid = ld32(p + 12);
 				uint32_t ptr = 16;
 				bool bad = false;
 				while (ptr < len) {
 					if ((ptr + 4) > len) { bad = true; break; }
 					const uint32_t fsid = be16(p + ptr), length = be16(p + ptr + 2);
-					if ((length < 4) || (fsid == 2)) { bad = true; break; }
-					if (fsid > 255) {
+					if (length < 4) { bad = true; break; }
+					if (fsid == 2) {
+						xe_thent e;
+						if (((ptr + 8) > len) || (length < 8)
+							|| !tmpl_lookup(in, (10u << 16) | p[ptr + 4] | ((uint32_t)p[ptr + 5] << 8), src, sid, e)
+							|| !tmpl_same_ipfix(in, e, p, ptr + 4, length - 4, len)) { bad = true; break; }
+					} else if (fsid > 255) {
 						xe_thent e;
 						bad = true;
 						if ((k < XE_WALK_SETS)
@@ -330,7 +403,7 @@ xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular, void *
 					}
 					ptr += length;
 				}
-				ok = !bad && k && exporter_plain(in, src, sid, r.rate);
+				ok = !bad && (!k || exporter_plain(in, src, sid, r.rate));
 				if (ok) {
 					for (uint32_t j = 0; j < k; j++) runs[j * n + i].rate = r.rate;
 				}
