@@ -2651,7 +2651,7 @@ walk_finish(xe_gpu *h, xe_batch *b)
 			walk_mark(h, w, st);
 			HIPCHK(h, hipMemcpyAsync(fbase + o_up, gr, up_bytes, hipMemcpyHostToDevice, st));
 			rc = xe_walk_nf_tables(&in, w->d_dgruns, w->nsets, w->d_walked, d_hostfirst, fbase + o_up + gr_bytes, (uint32_t)npass,
-				(uint32_t)nactive, w->d_groups, fbase + o_work, w->d_fruns2, w->d_ftiles2, w->d_recbase, st);
+				(uint32_t)nactive, w->d_groups, fbase + o_work, w->d_fruns2, w->nfruns2, w->d_ftiles2, w->ntiles2, w->d_recbase, st);
 			walk_mark(h, w, st);
 			if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (runs and tiles)");
 		}

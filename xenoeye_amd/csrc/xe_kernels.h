@@ -313,13 +313,14 @@ struct xe_wgroup { uint32_t pos0, run0, tile0, pad; };
  * tables: tmaps[p * (ntmpl + 1) + template] = the template's place among the XE_WTUPLE templates of pass p (0xFF = another
  * pass), nactive = templates with runs in this batch; out[groups[t].run0 + ...] the runs of template t in arrival order,
  * tiles[] the tile list in the order of the batch index of each tile's first record, recbase[0..n] the batch index of
- * every datagram's first record (hostfirst: what the host walk made of the datagrams it walked, NULL = it walked none);
+ * every datagram's first record (hostfirst: what the host walk made of the datagrams it walked, NULL = it walked none;
+ * nruns / ntiles: entries the two tables hold);
  * work = xe_walk_nf_work_bytes() bytes of device scratch */
 #define XE_WTUPLE 8
 size_t xe_walk_nf_work_bytes(size_t n, uint32_t nsets);
 int xe_walk_nf_tables(const struct xe_walk_in *in, const struct xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
 	const uint8_t *tmaps, uint32_t npass, uint32_t nactive, const struct xe_wgroup *groups, void *work,
-	struct xe_frun *out, struct xe_ftile *tiles, uint32_t *recbase, void *stream);
+	struct xe_frun *out, uint32_t nruns, struct xe_ftile *tiles, uint32_t ntiles, uint32_t *recbase, void *stream);
 #ifdef __cplusplus
 }
 #endif

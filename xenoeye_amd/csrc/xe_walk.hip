@@ -282,6 +282,10 @@ __global__ void __launch_bounds__(XW_BLOCK)
 xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular, void *sums)
 {
 	__shared__ wtotals T;
+	/* the first 32 bytes of every thread's datagram (dword d of thread t at
+	 * hw[d][t]): datagram header and first set header, fetched with two wide loads
+	 * instead of a dozen dependent narrow ones */
+	__shared__ uint32_t hw[8][XW_BLOCK];
 	const uint32_t i = blockIdx.x * XW_BLOCK + threadIdx.x;
 	const size_t n = in.n;
 	uint32_t k = 0;
@@ -296,11 +300,28 @@ xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular, void *
 		const uint8_t *p = in.pkt + off;
 		const uint32_t src = in.src[i];
 		xe_dgrun r = { 0, 0, 0, 0 };
+		const uint32_t have = (len >= 32) ? 32u : 0u;
+		if (have) {
+			u32x4 a, b;
+			__builtin_memcpy(&a, p, 16);
+			__builtin_memcpy(&b, p + 16, 16);
+			hw[0][threadIdx.x] = a.x; hw[1][threadIdx.x] = a.y; hw[2][threadIdx.x] = a.z; hw[3][threadIdx.x] = a.w;
+			hw[4][threadIdx.x] = b.x; hw[5][threadIdx.x] = b.y; hw[6][threadIdx.x] = b.z; hw[7][threadIdx.x] = b.w;
+		}
+		/* byte x of the datagram (callers keep x below len) */
+		auto B = [&](uint32_t x) -> uint32_t {
+			return (x < have) ? ((hw[x >> 2][threadIdx.x] >> (8 * (x & 3))) & 0xFFu) : (uint32_t)p[x];
+		};
+		auto H16 = [&](uint32_t x) -> uint32_t { return (B(x) << 8) | B(x + 1); };
+		auto W32 = [&](uint32_t x) -> uint32_t {     /* four bytes in memory order, as ld32() */
+			if (!(x & 3) && (x + 4 <= have)) return hw[x >> 2][threadIdx.x];
+			return B(x) | (B(x + 1) << 8) | (B(x + 2) << 16) | (B(x + 3) << 24);
+		};
 		if (len >= 24) {
-			const uint32_t ver = be16(p);
+			const uint32_t ver = H16(0);
 			if (ver == 5) {
 				/* parse_netflow_v5(), netflow.c:727-786 */
-				const uint32_t nr = be16(p + 2), sid = p[21];
+				const uint32_t nr = H16(2), sid = B(21);
 				if (nr && ((24 + 48 * nr) == len) && in.v5_slot_plus1 && in.twalk[in.v5_slot_plus1 - 1].fast
 					&& exporter_plain(in, src, sid, r.rate)) {
 					r.nrec = nr;
@@ -319,18 +340,18 @@ xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular, void *
 				 * Whatever else (new or changed templates, flowset headers or templates cut by
 				 * the end of the datagram, a second data set - which the reference misreads)
 				 * is the host's */
-				const uint32_t count = be16(p + 2), sid = ld32(p + 16);
+				const uint32_t count = H16(2), sid = W32(16);
 				uint32_t ptr = 20;
 				bool bad = false;
 				while (ptr < len) {
 					if ((ptr + 4) > len) { bad = true; break; }
-					const uint32_t fsid = be16(p + ptr), length = be16(p + ptr + 2);
+					const uint32_t fsid = H16(ptr), length = H16(ptr + 2);
 					if (fsid == 0) {
 						xe_thent e;
 						if ((ptr + 8) > len) { bad = true; break; }
-						const uint32_t tsize = 4 + 4 * be16(p + ptr + 6);
+						const uint32_t tsize = 4 + 4 * H16(ptr + 6);
 						if ((tsize > length) || ((ptr + 4 + tsize) > len)
-							|| !tmpl_lookup(in, (9u << 16) | p[ptr + 4] | ((uint32_t)p[ptr + 5] << 8), src, sid, e)
+							|| !tmpl_lookup(in, (9u << 16) | B(ptr + 4) | (B(ptr + 5) << 8), src, sid, e)
 							|| !tmpl_same(in, e, p + ptr + 4, tsize)) { bad = true; break; }
 						ptr += 4 + tsize;
 						continue;
@@ -340,7 +361,7 @@ xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular, void *
 						xe_thent e;
 						bad = true;
 						if (((ptr + length) == len) && count
-							&& tmpl_lookup(in, (9u << 16) | p[ptr] | ((uint32_t)p[ptr + 1] << 8), src, sid, e)
+							&& tmpl_lookup(in, (9u << 16) | B(ptr) | (B(ptr + 1) << 8), src, sid, e)
 							&& (e.slot < in.ntmpl)) {
 							const xe_twalk tw = in.twalk[e.slot];
 							if (tw.fast && (count * tw.stride <= length) && ((ptr + 4 + count * tw.stride) <= len)
@@ -365,23 +386,23 @@ xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular, void *
 				 * ids that mean nothing between them; a new or changed template, a set
 				 * length below 4 or a header cut by the end of the datagram leave the
 				 * datagram to the host */
-				const uint32_t sid = ld32(p + 12);
+				const uint32_t sid = W32(12);
 				uint32_t ptr = 16;
 				bool bad = false;
 				while (ptr < len) {
 					if ((ptr + 4) > len) { bad = true; break; }
-					const uint32_t fsid = be16(p + ptr), length = be16(p + ptr + 2);
+					const uint32_t fsid = H16(ptr), length = H16(ptr + 2);
 					if (length < 4) { bad = true; break; }
 					if (fsid == 2) {
 						xe_thent e;
 						if (((ptr + 8) > len) || (length < 8)
-							|| !tmpl_lookup(in, (10u << 16) | p[ptr + 4] | ((uint32_t)p[ptr + 5] << 8), src, sid, e)
+							|| !tmpl_lookup(in, (10u << 16) | B(ptr + 4) | (B(ptr + 5) << 8), src, sid, e)
 							|| !tmpl_same_ipfix(in, e, p, ptr + 4, length - 4, len)) { bad = true; break; }
 					} else if (fsid > 255) {
 						xe_thent e;
 						bad = true;
 						if ((k < XE_WALK_SETS)
-							&& tmpl_lookup(in, (10u << 16) | p[ptr] | ((uint32_t)p[ptr + 1] << 8), src, sid, e)
+							&& tmpl_lookup(in, (10u << 16) | B(ptr) | (B(ptr + 1) << 8), src, sid, e)
 							&& (e.slot < in.ntmpl)) {
 							const xe_twalk tw = in.twalk[e.slot];
 							if (tw.fast && (e.fc == tw.nfields) && (length >= e.fc)) {
@@ -681,7 +702,7 @@ xw_val_sums_kernel(const unsigned long long *val, size_t nslots, unsigned long l
 __global__ void __launch_bounds__(XW_BLOCK)
 xw_nf_runs_kernel(const xe_walk_in in, const xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint2 *pos,
 	const unsigned long long *val, const unsigned long long *vpre, int inline_prefix, const xe_wgroup *groups, xe_frun *out,
-	xe_ftile *tiles, uint32_t *recbase)
+	uint32_t nruns, xe_ftile *tiles, uint32_t ntiles, uint32_t *recbase)
 {
 	__shared__ unsigned long long wsum[XW_BLOCK / 64];
 	const size_t n = in.n, nslots = n * nsets;
@@ -717,10 +738,13 @@ xw_nf_runs_kernel(const xe_walk_in in, const xe_dgrun *runs, uint32_t nsets, con
 		f.rate = r.rate & 0x7FFFFFFFu;
 		f.dev_ip = __builtin_bswap32(in.src[i]);
 		f.dev_id = r.dev_id;
+		/* (the tables were sized from the sums of another pass over the same runs: a
+		 * place beyond them cannot come up, and must not be written if it did) */
+		if (g.run0 + p.y >= nruns) continue;
 		out[g.run0 + p.y] = f;
 		/* the tiles that start inside this run */
 		uint32_t at = (uint32_t)x;
-		for (uint32_t tq = (p.x + 63) / 64; (uint64_t)tq * 64 < (uint64_t)p.x + r.nrec; tq++, at++) {
+		for (uint32_t tq = (p.x + 63) / 64; ((uint64_t)tq * 64 < (uint64_t)p.x + r.nrec) && (at < ntiles); tq++, at++) {
 			xe_ftile ft;
 			ft.first_run = g.run0 + p.y;
 			ft.tmpl = tm;
@@ -807,7 +831,7 @@ xe_walk_nf_chunks(size_t n, uint32_t nsets)
 extern "C" int
 xe_walk_nf_tables(const struct xe_walk_in *in, const struct xe_dgrun *runs, uint32_t nsets, const uint8_t *walked, const uint32_t *hostfirst,
 	const uint8_t *tmaps, uint32_t npass, uint32_t nactive, const struct xe_wgroup *groups, void *work,
-	struct xe_frun *out, struct xe_ftile *tiles, uint32_t *recbase, void *stream)
+	struct xe_frun *out, uint32_t nruns, struct xe_ftile *tiles, uint32_t ntiles, uint32_t *recbase, void *stream)
 {
 	hipStream_t st = (hipStream_t)stream;
 	const size_t nslots = (size_t)in->n * nsets;
@@ -836,7 +860,7 @@ xe_walk_nf_tables(const struct xe_walk_in *in, const struct xe_dgrun *runs, uint
 	if (npass != 1) hipLaunchKernelGGL(xw_val_sums_kernel, dim3(nchunks), dim3(XW_BLOCK), 0, st, val, nslots, vsum);
 	if (!inl) hipLaunchKernelGGL(xw_chunk_scan_kernel, dim3(1), dim3(64 * XE_WTUPLE), 0, st, vsum, vpre, nchunks, 1u);
 	hipLaunchKernelGGL(xw_nf_runs_kernel, dim3(nchunks), dim3(XW_BLOCK), 0, st, *in, runs, nsets, walked, pos, val, inl ? vsum : vpre, inl,
-		groups, out, tiles, recbase);
+		groups, out, nruns, tiles, ntiles, recbase);
 	return xw_done();
 }
 
