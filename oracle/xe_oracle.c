@@ -1669,6 +1669,20 @@ geodb_lookup(int kind, const uint8_t *addr, int nbits)
 	return leaf ? db + (size_t)node * ns + 12 : NULL;
 }
 
+/* the lookup alone, for tests: copies the payload of the node the walk ends on
+ * (214 bytes of struct geoip_info / 204 bytes of struct as_info) and returns 1,
+ * or returns 0 as geoip_lookup4/6 / as_lookup4/6 do (geoip.c:33-88) */
+int
+xo_geodb_lookup(int kind, int family, const uint8_t *addr, uint8_t *payload)
+{
+	const uint8_t *pay;
+	if ((kind < 0) || (kind > 1)) return 0;
+	pay = geodb_lookup(kind, addr, (family == 6) ? 128 : 32);
+	if (!pay) return 0;
+	memcpy(payload, pay, kind ? 204 : 214);
+	return 1;
+}
+
 /* filter_function_geoip() / filter_function_as(), filter.c:753-834: the field's
  * bytes are read whether the field is present or not; only fields of 4 and 16
  * bytes have a defined meaning */

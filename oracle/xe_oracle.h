@@ -120,6 +120,7 @@ void xo_ports_pair_to_str(char *res, uint16_t port1, uint16_t port2);
 /* geo / AS database image as the reference maps it from geo4.db / geo6.db
  * (kind 0) or as4.db / as6.db (kind 1); family 4 or 6; 0 bytes = none */
 int xo_geodb_set(int kind, int family, const void *img, size_t bytes);
+int xo_geodb_lookup(int kind, int family, const uint8_t *addr, uint8_t *payload);
 /* text of a TCP flags byte, as tcp_flags_to_str() (utils.c:22-26) gives it */
 void xo_tcp_flags_str(uint8_t tf, char out[40]);
 

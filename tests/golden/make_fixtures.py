@@ -16,6 +16,13 @@ netflow_oracle.npz    Netflow v9 / IPFIX / v5 datagrams with the records, match
                       absent pcap, tkvdb and aajson headers), so these are
                       regression pins of the restatement, not reference output.
 
+geo_reference.npz     geo / AS database images built with the REFERENCE's
+                      IP_BTRIE_ADD macro (geoip.h + ip-btrie.h under
+                      oracle/ref_geo_harness.c), probe addresses and what its
+                      IP_BTRIE_LOOKUP, instantiated as in geoip.c:33-88, answers.
+port_names.json       port -> service name as the REFERENCE's port_to_str()
+                      (utils.c:28-37, oracle/_ref/libref_utils.so) prints them.
+
 Fixtures are data only: inputs and expected outputs.
 """
 import os
@@ -29,7 +36,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-from oracle_binding import Oracle, RefIplist, RefSflow, have_ref  # noqa: E402
+from oracle_binding import Oracle, RefGeo, RefIplist, RefSflow, RefUtils, have_ref  # noqa: E402
 from xenoeye_amd import synth  # noqa: E402
 from helpers import configure, run_oracle  # noqa: E402
 
@@ -175,9 +182,103 @@ def make_netflow():
     np.savez_compressed(os.path.join(HERE, "netflow_oracle.npz"), **arrays)
 
 
+GEO_SIZES = [3, 3, 35, 64, 51, 15, 20, 23]
+
+
+def geo_entries():
+    """(as4, as6, geo4, geo6) lists of (address bytes, mask length, payload bytes): prefixes over the
+    addresses workload_c2 draws from, nested ones among them, and a prefix that holds the zero address"""
+    rng = synth.Rng(0x601D3)
+    names = ["Example Net", "ACME", "Universitaet", "x"]
+    cities = [("EU", "DE", "Germany", "Berlin", "Berlin", "10115", "52.5", "13.4"),
+              ("EU", "RU", "Russia", "Moscow", "Moscow", "101000", "55.7", "37.6"),
+              ("NA", "US", "United States", "California", "San Jose", "95101", "37.3", "-121.9"),
+              ("AS", "JP", "Japan", "Tokyo", "Tokyo", "100-0001", "35.6", "139.7")]
+
+    def asp(asn, asd):
+        return struct.pack("<I", asn) + asd.encode().ljust(200, b"\0")
+
+    def geop(*f):
+        return b"".join(x.encode().ljust(n, b"\0") for x, n in zip(f, GEO_SIZES))
+    as4, as6, geo4, geo6 = [], [], [], []
+    as4.append((bytes(4), 8, asp(7, "Zero Net")))
+    geo4.append((bytes(4), 8, geop("ZZ", "ZZ", "Nowhere", "", "", "", "0", "0")))
+    as6.append((bytes(16), 16, asp(7, "Zero Net")))
+    for k in range(600):
+        a = bytes(rng.bytes(4))
+        if a[0] == 0:
+            a = b"\x01" + a[1:]
+        m = int(rng.below(1, 21)[0]) + 4
+        as4.append((a, m, asp(64000 + k % 40 * 37, names[k % 4])))
+        geo4.append((a, min(m + 2, 32), geop(*cities[k % 4])))
+        if k % 5 == 0:
+            as4.append((a, min(m + 6, 32), asp(100 + k, names[(k + 1) % 4])))
+    for k in range(300):
+        a = bytes([0x20, int(rng.below(1, 16)[0])]) + bytes(rng.bytes(14))
+        m = int(rng.below(1, 60)[0]) + 10
+        as6.append((a, m, asp(65000 + k % 10, names[k % 4])))
+        geo6.append((a, m, geop(*cities[k % 4])))
+    return as4, as6, geo4, geo6
+
+
+def make_geo():
+    ref = RefGeo()
+    rng = synth.Rng(0x601D4)
+    as4, as6, geo4, geo6 = geo_entries()
+    arrays = {}
+    for name, kind, fam, ents in (("as4", 1, 4, as4), ("as6", 1, 6, as6), ("geo4", 0, 4, geo4), ("geo6", 0, 6, geo6)):
+        img = ref.build(kind, ents)
+        n = 4 if fam == 4 else 16
+        probes = [bytes(n), bytes([255] * n)]
+        for a, m, _ in ents[:400]:
+            # inside the prefix, and just beside it
+            r = bytearray(rng.bytes(n))
+            full, rest = m // 8, m % 8
+            r[:full] = a[:full]
+            if rest:
+                mask = (0xFF00 >> rest) & 0xFF
+                r[full] = (a[full] & mask) | (r[full] & ~mask & 0xFF)
+            probes.append(bytes(r))
+            if m:
+                q = bytearray(r)
+                q[(m - 1) // 8] ^= 1 << (7 - (m - 1) % 8)
+                probes.append(bytes(q))
+        probes += [bytes(x) for x in rng.bytes(600 * n).reshape(-1, n)]
+        psz = 204 if kind else 214
+        found = np.zeros(len(probes), dtype=np.uint8)
+        pay = np.zeros((len(probes), psz), dtype=np.uint8)
+        for i, a in enumerate(probes):
+            got = ref.lookup(kind, fam, img, a)
+            if got is not None:
+                found[i] = 1
+                pay[i] = np.frombuffer(got, dtype=np.uint8)
+        arrays[name + "_image"] = np.frombuffer(img, dtype=np.uint8)
+        arrays[name + "_probes"] = np.frombuffer(b"".join(probes), dtype=np.uint8).reshape(-1, n)
+        arrays[name + "_found"] = found
+        arrays[name + "_payload"] = pay
+        print("geo_reference/%s: %d nodes, %d probes, %d found" % (name, len(img) // ref.node_size(kind), len(probes), int(found.sum())))
+    np.savez_compressed(os.path.join(HERE, "geo_reference.npz"), **arrays)
+
+
+def make_port_names():
+    import json
+    names = RefUtils().port_names()
+    named = {str(p): n for p, n in enumerate(names) if n}
+    with open(os.path.join(HERE, "port_names.json"), "w") as f:
+        json.dump(named, f, sort_keys=True, separators=(",", ":"))
+    print("port_names: %d ports with a name" % len(named))
+
+
 if __name__ == "__main__":
     if not (have_ref("libref_sflow.so") and have_ref("libref_iplist.so")):
         raise SystemExit("oracle/_ref is not built (needs the reference checkout): run `make -C oracle ref`")
+    if not (have_ref("libref_geo.so") and have_ref("libref_utils.so")):
+        raise SystemExit("oracle/_ref is not complete: run `make -C oracle ref`")
+    make_port_names()
+    if len(sys.argv) > 1 and sys.argv[1] == "new":      # only the fixtures added later (the older ones stay as committed)
+        make_geo()
+        raise SystemExit(0)
     make_sflow()
     make_iplist()
     make_netflow()
+    make_geo()

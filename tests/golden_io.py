@@ -29,6 +29,13 @@ def iplist_reference():
     return texts, z["probes4"], z["probes6"], z["want4"], z["want6"]
 
 
+def geo_reference():
+    """{name: (image bytes, probes, found, payload)} for as4 / as6 / geo4 / geo6: answers of the reference's
+    IP_BTRIE_LOOKUP over images its IP_BTRIE_ADD built"""
+    z = load("geo_reference.npz")
+    return {n: (bytes(z[n + "_image"]), z[n + "_probes"], z[n + "_found"], z[n + "_payload"]) for n in ("as4", "as6", "geo4", "geo6")}
+
+
 def netflow_oracle():
     z = load("netflow_oracle.npz")
     for case in [bytes(c).decode() for c in z["cases"]]:

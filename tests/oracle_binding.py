@@ -158,6 +158,14 @@ class Oracle:
         self.L.xo_geodb_set.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_size_t]
         assert self.L.xo_geodb_set(kind, family, bytes(image), len(image))
 
+    def geodb_lookup(self, kind, family, addr):
+        """payload bytes of the node the database walk ends on, or None (geoip.c:33-88)"""
+        self.L.xo_geodb_lookup.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_char_p]
+        buf = C.create_string_buffer(216)
+        if not self.L.xo_geodb_lookup(kind, family, bytes(addr), buf):
+            return None
+        return buf.raw[:204 if kind else 214]
+
     def set_port_names(self, names):
         """65536 service names ('' / None = none) for portstr() / ppstr(); None removes them"""
         if names is None:
@@ -264,6 +272,60 @@ class RefSflow:
         return rc, recs
 
 
+class RefGeo:
+    """The reference's geo / AS database structures and trie macros (geoip.h,
+    ip-btrie.h under oracle/ref_geo_harness.c -> oracle/_ref/libref_geo.so):
+    images built with IP_BTRIE_ADD, looked up with IP_BTRIE_LOOKUP as geoip.c does."""
+
+    def __init__(self):
+        L = self.L = C.CDLL(os.path.join(REF_DIR, "libref_geo.so"))
+        L.ref_geo_node_size.restype = C.c_size_t
+        L.ref_geo_payload_offset.restype = C.c_size_t
+        L.ref_geo_field_offset.restype = C.c_size_t
+        L.ref_geo_db_new.restype = C.c_void_p
+        L.ref_geo_db_add.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_char_p]
+        L.ref_geo_db_image.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
+        L.ref_geo_db_image.restype = C.c_void_p
+        L.ref_geo_db_free.argtypes = [C.c_void_p, C.c_int]
+        for fn in ("ref_geo_lookup4", "ref_as_lookup4"):
+            getattr(L, fn).argtypes = [C.c_char_p, C.c_uint32, C.c_char_p]
+        for fn in ("ref_geo_lookup6", "ref_as_lookup6"):
+            getattr(L, fn).argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+
+    def node_size(self, kind):
+        return self.L.ref_geo_node_size(kind)
+
+    def payload_offset(self, kind):
+        return self.L.ref_geo_payload_offset(kind)
+
+    def field_layout(self):
+        """(offset, size) of the 8 fields of struct geoip_info"""
+        return [(self.L.ref_geo_field_offset(f), self.L.ref_geo_field_size(f)) for f in range(8)]
+
+    def build(self, kind, entries):
+        """image of a database made of (address bytes, mask length, payload bytes) with the reference's insertion macro"""
+        db = self.L.ref_geo_db_new(kind)
+        psize = self.node_size(kind) - 12
+        for addr, mask, payload in entries:
+            assert self.L.ref_geo_db_add(db, kind, bytes(addr), mask, bytes(payload).ljust(psize, b"\0")) == 1
+        n = C.c_size_t()
+        p = self.L.ref_geo_db_image(db, kind, C.byref(n))
+        img = C.string_at(p, n.value) if n.value else b""
+        self.L.ref_geo_db_free(db, kind)
+        return img
+
+    def lookup(self, kind, family, image, addr):
+        """payload bytes or None"""
+        out = C.create_string_buffer(256)
+        if family == 4:
+            fn = self.L.ref_as_lookup4 if kind else self.L.ref_geo_lookup4
+            ok = fn(image, int.from_bytes(bytes(addr), "little"), out)
+        else:
+            fn = self.L.ref_as_lookup6 if kind else self.L.ref_geo_lookup6
+            ok = fn(image, bytes(addr), out)
+        return out.raw[:204 if kind else 214] if ok else None
+
+
 class RefUtils:
     def __init__(self):
         L = self.L = C.CDLL(os.path.join(REF_DIR, "libref_utils.so"))
@@ -295,16 +357,13 @@ class RefUtils:
 
 
 def port_names():
-    """the reference's service names when its utils.c was built here (oracle/_ref), else a made-up
-    table of the same shape: a few hundred named ports, names with digits, dashes and mixed case"""
-    if have_ref("libref_utils.so"):
-        return RefUtils().port_names()
+    """the reference's service name of every port ('' = none): what its port_to_str() (utils.c:28-37)
+    printed when its utils.c was built in the build container, kept as a fixture
+    (tests/golden/port_names.json, written by tests/golden/make_fixtures.py)"""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "port_names.json")) as f:
+        named = json.load(f)
     names = [""] * 65536
-    for p, n in {20: "ftp-data", 21: "ftp", 22: "ssh", 23: "telnet", 25: "smtp", 53: "domain", 80: "http",
-                 110: "pop3", 123: "ntp", 143: "imap2", 161: "snmp", 179: "bgp", 443: "https", 445: "microsoft-ds",
-                 993: "imaps", 1194: "openvpn", 3306: "mysql", 3389: "ms-wbt-server", 5060: "sip", 8080: "http-alt",
-                 0: "reserved", 65535: "Last", 1: "tcpmux"}.items():
-        names[p] = n
-    for p in range(1024, 40000, 97):
-        names[p] = "svc%d-x" % (p % 1000)
+    for p, n in named.items():
+        names[int(p)] = n
     return names

@@ -9,7 +9,7 @@ import tempfile
 import numpy as np
 import pytest
 
-from oracle_binding import Oracle, RefIplist, RefSflow, RefUtils, have_ref, FLOW_INFO_SIZE
+from oracle_binding import Oracle, RefGeo, RefIplist, RefSflow, RefUtils, have_ref, port_names, FLOW_INFO_SIZE
 from xenoeye_amd import synth
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -18,6 +18,7 @@ KNOWN = json.load(open(os.path.join(HERE, "golden", "known_answers.json")))
 needs_ref_iplist = pytest.mark.skipif(not have_ref("libref_iplist.so"), reason="oracle/_ref not built")
 needs_ref_sflow = pytest.mark.skipif(not have_ref("libref_sflow.so"), reason="oracle/_ref not built")
 needs_ref_utils = pytest.mark.skipif(not have_ref("libref_utils.so"), reason="oracle/_ref not built")
+needs_ref_geo = pytest.mark.skipif(not have_ref("libref_geo.so"), reason="oracle/_ref not built")
 
 _uniq = [0]
 
@@ -339,3 +340,143 @@ def test_field_table_matches_reference_definition(orc):
                          int(m.group(4)), mx))
     got = [(f["name"], f["type"], f["id"], f["min"], f["max"]) for f in orc.fields()[:63]]
     assert got == want
+
+
+# ------------------------------------------------------------------ geo / AS databases
+GEO_KINDS = {"as4": (1, 4), "as6": (1, 6), "geo4": (0, 4), "geo6": (0, 6)}
+
+
+@needs_ref_geo
+def test_geo_node_layout_matches_reference():
+    """struct btrie_node_geo / btrie_node_as as the reference's compiler lays them out (geoip.h:43-55):
+    the sizes and offsets the oracle and the library use for the database images"""
+    ref = RefGeo()
+    assert (ref.node_size(0), ref.node_size(1)) == (228, 216)
+    assert (ref.payload_offset(0), ref.payload_offset(1)) == (12, 12)
+    assert ref.field_layout() == [(0, 3), (3, 3), (6, 35), (41, 64), (105, 51), (156, 15), (171, 20), (191, 23)]
+
+
+@needs_ref_geo
+def test_geo_lookup_matches_reference(orc):
+    """database images made by the reference's IP_BTRIE_ADD; every probe answered by its
+    IP_BTRIE_LOOKUP (instantiated as geoip.c:33-88 does) and by the oracle"""
+    import golden_io
+    sys_path_make = os.path.join(HERE, "golden")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_fixtures", os.path.join(sys_path_make, "make_fixtures.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    ref = RefGeo()
+    ents = dict(zip(("as4", "as6", "geo4", "geo6"), mk.geo_entries()))
+    fix = golden_io.geo_reference()
+    rng = np.random.default_rng(11)
+    for name, (kind, fam) in GEO_KINDS.items():
+        img = ref.build(kind, ents[name])
+        assert img == fix[name][0], "the committed image of %s is not what the reference builds today" % name
+        orc.geodb_set(kind, fam, img)
+        n = 4 if fam == 4 else 16
+        probes = [bytes(p) for p in fix[name][1]] + [bytes(rng.integers(0, 256, n, dtype=np.uint8)) for _ in range(2000)]
+        nfound = 0
+        for a in probes:
+            want = ref.lookup(kind, fam, img, a)
+            got = orc.geodb_lookup(kind, fam, a)
+            assert got == want, (name, a.hex())
+            nfound += want is not None
+        assert nfound > 200
+
+
+def test_geo_fixture_pins_the_oracle(orc):
+    """the same without the reference at hand: its recorded answers"""
+    import golden_io
+    for name, (img, probes, found, payload) in golden_io.geo_reference().items():
+        kind, fam = GEO_KINDS[name]
+        orc.geodb_set(kind, fam, img)
+        for a, f, pay in zip(probes, found, payload):
+            got = orc.geodb_lookup(kind, fam, bytes(a))
+            assert (got is not None) == bool(f), (name, bytes(a).hex())
+            if f:
+                assert got == bytes(pay)
+
+
+@needs_ref_utils
+def test_port_names_fixture_matches_reference():
+    assert port_names() == RefUtils().port_names()
+
+
+# ------------------------------------------------------------------ keyword tables of the filter compiler
+def _keyword_rows():
+    import ctypes as C
+    import host_binding
+    L = host_binding.load_hosttest()
+    kw = C.c_char_p()
+    a, b, c = C.c_int(), C.c_int(), C.c_int()
+    fields, aggr = [], []
+    i = 0
+    while L.xe_filter_keyword(i, C.byref(kw), C.byref(a), C.byref(b), C.byref(c)):
+        fields.append((kw.value.decode(), a.value, b.value, c.value))
+        i += 1
+    i = 0
+    while L.xe_filter_aggr_keyword(i, C.byref(kw), C.byref(a), C.byref(b)):
+        aggr.append((kw.value.decode(), a.value, b.value))
+        i += 1
+    return fields, aggr
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/filter.def"), reason="reference checkout absent")
+def test_filter_keyword_tables_match_reference_definitions(orc):
+    """the library's filter keywords with their operand type and source / destination flow fields
+    against the reference's X-macro tables filter.def and filter-ag.def, row by row"""
+    import re
+    index = {f["name"]: f["idx"] for f in orc.fields()}
+    types = {"ADDR4": 0, "ADDR6": 1, "RANGE": 2, "MAC": 3, "STRING": 4}
+    want = []
+    for line in open("/root/reference/filter.def"):
+        m = re.match(r'FIELD\((\w+),\s*"([^"]*)",\s*(\w+),\s*(\w+),\s*(\w+)\)', line)
+        if m:
+            want.append((m.group(2), types[m.group(3)], index[m.group(4)], index[m.group(5)]))
+    want_ag = []
+    for line in open("/root/reference/filter-ag.def"):
+        m = re.match(r'FIELD\((\w+),\s*"([^"]*)",\s*(\w+),\s*(\d+)\)', line)
+        if m:
+            want_ag.append((m.group(2), index[m.group(3)], int(m.group(4))))
+    fields, aggr = _keyword_rows()
+    assert len(want) == 36 and len(want_ag) == 7
+    assert fields == want
+    assert aggr == want_ag
+
+
+# ------------------------------------------------------------------ the shim's view of the reference's structures
+@pytest.mark.skipif(not os.path.exists("/root/reference/flow-info.h"), reason="reference checkout absent")
+def test_shim_compiles_against_the_reference_flow_info_header(tmp_path):
+    """shim/xenoeye_gpu_shim.c built with the reference's own flow-info.h in front of it (its struct
+    flow_packet_info then replaces the shim header's copy), plus compile-time checks that the copy in
+    include/xenoeye_gpu_shim.h and XE_FLOW_INFO_SIZE agree with the reference's structures"""
+    import subprocess
+    root = os.path.dirname(HERE)
+    check = tmp_path / "layout_check.c"
+    check.write_text("""
+#include <stddef.h>
+#include <stdint.h>
+#include <sys/socket.h>
+#include "utils.h"
+#include "flow-info.h"                 /* the reference's */
+#define flow_packet_info shim_flow_packet_info
+#undef flow_info_h_included
+#undef MAX_NF_PACKET_SIZE
+#include "xenoeye_gpu_shim.h"          /* the shim's own copy, under another name */
+#undef flow_packet_info
+#include "xe_gpu.h"
+#define SAME(M) _Static_assert(offsetof(struct flow_packet_info, M) == offsetof(struct shim_flow_packet_info, M), #M)
+SAME(src_addr); SAME(src_addr_ipv4); SAME(source_id); SAME(epoch); SAME(time_ns); SAME(rawpacket); SAME(sampling_rate);
+_Static_assert(sizeof(struct flow_packet_info) == sizeof(struct shim_flow_packet_info), "struct flow_packet_info");
+_Static_assert(sizeof(struct flow_info) == XE_FLOW_INFO_SIZE, "struct flow_info");
+int main(void) { return 0; }
+""")
+    r = subprocess.run(["gcc", "-std=gnu11", "-Wall", "-I/root/reference", "-I", os.path.join(root, "include"),
+                        "-c", str(check), "-o", str(tmp_path / "layout_check.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run(["gcc", "-std=gnu11", "-O2", "-fPIC", "-Wall", "-I/root/reference", "-include", "utils.h", "-include",
+                        "flow-info.h", "-I", os.path.join(root, "include"), "-c",
+                        os.path.join(root, "shim", "xenoeye_gpu_shim.c"), "-o", str(tmp_path / "shim.o")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

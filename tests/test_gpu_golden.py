@@ -107,3 +107,82 @@ def test_netflow_regression_pins(eng):
         assert np.array_equal(out.flow_info()[keep], case["flows"][keep]), case["name"]
         out.free()
         e.close()
+
+
+def test_geo_functions_equal_reference_answers(eng):
+    """asn(), asd() and the geo functions (filter.c:753-834) over records that
+    carry the probe addresses of the geo fixture, against what the reference's
+    own IP_BTRIE_LOOKUP (ip-btrie.h:90-115, instantiated as geoip.c:33-88 does)
+    found in database images made by its IP_BTRIE_ADD"""
+    fix = golden_io.geo_reference()
+    for name, (kind, fam) in {"as4": (1, 4), "as6": (1, 6), "geo4": (0, 4), "geo6": (0, 6)}.items():
+        eng.set_geodb(kind, fam, fix[name][0])
+    geo_off = [0, 3, 6, 41, 105, 156, 171, 191]
+
+    def cstr(row, off):
+        b = bytes(row[off:])
+        return b[:b.index(0)].decode() if 0 in b else b.decode()
+
+    def asn(name):
+        _, _, found, pay = fix[name]
+        return found.astype(bool), pay[:, :4].copy().view("<u4")[:, 0].astype(np.int64)
+
+    def text(name, off):
+        _, _, found, pay = fix[name]
+        return found.astype(bool), [cstr(r, off) if f else None for r, f in zip(pay, found)]
+
+    f4, n4 = asn("as4")
+    f6, n6 = asn("as6")
+    _, d4 = text("as4", 4)
+    _, cc4 = text("geo4", geo_off[1])
+    _, city4 = text("geo4", geo_off[4])
+    _, cont6 = text("geo6", geo_off[0])
+    g4 = fix["geo4"][2].astype(bool)
+    g6 = fix["geo6"][2].astype(bool)
+    n = min(len(fix["as4"][1]), len(fix["as6"][1]), len(fix["geo4"][1]), len(fix["geo6"][1]))
+    # one record per probe: IPv4 source = as4 probe, IPv4 destination = geo4 probe,
+    # IPv6 source = as6 probe, IPv6 destination = geo6 probe
+    mos = [("asn(src host) 64000-64400", lambda i: f4[i] and 64000 <= n4[i] <= 64400),
+           ("asn(src host) 100-700 or 64740", lambda i: f4[i] and (100 <= n4[i] <= 700 or n4[i] == 64740)),
+           ("asn(src host) 7", lambda i: f4[i] and n4[i] == 7),
+           ("asd(src host) 'ACME'", lambda i: f4[i] and d4[i] == "ACME"),
+           ("asd(src host) 'Example Net' or 'x'", lambda i: f4[i] and d4[i] in ("Example Net", "x")),
+           ("country_code(dst host) 'DE'", lambda i: g4[i] and cc4[i] == "DE"),
+           ("city(dst host) 'San Jose' or 'Tokyo'", lambda i: g4[i] and city4[i] in ("San Jose", "Tokyo")),
+           ("asn(src host6) 65000-65004", lambda i: f6[i] and 65000 <= n6[i] <= 65004),
+           ("not asn(src host6) 7", lambda i: not (f6[i] and n6[i] == 7)),
+           ("continent(dst host6) 'EU'", lambda i: g6[i] and cont6[i] == "EU")]
+    for filt, _ in mos:
+        m = eng.add_mo("mo", filt)
+        assert not eng.mo_host_only(m), filt
+    eng.commit()
+    t = [(8, 4), (12, 4), (27, 16), (28, 16), (4, 1)]
+    rec = np.zeros((n, 41), dtype=np.uint8)
+    rec[:, 0:4] = fix["as4"][1][:n]
+    rec[:, 4:8] = fix["geo4"][1][:n]
+    rec[:, 8:24] = fix["as6"][1][:n]
+    rec[:, 24:40] = fix["geo6"][1][:n]
+    rec[:, 40] = 6
+    exp = bytes([192, 0, 2, 9])
+    b = synth.Batch()
+    b.add(synth.ipfix_template_packet(400, t, 5), exp)
+    for i in range(0, n, 30):
+        body = rec[i:i + 30].tobytes()
+        body = struct.pack(">HH", 400, 4 + len(body)) + body
+        b.add(synth.ipfix_header(16 + len(body), 5) + body, exp)
+    for rnd in range(2):         # host walk, then device walk
+        out = eng.prepare(b)
+        out.run()
+        m = out.masks()[:, 0]
+        fi = out.flow_info()
+        proto = [f for f in xenoeye_amd.fields() if f["name"] == "protocol"][0]
+        has_proto = fi[:, ((proto["off"] + proto["max"] + 3) & ~3) + 4]
+        sel = np.nonzero(has_proto)[0]
+        assert len(sel) == n
+        for k, (filt, want) in enumerate(mos):
+            got = ((m[sel] >> np.uint64(k)) & np.uint64(1)).astype(bool)
+            exp_bits = np.array([bool(want(i)) for i in range(n)])
+            bad = np.nonzero(got != exp_bits)[0]
+            assert bad.size == 0, (filt, rnd, bad[:5])
+            assert exp_bits.any() and not exp_bits.all(), filt
+        out.free()

@@ -89,6 +89,28 @@ static const struct { const char *kw; uint8_t field; uint8_t scale; } kaggr[] = 
 };
 #define NKAGGR ((int)(sizeof(kaggr) / sizeof(kaggr[0])))
 
+/* the two tables above row by row, for checks against filter.def / filter-ag.def */
+int
+xe_filter_keyword(int i, const char **kw, int *type, int *src, int *dst)
+{
+	if ((i < 0) || (i >= NKFIELDS)) return 0;
+	*kw = kfields[i].kw;
+	*type = kfields[i].type;
+	*src = kfields[i].src;
+	*dst = kfields[i].dst;
+	return 1;
+}
+
+int
+xe_filter_aggr_keyword(int i, const char **kw, int *field, int *scale)
+{
+	if ((i < 0) || (i >= NKAGGR)) return 0;
+	*kw = kaggr[i].kw;
+	*field = kaggr[i].field;
+	*scale = kaggr[i].scale;
+	return 1;
+}
+
 static const struct { const char *kw; enum tok t; } kwords[] = {
 	{ "or", T_OR }, { "and", T_AND }, { "not", T_NOT }, { "asc", T_ASC }, { "desc", T_DESC },
 	{ "div", T_DIV }, { "div_r", T_DIV_R }, { "div_l", T_DIV_L }, { "min", T_MIN },

@@ -422,6 +422,9 @@ int xe_filter_dump_text(const struct xe_iplists *reg, const struct xe_filter *f,
 /* a field of a fixed-window table (struct field, monit-objects.h) */
 struct xe_agfield { uint8_t aggr, field, descending, scale; uint32_t size; };
 int xe_field_parse(const char *text, struct xe_agfield *out, char *err, size_t errlen);
+/* row i of the keyword tables (filter.def, filter-ag.def); 0 past the end */
+int xe_filter_keyword(int i, const char **kw, int *type, int *src, int *dst);
+int xe_filter_aggr_keyword(int i, const char **kw, int *field, int *scale);
 /* static analysis of the stack discipline (filter.c:960-1012): returns 1 and
  * sets *cval when the result does not depend on the record */
 int xe_filter_constant(const struct xe_filter *f, int *cval);

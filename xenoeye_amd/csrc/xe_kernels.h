@@ -208,8 +208,17 @@ struct xe_thent
 static inline XE_HD uint32_t
 xe_thent_hash(uint32_t ver_tid, uint32_t src_ip, uint32_t source_id)
 {
+	/* every bit of the three words reaches the low bits the table is indexed with
+	 * (exporter addresses differ in their last byte, which is the top byte of the
+	 * word) */
 	uint32_t h = (ver_tid * 0x9E3779B1u) ^ (src_ip * 0x85EBCA77u) ^ (source_id * 0xC2B2AE3Du);
-	return h ^ (h >> 15);
+	h ^= (src_ip >> 16) ^ (src_ip >> 24);
+	h ^= h >> 16;
+	h *= 0x7FEB352Du;
+	h ^= h >> 15;
+	h *= 0x846CA68Bu;
+	h ^= h >> 16;
+	return h;
 }
 
 /* what the Netflow walk needs of a device template */

@@ -289,8 +289,10 @@ xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular, void *
 	const uint32_t i = blockIdx.x * XW_BLOCK + threadIdx.x;
 	const size_t n = in.n;
 	uint32_t k = 0;
+	uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
 	bool ok = false;
 
+	static_assert(XE_WALK_SETS == 4, "the shape kernel notes four runs per datagram");
 	wtotals_init(T);
 
 	if ((i < in.n) && !(in.kinds && (in.kinds[i] == XE_KIND_SFLOW))) {
@@ -301,6 +303,9 @@ xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular, void *
 		const uint32_t src = in.src[i];
 		xe_dgrun r = { 0, 0, 0, 0 };
 		const uint32_t have = (len >= 32) ? 32u : 0u;
+		/* (what the thread lists, kept for the sums at the end) */
+#define XW_NOTE(K, R) do { if ((K) == 0) { n0 = (R).nrec; t0 = (R).tmpl & 0xFFFFu; } else if ((K) == 1) { n1 = (R).nrec; t1 = (R).tmpl & 0xFFFFu; } \
+	else if ((K) == 2) { n2 = (R).nrec; t2 = (R).tmpl & 0xFFFFu; } else { n3 = (R).nrec; t3 = (R).tmpl & 0xFFFFu; } } while (0)
 		if (have) {
 			u32x4 a, b;
 			__builtin_memcpy(&a, p, 16);
@@ -328,6 +333,7 @@ xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular, void *
 					r.tmpl = (in.v5_slot_plus1 - 1) | (24u << 16);
 					r.dev_id = __builtin_bswap32(sid);
 					runs[i] = r;
+					XW_NOTE(0, r);
 					k = 1;
 					ok = true;
 				}
@@ -370,6 +376,7 @@ xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular, void *
 								r.tmpl = e.slot | ((ptr + 4) << 16);
 								r.dev_id = __builtin_bswap32(sid);
 								runs[i] = r;
+								XW_NOTE(0, r);
 								k = 1;
 								bad = false;
 							}
@@ -415,6 +422,7 @@ xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular, void *
 									r.tmpl = e.slot | ((ptr + 4) << 16);
 									r.dev_id = __builtin_bswap32(sid);
 									runs[k * n + i] = r;
+									XW_NOTE(k, r);
 									k++;
 									bad = false;
 								}
@@ -454,9 +462,8 @@ xw_nf_shape_kernel(const xe_walk_in in, xe_dgrun *runs, uint8_t *regular, void *
 		for (uint32_t q = 0; q < m; q++) {
 			uint32_t mine = 0xFFFFFFFFu, nrec = 0;
 			if (q < k) {
-				const xe_dgrun r = runs[q * n + i];   /* (this thread's own store) */
-				mine = r.tmpl & 0xFFFFu;
-				nrec = r.nrec;
+				mine = (q == 0) ? t0 : (q == 1) ? t1 : (q == 2) ? t2 : t3;
+				nrec = (q == 0) ? n0 : (q == 1) ? n1 : (q == 2) ? n2 : n3;
 				all += nrec;
 			}
 			wtotals_add(T, mine, nrec, sums, in.ntmpl);
