@@ -340,15 +340,18 @@ size_t xe_field_offset(int field);   /* offsetof(struct flow_info, <field>) */
 int xe_gpu_iplist_match(xe_gpu *h, const char *list, int family, const uint8_t *addrs,
 	size_t n, uint8_t *out);
 
-/* xe_gpu_iplist_match() for callers that cannot allocate device memory (code
- * under HIP graph capture, tight serving loops, harnesses that forbid
- * hipMalloc).  No counterpart in the reference.  Addresses and answers are
- * staged in a static device array of the library instead of freshly
- * allocated buffers (every GPU the library is used on holds it until the
- * process ends: 17 * XE_GPU_NOALLOC_MAX_ADDRS bytes), so the call makes no
- * hipMalloc / hipFree.  n above XE_GPU_NOALLOC_MAX_ADDRS is refused with
- * XE_EINVAL.  All calls on one GPU share that array: calls that overlap on
- * one GPU (from any handle or thread) race; serialise them. */
+/* xe_gpu_iplist_match() for callers that cannot allocate device memory (tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  Addresses and answers are staged in a static device array of
+ * the library instead of freshly allocated buffers (every GPU the library is
+ * used on holds it until the process ends: 17 * XE_GPU_NOALLOC_MAX_ADDRS
+ * bytes), so the call makes no hipMalloc / hipFree.  It copies from and to
+ * the caller's host memory on the null stream and waits for the result: it is
+ * not meant for (and cannot run under) stream capture.  n above
+ * XE_GPU_NOALLOC_MAX_ADDRS is refused with XE_EINVAL; on a device index of 64
+ * or more the call answers XE_ESTATE.  All calls on one GPU share that array:
+ * calls that overlap on one GPU (from any handle or thread) race; serialise
+ * them. */
 #define XE_GPU_NOALLOC_MAX_ADDRS 65536
 int xe_gpu_iplist_match_noalloc(xe_gpu *h, const char *list, int family, const uint8_t *addrs,
 	size_t n, uint8_t *out);

@@ -123,6 +123,16 @@ xenoeye_gpu_shim_init(const struct xe_shim_config *cfg)
 
 	for (t = 0; t < cfg->nthreads; t++) {
 		if (!cfg->gpu[t] || ((size_t)xe_gpu_mo_count(cfg->gpu[t]) != S.nmo)) { rc = XE_EINVAL; goto fail; }
+		/* every handle must see the objects as the first one does: the same tree,
+		 * the same objects left to filter_match() (a handle without the port names
+		 * or databases of another would hand out candidate bits as matches) */
+		for (m = 0; (t > 0) && (m < S.nmo); m++) {
+			if ((xe_gpu_mo_parent(cfg->gpu[t], (int)m) != xe_gpu_mo_parent(cfg->gpu[0], (int)m))
+				|| (xe_gpu_mo_host_only(cfg->gpu[t], (int)m) != xe_gpu_mo_host_only(cfg->gpu[0], (int)m))) {
+				rc = XE_EINVAL;
+				goto fail;
+			}
+		}
 	}
 	for (m = 0; m < S.nmo; m++) {
 		const int parent = xe_gpu_mo_parent(cfg->gpu[0], (int)m);

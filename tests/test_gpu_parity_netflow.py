@@ -140,6 +140,35 @@ def test_v9_long_records(eng, orc):
         e.close()
 
 
+@pytest.mark.parametrize("nobj", [8, 64])
+def test_long_records_beside_the_counter_copies(orc, nobj):
+    """records of 209-241 bytes with few objects: a block keeps several copies
+    of its counters in LDS then, and the staging area of the longest records
+    must leave room for all of them (host walk, then device walk)"""
+    rng = synth.Rng(6)
+    for pad_fields in (47, 50, 53, 54, 55):
+        tmpl = [(8, 4), (12, 4), (7, 2), (11, 2), (4, 1)] + [(30000 + i, 4) for i in range(pad_fields)] + [(1, 4), (2, 4)]
+        rl = sum(l for _, l in tmpl)
+        nrec = 60 * (1400 // rl) + 2
+        rec = rng.bytes(nrec * rl).reshape(nrec, rl)
+        b = synth.Batch()
+        b.add(synth.v9_template_packet(300, tmpl, 9), EXP)
+        b.extend(synth.v9_data_packets(300, rec, 1400 // rl, 9), EXP)
+        e = xenoeye_amd.Engine(device=0)
+        orc.reset()
+        mos = [("proto 6", -1), ("src net 10.0.0.0/8 or dst port 0-1023", -1), ("", -1)] + \
+            [("dst port %d-%d" % (900 * i, 900 * i + 700), -1) for i in range(nobj - 3)]
+        configure(e, orc, None, mos)
+        for rnd in range(2):
+            orc.log_clear()
+            out = e.prepare(b)
+            out.run()
+            run_oracle(orc, b)
+            compare(out, orc)
+            out.free()
+        e.close()
+
+
 def test_v9_two_templates_in_one_flowset(eng, orc):
     """only the first template of a template flowset is registered; the second
     one's header is then read as a flowset header"""

@@ -2480,6 +2480,13 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
  * inside the batch is walked by the host from its first datagram on (the store
  * is put back to where it was and the walk repeated). */
 static int
+u32_cmp(const void *a, const void *b)
+{
+	const uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+	return (x > y) - (x < y);
+}
+
+static int
 walk_host_part(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets, const uint32_t *src, size_t n)
 {
 	struct walk_dev *w = &b->w;
@@ -2492,21 +2499,17 @@ walk_host_part(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offs
 		uint32_t *ips = (uint32_t *)malloc(nu * 4);
 		size_t nips = 0, changed = 0;
 		if (!ips) { xe_plan_free(&b->plan); return XE_ENOMEM; }
-		for (size_t i = 0; i < nu; i++) {
-			const uint32_t ip = xe_host_undo_src_ip(&h->hs, i);
-			size_t j;
-			for (j = 0; (j < nips) && (ips[j] != ip); j++) {}
-			if (j == nips) ips[nips++] = ip;
-		}
+		/* the exporters whose templates changed, sorted: every datagram is then
+		 * looked up in a few steps however many exporters changed at once */
+		for (size_t i = 0; i < nu; i++) ips[i] = xe_host_undo_src_ip(&h->hs, i);
+		qsort(ips, nu, 4, u32_cmp);
+		for (size_t i = 0; i < nu; i++) if (!i || (ips[i] != ips[i - 1])) ips[nips++] = ips[i];
 		for (size_t i = 0; i < n; i++) {
 			if (!w->h_walked[i]) continue;
-			for (size_t j = 0; j < nips; j++) {
-				if (ips[j] == src[i]) {
-					w->h_walked[i] = 0;
-					w->kinds2[i] &= (uint8_t)~XE_KIND_ON_DEVICE;
-					changed++;
-					break;
-				}
+			if (bsearch(&src[i], ips, nips, 4, u32_cmp)) {
+				w->h_walked[i] = 0;
+				w->kinds2[i] &= (uint8_t)~XE_KIND_ON_DEVICE;
+				changed++;
 			}
 		}
 		free(ips);
@@ -2713,12 +2716,27 @@ xe_gpu_batch_free(xe_batch *b)
  * to whole 64-record tiles: a wave then works on one template only. */
 /* can the fast kernel decode records of this template (fixed length, no
  * repeated, string or over-long element, staging fits the LDS)? */
+/* copies of the per-object counters a block of the kernels keeps in LDS: as
+ * many as 3 KB hold, 16 at most (0: more objects than LDS counters are kept for) */
+static uint32_t
+lds_counter_copies(const xe_gpu *h)
+{
+	uint32_t copies = 1;
+	if (h->hs.nmos > XE_MAX_LDS_COUNTER_MOS) return 0;
+	while ((copies < 16) && ((size_t)h->hs.nmos * 24 * copies * 2 <= 3072)) copies *= 2;
+	if (h->diag_counter_copies) {       /* diagnostic builds only */
+		const int want = h->diag_counter_copies;
+		if ((want == 1) || (want == 2) || (want == 4) || (want == 8) || (want == 16)) copies = (uint32_t)want;
+	}
+	return copies;
+}
+
 static int
 tmpl_fast(const xe_gpu *h, const struct xe_tmpl *t, const struct xe_tent *te)
 {
-	/* a block stages 4 tiles of 64 records in LDS, beside the counters and
-	 * the atom-table copy: long records only while all of it fits */
-	const size_t cnt_bytes = (h->hs.nmos <= XE_MAX_LDS_COUNTER_MOS) ? h->hs.nmos * 24 : 0;
+	/* a block stages 4 tiles of 64 records in LDS, beside the counters (all
+	 * their copies) and the atom-table copy: long records only while all of it fits */
+	const size_t cnt_bytes = (size_t)lds_counter_copies(h) * h->hs.nmos * 24;
 	const size_t motab_bytes = (h->motab_words * 8 <= 8192 + 64) ? h->motab_words * 8 : 0;
 	const size_t stage_bytes = (size_t)4 * 64 * 4 * (4 * (((size_t)t->stride + 15) / 16) + 1);
 	int ok = h->fast_ok && !t->varlen && !t->repeats
@@ -2761,7 +2779,7 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 	 * kernel.  The environment variable is a diagnostic: time the general kernel */
 	const int force_general = h->diag_force_general || (b->ntot >= fast_record_limit(h));
 	uint32_t maxchunk = 1, R, tilesz;
-	size_t cnt_bytes = (h->hs.nmos <= XE_MAX_LDS_COUNTER_MOS) ? h->hs.nmos * 24 : 0;
+	size_t cnt_bytes = (size_t)lds_counter_copies(h) * h->hs.nmos * 24;
 	int rc = XE_ENOMEM;
 
 	tfast = (uint8_t *)calloc(nt + 1, 1);
@@ -2946,17 +2964,7 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 		b->kp.motab_lds = (h->motab_words * 8 <= 8192 + 64) ? 1u : 0u;
 		b->kp.probes = (const struct xe_probe *)h->d_lookups;
 		b->kp.nprobes = h->nlookups;
-		/* copies of the counters per block: as many as 3 KB of LDS hold, 16 at most */
-		b->kp.lds_counters = 0;
-		if (h->hs.nmos <= XE_MAX_LDS_COUNTER_MOS) {
-			uint32_t copies = 1;
-			while ((copies < 16) && ((size_t)h->hs.nmos * 24 * copies * 2 <= 3072)) copies *= 2;
-			if (h->diag_counter_copies) {       /* diagnostic */
-				const int want = h->diag_counter_copies;
-				if ((want == 1) || (want == 2) || (want == 4) || (want == 8) || (want == 16)) copies = (uint32_t)want;
-			}
-			b->kp.lds_counters = copies;
-		}
+		b->kp.lds_counters = lds_counter_copies(h);
 	}
 out:
 	free(tfast); free(is_fast); free(gcount); free(gpos);

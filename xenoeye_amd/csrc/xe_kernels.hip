@@ -2973,6 +2973,12 @@ fwm_global_add(const xe_fwm_dev &F, const uint64_t (&kw)[XE_FWM_MAX_KWORDS], uin
 			bool eq = mine;
 			if (st == 2) {
 				eq = true;
+				/* the key words are read after the state said "ready": the loads are
+				 * relaxed (an acquire load would invalidate the CU's whole L1 at every
+				 * probe step) and return in issue order on this part; this fence costs
+				 * no instruction and keeps the compiler from moving them above the
+				 * state load, which the memory model alone would let it do */
+				__atomic_signal_fence(__ATOMIC_ACQUIRE);
 #pragma unroll
 				for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
 					if ((uint32_t)i < F.kwords) {
@@ -3376,12 +3382,20 @@ xe_launch_init_tables(void)
 	hipError_t e = upload_tables();
 	int dev = -1;
 	if (e != hipSuccess) return XE_EHIP;
-	/* this device's copy of the static staging area */
-	if ((hipGetDevice(&dev) != hipSuccess) || (dev < 0) || (dev >= XE_MAX_DEVICES)) return XE_EHIP;
-	if (!g_scratch_ptr[dev]) {
-		uint8_t *p = NULL;
-		if ((hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)) != hipSuccess) || !p) return XE_EHIP;
-		g_scratch_ptr[dev] = p;
+	/* this device's copy of the static staging area (a device beyond the table
+	 * only goes without the entry point that uses it) */
+	if ((hipGetDevice(&dev) != hipSuccess) || (dev < 0)) return XE_EHIP;
+	if (dev < XE_MAX_DEVICES) {
+		static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;   /* handles may be made on several threads */
+		int rc = XE_OK;
+		pthread_mutex_lock(&mu);
+		if (!g_scratch_ptr[dev]) {
+			uint8_t *p = NULL;
+			if ((hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)) != hipSuccess) || !p) rc = XE_EHIP;
+			else g_scratch_ptr[dev] = p;
+		}
+		pthread_mutex_unlock(&mu);
+		if (rc != XE_OK) return rc;
 	}
 	g_tables_ready = 1;
 	return XE_OK;
