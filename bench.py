@@ -64,6 +64,8 @@ def parse_args():
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--traffic", type=float, default=None,
                     help="HBM bytes per launch from a rocprofv3 --pmc pass (reported as roofline.traffic)")
+    ap.add_argument("--root-bits", type=int, default=0, choices=[0, 16, 24],
+                    help="width of the list tables' roots (0 = the library's own choice per table)")
     ap.add_argument("--walk-reps", type=int, default=4,
                     help="prepare() calls the device header walk is timed over (0 = skip)")
     ap.add_argument("--spawn-check", action="store_true",
@@ -113,9 +115,14 @@ def replicate(batch, times):
         batch.kind.extend(batch.kind[:n0])
 
 
+ROOT_BITS = 0
+
+
 def make_engine(w, device):
     import xenoeye_amd
     eng = xenoeye_amd.Engine(device=device)
+    if ROOT_BITS:
+        eng.set_list_root_bits(ROOT_BITS)
     for name, text in w["iplists"].items():
         eng.add_iplist(name, text)
     for filt, parent in w["mos"]:
@@ -489,6 +496,8 @@ def main():
     if args.spawn_check:
         spawn_check(args)
         return
+    global ROOT_BITS
+    ROOT_BITS = args.root_bits
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -617,6 +626,8 @@ def main():
             engines, inputs = [], []
             for t in range(nthr):
                 e = xenoeye_amd.Engine(device=local_rank)
+                if ROOT_BITS:
+                    e.set_list_root_bits(ROOT_BITS)
                 for name, text in w["iplists"].items():
                     e.add_iplist(name, text)
                 for filt, parent in w["mos"]:

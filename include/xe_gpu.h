@@ -181,6 +181,15 @@ int xe_gpu_set_geodb(xe_gpu *h, int kind, int family, const void *image, size_t 
 /* the four files of `dir` that exist (geoip.c:146-149); returns how many were loaded */
 int xe_gpu_load_geodb(xe_gpu *h, const char *dir);
 
+/* IP lists on the device (iplist_match4/6, iplist.c:160-216, flattened): the
+ * table of a group of 8 lists starts with a root indexed by the first 16
+ * address bits (256 KiB, stays in the L2: the default) or the first 24 (64 MiB
+ * per group and address family: every IPv4 prefix up to /24 is answered by
+ * one load, which then comes from memory instead of the L2 - worth trying
+ * only for lists of a million prefixes and more).  bits: 16 or 24 (0 = 16).
+ * Takes effect at the next xe_gpu_commit(); results do not depend on it. */
+int xe_gpu_set_list_root_bits(xe_gpu *h, int bits);
+
 /* Host threads xe_gpu_batch_prepare() walks datagram headers with (default 8,
  * or the environment's XE_PREPASS_THREADS; 1 = the calling thread only).
  * Datagrams of one exporter stay on one thread, in arrival order, the way the

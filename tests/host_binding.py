@@ -25,7 +25,7 @@ def load_hosttest():
 
 class ListDev(C.Structure):
     _fields_ = [("root4", C.c_uint32), ("root6", C.c_uint32), ("nodes4", C.c_uint32), ("nodes6", C.c_uint32),
-                ("bit", C.c_uint32), ("chains4", C.c_uint32), ("chains6", C.c_uint32), ("pad", C.c_uint32)]
+                ("bit", C.c_uint32), ("chains4", C.c_uint32), ("chains6", C.c_uint32), ("rbits", C.c_uint32)]
 
 
 class Set(C.Structure):
@@ -51,7 +51,7 @@ class Host:
         L.xe_ht_load_iplists.argtypes = [C.c_void_p, C.c_char_p]
         L.xe_ht_filter_dump.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
         L.xe_ht_flatten.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_size_t),
-                                    C.POINTER(ListDev), C.c_size_t]
+                                    C.POINTER(ListDev), C.c_size_t, C.c_int]
         L.xe_ht_release.argtypes = [C.c_void_p]
         L.xe_ht_nlists.argtypes = [C.c_void_p]
         L.xe_ht_nlists.restype = C.c_size_t
@@ -130,15 +130,18 @@ class Host:
         rc = self.L.xe_ht_filter_dump(self.h, text.encode(), out, len(out), err, len(err))
         return rc, out.value.decode(), err.value.decode(errors="replace")
 
-    def flatten(self):
+    def flatten(self, root_bits=0):
+        """(words, per list (root4, root6, nodes4, nodes6, bit, chains4, chains6)); the roots are
+        Root numbers that remember how many address bits index them"""
         n = self.L.xe_ht_nlists(self.h)
         dev = (ListDev * max(n, 1))()
         words = C.POINTER(C.c_uint32)()
         nw = C.c_size_t()
-        assert self.L.xe_ht_flatten(self.h, C.byref(words), C.byref(nw), dev, n) == 0
+        assert self.L.xe_ht_flatten(self.h, C.byref(words), C.byref(nw), dev, n, root_bits) == 0
         arr = np.ctypeslib.as_array(words, shape=(max(nw.value, 1),)).copy() if nw.value else np.zeros(1, np.uint32)
         self.L.xe_ht_release(words)
-        return arr, [(d.root4, d.root6, d.nodes4, d.nodes6, d.bit, d.chains4, d.chains6) for d in dev[:n]]
+        return arr, [(Root(d.root4, d.rbits & 0xFF), Root(d.root6, (d.rbits >> 8) & 0xFF), d.nodes4, d.nodes6, d.bit,
+                      d.chains4, d.chains6) for d in dev[:n]]
 
     def field_parse(self, text):
         out = (C.c_int * 5)()
@@ -205,9 +208,17 @@ def _resolve(e, addr, nbits, depth):
     return TERM | base | (int(m) << lst)
 
 
+class Root(int):
+    """word offset of a root table + the number of address bits it is indexed with (16 or 24)"""
+    def __new__(cls, off, rbits):
+        o = int.__new__(cls, off)
+        o.rbits = rbits or 16
+        return o
+
+
 def walk_flat(words, root, nodes, addr_bytes, bit=0, chains=0):
     """Reference walker of the flattened list format (tests only): the
-    group's root table over the first 16 bits, then one
+    group's root table over the first 16 (or 24) bits, then one
     directly indexed node per NODE_BITS address bits; a tail of one prefix is a
     chain record or sits in the entry itself; `bit` selects the list inside the
     group's answer bits."""
@@ -215,10 +226,11 @@ def walk_flat(words, root, nodes, addr_bytes, bit=0, chains=0):
         return 0
     nbits = 8 * len(addr_bytes)
     addr = int.from_bytes(addr_bytes, "big")
-    top = addr >> (nbits - 16)
+    rbits = getattr(root, "rbits", 16)
+    top = addr >> (nbits - rbits)
     e = int(words[root + top])
-    e = _resolve(e, addr, nbits, 16)
-    depth = 16
+    e = _resolve(e, addr, nbits, rbits)
+    depth = rbits
     while not (e & TERM) and depth < nbits:
         if e & CHAIN:
             c = chains + (e & ~CHAIN) * CHAIN_WORDS

@@ -231,6 +231,10 @@ def test_flattened_lists_match_oracle(host, orc):
         host.add_iplist(n, t)
         orc.iplist_add(n, t)
     words, devs = host.flatten()
+    # ... and with the roots over 24 address bits (one group of lists here: 2 x 64 MB of tables)
+    words24, devs24 = host.flatten(root_bits=24)
+    assert all(d[0].rbits == 16 and d[1].rbits == 16 for d in devs)
+    assert all(d[0].rbits == 24 and d[1].rbits == 24 for d in devs24 if d[0] or d[1])
     probe4 = [struct.pack(">I", x) for x in [0, 0xFFFFFFFF, 0x0A010203, 0x0A010204, 0x0A010300, 0x0A020000,
                                               0x07070707, 0x07070706, 0x09090909, 0x08000001, 0x7FFFFFFF, 0x80000000,
                                               # below 10.1.2.0/24 towards 10.1.2.3/32: leaves with the first bit
@@ -251,6 +255,11 @@ def test_flattened_lists_match_oracle(host, orc):
             assert walk_flat(words, root4, nodes4, a, bit, chains4) == orc.match4(name, a), (name, a.hex())
         for a in probe6:
             assert walk_flat(words, root6, nodes6, a, bit, chains6) == orc.match6(name, a), (name, a.hex())
+    for (name, _), (root4, root6, nodes4, nodes6, bit, chains4, chains6) in zip(lists.items(), devs24):
+        for a in probe4[::3]:
+            assert walk_flat(words24, root4, nodes4, a, bit, chains4) == orc.match4(name, a), (name, a.hex())
+        for a in probe6[::3]:
+            assert walk_flat(words24, root6, nodes6, a, bit, chains6) == orc.match6(name, a), (name, a.hex())
 
 
 def _count_cases():
@@ -554,3 +563,11 @@ def test_empty_sets_cannot_blow_a_batch_up(host, orc):
     orc.netflow(b.pkts[0], EXP)
     orc.netflow(mild, EXP)
     assert orc.nrecords() == 10000
+
+
+def test_product_library_has_no_diagnostic_switches():
+    """the kernel ablation / phase-timing switches exist only in builds made with -DXE_DIAG
+    (tools/build_variant.sh): the shipped library does not even hold their names"""
+    blob = open(os.path.join(ROOT, "xenoeye_amd", "libxenoeye_gpu.so"), "rb").read()
+    for name in (b"XE_ABLATE", b"XE_FAST_BLOCKS", b"XE_FAST_R", b"XE_COUNTER_COPIES", b"XE_FORCE_GENERAL"):
+        assert name not in blob, name

@@ -37,8 +37,11 @@ def test_sflow_records_equal_reference(eng):
     assert (out.masks()[st != 2, 0] == 1).all()
 
 
-def test_device_list_lookup_equals_reference(eng):
+@pytest.mark.parametrize("root_bits", [16, 24])
+def test_device_list_lookup_equals_reference(eng, root_bits):
+    """(with the list tables' roots over 16 and over 24 address bits)"""
     texts, p4, p6, want4, want6 = golden_io.iplist_reference()
+    eng.set_list_root_bits(root_bits)
     for i, t in enumerate(texts):
         eng.add_iplist("l%d" % i, t)
     eng.commit()
@@ -51,6 +54,7 @@ def test_list_filters_equal_reference_answers(eng):
     """the same answers through the classification kernels: one object per
     list and direction over records that carry the probe addresses"""
     texts, p4, p6, want4, want6 = golden_io.iplist_reference()
+    eng.set_list_root_bits(24)       # (the narrow root is what every other test runs with)
     for i, t in enumerate(texts):
         eng.add_iplist("l%d" % i, t)
     for i in range(len(texts)):

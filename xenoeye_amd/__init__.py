@@ -86,6 +86,7 @@ def load_library(path=LIB_PATH):
         "xe_gpu_batch_timing": (i32, [vp, i32]),
         "xe_gpu_batch_kernel_ms": (i32, [vp, C.POINTER(C.c_float)]),
         "xe_gpu_set_walk_timing": (i32, [vp, i32]),
+        "xe_gpu_set_list_root_bits": (i32, [vp, i32]),
         "xe_gpu_batch_walk_ms": (i32, [vp, C.POINTER(C.c_float)]),
         "xe_gpu_batch_records": (sz, [vp]),
         "xe_gpu_batch_mask_words": (sz, [vp]),
@@ -355,6 +356,10 @@ class Engine:
     def set_device_walk(self, mode):
         """which headers the device walks itself: bit 0 sFlow, bit 1 Netflow datagrams of the usual shape"""
         self._chk(self.L.xe_gpu_set_device_walk(self._h, int(mode)))
+
+    def set_list_root_bits(self, bits):
+        """width of the list tables' roots: 0 = chosen per table, 16 or 24 (before commit())"""
+        self._chk(self.L.xe_gpu_set_list_root_bits(self._h, int(bits)))
 
     def set_walk_timing(self, enable=True):
         """record HIP events around the device header walk of every prepare()"""

@@ -57,6 +57,7 @@ struct xe_gpu
 	/* header walk on the device (xe_walk.hip): bit 0 sFlow, bit 1 Netflow */
 	int device_walk;
 	int walk_timing;           /* record HIP events around the walk's launches of every prepare */
+	int list_root_bits;        /* width of the list tables' roots: 0 = chosen per table, 16, 24 */
 	/* read from the environment once, when the handle is made */
 	int dbg;                   /* XE_DEBUG: timers of prepare on stderr */
 	int diag_force_general, diag_fast_r, diag_counter_copies;   /* diagnostic builds (-DXE_DIAG) only, else 0 */
@@ -1691,7 +1692,7 @@ xe_gpu_commit(xe_gpu *h)
 	if (rc == XE_OK) {
 		h->h_lists = (struct xe_list_dev *)calloc(h->hs.lists.n ? h->hs.lists.n : 1, sizeof(struct xe_list_dev));
 		if (!h->h_lists) rc = XE_ENOMEM;
-		else rc = xe_iplists_flatten(&h->hs.lists, &trie, h->h_lists);
+		else rc = xe_iplists_flatten(&h->hs.lists, &trie, h->h_lists, h->list_root_bits);
 	}
 	h->port_named_off = 0;
 	if ((rc == XE_OK) && h->port_names && (strs.offs.n || 1)) {
@@ -1744,6 +1745,7 @@ xe_gpu_commit(xe_gpu *h)
 			pp[i].root_off = (pp[i].family == 4) ? ld->root4 : ld->root6;
 			pp[i].nodes_off = (pp[i].family == 4) ? ld->nodes4 : ld->nodes6;
 			pp[i].chains_off = (pp[i].family == 4) ? ld->chains4 : ld->chains6;
+			pp[i].root_bits = (pp[i].family == 4) ? (ld->rbits & 0xFF) : ((ld->rbits >> 8) & 0xFF);
 		}
 	}
 	if (rc == XE_OK) {
@@ -3005,6 +3007,15 @@ xe_gpu_set_device_walk(xe_gpu *h, int mode)
 {
 	if (!h || (mode < 0) || (mode > 3)) return XE_EINVAL;
 	h->device_walk = mode;
+	return XE_OK;
+}
+
+extern "C" int
+xe_gpu_set_list_root_bits(xe_gpu *h, int bits)
+{
+	if (!h || ((bits != 0) && (bits != 16) && (bits != 24))) return XE_EINVAL;
+	h->list_root_bits = bits;
+	h->committed = 0;
 	return XE_OK;
 }
 

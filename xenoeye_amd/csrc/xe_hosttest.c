@@ -66,12 +66,12 @@ xe_ht_filter_dump(struct xe_host *hs, const char *text, char *out, size_t outlen
 /* flattened lists: *words is malloc'd (caller frees with xe_ht_release),
  * dev[] gets one entry per list in load order */
 int
-xe_ht_flatten(struct xe_host *hs, uint32_t **words, size_t *nwords, struct xe_list_dev *dev, size_t ndev)
+xe_ht_flatten(struct xe_host *hs, uint32_t **words, size_t *nwords, struct xe_list_dev *dev, size_t ndev, int root_bits)
 {
 	struct xe_blob b = {0};
 	int rc;
 	if (ndev < hs->lists.n) return XE_EINVAL;
-	rc = xe_iplists_flatten(&hs->lists, &b, dev);
+	rc = xe_iplists_flatten(&hs->lists, &b, dev, root_bits);
 	if (rc != XE_OK) { free(b.p); return rc; }
 	*words = b.p;
 	*nwords = b.n;

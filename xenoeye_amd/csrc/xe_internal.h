@@ -188,9 +188,13 @@ struct xe_prog
 };
 
 /* Flattened IP lists.  Lists are merged in groups of XE_LIST_GROUP (registry
- * order); per group and address family: a 65536-entry root over the first 16
- * address bits, then nodes of 2^XE_NODE_BITS entries, one per value of the next
- * XE_NODE_BITS address bits.  8 bits per node measured faster on MI355X than 4
+ * order); per group and address family: a root over the first 16 address bits
+ * (65536 entries, 256 KB: it stays in the L2) or, on request, over the first
+ * 24 (2^24 entries, 64 MB: every IPv4 prefix up to /24 is answered by ONE
+ * load, but that load no longer hits the L2 - measured on MI355X: 8 lists of a
+ * million prefixes 3 % faster, lists of 10 000 prefixes 25-80 % slower), then
+ * nodes of 2^XE_NODE_BITS entries, one per value of the next XE_NODE_BITS
+ * address bits.  8 bits per node measured faster on MI355X than 4
  * (tables a quarter of the size, but one more dependent load per walk).
  * An entry (root and node alike), by its top two bits:
  *   10  the walk ends here, bits 0..7 are the answers of the group's lists
@@ -246,7 +250,8 @@ struct xe_probe
 	uint32_t group;
 	uint32_t nodes_off;  /* word offset of node 0 */
 	uint32_t chains_off; /* word offset of chain record 0 */
-	uint32_t pad[3];
+	uint32_t root_bits;  /* address bits the root table is indexed with: 16 or 24 */
+	uint32_t pad[2];
 };
 
 /* ---- fast kernel tables (built per batch: they hold output addresses) ---- */
@@ -375,7 +380,7 @@ struct xe_list_dev
 	uint32_t nodes4, nodes6; /* word offsets of node 0 */
 	uint32_t bit;            /* the list's bit in the group's answer bytes */
 	uint32_t chains4, chains6; /* word offsets of chain record 0 */
-	uint32_t pad;
+	uint32_t rbits;          /* address bits the roots are indexed with: IPv4 table in bits 0-7, IPv6 table in bits 8-15 */
 };
 
 /* ------------------------------------------------------------------ host side */
@@ -398,7 +403,8 @@ int xe_iplist_find(const struct xe_iplists *reg, const char *name);  /* first ma
 void xe_iplists_free(struct xe_iplists *reg);
 /* appends the flattened form of every list to `words` (uint32 array) and
  * fills dev[] (reg->n entries) */
-int xe_iplists_flatten(const struct xe_iplists *reg, struct xe_blob *words, struct xe_list_dev *dev);
+/* root_bits: 16 or 24 (0 = 16) for every table */
+int xe_iplists_flatten(const struct xe_iplists *reg, struct xe_blob *words, struct xe_list_dev *dev, int root_bits);
 
 /* filters */
 struct xe_filter     /* one compiled expression, host form */

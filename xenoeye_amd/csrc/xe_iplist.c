@@ -266,7 +266,7 @@ struct gpending { struct gstate st; };
 struct gfl_ctx
 {
 	const struct xe_bnode *const *bt;
-	uint32_t *root;           /* 65536 entries while the root is expanded */
+	uint32_t *root;           /* 2^root_bits entries while the root is expanded */
 	uint32_t *node;           /* XE_NODE_WORDS words while a node is expanded */
 	struct xe_blob *queue;    /* struct gpending; queue index = device node index */
 	struct xe_blob *chains;   /* XE_CHAIN_WORDS words per record */
@@ -391,22 +391,43 @@ gnode_cb(void *vctx, uint32_t first, uint32_t count, uint8_t res, const struct g
 	return child_entry(c, child, &c->node[first]);
 }
 
-/* one address family of one group of lists; bt[l] == NULL: list l has no
- * entries of this family (answers 0).  Returns 0 on allocation failure. */
+/* n zero words at the end of b */
 static int
-flatten_group(const struct xe_bnode *const *bt, struct xe_blob *words,
-	uint32_t *root_off, uint32_t *nodes_off, uint32_t *chains_off)
+blob_zeros(struct xe_blob *b, size_t n)
+{
+	const size_t want = (b->n + n) * 4;
+	if (want > b->cap) {
+		size_t nc = b->cap ? b->cap : 4096;
+		void *np;
+		while (nc < want) nc *= 2;
+		np = realloc(b->p, nc);
+		if (!np) return 0;
+		b->p = np;
+		b->cap = nc;
+	}
+	memset((uint8_t *)b->p + b->n * 4, 0, n * 4);
+	b->n += n;
+	return 1;
+}
+
+/* one address family of one group of lists; bt[l] == NULL: list l has no
+ * entries of this family (answers 0).  want_bits: the root's width, 24 or
+ * (anything else) 16.  Returns 0 on allocation failure. */
+static int
+flatten_group(const struct xe_bnode *const *bt, struct xe_blob *words, int want_bits,
+	uint32_t *root_off, uint32_t *nodes_off, uint32_t *chains_off, uint32_t *root_bits)
 {
 	struct xe_blob queue = {0}, chains = {0};
 	struct gfl_ctx c;
 	struct gstate st0;
 	size_t qi, i, root_pos, nodes_pos, chains_pos;
 	uint32_t zero = 0;
-	int l, any = 0, ok = 0;
+	int l, any = 0, ok = 0, rb = (want_bits == 24) ? 24 : 16;
 
 	*root_off = 0;
 	*nodes_off = 0;
 	*chains_off = 0;
+	*root_bits = 16;
 	memset(&st0, 0, sizeof(st0));
 	for (l = 0; l < XE_LIST_GROUP; l++) {
 		if (bt[l]) { st0.walking |= (uint8_t)(1u << l); any = 1; }
@@ -418,18 +439,14 @@ flatten_group(const struct xe_bnode *const *bt, struct xe_blob *words,
 		if (!xe_blob_push(words, &zero, 4)) return 0;
 	}
 	root_pos = words->n;
-	for (i = 0; i < 65536; i++) {
-		if (!xe_blob_push(words, &zero, 4)) return 0;
-	}
 	c.bt = bt;
 	c.queue = &queue;
 	c.chains = &chains;
 	c.node = NULL;
-	{
-		/* the root lives in `words`, which does not grow while it is expanded */
-		c.root = (uint32_t *)words->p + root_pos;
-		if (!gexpand(bt, &st0, 16, 0, groot_cb, &c)) goto out;
-	}
+	if (!blob_zeros(words, (size_t)1 << rb)) goto out;
+	/* the root lives in `words`, which does not grow while it is expanded */
+	c.root = (uint32_t *)words->p + root_pos;
+	if (!gexpand(bt, &st0, rb, 0, groot_cb, &c)) goto out;
 	while (words->n % 16) {
 		if (!xe_blob_push(words, &zero, 4)) goto out;
 	}
@@ -460,6 +477,7 @@ flatten_group(const struct xe_bnode *const *bt, struct xe_blob *words,
 	*root_off = (uint32_t)root_pos;
 	*nodes_off = (uint32_t)nodes_pos;
 	*chains_off = (uint32_t)chains_pos;
+	*root_bits = (uint32_t)rb;
 	ok = 1;
 out:
 	free(queue.p);
@@ -468,27 +486,28 @@ out:
 }
 
 int
-xe_iplists_flatten(const struct xe_iplists *reg, struct xe_blob *words, struct xe_list_dev *dev)
+xe_iplists_flatten(const struct xe_iplists *reg, struct xe_blob *words, struct xe_list_dev *dev, int root_bits)
 {
 	size_t g, l;
 
 	for (g = 0; g * XE_LIST_GROUP < reg->n; g++) {
 		const struct xe_bnode *b4[XE_LIST_GROUP], *b6[XE_LIST_GROUP];
-		uint32_t r4, n4, c4, r6, n6, c6;
+		uint32_t r4, n4, c4, r6, n6, c6, b4bits, b6bits;
 
 		for (l = 0; l < XE_LIST_GROUP; l++) {
 			size_t li = g * XE_LIST_GROUP + l;
 			b4[l] = (li < reg->n) ? reg->l[li].n4 : NULL;
 			b6[l] = (li < reg->n) ? reg->l[li].n6 : NULL;
 		}
-		if (!flatten_group(b4, words, &r4, &n4, &c4)) return XE_ENOMEM;
-		if (!flatten_group(b6, words, &r6, &n6, &c6)) return XE_ENOMEM;
+		if (!flatten_group(b4, words, root_bits, &r4, &n4, &c4, &b4bits)) return XE_ENOMEM;
+		if (!flatten_group(b6, words, root_bits, &r6, &n6, &c6, &b6bits)) return XE_ENOMEM;
 		for (l = 0; (l < XE_LIST_GROUP) && (g * XE_LIST_GROUP + l < reg->n); l++) {
 			struct xe_list_dev *d = &dev[g * XE_LIST_GROUP + l];
 			memset(d, 0, sizeof(*d));
 			d->root4 = r4; d->nodes4 = n4; d->chains4 = c4;
 			d->root6 = r6; d->nodes6 = n6; d->chains6 = c6;
 			d->bit = (uint32_t)l;
+			d->rbits = b4bits | (b6bits << 8);
 		}
 	}
 	return XE_OK;

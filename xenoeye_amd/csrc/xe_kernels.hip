@@ -135,12 +135,14 @@ entry_resolve(uint32_t e, uint32_t next16)
 /* answers of all lists of a group for one address (left-aligned in hi:lo,
  * `bits` wide): bit l = list l.  iplist_match4/6, iplist.c:160-216 */
 __device__ __forceinline__ uint32_t
-group_match(const uint32_t *T, uint32_t root, uint32_t nodes, uint32_t chains, uint64_t hi, uint64_t lo, uint32_t bits)
+group_match(const uint32_t *T, uint32_t root, uint32_t nodes, uint32_t chains, uint64_t hi, uint64_t lo, uint32_t bits,
+	uint32_t rbits)
 {
 	if (!root) return 0;
-	const uint32_t top = (uint32_t)(hi >> 48);
-	uint32_t e = entry_resolve(T[root + top], addr_bits16(hi, lo, 16));
-	for (uint32_t depth = 16; !(e & XE_TRIE_TERM) && (depth < bits); depth += XE_NODE_BITS) {
+	/* the root is indexed with the first rbits (16 or 24) address bits */
+	const uint32_t top = (uint32_t)(hi >> (64 - rbits));
+	uint32_t e = entry_resolve(T[root + top], addr_bits16(hi, lo, rbits));
+	for (uint32_t depth = rbits; !(e & XE_TRIE_TERM) && (depth < bits); depth += XE_NODE_BITS) {
 		if (e & XE_TRIE_CHAIN) {
 			const uint32_t *c = T + chains + (size_t)(e & ~XE_TRIE_CHAIN) * XE_CHAIN_WORDS;
 			const uint32_t w[6] = { c[0], c[1], c[2], c[3], c[4], c[5] };
@@ -164,11 +166,11 @@ struct walk_cache
 
 __device__ __forceinline__ uint32_t
 group_match_cached(walk_cache &wc, const uint32_t *T, uint32_t root, uint32_t nodes, uint32_t chains,
-	uint64_t hi, uint64_t lo, uint32_t bits)
+	uint64_t hi, uint64_t lo, uint32_t bits, uint32_t rbits)
 {
 	if (!root) return 0;
 	if ((wc.root != root) || (wc.hi != hi) || (wc.lo != lo)) {
-		wc.ans = group_match(T, root, nodes, chains, hi, lo, bits);
+		wc.ans = group_match(T, root, nodes, chains, hi, lo, bits, rbits);
 		wc.root = root;
 		wc.hi = hi;
 		wc.lo = lo;
@@ -179,13 +181,13 @@ group_match_cached(walk_cache &wc, const uint32_t *T, uint32_t root, uint32_t no
 __device__ __forceinline__ uint32_t
 trie_match4(const uint32_t *T, const xe_list_dev &L, uint32_t a)
 {
-	return (group_match(T, L.root4, L.nodes4, L.chains4, (uint64_t)a << 32, 0, 32) >> L.bit) & 1;
+	return (group_match(T, L.root4, L.nodes4, L.chains4, (uint64_t)a << 32, 0, 32, L.rbits & 0xFF) >> L.bit) & 1;
 }
 
 __device__ __forceinline__ uint32_t
 trie_match6(const uint32_t *T, const xe_list_dev &L, uint64_t hi, uint64_t lo)
 {
-	return (group_match(T, L.root6, L.nodes6, L.chains6, hi, lo, 128) >> L.bit) & 1;
+	return (group_match(T, L.root6, L.nodes6, L.chains6, hi, lo, 128, (L.rbits >> 8) & 0xFF) >> L.bit) & 1;
 }
 
 /* ------------------------------------------------------------------ field sources */
@@ -427,14 +429,14 @@ term_match(const xe_kparams &kp, const REC &rec, const xe_term &t, walk_cache &w
 						uint32_t a = wide4 ? (uint32_t)(c[k].v.hi >> 32) : (uint32_t)c[k].v.lo;
 						if (o[i].is_list) {
 							const xe_list_dev &L = kp.lists[o[i].list];
-							if ((group_match_cached(wc, kp.trie, L.root4, L.nodes4, L.chains4, (uint64_t)a << 32, 0, 32) >> L.bit) & 1) return true;
+							if ((group_match_cached(wc, kp.trie, L.root4, L.nodes4, L.chains4, (uint64_t)a << 32, 0, 32, L.rbits & 0xFF) >> L.bit) & 1) return true;
 						} else if ((a & (uint32_t)o[i].mask_lo) == (uint32_t)o[i].net_lo) {
 							return true;
 						}
 					} else {
 						if (o[i].is_list) {
 							const xe_list_dev &L = kp.lists[o[i].list];
-							if ((group_match_cached(wc, kp.trie, L.root6, L.nodes6, L.chains6, c[k].v.hi, c[k].v.lo, 128) >> L.bit) & 1) return true;
+							if ((group_match_cached(wc, kp.trie, L.root6, L.nodes6, L.chains6, c[k].v.hi, c[k].v.lo, 128, (L.rbits >> 8) & 0xFF) >> L.bit) & 1) return true;
 						} else if (((c[k].v.hi & o[i].mask_hi) == o[i].net_hi)
 							&& ((c[k].v.lo & o[i].mask_lo) == o[i].net_lo)) {
 							return true;
@@ -776,7 +778,7 @@ fast_lookups(const xe_kparams &kp, const TT &T, const uint64_t (&plists)[LW], ui
 #pragma unroll
 	for (int k = 1; k < LW; k++) plist = (pw == k) ? plists[k] : plist;
 	while ((plist & 0xFF) != 0xFF) {
-		uint32_t nodes[PC], chains[PC], used[PC], pidx[PC], bits[PC];
+		uint32_t nodes[PC], chains[PC], used[PC], pidx[PC], bits[PC], rskip[PC];
 		bool act[PC];
 		uint32_t e[PC][R], roots[PC];
 		uint64_t hi[PC][R], lo[PC][R];
@@ -792,6 +794,9 @@ fast_lookups(const xe_kparams &kp, const TT &T, const uint64_t (&plists)[LW], ui
 			const uint32_t root = q[0], w1 = q[1];
 			nodes[c] = q[3];
 			chains[c] = q[4];
+			/* address bits the root takes beyond 16 (0 or 8): this probe's walk is
+			 * that much deeper at every step of the loop below */
+			rskip[c] = (q[5] == 24) ? 8u : 0u;
 			used[c] = w1 >> 24;
 			pidx[c] = pr;
 			bits[c] = act[c] ? (((w1 & 0xFF) == 4) ? 32u : 128u) : 0u;
@@ -822,13 +827,15 @@ fast_lookups(const xe_kparams &kp, const TT &T, const uint64_t (&plists)[LW], ui
 #pragma unroll
 			for (int r = 0; r < R; r++) {
 				if (!need[c][r]) continue;
-				e[c][r] = XE_GATHER_LOAD(&((const XE_CONST uint32_t *)(kp.trie + roots[c]))[(uint32_t)(hi[c][r] >> 48)]);
+				e[c][r] = XE_GATHER_LOAD(&((const XE_CONST uint32_t *)(kp.trie + roots[c]))[(uint32_t)(hi[c][r] >> (48 - rskip[c]))]);
 			}
 		}
 #pragma unroll
 		for (int c = 0; c < PC; c++) {
 #pragma unroll
-			for (int r = 0; r < R; r++) e[c][r] = entry_resolve(e[c][r], addr_bits16(hi[c][r], lo[c][r], 16));
+			for (int r = 0; r < R; r++) {
+				e[c][r] = entry_resolve(e[c][r], addr_bits16(hi[c][r], lo[c][r], 16 + rskip[c]));
+			}
 		}
 		for (uint32_t depth = 16; depth < maxbits; depth += XE_NODE_BITS) {
 			bool walk[PC][R], any = false;
@@ -839,7 +846,7 @@ fast_lookups(const xe_kparams &kp, const TT &T, const uint64_t (&plists)[LW], ui
 			for (int c = 0; c < PC; c++) {
 #pragma unroll
 				for (int r = 0; r < R; r++) {
-					walk[c][r] = act[c] && (depth < bits[c]) && !(e[c][r] & XE_TRIE_TERM);
+					walk[c][r] = act[c] && (depth + rskip[c] < bits[c]) && !(e[c][r] & XE_TRIE_TERM);
 					any |= walk[c][r];
 				}
 			}
@@ -847,7 +854,7 @@ fast_lookups(const xe_kparams &kp, const TT &T, const uint64_t (&plists)[LW], ui
 			/* only lanes that still walk touch memory */
 #pragma unroll
 			for (int c = 0; c < PC; c++) {
-				if (!act[c] || (depth >= bits[c])) continue;
+				if (!act[c] || (depth + rskip[c] >= bits[c])) continue;
 #pragma unroll
 				for (int r = 0; r < R; r++) {
 					nx[c][r] = e[c][r];
@@ -861,21 +868,21 @@ fast_lookups(const xe_kparams &kp, const TT &T, const uint64_t (&plists)[LW], ui
 							cb[c][r] = XE_GATHER_LOAD((const XE_CONST u32x2 *)(cp + 4));
 						} else {
 							nx[c][r] = XE_GATHER_LOAD(&((const XE_CONST uint32_t *)(kp.trie + nodes[c]))[(size_t)(e[c][r] & (XE_ABL(128) ? 15u : ~0u)) * XE_NODE_WORDS
-								+ addr_byte(hi[c][r], lo[c][r], depth)]);
+								+ addr_byte(hi[c][r], lo[c][r], depth + rskip[c])]);
 						}
 					}
 				}
 			}
 #pragma unroll
 			for (int c = 0; c < PC; c++) {
-				if (!act[c] || (depth >= bits[c])) continue;
+				if (!act[c] || (depth + rskip[c] >= bits[c])) continue;
 #pragma unroll
 				for (int r = 0; r < R; r++) {
 					if (walk[c][r] && (e[c][r] & XE_TRIE_CHAIN)) {
 						const uint32_t w[6] = { ca[c][r].x, ca[c][r].y, ca[c][r].z, ca[c][r].w, cb[c][r].x, cb[c][r].y };
-						e[c][r] = chain_answer(w, hi[c][r], lo[c][r], depth);
+						e[c][r] = chain_answer(w, hi[c][r], lo[c][r], depth + rskip[c]);
 					} else if (walk[c][r]) {
-						e[c][r] = entry_resolve(nx[c][r], addr_bits16(hi[c][r], lo[c][r], depth + XE_NODE_BITS));
+						e[c][r] = entry_resolve(nx[c][r], addr_bits16(hi[c][r], lo[c][r], depth + rskip[c] + XE_NODE_BITS));
 					}
 				}
 			}
