@@ -345,15 +345,30 @@ def measure_other(torch, name, args, device, stream):
            "payload_GBps": batch.payload_bytes * args.other_steps / dt / 1e9,
            "roofline": roofline_of(batch, kms, name, n)}
     out["device_path"] = device_path(out["roofline"], walk_ms, n)
-    if name == "c4":
-        out["list_table_bytes"] = tb = list_table_bytes(w)
-        out["random_gathers_per_s"] = gather_rate(torch, device, tb)
+    if name in ("c4", "c2", "c5"):
+        out["list_walks"] = list_walks(torch, batch, stream, w, device, out["roofline"]["kernel_ms"])
     if rep > 1:
         out["distinct_records"] = n // rep
     batch.free()
     eng.close()
     out["setup_s"] = time.perf_counter() - t0 - dt
     return out
+
+
+def list_walks(torch, batch, stream, w, device, kernel_ms):
+    """the IP-list walks of one launch against what the memory system gives random gathers: loads
+    counted by the kernel itself (one more run with its counters on), the rate of independent 4-byte
+    gathers from a table as large as the workload's list tables measured now, and the share of the
+    kernel's time those gathers alone would take at that rate"""
+    tb = list_table_bytes(w)
+    g = gather_rate(torch, device, tb)
+    root, deep = batch.count_gathers(stream)
+    n = max(batch.records, 1)
+    return {"table_bytes": tb, "random_gathers_per_s": g, "root_loads_per_record": root / n,
+            "node_and_chain_loads_per_record": deep / n,
+            "gathers_per_s_in_kernel": deep / (kernel_ms * 1e-3),
+            "frac_of_gather_bound": (deep / g) / (kernel_ms * 1e-3) if g else None,
+            "note": "root tables (256 KB each) stay in the L2; node and chain-record loads are the gathers that leave it"}
 
 
 def list_table_bytes(w):
@@ -746,13 +761,9 @@ def main():
             roof["peak_measured_error"] = repr(ex)
         if args.workload in ("c2", "c4", "c5"):
             try:
-                tb = list_table_bytes(w)
-                g = gather_rate(torch, torch.device("cuda", local_rank), tb)
-                roof["list_tables"] = {"bytes": tb, "random_gathers_per_s": g,
-                                       "note": "independent 4-byte gathers from a table of that size; the kernel's "
-                                               "list walks are chains of 2-4 dependent gathers per address"}
+                roof["list_walks"] = list_walks(torch, batch, stream, w, torch.device("cuda", local_rank), roof["kernel_ms"])
             except Exception as ex:
-                roof["list_tables"] = {"error": repr(ex)}
+                roof["list_walks"] = {"error": repr(ex)}
         out = {
             "metric": "device-resident flow records/sec decoded+classified",
             "value": value,

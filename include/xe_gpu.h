@@ -250,6 +250,11 @@ int xe_gpu_batch_sync(xe_batch *b);
 int xe_gpu_batch_timing(xe_batch *b, int enable);
 int xe_gpu_batch_kernel_ms(xe_batch *b, float ms[3]);
 int xe_gpu_batch_fwm_ms(xe_batch *b, float *ms);   /* the fixed-window kernel, -1 without tables */
+/* one more run of the batch that counts the loads of the IP-list walks
+ * (iplist_match4/6, iplist.c:160-216, on the flattened tables): out[0] = loads
+ * from the root tables (cache-resident), out[1] = loads of nodes and chain
+ * records behind them (what a walk waits for); blocks until the run is done */
+int xe_gpu_batch_count_gathers(xe_batch *b, void *stream, uint64_t out[2]);
 /* the header walk on the device: with walk timing enabled on the handle every
  * xe_gpu_batch_prepare() records HIP events around the walk's launches (the
  * device side of netflow.c:319-365, :628-678, sflow-impl.h:293-405: shape,

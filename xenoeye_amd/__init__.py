@@ -85,6 +85,7 @@ def load_library(path=LIB_PATH):
         "xe_gpu_batch_sync": (i32, [vp]),
         "xe_gpu_batch_timing": (i32, [vp, i32]),
         "xe_gpu_batch_kernel_ms": (i32, [vp, C.POINTER(C.c_float)]),
+        "xe_gpu_batch_count_gathers": (i32, [vp, vp, C.POINTER(C.c_uint64)]),
         "xe_gpu_set_walk_timing": (i32, [vp, i32]),
         "xe_gpu_set_list_root_bits": (i32, [vp, i32]),
         "xe_gpu_batch_walk_ms": (i32, [vp, C.POINTER(C.c_float)]),
@@ -468,6 +469,12 @@ class PreparedBatch:
         ms = (C.c_float * 3)()
         self.eng._chk(self.L.xe_gpu_batch_kernel_ms(self._b, ms))
         return tuple(ms)
+
+    def count_gathers(self, stream=None):
+        """(root-table loads, node / chain-record loads) of the list walks of one more run"""
+        out = (C.c_uint64 * 2)()
+        self.eng._chk(self.L.xe_gpu_batch_count_gathers(self._b, stream, out))
+        return int(out[0]), int(out[1])
 
     def walk_ms(self):
         """device time of the header walk of this batch's prepare(), -1 = not timed / walked by the host"""

@@ -3399,6 +3399,25 @@ xe_gpu_batch_run(xe_batch *b, void *stream)
 }
 
 extern "C" int
+xe_gpu_batch_count_gathers(xe_batch *b, void *stream, uint64_t out[2])
+{
+	void *d = NULL;
+	int rc;
+	if (!b || !out) return XE_EINVAL;
+	HIPCHK(b->h, hipSetDevice(b->h->device));
+	rc = dev_get(b->h, &d, 256);
+	if (rc != XE_OK) return rc;
+	if (hipMemsetAsync(d, 0, 16, (hipStream_t)stream) != hipSuccess) { dev_put(b->h, d); return hip_fail(b->h, hipGetLastError(), "hipMemsetAsync"); }
+	b->kp.gathers = (unsigned long long *)d;
+	rc = xe_gpu_batch_run(b, stream);
+	b->kp.gathers = NULL;
+	if ((rc == XE_OK) && (hipStreamSynchronize((hipStream_t)stream) != hipSuccess)) rc = hip_fail(b->h, hipGetLastError(), "hipStreamSynchronize");
+	if ((rc == XE_OK) && (hipMemcpy(out, d, 16, hipMemcpyDeviceToHost) != hipSuccess)) rc = hip_fail(b->h, hipGetLastError(), "hipMemcpy");
+	dev_put(b->h, d);
+	return rc;
+}
+
+extern "C" int
 xe_gpu_batch_sync(xe_batch *b)
 {
 	if (!b) return XE_EINVAL;

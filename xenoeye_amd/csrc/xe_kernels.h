@@ -115,6 +115,8 @@ struct xe_kparams
 	const uint32_t *sfbase;
 	const struct xe_sfrd *sfrd;
 	uint32_t *sf_rate;           /* per sFlow record: the sampling rate of its sample */
+	/* instrumentation (NULL = off): [0] += root-table loads, [1] += node and chain-record loads of the list walks */
+	unsigned long long *gathers;
 };
 
 #define XE_MAX_FAST_TERMS 256

@@ -822,6 +822,15 @@ fast_lookups(const xe_kparams &kp, const TT &T, const uint64_t (&plists)[LW], ui
 			}
 			roots[c] = root;
 		}
+		if (kp.gathers) {
+			uint32_t nroot = 0;
+#pragma unroll
+			for (int c = 0; c < PC; c++) {
+#pragma unroll
+				for (int r = 0; r < R; r++) nroot += (uint32_t)__popcll(__ballot(need[c][r]));
+			}
+			if (((threadIdx.x & 63) == 0) && nroot) atomicAdd(kp.gathers, (unsigned long long)nroot);
+		}
 #pragma unroll
 		for (int c = 0; c < PC; c++) {
 #pragma unroll
@@ -851,6 +860,15 @@ fast_lookups(const xe_kparams &kp, const TT &T, const uint64_t (&plists)[LW], ui
 				}
 			}
 			if (!__ballot(any)) break;
+			if (kp.gathers) {
+				uint32_t nw = 0;
+#pragma unroll
+				for (int c = 0; c < PC; c++) {
+#pragma unroll
+					for (int r = 0; r < R; r++) nw += (uint32_t)__popcll(__ballot(walk[c][r]));
+				}
+				if ((threadIdx.x & 63) == 0) atomicAdd(kp.gathers + 1, (unsigned long long)nw);
+			}
 			/* only lanes that still walk touch memory */
 #pragma unroll
 			for (int c = 0; c < PC; c++) {
