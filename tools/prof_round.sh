@@ -23,7 +23,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     acc = collections.defaultdict(lambda: [0.0, 0])
     for f in glob.glob("%s/pmc_%s_%s/**/*counter_collection.csv" % (out, w, c), recursive=True):
         for row in csv.DictReader(open(f)):
-            if "xe_" not in row["Kernel_Name"] or "probe" in row["Kernel_Name"]:
+            if ("xe_" not in row["Kernel_Name"] and "xw_" not in row["Kernel_Name"]) or "probe" in row["Kernel_Name"]:
                 continue
             k = (row["Kernel_Name"].split("(")[0], row["Counter_Name"])
             acc[k][0] += float(row["Counter_Value"]); acc[k][1] += 1
