@@ -102,6 +102,17 @@ struct xe_shim_config
 	 * xenoeye_gpu_shim_poll()) */
 	size_t max_datagrams, max_bytes;
 	uint64_t max_wait_ns;
+	/* idle flush without a change to the capture loop.  scapture_thread() blocks
+	 * in recvfrom() and has no idle branch (scapture.c:25-37), so a thread whose
+	 * exporters fall silent would keep its last partial batch.  NULL: the caller
+	 * polls (below).  Else per thread the UDP port of its capture socket
+	 * (cap->port, scapture.c:143-144; 0 for threads without a socket, e.g. pcap
+	 * captures): when a thread's batch is due, a helper thread of the shim sends
+	 * one 16-byte datagram to 127.0.0.1:port; recvfrom() returns, the loop makes
+	 * its usual entry call, and the shim runs the due batch ON THE CAPTURE THREAD
+	 * and drops the datagram.  The helper thread touches no batch and makes no
+	 * exit call. */
+	const uint16_t *wake_port;
 };
 
 /* after the reference has loaded its objects (monit_objects_init(),
@@ -110,9 +121,13 @@ struct xe_shim_config
 int xenoeye_gpu_shim_init(const struct xe_shim_config *cfg);
 /* runs what thread `thread_id` has collected, on the calling thread (which
  * must be the one that makes the thread's entry calls): for the idle branch of
- * a capture loop and before shutdown.  poll only runs a batch that is due. */
+ * a capture loop that has one (a socket with SO_RCVTIMEO: call poll where
+ * recvfrom() returns -1 / EAGAIN, scapture.c:33-37) and before shutdown.  poll
+ * only runs a batch that is due.  With wake_port set no such branch is needed. */
 int xenoeye_gpu_shim_flush(struct xe_data *globl, size_t thread_id);
 int xenoeye_gpu_shim_poll(struct xe_data *globl, size_t thread_id);
+/* wake-up datagrams sent so far (0 without wake_port) */
+uint64_t xenoeye_gpu_shim_wakeups(void);
 /* after the capture threads have stopped and flushed */
 void xenoeye_gpu_shim_shutdown(void);
 /* datagrams taken, batches run, records decoded, exit calls made, batches that

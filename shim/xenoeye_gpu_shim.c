@@ -11,12 +11,15 @@
  * caller's own filter_match() (filter.h:331).
  */
 #define _GNU_SOURCE
+#include <arpa/inet.h>
 #include <errno.h>
+#include <netinet/in.h>
 #include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 #include "xenoeye_gpu_shim.h"
 
 /* resolved by the program the shim is linked into, unless the configuration
@@ -40,6 +43,10 @@ struct shim_thread
 	uint64_t *time_ns;           /* arrival time of every datagram */
 	size_t n;
 	uint64_t first_mono;         /* monotonic clock at the arrival of the batch's first datagram */
+	/* when the batch being collected is due (0: nothing collected); written by
+	 * the capture thread, read by the wake-up thread */
+	uint64_t due_at;
+	uint64_t woken_for;          /* wake-up thread only: the due_at it has sent a datagram for */
 	/* results of the batch being delivered */
 	uint64_t *masks;
 	uint8_t *status;
@@ -64,7 +71,21 @@ static struct
 	size_t nmo, mask_words;
 	xe_shim_process_nf_fn process_nf;
 	xe_shim_filter_match_fn filter_match;
+	/* idle flush: a thread that sends a wake-up datagram to the capture socket
+	 * of a thread whose batch is due */
+	uint16_t *wake_port;
+	pthread_t waker;
+	int waker_on, wake_fd;
+	pthread_mutex_t wake_mu;
+	pthread_cond_t wake_cv;
+	int wake_stop;
+	uint64_t wake_sent;
 } S;
+
+/* the wake-up datagram: too short and of no version the path takes, so a
+ * reference build that received it would log and leave it (netflow.c:804-819);
+ * the shim recognises it and batches nothing */
+static const uint8_t wake_magic[16] = { 0, 0, 'x', 'e', '-', 'g', 'p', 'u', '-', 'w', 'a', 'k', 'e', 0, 0, 1 };
 
 static uint64_t
 mono_ns(void)
@@ -74,11 +95,76 @@ mono_ns(void)
 	return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
 }
 
+/* The reference's capture loop blocks in recvfrom() and has no idle branch
+ * (scapture.c:25-61), so a thread whose exporters fall silent would keep its
+ * last partial batch.  This thread only wakes the owner: it sends one small
+ * datagram to the owner's own capture socket over the loopback; recvfrom()
+ * returns, the loop calls netflow_process() / sflow_process() as for any
+ * datagram, and the shim - on the capture thread, where the exit calls belong -
+ * finds the batch due and runs it. */
+static void *
+waker_main(void *arg)
+{
+	(void)arg;
+	pthread_mutex_lock(&S.wake_mu);
+	while (!S.wake_stop) {
+		struct timespec ts;
+		uint64_t step = S.cfg.max_wait_ns / 2, now;
+		size_t t;
+
+		if (step < 1000000ull) step = 1000000ull;
+		clock_gettime(CLOCK_REALTIME, &ts);
+		ts.tv_nsec += (long)(step % 1000000000ull);
+		ts.tv_sec += (time_t)(step / 1000000000ull) + ts.tv_nsec / 1000000000l;
+		ts.tv_nsec %= 1000000000l;
+		pthread_cond_timedwait(&S.wake_cv, &S.wake_mu, &ts);
+		if (S.wake_stop) break;
+		now = mono_ns();
+		for (t = 0; t < S.cfg.nthreads; t++) {
+			struct shim_thread *T = &S.th[t];
+			const uint64_t due = __atomic_load_n(&T->due_at, __ATOMIC_ACQUIRE);
+			struct sockaddr_in to;
+
+			if (!S.wake_port[t] || !due || (now < due) || (T->woken_for == due)) continue;
+			memset(&to, 0, sizeof(to));
+			to.sin_family = AF_INET;
+			to.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+			to.sin_port = htons(S.wake_port[t]);
+			if (sendto(S.wake_fd, wake_magic, sizeof(wake_magic), MSG_DONTWAIT, (struct sockaddr *)&to, sizeof(to))
+				== (ssize_t)sizeof(wake_magic)) {
+				T->woken_for = due;
+				__atomic_add_fetch(&S.wake_sent, 1, __ATOMIC_RELAXED);
+			}
+		}
+	}
+	pthread_mutex_unlock(&S.wake_mu);
+	return NULL;
+}
+
+static void
+waker_stop(void)
+{
+	if (S.waker_on) {
+		pthread_mutex_lock(&S.wake_mu);
+		S.wake_stop = 1;
+		pthread_cond_signal(&S.wake_cv);
+		pthread_mutex_unlock(&S.wake_mu);
+		pthread_join(S.waker, NULL);
+		pthread_mutex_destroy(&S.wake_mu);
+		pthread_cond_destroy(&S.wake_cv);
+		close(S.wake_fd);
+		S.waker_on = 0;
+	}
+	free(S.wake_port);
+	S.wake_port = NULL;
+}
+
 void
 xenoeye_gpu_shim_shutdown(void)
 {
 	size_t t;
 
+	waker_stop();
 	if (S.th) {
 		for (t = 0; t < S.cfg.nthreads; t++) {
 			struct shim_thread *T = &S.th[t];
@@ -175,6 +261,28 @@ xenoeye_gpu_shim_init(const struct xe_shim_config *cfg)
 		T->time_ns = calloc(nd, sizeof(uint64_t));
 		T->flows = malloc((size_t)SHIM_CHUNK * XE_FLOW_INFO_SIZE);
 		if (!T->data || !T->off || !T->src || !T->kind || !T->time_ns || !T->flows) goto fail;
+	}
+	if (cfg->wake_port) {
+		int any = 0;
+		S.wake_port = calloc(cfg->nthreads, sizeof(uint16_t));
+		if (!S.wake_port) goto fail;
+		for (t = 0; t < cfg->nthreads; t++) any |= (S.wake_port[t] = cfg->wake_port[t]) != 0;
+		S.cfg.wake_port = S.wake_port;
+		if (any) {
+			S.wake_fd = socket(AF_INET, SOCK_DGRAM, 0);
+			if (S.wake_fd < 0) { rc = XE_EINVAL; goto fail; }
+			pthread_mutex_init(&S.wake_mu, NULL);
+			pthread_cond_init(&S.wake_cv, NULL);
+			S.wake_stop = 0;
+			if (pthread_create(&S.waker, NULL, waker_main, NULL)) {
+				pthread_mutex_destroy(&S.wake_mu);
+				pthread_cond_destroy(&S.wake_cv);
+				close(S.wake_fd);
+				rc = XE_ENOMEM;
+				goto fail;
+			}
+			S.waker_on = 1;
+		}
 	}
 	S.ready = 1;
 	return XE_OK;
@@ -274,6 +382,7 @@ run_batch(struct xe_data *globl, size_t thread_id, struct shim_thread *T)
 	T->stats[1]++;
 	T->n = 0;
 	T->used = 0;
+	__atomic_store_n(&T->due_at, 0, __ATOMIC_RELEASE);
 	return rc;
 }
 
@@ -293,6 +402,12 @@ xenoeye_gpu_shim_poll(struct xe_data *globl, size_t thread_id)
 	T = &S.th[thread_id];
 	if (T->n && ((mono_ns() - T->first_mono) >= S.cfg.max_wait_ns)) return run_batch(globl, thread_id, T);
 	return XE_OK;
+}
+
+uint64_t
+xenoeye_gpu_shim_wakeups(void)
+{
+	return S.waker_on ? __atomic_load_n(&S.wake_sent, __ATOMIC_RELAXED) : 0;
 }
 
 void
@@ -324,6 +439,12 @@ take(struct xe_data *globl, size_t thread_id, struct flow_packet_info *fpi, int 
 	if (clock_gettime(CLOCK_REALTIME_COARSE, &tmsp) < 0) return 0;
 	fpi->time_ns = tmsp.tv_sec * 1e9 + tmsp.tv_nsec;
 	if ((len < 0) || (len > MAX_NF_PACKET_SIZE)) return 0;
+	if ((len == (int)sizeof(wake_magic)) && !memcmp(fpi->rawpacket, wake_magic, sizeof(wake_magic))) {
+		/* the wake-up thread's datagram: nothing to batch, only the due check */
+		T = &S.th[thread_id];
+		if (T->n && ((mono_ns() - T->first_mono) >= S.cfg.max_wait_ns)) (void)run_batch(globl, thread_id, T);
+		return 0;
+	}
 	if (kind == XE_KIND_NETFLOW) {
 		/* netflow.c:804-819: other versions are logged and left */
 		const unsigned version = (len >= 2) ? (((unsigned)fpi->rawpacket[0] << 8) | fpi->rawpacket[1]) : 0;
@@ -335,7 +456,11 @@ take(struct xe_data *globl, size_t thread_id, struct flow_packet_info *fpi, int 
 		|| ((now - T->first_mono) >= S.cfg.max_wait_ns))) {
 		(void)run_batch(globl, thread_id, T);
 	}
-	if (!T->n) { T->off[0] = 0; T->first_mono = now; }
+	if (!T->n) {
+		T->off[0] = 0;
+		T->first_mono = now;
+		__atomic_store_n(&T->due_at, now + S.cfg.max_wait_ns, __ATOMIC_RELEASE);
+	}
 	memcpy(T->data + T->used, fpi->rawpacket, (size_t)len);
 	T->used += (size_t)len;
 	T->src[T->n] = fpi->src_addr_ipv4;

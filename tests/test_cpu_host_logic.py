@@ -565,6 +565,24 @@ def test_empty_sets_cannot_blow_a_batch_up(host, orc):
     assert orc.nrecords() == 10000
 
 
+def test_shim_idle_flush_wakes_the_capture_thread(tmp_path):
+    """scapture_thread() (scapture.c:25-61) blocks in recvfrom() and has no idle
+    branch: three datagrams, then silence.  The shim's wake-up datagram must bring
+    the capture thread back so that the due batch is delivered - on that thread,
+    once - with the flow-path library replaced by stand-ins (no GPU), also under
+    ThreadSanitizer."""
+    import subprocess
+    src = [os.path.join(ROOT, "tests", "idle_flush_driver.c"), os.path.join(ROOT, "shim", "xenoeye_gpu_shim.c")]
+    for extra in ([], ["-fsanitize=thread", "-g"]):
+        exe = str(tmp_path / ("idle" + str(len(extra))))
+        subprocess.run(["gcc", "-O1", "-Wall", "-Wextra", "-Werror", "-pthread"] + extra
+                       + ["-I", os.path.join(ROOT, "include")] + src + ["-o", exe], check=True)
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "ThreadSanitizer" not in r.stderr, r.stderr
+        assert r.stdout.split() == ["calls=3", "on_capture_thread=1", "wakeups=1", "before_due=0"], r.stdout
+
+
 def test_product_library_has_no_diagnostic_switches():
     """the kernel ablation / phase-timing switches exist only in builds made with -DXE_DIAG
     (tools/build_variant.sh): the shipped library does not even hold their names"""
