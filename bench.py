@@ -629,6 +629,46 @@ def main():
     t_e2e_pinned_1 = pinned_pass()
     eng.set_prepass_threads(0)
 
+    # ONE host thread, ONE handle, consecutive batches overlapped: the bytes of batch k + 1 travel while
+    # batch k's kernel runs and its masks come back (two page-locked input buffers, as a capture thread
+    # that fills one while the other is on the link would hold them)
+    overlapped = None
+    if world == 1:
+        try:
+            eng.set_overlap(True)
+            ins = [pinned, (eng.pinned(packed[0]),) + tuple(packed[1:])]
+            mb2 = [mbuf, eng.pinned_array((batch.records * batch.mask_words,), np.uint64)]
+            rounds = max(8, 2 * args.pipeline_rounds)
+
+            def overlapped_pass(rounds):
+                prev = None
+                done = 0
+                t1 = time.perf_counter()
+                for k in range(rounds):
+                    cur = eng.prepare(ins[k & 1])
+                    cur.run(stream)
+                    if prev is not None:
+                        prev.masks(out=mb2[(k - 1) & 1])
+                        prev.counters()
+                        done += prev.records
+                        prev.free()
+                    prev = cur
+                prev.masks(out=mb2[(rounds - 1) & 1])
+                cl = prev.counters()
+                done += prev.records
+                prev.free()
+                return time.perf_counter() - t1, done, cl
+
+            overlapped_pass(2)
+            dt_o, done_o, c_o = overlapped_pass(rounds)
+            assert (c_o == c).all()
+            overlapped = {"rounds": rounds, "records": int(done_o), "seconds": dt_o, "records_per_s": done_o / dt_o,
+                          "ms_per_batch": dt_o / rounds * 1e3}
+        except Exception as ex:
+            overlapped = {"error": repr(ex)}
+        finally:
+            eng.set_overlap(False)
+
     # sustained host-inclusive rate: `args.pipeline` capture threads, each with a handle of its own
     # (the arrangement a collector with several capture threads would use), take turns on this GPU: while one walks headers on the host,
     # another copies or runs.  Every thread owns a share of the exporters and a page-locked buffer.
@@ -793,6 +833,7 @@ def main():
                                "page_locked_input_records_per_s": nrec / t_e2e_pinned,
                                "page_locked_input_one_host_thread_records_per_s": nrec / t_e2e_pinned_1,
                                "headers_walked_on_device": walked,
+                               "one_thread_one_handle_overlapped": overlapped,
                                "pipelined": piped},
             "fixed_window": fixed_window,
         }

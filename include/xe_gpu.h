@@ -235,6 +235,22 @@ int xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets
 	const uint32_t *src_ip4, const uint8_t *kinds, size_t n, xe_batch **out);
 void xe_gpu_batch_free(xe_batch *b);
 
+/* Overlap of consecutive batches on ONE handle (off by default).  With it on,
+ * xe_gpu_batch_prepare() does not wait for the datagram bytes to reach the
+ * device: they travel on a stream of their own, xe_gpu_batch_run() orders the
+ * kernels behind them, and the caller fetches the results of batch k while the
+ * bytes of batch k + 1 are on the link (both directions of the link carry data
+ * at once).  The caller keeps `data` unchanged until xe_gpu_batch_input_done()
+ * has returned (or the batch has run and been waited for), i.e. it fills a
+ * second buffer meanwhile.  The header walk then reads Netflow headers in
+ * place from a page-locked `data` (xe_gpu_host_alloc); from ordinary memory,
+ * and for sFlow, prepare still waits for the copy.  No counterpart in the
+ * reference, which handles one datagram at a time (scapture.c:25-61). */
+int xe_gpu_set_overlap(xe_gpu *h, int on);
+int xe_gpu_batch_input_done(xe_batch *b);
+/* 1 when the batch's last run has finished, 0 while it has not (never blocks) */
+int xe_gpu_batch_done(xe_batch *b);
+
 /* decode + classify every record of the batch on the device.  stream is a
  * hipStream_t (NULL = the null stream); the call only enqueues work.  May be
  * repeated; each run overwrites the batch's outputs and re-zeroes its counters. */

@@ -113,6 +113,13 @@ struct xe_shim_config
 	 * and drops the datagram.  The helper thread touches no batch and makes no
 	 * exit call. */
 	const uint16_t *wake_port;
+	/* not 0: a full batch is left running on the GPU while the thread collects
+	 * the next one (xe_gpu_set_overlap(): two page-locked datagram buffers per
+	 * thread, the bytes of batch k + 1 travel while batch k is decoded); its
+	 * exit calls are made - on the capture thread, in arrival order - at the
+	 * first entry call that finds it finished, before those of any later batch,
+	 * or by the idle flush */
+	int overlap;
 };
 
 /* after the reference has loaded its objects (monit_objects_init(),

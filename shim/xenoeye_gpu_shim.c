@@ -42,6 +42,12 @@ struct shim_thread
 	uint8_t *kind;
 	uint64_t *time_ns;           /* arrival time of every datagram */
 	size_t n;
+	/* overlap: the batch that runs on the GPU while the next one is collected
+	 * (its datagram buffer and arrival times stay with it until it is delivered) */
+	xe_batch *pend;
+	uint8_t *pend_data;
+	uint64_t *pend_time_ns;
+	unsigned since_query;
 	uint64_t first_mono;         /* monotonic clock at the arrival of the batch's first datagram */
 	/* when the batch being collected is due (0: nothing collected); written by
 	 * the capture thread, read by the wake-up thread */
@@ -168,8 +174,11 @@ xenoeye_gpu_shim_shutdown(void)
 	if (S.th) {
 		for (t = 0; t < S.cfg.nthreads; t++) {
 			struct shim_thread *T = &S.th[t];
+			if (T->pend) xe_gpu_batch_free(T->pend);
+			if (S.cfg.overlap && T->h) (void)xe_gpu_set_overlap(T->h, 0);
 			if (T->data) xe_gpu_host_free(T->h, T->data);
-			free(T->off); free(T->src); free(T->kind); free(T->time_ns);
+			if (T->pend_data) xe_gpu_host_free(T->h, T->pend_data);
+			free(T->off); free(T->src); free(T->kind); free(T->time_ns); free(T->pend_time_ns);
 			free(T->masks); free(T->status); free(T->dgram); free(T->flows);
 		}
 	}
@@ -261,6 +270,13 @@ xenoeye_gpu_shim_init(const struct xe_shim_config *cfg)
 		T->time_ns = calloc(nd, sizeof(uint64_t));
 		T->flows = malloc((size_t)SHIM_CHUNK * XE_FLOW_INFO_SIZE);
 		if (!T->data || !T->off || !T->src || !T->kind || !T->time_ns || !T->flows) goto fail;
+		if (S.cfg.overlap) {
+			T->pend_data = xe_gpu_host_alloc(T->h, T->cap + 64);
+			T->pend_time_ns = calloc(nd, sizeof(uint64_t));
+			if (!T->pend_data || !T->pend_time_ns) goto fail;
+			if ((rc = xe_gpu_set_overlap(T->h, 1)) != XE_OK) goto fail;
+			rc = XE_ENOMEM;
+		}
 	}
 	if (cfg->wake_port) {
 		int any = 0;
@@ -295,7 +311,7 @@ fail:
  * (= arrival order: a batch holds datagrams of one kind), objects low to high
  * (= the reference's pre-order, netflow.c:213-244) */
 static int
-deliver(struct xe_data *globl, size_t thread_id, struct shim_thread *T, xe_batch *b, size_t nrec)
+deliver(struct xe_data *globl, size_t thread_id, struct shim_thread *T, xe_batch *b, size_t nrec, const uint64_t *time_ns)
 {
 	const size_t w = S.mask_words;
 	size_t c0;
@@ -332,7 +348,7 @@ deliver(struct xe_data *globl, size_t thread_id, struct shim_thread *T, xe_batch
 		for (r = first; r <= last; r++) {
 			struct flow_info *flow = (struct flow_info *)(T->flows + (r - first) * XE_FLOW_INFO_SIZE);
 			const uint64_t *mk = &T->masks[r * w];
-			const uint64_t tns = T->time_ns[T->dgram[r]];
+			const uint64_t tns = time_ns[T->dgram[r]];
 			size_t m;
 
 			if (T->status[r]) continue;
@@ -356,33 +372,82 @@ deliver(struct xe_data *globl, size_t thread_id, struct shim_thread *T, xe_batch
 	return XE_OK;
 }
 
+static void
+batch_lost(struct shim_thread *T, size_t n, int rc)
+{
+	T->stats[4]++;
+	snprintf(T->err, sizeof(T->err), "batch of %zu datagrams lost: %s: %.200s", n, xe_gpu_strerror(rc),
+		xe_gpu_last_error(T->h));
+}
+
+/* overlap: the exit calls of the batch that was left running (caller holds the handle's lock) */
 static int
-run_batch(struct xe_data *globl, size_t thread_id, struct shim_thread *T)
+deliver_pending(struct xe_data *globl, size_t thread_id, struct shim_thread *T)
+{
+	int rc;
+
+	if (!T->pend) return XE_OK;
+	rc = deliver(globl, thread_id, T, T->pend, xe_gpu_batch_records(T->pend), T->pend_time_ns);
+	if (rc != XE_OK) batch_lost(T, 0, rc);
+	xe_gpu_batch_free(T->pend);
+	T->pend = NULL;
+	return rc;
+}
+
+/* when the waker should look at this thread: a parked batch in a millisecond
+ * (every call moves the time on, so the waker asks again while the batch is
+ * still running), else when the batch being collected is due */
+static void
+set_due(struct shim_thread *T, uint64_t now)
+{
+	const uint64_t due = T->pend ? now + 1000000ull : (T->n ? T->first_mono + S.cfg.max_wait_ns : 0);
+	__atomic_store_n(&T->due_at, due, __ATOMIC_RELEASE);
+}
+
+/* runs what the thread has collected.  Without overlap the exit calls follow
+ * at once.  With it, the batch is left running while the thread collects the
+ * next one (`park`), and what was left running before is delivered first, so
+ * the order of the exit calls stays the order of arrival. */
+static int
+run_batch(struct xe_data *globl, size_t thread_id, struct shim_thread *T, int park)
 {
 	xe_batch *b = NULL;
 	size_t nrec;
-	int rc;
+	int rc = XE_OK;
 
-	if (!T->n) return XE_OK;
 	if (T->lock) pthread_mutex_lock(T->lock);
+	if (!T->n) {
+		rc = deliver_pending(globl, thread_id, T);
+		if (T->lock) pthread_mutex_unlock(T->lock);
+		set_due(T, mono_ns());
+		return rc;
+	}
 	rc = xe_gpu_batch_prepare(T->h, T->data, T->off, T->src, T->kind, T->n, &b);
 	if (rc == XE_OK) rc = xe_gpu_batch_run(b, NULL);
+	/* (the batch before this one: its exit calls while this one's bytes travel) */
+	(void)deliver_pending(globl, thread_id, T);
 	if (rc == XE_OK) {
 		nrec = xe_gpu_batch_records(b);
 		T->stats[2] += nrec;
-		rc = deliver(globl, thread_id, T, b, nrec);
+		if (S.cfg.overlap && park) {
+			uint8_t *d = T->data;
+			uint64_t *tn = T->time_ns;
+			T->pend = b;
+			b = NULL;
+			T->data = T->pend_data; T->pend_data = d;
+			T->time_ns = T->pend_time_ns; T->pend_time_ns = tn;
+			T->since_query = 0;
+		} else {
+			rc = deliver(globl, thread_id, T, b, nrec, T->time_ns);
+		}
 	}
-	if (rc != XE_OK) {
-		T->stats[4]++;
-		snprintf(T->err, sizeof(T->err), "batch of %zu datagrams lost: %s: %.200s", T->n, xe_gpu_strerror(rc),
-			xe_gpu_last_error(T->h));
-	}
+	if (rc != XE_OK) batch_lost(T, T->n, rc);
 	if (b) xe_gpu_batch_free(b);
 	if (T->lock) pthread_mutex_unlock(T->lock);
 	T->stats[1]++;
 	T->n = 0;
 	T->used = 0;
-	__atomic_store_n(&T->due_at, 0, __ATOMIC_RELEASE);
+	set_due(T, mono_ns());
 	return rc;
 }
 
@@ -390,7 +455,26 @@ int
 xenoeye_gpu_shim_flush(struct xe_data *globl, size_t thread_id)
 {
 	if (!S.ready || (thread_id >= S.cfg.nthreads)) return XE_EINVAL;
-	return run_batch(globl, thread_id, &S.th[thread_id]);
+	return run_batch(globl, thread_id, &S.th[thread_id], 0);
+}
+
+/* what an idle moment is for: a due batch runs (and is delivered at once: no
+ * next batch is in sight), a parked batch that has finished is delivered */
+static int
+attend(struct xe_data *globl, size_t thread_id, struct shim_thread *T, uint64_t now)
+{
+	if (T->n && ((now - T->first_mono) >= S.cfg.max_wait_ns)) return run_batch(globl, thread_id, T, 0);
+	if (T->pend && !T->n) return run_batch(globl, thread_id, T, 0);
+	if (T->pend && (xe_gpu_batch_done(T->pend) != 0)) {
+		int rc;
+		if (T->lock) pthread_mutex_lock(T->lock);
+		rc = deliver_pending(globl, thread_id, T);
+		if (T->lock) pthread_mutex_unlock(T->lock);
+		set_due(T, now);
+		return rc;
+	}
+	if (T->pend) set_due(T, now);
+	return XE_OK;
 }
 
 int
@@ -400,8 +484,7 @@ xenoeye_gpu_shim_poll(struct xe_data *globl, size_t thread_id)
 
 	if (!S.ready || (thread_id >= S.cfg.nthreads)) return XE_EINVAL;
 	T = &S.th[thread_id];
-	if (T->n && ((mono_ns() - T->first_mono) >= S.cfg.max_wait_ns)) return run_batch(globl, thread_id, T);
-	return XE_OK;
+	return attend(globl, thread_id, T, mono_ns());
 }
 
 uint64_t
@@ -442,7 +525,7 @@ take(struct xe_data *globl, size_t thread_id, struct flow_packet_info *fpi, int 
 	if ((len == (int)sizeof(wake_magic)) && !memcmp(fpi->rawpacket, wake_magic, sizeof(wake_magic))) {
 		/* the wake-up thread's datagram: nothing to batch, only the due check */
 		T = &S.th[thread_id];
-		if (T->n && ((mono_ns() - T->first_mono) >= S.cfg.max_wait_ns)) (void)run_batch(globl, thread_id, T);
+		(void)attend(globl, thread_id, T, mono_ns());
 		return 0;
 	}
 	if (kind == XE_KIND_NETFLOW) {
@@ -452,14 +535,24 @@ take(struct xe_data *globl, size_t thread_id, struct flow_packet_info *fpi, int 
 	}
 	T = &S.th[thread_id];
 	now = mono_ns();
-	if (T->n && ((T->n >= S.cfg.max_datagrams) || (T->used + (size_t)len > T->cap) || (T->kind[0] != kind)
-		|| ((now - T->first_mono) >= S.cfg.max_wait_ns))) {
-		(void)run_batch(globl, thread_id, T);
+	if (T->n && ((T->n >= S.cfg.max_datagrams) || (T->used + (size_t)len > T->cap) || (T->kind[0] != kind))) {
+		/* full (or the other kind follows): more is on its way, the batch may run beside it */
+		(void)run_batch(globl, thread_id, T, 1);
+	} else if (T->n && ((now - T->first_mono) >= S.cfg.max_wait_ns)) {
+		(void)run_batch(globl, thread_id, T, 0);
+	} else if (T->pend && (++T->since_query >= 64)) {
+		/* a parked batch is delivered as soon as it has finished: looked at every 64 datagrams */
+		T->since_query = 0;
+		if (xe_gpu_batch_done(T->pend) != 0) {
+			if (T->lock) pthread_mutex_lock(T->lock);
+			(void)deliver_pending(globl, thread_id, T);
+			if (T->lock) pthread_mutex_unlock(T->lock);
+			set_due(T, now);
+		}
 	}
 	if (!T->n) {
 		T->off[0] = 0;
 		T->first_mono = now;
-		__atomic_store_n(&T->due_at, now + S.cfg.max_wait_ns, __ATOMIC_RELEASE);
 	}
 	memcpy(T->data + T->used, fpi->rawpacket, (size_t)len);
 	T->used += (size_t)len;
@@ -469,6 +562,7 @@ take(struct xe_data *globl, size_t thread_id, struct flow_packet_info *fpi, int 
 	T->n++;
 	T->off[T->n] = T->used;
 	T->stats[0]++;
+	if (T->n == 1) set_due(T, now);
 	return 1;
 }
 

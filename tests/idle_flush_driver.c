@@ -48,6 +48,8 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 
 void xe_gpu_batch_free(xe_batch *b) { free(b); }
 int xe_gpu_batch_run(xe_batch *b, void *stream) { (void)b; (void)stream; return XE_OK; }
+int xe_gpu_batch_done(xe_batch *b) { (void)b; return 1; }
+int xe_gpu_set_overlap(xe_gpu *h, int on) { (void)h; (void)on; return XE_OK; }
 size_t xe_gpu_batch_records(const xe_batch *b) { return b->n; }
 
 int

@@ -28,7 +28,7 @@ class ShimConfig(C.Structure):
     _fields_ = [("nthreads", C.c_size_t), ("gpu", C.POINTER(C.c_void_p)), ("mo", C.POINTER(C.c_void_p)),
                 ("nmo", C.c_size_t), ("expr", C.POINTER(C.c_void_p)), ("process_nf", PROCESS_NF),
                 ("filter_match", FILTER_MATCH), ("max_datagrams", C.c_size_t), ("max_bytes", C.c_size_t),
-                ("max_wait_ns", C.c_uint64), ("wake_port", C.POINTER(C.c_uint16))]
+                ("max_wait_ns", C.c_uint64), ("wake_port", C.POINTER(C.c_uint16)), ("overlap", C.c_int)]
 
 
 class Shim:
@@ -39,7 +39,7 @@ class Shim:
 
     GLOBL = 0xABCD0000   # stands in for struct xe_data *: handed through untouched
 
-    def __init__(self, engines, host_match=None, max_datagrams=0, max_bytes=0, max_wait_ns=0, keep_flows=True):
+    def __init__(self, engines, host_match=None, max_datagrams=0, max_bytes=0, max_wait_ns=0, keep_flows=True, overlap=0):
         if not os.path.exists(SHIM_SO):
             raise RuntimeError("%s is missing: run build() first" % SHIM_SO)
         xenoeye_amd.load_library()
@@ -74,7 +74,7 @@ class Shim:
         self._mo = (C.c_void_p * max(nmo, 1))(*[m + 1 for m in range(nmo)])
         self._expr = (C.c_void_p * max(nmo, 1))(*[m + 1 for m in range(nmo)])
         cfg = ShimConfig(len(engines), self._gpu, self._mo, nmo, self._expr, self._cb[0], self._cb[1],
-                         max_datagrams, max_bytes, max_wait_ns, None)
+                         max_datagrams, max_bytes, max_wait_ns, None, overlap)
         rc = L.xenoeye_gpu_shim_init(C.byref(cfg))
         if rc != 0:
             raise xenoeye_amd.XeError(rc, "xenoeye_gpu_shim_init")

@@ -44,3 +44,43 @@ def test_batches_of_changing_size_on_one_handle(orc):
         else:
             b.free()
     eng.close()
+
+
+def test_overlapped_batches_equal_the_oracle(orc):
+    """Overlap mode: prepare() does not wait for the datagram bytes, the next batch is prepared while
+    the one before still runs, results are fetched one batch late - every batch must still equal the
+    oracle (Netflow from page-locked buffers read in place, from ordinary memory, and sFlow, whose walk
+    waits for the bytes)."""
+    w = synth.workload_c2(20000, prefixes=500, seed=31)
+    eng = xenoeye_amd.Engine(device=0)
+    configure(eng, orc, w["iplists"], w["mos"])
+    eng.set_overlap(True)
+    batches = [w["batch"],
+               synth.workload_c2(15000, prefixes=500, seed=32)["batch"],
+               synth.workload_c3(3000, seed=9)["batch"],
+               synth.workload_c2(18000, prefixes=500, seed=33)["batch"],
+               synth.workload_c2(500, prefixes=500, seed=34)["batch"]]
+    prev = None
+    for i, batch in enumerate(batches + [None]):
+        cur = None
+        if batch is not None:
+            packed = batch.packed()
+            if i != 1:      # batch 1 comes from ordinary memory
+                packed = (eng.pinned(packed[0]),) + tuple(packed[1:])
+            cur = (eng.prepare(packed), batch, packed)
+            cur[0].run()
+        if prev is not None:
+            orc.log_clear()
+            run_oracle(orc, prev[1])
+            compare(prev[0], orc)
+            prev[0].input_done()
+            prev[0].free()
+        prev = cur
+    eng.set_overlap(False)
+    b = eng.prepare(batches[0])
+    b.run()
+    orc.log_clear()
+    run_oracle(orc, batches[0])
+    compare(b, orc)
+    b.free()
+    eng.close()

@@ -84,10 +84,12 @@ def check(shim, orc, batch, thread_id=0, first_call=0):
     return want
 
 
-def test_c1_sequence(eng, orc):
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_c1_sequence(eng, orc, overlap):
     w = synth.workload_c1(5000, per_packet=24)
     configure(eng, orc, w["iplists"], w["mos"])
-    shim = Shim([eng], max_datagrams=64)      # several batches, the last one partial
+    # several batches, the last one partial; with overlap a full batch runs while the next is collected
+    shim = Shim([eng], max_datagrams=64, overlap=overlap)
     try:
         want = check(shim, orc, w["batch"])
         assert 0 < len(want) < 5000
@@ -100,7 +102,8 @@ def test_c1_sequence(eng, orc):
         shim.close()
 
 
-def test_c2_nested_objects_and_batch_limits(eng, orc):
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_c2_nested_objects_and_batch_limits(eng, orc, overlap):
     w = synth.workload_c2(4000, prefixes=300, n_exporters=8)
     mos = list(w["mos"])
     # children and grandchildren under the list objects, and an object that takes everything
@@ -120,7 +123,7 @@ def test_c2_nested_objects_and_batch_limits(eng, orc):
             add(j)
     mos = [(mos[i][0], remap[mos[i][1]] if mos[i][1] >= 0 else -1) for i in order]
     configure(eng, orc, w["iplists"], mos)
-    shim = Shim([eng], max_bytes=65536)       # a few datagrams per batch
+    shim = Shim([eng], max_bytes=65536, overlap=overlap)       # a few datagrams per batch
     try:
         want = check(shim, orc, w["batch"])
         objs = {c[0] for c in want}
@@ -130,7 +133,8 @@ def test_c2_nested_objects_and_batch_limits(eng, orc):
         shim.close()
 
 
-def test_c3_sflow_and_mixed_kinds(eng, orc):
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_c3_sflow_and_mixed_kinds(eng, orc, overlap):
     w = synth.workload_c3(700)
     c1 = synth.workload_c1(600, per_packet=10)
     mos = list(w["mos"]) + [("", -1)]
@@ -149,7 +153,7 @@ def test_c3_sflow_and_mixed_kinds(eng, orc):
         for _ in range(2):
             if nf:
                 b.add(*nf.pop(0), kind=0)
-    shim = Shim([eng])
+    shim = Shim([eng], overlap=overlap)
     try:
         want = check(shim, orc, b)
         assert len(want) > 700
@@ -177,7 +181,8 @@ def test_device_rules_and_unknown_versions(eng, orc):
         shim.close()
 
 
-def test_two_threads_keep_their_own_order(eng, orc):
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_two_threads_keep_their_own_order(eng, orc, overlap):
     import threading
     e2 = xenoeye_amd.Engine(device=0)
     try:
@@ -189,7 +194,7 @@ def test_two_threads_keep_their_own_order(eng, orc):
         # exporters stay on one thread, as the operator pins them to capture ports
         for p, s, k in zip(w["batch"].pkts, w["batch"].src, w["batch"].kind):
             parts[s[3] & 1].add(p, s, k)
-        shim = Shim([eng, e2], max_datagrams=50)
+        shim = Shim([eng, e2], max_datagrams=50, overlap=overlap)
         try:
             times = [None, None]
 
@@ -264,3 +269,27 @@ def test_host_only_objects_are_decided_by_the_callers_filter_match(eng, orc):
             shim.close()
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def test_parked_batch_is_delivered_without_more_datagrams(eng, orc):
+    """Overlap: a full batch is left running; when nothing else arrives, the idle path (poll, which is
+    also what the wake-up datagram triggers) delivers it, then the partial batch behind it once that is due."""
+    import time
+    w = synth.workload_c1(1500, per_packet=10)
+    configure(eng, orc, w["iplists"], w["mos"])
+    shim = Shim([eng], max_datagrams=100, max_wait_ns=30_000_000, overlap=1)
+    try:
+        times = []
+        for p, s in zip(w["batch"].pkts, w["batch"].src):
+            rc, t = shim.netflow(p, s)
+            assert rc == 1
+            times.append(t)
+        want = expected_calls(orc, w["batch"], times)
+        deadline = time.time() + 10
+        while len(shim.calls) < len(want) and time.time() < deadline:
+            assert shim.poll() == 0
+            time.sleep(0.005)
+        assert [g[:3] for g in shim.calls] == [x[:3] for x in want]
+        assert [g[3] for g in shim.calls] == [x[3] for x in want]
+    finally:
+        shim.close()

@@ -86,6 +86,9 @@ def load_library(path=LIB_PATH):
         "xe_gpu_batch_timing": (i32, [vp, i32]),
         "xe_gpu_batch_kernel_ms": (i32, [vp, C.POINTER(C.c_float)]),
         "xe_gpu_batch_count_gathers": (i32, [vp, vp, C.POINTER(C.c_uint64)]),
+        "xe_gpu_set_overlap": (i32, [vp, i32]),
+        "xe_gpu_batch_input_done": (i32, [vp]),
+        "xe_gpu_batch_done": (i32, [vp]),
         "xe_gpu_set_walk_timing": (i32, [vp, i32]),
         "xe_gpu_set_list_root_bits": (i32, [vp, i32]),
         "xe_gpu_batch_walk_ms": (i32, [vp, C.POINTER(C.c_float)]),
@@ -362,6 +365,10 @@ class Engine:
         """width of the list tables' roots: 0 = chosen per table, 16 or 24 (before commit())"""
         self._chk(self.L.xe_gpu_set_list_root_bits(self._h, int(bits)))
 
+    def set_overlap(self, on=True):
+        """consecutive batches of this handle overlap: prepare() no longer waits for the datagram copy"""
+        self._chk(self.L.xe_gpu_set_overlap(self._h, int(on)))
+
     def set_walk_timing(self, enable=True):
         """record HIP events around the device header walk of every prepare()"""
         self._chk(self.L.xe_gpu_set_walk_timing(self._h, int(enable)))
@@ -469,6 +476,17 @@ class PreparedBatch:
         ms = (C.c_float * 3)()
         self.eng._chk(self.L.xe_gpu_batch_kernel_ms(self._b, ms))
         return tuple(ms)
+
+    def input_done(self):
+        """overlap mode: blocks until the datagram buffer given to prepare() may be reused"""
+        self.eng._chk(self.L.xe_gpu_batch_input_done(self._b))
+
+    def done(self):
+        """has the last run finished? (never blocks)"""
+        rc = self.L.xe_gpu_batch_done(self._b)
+        if rc < 0:
+            self.eng._chk(rc)
+        return bool(rc)
 
     def count_gathers(self, stream=None):
         """(root-table loads, node / chain-record loads) of the list walks of one more run"""

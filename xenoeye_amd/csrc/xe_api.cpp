@@ -36,6 +36,10 @@ struct xe_gpu
 	/* fixed-window tables: they live as long as the handle, batches add to them */
 	hipStream_t copy_stream;   /* datagrams travel on it while the host walks their headers */
 	hipStream_t walk_stream;   /* the device's header walk over a page-locked datagram buffer runs beside the copy */
+	/* overlap of consecutive batches on one handle: the datagram bytes travel on a stream of their own
+	 * that prepare does not wait for */
+	hipStream_t bulk_stream;
+	int overlap;
 	/* device buffers of freed batches, kept for the next ones: hipMalloc and
 	 * hipFree of hundreds of MB cost about a millisecond each, and hipFree
 	 * waits for the whole device, which serialises handles that share a GPU */
@@ -142,6 +146,8 @@ struct xe_batch
 	struct xe_kparams kp;
 	hipStream_t last_stream;
 	int ran;
+	hipEvent_t ev_bulk;        /* overlap mode: the datagram bytes have arrived */
+	hipEvent_t ev_ran;         /* overlap mode: this batch's last run has finished (the stream may carry the next batch already) */
 	int timing;              /* record events around each kernel launch */
 	hipEvent_t ev[6];
 	hipEvent_t ev_fwm[2];      /* around the fixed-window kernel */
@@ -296,6 +302,7 @@ xe_gpu_destroy(xe_gpu *h)
 	free(h->fwms);
 	if (h->d_fwmdesc) (void)hipFree(h->d_fwmdesc);
 	if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+	if (h->bulk_stream) (void)hipStreamDestroy(h->bulk_stream);
 	if (h->walk_stream) (void)hipStreamDestroy(h->walk_stream);
 	for (int i = 0; i < XE_DPOOL; i++) if (h->dpool[i].p) (void)hipFree(h->dpool[i].p);
 	if (h->stage) (void)hipHostFree(h->stage);
@@ -2363,6 +2370,10 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 		}
 	}
 	w->st = st;
+	if (b->ev_bulk && ((mode & 1) || (w->hdr_src == (const uint8_t *)b->d_pkt))) {
+		/* the walk reads the device copy of the datagrams */
+		HIPCHK(h, hipStreamWaitEvent(st, b->ev_bulk, 0));
+	}
 	if (mode & 2) {
 		rc = walk_tables_sync(h);
 		if (rc != XE_OK) return rc;
@@ -2691,9 +2702,16 @@ xe_gpu_batch_free(xe_batch *b)
 {
 	if (!b) return;
 	(void)hipSetDevice(b->h->device);
-	if (b->ran) (void)hipStreamSynchronize(b->last_stream);
+	if (b->ran && b->ev_ran) (void)hipEventSynchronize(b->ev_ran);
+	else if (b->ran) (void)hipStreamSynchronize(b->last_stream);
+	if (b->ev_ran) (void)hipEventDestroy(b->ev_ran);
 	if (b->h && b->h->copy_stream) (void)hipStreamSynchronize(b->h->copy_stream);
 	if (b->h && b->h->walk_stream && b->w.mode) (void)hipStreamSynchronize(b->h->walk_stream);
+	if (b->ev_bulk) {
+		/* (this batch's bytes only: the stream may already carry the next batch) */
+		(void)hipEventSynchronize(b->ev_bulk);
+		(void)hipEventDestroy(b->ev_bulk);
+	}
 	dev_put(b->h, b->d_pkt);
 	dev_put(b->h, b->d_sets);
 	dev_put(b->h, b->d_exps);
@@ -3081,9 +3099,16 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 	if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
 	{
 		hipError_t e = hipSuccess;
-		if (total) e = hipMemcpyAsync(b->d_pkt, data, total, hipMemcpyHostToDevice, h->copy_stream);
-		if (e == hipSuccess) e = hipMemsetAsync((uint8_t *)b->d_pkt + total, 0, 64, h->copy_stream);
+		const hipStream_t bulk = h->overlap ? h->bulk_stream : h->copy_stream;
+		if (total) e = hipMemcpyAsync(b->d_pkt, data, total, hipMemcpyHostToDevice, bulk);
+		if (e == hipSuccess) e = hipMemsetAsync((uint8_t *)b->d_pkt + total, 0, 64, bulk);
+		if ((e == hipSuccess) && h->overlap) {
+			/* whoever reads the bytes on the device waits for this event; the call itself does not */
+			e = hipEventCreateWithFlags(&b->ev_bulk, hipEventDisableTiming);
+			if (e == hipSuccess) e = hipEventRecord(b->ev_bulk, bulk);
+		}
 		if (e != hipSuccess) {
+			if (h->overlap) (void)hipStreamSynchronize(h->bulk_stream);
 			(void)hipStreamSynchronize(h->copy_stream);
 			xe_gpu_batch_free(b);
 			return hip_fail(h, e, "hipMemcpyAsync(packets)");
@@ -3129,6 +3154,7 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 		if (walk_mode & 2) xe_host_undo_end(&h->hs);
 		(void)hipStreamSynchronize(h->copy_stream);
 		if (b->w.mode && b->w.st) (void)hipStreamSynchronize(b->w.st);
+		if (b->ev_bulk) { (void)hipEventSynchronize(b->ev_bulk); (void)hipEventDestroy(b->ev_bulk); }
 		dev_put(h, b->d_pkt);
 		walk_free(h, &b->w);
 		free(b);
@@ -3379,6 +3405,7 @@ xe_gpu_batch_run(xe_batch *b, void *stream)
 	/* templates learnt by later batches may have moved the device tables */
 	b->kp.tmpls = (const struct xe_tmpl *)b->h->d_tmpls;
 	b->kp.tents = (const struct xe_tent *)b->h->d_tents;
+	if (b->ev_bulk) HIPCHK(b->h, hipStreamWaitEvent((hipStream_t)stream, b->ev_bulk, 0));
 	rc = xe_launch_batch(&b->kp, stream, b->timing ? (void **)b->ev : NULL);
 	if ((rc == XE_OK) && b->h->nfwm) {
 		uint32_t kwmax = 1, nvmax = 1;
@@ -3395,6 +3422,10 @@ xe_gpu_batch_run(xe_batch *b, void *stream)
 	}
 	b->last_stream = (hipStream_t)stream;
 	b->ran = 1;
+	if (b->ev_bulk) {
+		if (!b->ev_ran) HIPCHK(b->h, hipEventCreateWithFlags(&b->ev_ran, hipEventDisableTiming));
+		HIPCHK(b->h, hipEventRecord(b->ev_ran, (hipStream_t)stream));
+	}
 	return XE_OK;
 }
 
@@ -3418,12 +3449,46 @@ xe_gpu_batch_count_gathers(xe_batch *b, void *stream, uint64_t out[2])
 }
 
 extern "C" int
+xe_gpu_set_overlap(xe_gpu *h, int on)
+{
+	if (!h) return XE_EINVAL;
+	HIPCHK(h, hipSetDevice(h->device));
+	if (on && !h->bulk_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->bulk_stream, hipStreamNonBlocking));
+	h->overlap = on ? 1 : 0;
+	return XE_OK;
+}
+
+extern "C" int
+xe_gpu_batch_input_done(xe_batch *b)
+{
+	if (!b) return XE_EINVAL;
+	if (!b->ev_bulk) return XE_OK;
+	HIPCHK(b->h, hipSetDevice(b->h->device));
+	HIPCHK(b->h, hipEventSynchronize(b->ev_bulk));
+	return XE_OK;
+}
+
+extern "C" int
+xe_gpu_batch_done(xe_batch *b)
+{
+	hipError_t e;
+	if (!b) return XE_EINVAL;
+	if (!b->ran) return XE_ESTATE;
+	HIPCHK(b->h, hipSetDevice(b->h->device));
+	e = b->ev_ran ? hipEventQuery(b->ev_ran) : hipStreamQuery(b->last_stream);
+	if (e == hipSuccess) return 1;
+	if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+	return hip_fail(b->h, e, "hipEventQuery");
+}
+
+extern "C" int
 xe_gpu_batch_sync(xe_batch *b)
 {
 	if (!b) return XE_EINVAL;
 	if (!b->ran) return XE_ESTATE;
 	HIPCHK(b->h, hipSetDevice(b->h->device));
-	HIPCHK(b->h, hipStreamSynchronize(b->last_stream));
+	if (b->ev_ran) HIPCHK(b->h, hipEventSynchronize(b->ev_ran));
+	else HIPCHK(b->h, hipStreamSynchronize(b->last_stream));
 	return XE_OK;
 }
 
@@ -3658,6 +3723,7 @@ sf_field_size(int f)
 static int
 sf_meta_fetch(xe_batch *b, size_t first, size_t count, struct xe_sfrec **out)
 {
+	if (b && b->ev_bulk) (void)hipEventSynchronize(b->ev_bulk);   /* reads the device copy of the datagrams */
 	xe_gpu *h = b->h;
 	struct xe_sfrec *sl = (struct xe_sfrec *)calloc(count + 1, sizeof(*sl));
 	struct xe_sfrd *r2d = (struct xe_sfrd *)malloc((count + 1) * sizeof(*r2d));
