@@ -2102,11 +2102,15 @@ xo_counters(void)
 /* ------------------------------------------------------------------ */
 /* fixed-window tables (monit-objects.c:923-1023, filter-parser.c:348-484) */
 /* ------------------------------------------------------------------ */
-struct ofield   /* struct field, monit-objects.h; plain and aggregable fields only */
+struct ofield   /* struct field, monit-objects.h; without mfreq and the database functions */
 {
 	int aggr, descending;
 	size_t off, size;
 	int scale;
+	/* function forms (field.func_data): which, arguments, div's is_log and k */
+	int func;
+	unsigned int a_off, a_size, b_off, b_size;
+	int is_log, k;
 };
 
 struct ofwm
@@ -2126,7 +2130,7 @@ struct ofwm
 static struct ofwm *fwms = NULL;
 static size_t n_fwms = 0;
 
-/* parse_field(), filter-parser.c:396-484, without the function forms */
+/* parse_field(), filter-parser.c:396-484, without mfreq and the database functions */
 static int
 parse_field(const char *text, struct ofield *fld, char *err, size_t errlen)
 {
@@ -2140,13 +2144,53 @@ parse_field(const char *text, struct ofield *fld, char *err, size_t errlen)
 	if (in.error) { snprintf(err, errlen, "%s", in.errmsg); return 0; }
 	if (in.end) { snprintf(err, errlen, "Empty field not allowed"); return 0; }
 	switch (in.tok.id) {
-		case TK_DIV: case TK_DIV_R: case TK_DIV_L: case TK_MIN: case TK_MFREQ: case TK_GEOIP:
-		case TK_ASN: case TK_ASD: case TK_TFSTR: case TK_PORTSTR: case TK_PPSTR:
-			snprintf(err, errlen, "function fields are not restated by the oracle");
+		case TK_MFREQ: case TK_GEOIP: case TK_ASN: case TK_ASD:
+			snprintf(err, errlen, "mfreq, geo and AS function fields are not restated by the oracle");
 			return 0;
 		default:
 			break;
 	}
+	/* function_div_parse(), function_min_parse(), function_tfstr_parse(),
+	 * function_portstr_parse(), function_ppstr_parse() (filter-parser-funcs.c:83-282,
+	 * :526-705) as parse_field() tries them (filter-parser.c:413-442) */
+	if ((in.tok.id == TK_DIV) || (in.tok.id == TK_DIV_R) || (in.tok.id == TK_DIV_L)) {
+		const int tok = in.tok.id;
+		(void)accept_(&in, tok);
+		fld->func = (tok == TK_DIV) ? FN_DIV : (tok == TK_DIV_R) ? FN_DIV_R : FN_DIV_L;
+		fld->is_log = tok == TK_DIV_L;
+		fld->k = 1;
+		fld->size = sizeof(uint64_t);
+		if (!accept_(&in, TK_LPAREN)) { snprintf(err, errlen, "Expected '(' after 'div'"); return 0; }
+		if (!aggr_field_off_size(&in, &fld->a_off, &fld->a_size)) { snprintf(err, errlen, "Expected aggregable field name"); return 0; }
+		if (!accept_(&in, TK_COMMA)) { snprintf(err, errlen, "Expected ',' after field name"); return 0; }
+		if (!aggr_field_off_size(&in, &fld->b_off, &fld->b_size)) { snprintf(err, errlen, "Expected aggregable field name after comma"); return 0; }
+		if (tok != TK_DIV) {
+			int k;
+			if (!accept_(&in, TK_COMMA)) { snprintf(err, errlen, "Expected ',' after second field name"); return 0; }
+			k = in.tok.low;
+			if (!accept_(&in, TK_INT_RANGE)) { snprintf(err, errlen, "Expected INT"); return 0; }
+			fld->k = k;
+		}
+		if (!accept_(&in, TK_RPAREN)) { snprintf(err, errlen, "Expected ')'"); return 0; }
+		found = 2;
+	} else if ((in.tok.id == TK_MIN) || (in.tok.id == TK_TFSTR) || (in.tok.id == TK_PORTSTR) || (in.tok.id == TK_PPSTR)) {
+		const int tok = in.tok.id;
+		const int two = (tok == TK_MIN) || (tok == TK_PPSTR);
+		(void)accept_(&in, tok);
+		fld->func = (tok == TK_MIN) ? FN_MIN : (tok == TK_TFSTR) ? FN_TFSTR : (tok == TK_PORTSTR) ? FN_PORTSTR : FN_PPSTR;
+		/* utils.h:13-15 */
+		fld->size = (tok == TK_MIN) ? sizeof(uint64_t) : (tok == TK_TFSTR) ? 32 : (tok == TK_PORTSTR) ? 40 : 90;
+		if (!accept_(&in, TK_LPAREN)) { snprintf(err, errlen, "Expected '(' after function name"); return 0; }
+		if (!nonaggr_field(&in, &fld->a_off, &fld->a_size)) { snprintf(err, errlen, "Incorrect field name"); return 0; }
+		if (two) {
+			if (!accept_(&in, TK_COMMA)) { snprintf(err, errlen, "Expected ',' after field name"); return 0; }
+			if (!nonaggr_field(&in, &fld->b_off, &fld->b_size)) { snprintf(err, errlen, "Incorrect field name after comma"); return 0; }
+		}
+		if (!accept_(&in, TK_RPAREN)) { snprintf(err, errlen, "Expected ')'"); return 0; }
+		found = 2;
+	}
+	if (found == 2) fld->off = fld->a_off;
+	if (found != 2)
 	for (i = 0; i < N_AGFIELDS; i++) {
 		if (accept_(&in, TK_AGFIELD0 + i)) {
 			fld->aggr = 1;
@@ -2163,7 +2207,7 @@ parse_field(const char *text, struct ofield *fld, char *err, size_t errlen)
 		for (i = 0; i < N_FFIELDS; i++) {
 			if (accept_(&in, TK_FIELD0 + i)) {
 				int fi;
-				if (dir == DIR_BOTH) {
+				if (dir == DIR_BOTH) { /* (field_without_direction(), filter-parser.c:348-387) */
 					if (ffields[i].src != ffields[i].dst) {
 						snprintf(err, errlen, "This field requires direction");
 						return 0;
@@ -2190,13 +2234,19 @@ parse_field(const char *text, struct ofield *fld, char *err, size_t errlen)
 	return 1;
 }
 
-/* describes a field text: returns 1 and {aggr, offset, size, scale, descending} or 0 + err */
+/* describes a field text: returns 1 and {aggr, offset, size, scale, descending, function, offset of
+ * its second argument, k, sizes of the arguments as a * 256 + b} or 0 + err */
 int
-xo_field_parse(const char *text, int out[5], char *err, size_t errlen)
+xo_field_parse(const char *text, int out[9], char *err, size_t errlen)
 {
+	static const int fn_code[] = { 0, 1, 2, 3, 4, 5, 6, 7 };   /* FN_DIV .. FN_PPSTR as the product numbers them */
 	struct ofield f;
 	if (!parse_field(text, &f, err, errlen)) return 0;
 	out[0] = f.aggr; out[1] = (int)f.off; out[2] = (int)f.size; out[3] = f.scale; out[4] = f.descending;
+	out[5] = f.func ? fn_code[f.func] : 0;
+	out[6] = f.func ? (int)f.b_off : 0;
+	out[7] = f.func ? f.k : 0;
+	out[8] = f.func ? (int)(f.a_size * 256 + f.b_size) : 0;
 	return 1;
 }
 
@@ -2249,6 +2299,58 @@ fwm_grow(struct ofwm *w)
 	w->keys = nk; w->vals = nv; w->used = nu; w->cap = ncap;
 }
 
+/* monit_object_key_add_fld(), monit-objects.c:878-921, with the functions it
+ * calls (:679-717, :827-876) */
+static void
+key_add_fld(const struct ofield *fld, uint8_t *key, struct xo_flow *flow)
+{
+	const uint8_t *fl = (const uint8_t *)flow;
+	uint64_t a, b, res;
+	int i;
+
+	switch (fld->func) {
+		case FN_DIV: case FN_DIV_R: case FN_DIV_L:
+			a = get_nf_val(fl + fld->a_off, fld->a_size);
+			b = get_nf_val(fl + fld->b_off, fld->b_size);
+			/* htobe64(int): the quotient is sign-extended first */
+			res = b ? (uint64_t)(int64_t)xdiv(a, b, fld->is_log, fld->k) : 0;
+			for (i = 0; i < 8; i++) key[i] = (uint8_t)(res >> (56 - 8 * i));
+			break;
+		case FN_MIN:
+			a = get_nf_val(fl + fld->a_off, fld->a_size);
+			b = get_nf_val(fl + fld->b_off, fld->b_size);
+			res = (a < b) ? a : b;
+			for (i = 0; i < 8; i++) key[i] = (uint8_t)(res >> (56 - 8 * i));
+			break;
+		case FN_TFSTR: {
+			char txt[40];
+			memset(key, 0, 32);
+			xo_tcp_flags_str((fld->a_size == 2) ? fl[fld->a_off + 1] : (uint8_t)get_nf_val(fl + fld->a_off, 1), txt);
+			strcpy((char *)key, txt);
+			break;
+		}
+		case FN_PORTSTR: {
+			char txt[300];
+			memset(key, 0, 40);
+			xo_port_to_str(txt, (uint16_t)get_nf_val(fl + fld->a_off, fld->a_size));
+			memcpy(key, txt, (strlen(txt) < 39) ? strlen(txt) : 39);
+			break;
+		}
+		case FN_PPSTR: {
+			char txt[600];
+			memset(key, 0, 90);
+			txt[0] = '\0';
+			xo_ports_pair_to_str(txt, (uint16_t)get_nf_val(fl + fld->a_off, fld->a_size),
+				(uint16_t)get_nf_val(fl + fld->b_off, fld->b_size));
+			memcpy(key, txt, (strlen(txt) < 89) ? strlen(txt) : 89);
+			break;
+		}
+		default:
+			memcpy(key, fl + fld->off, fld->size);
+			break;
+	}
+}
+
 /* the fixed-window part of monit_object_process_nf(), monit-objects.c:927-1023 */
 static void
 fwm_update(struct ofwm *w, struct xo_flow *flow)
@@ -2257,7 +2359,7 @@ fwm_update(struct ofwm *w, struct xo_flow *flow)
 	size_t pos = 0, f, j, h = 1469598103934665603ull, ks = w->keysize ? w->keysize : 1, na = w->n_aggr ? w->n_aggr : 1;
 
 	for (f = 0; f < w->n_naggr; f++) {
-		memcpy(key + pos, (uint8_t *)flow + w->naggr[f].off, w->naggr[f].size);
+		key_add_fld(&w->naggr[f], key + pos, flow);
 		pos += w->naggr[f].size;
 	}
 	if ((w->n + 1) * 2 > w->cap) fwm_grow(w);

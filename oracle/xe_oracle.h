@@ -100,7 +100,7 @@ void xo_log_clear(void);
 int xo_mac_addr_read(const char *s, uint8_t mac[6]);
 /* fixed-window tables of an object (monit-objects.c:923-1023): fields as the
  * "fields" array of an mo.conf "fwm" entry gives them */
-int xo_field_parse(const char *text, int out[5], char *err, size_t errlen);
+int xo_field_parse(const char *text, int out[9], char *err, size_t errlen);
 int xo_fwm_add(int mo, const char *const *field_texts, int n, char *err, size_t errlen);
 size_t xo_fwm_rows(int fwm);
 size_t xo_fwm_keysize(int fwm);

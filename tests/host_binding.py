@@ -144,7 +144,7 @@ class Host:
                       d.chains4, d.chains6) for d in dev[:n]]
 
     def field_parse(self, text):
-        out = (C.c_int * 5)()
+        out = (C.c_int * 9)()
         err = C.create_string_buffer(1100)
         rc = self.L.xe_ht_field_parse(text.encode(), out, err, len(err))
         return rc, tuple(out), err.value.decode(errors="replace")

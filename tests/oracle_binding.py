@@ -99,8 +99,8 @@ class Oracle:
         return self.L.xo_filter_match(h, C.cast(b, C.c_void_p))
 
     def field_parse(self, text):
-        """(aggr, offset, size, scale, descending) of a fixed-window field text"""
-        out = (C.c_int * 5)()
+        """(aggr, offset, size, scale, descending, function, offset of its second argument, k, argument sizes) of a fixed-window field text"""
+        out = (C.c_int * 9)()
         err = C.create_string_buffer(1100)
         if not self.L.xo_field_parse(text.encode(), out, err, len(err)):
             raise ValueError(err.value.decode(errors="replace"))

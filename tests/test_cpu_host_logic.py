@@ -346,20 +346,26 @@ def test_fixed_window_field_parser_matches_oracle(host, orc):
     """`fields` strings of an mo.conf "fwm" entry (parse_field(), filter-parser.c:396-484)"""
     good = ["src host", "dst host desc", "proto", "octets", "bits desc", "packets asc", "src port", "dst port",
             "src host6", "dst mac", "src as", "tcp-flags", "src tos", "src ifidx", "dst vlan", "SRC HOST DESC", "dev-ip",
-            "ioctets", "rpackets", "src net", "dst net6 asc"]
+            "ioctets", "rpackets", "src net", "dst net6 asc",
+            # the function forms (filter-parser.c:413-442)
+            "div(octets, packets)", "div_r(octets, packets, 100) desc", "div_l(bits, packets, 2)", "min(src port, dst port)",
+            "MIN(src as, dst as) asc", "tfstr(tcp-flags)", "portstr(src port)", "portstr(dst port) desc",
+            "ppstr(src port, dst port)"]
     for f in good:
         rc, got, err = host.field_parse(f)
         assert rc == 0, (f, err)
         assert got == orc.field_parse(f), f
     assert host.field_parse("bits")[1][3] == 8 and host.field_parse("src host6")[1][2] == 16
     for f in ["", "host", "port", "tos", "src", "src nothing", "octets extra", "src host desc desc", "dev-id", "dev-mark",
-              "src host asc desc", "proto 6", "(proto)"]:
+              "src host asc desc", "proto 6", "(proto)", "div(octets)", "div(src port, packets)", "div_r(octets, packets)",
+              "min(src port)", "min(port, dst port)", "tfstr tcp-flags", "portstr(src port) 80", "ppstr(src port)",
+              "div(octets, packets", "min(src port, dst port) desc asc"]:
         rc, got, err = host.field_parse(f)
         assert rc == -4, (f, rc, got)
         with pytest.raises(ValueError):
             orc.field_parse(f)
-    for f in ["div(octets, packets)", "min(src port, dst port)", "tfstr(tcp-flags)", "portstr(src port)",
-              "country(src host)", "vashost", "sni"]:
+    for f in ["mfreq(src port, dst port)", "asn(src host)", "asd(dst host)", "country(src host)", "vashost", "sni",
+              "tfstr(sni)"]:
         rc, got, err = host.field_parse(f)
         assert rc == -5 and err, (f, rc)
 

@@ -246,7 +246,9 @@ def _case(seed):
             b.add(_damage(rng, p), a, k)
     # fixed-window tables over some objects
     keyf = ["src host", "dst host", "src host6", "dst host6", "proto", "src port", "dst port", "tcp-flags", "src as",
-            "dst as", "src mac", "dst mac", "src ifidx", "dst ifidx", "src tos", "src vlan", "dev-ip", "src mask"]
+            "dst as", "src mac", "dst mac", "src ifidx", "dst ifidx", "src tos", "src vlan", "dev-ip", "src mask",
+            "div(octets, packets)", "div_r(bits, packets, 8) desc", "div_l(octets, packets, 2)", "min(src port, dst port)",
+            "tfstr(tcp-flags)", "portstr(dst port)", "ppstr(src port, dst port)", "min(src as, dst ifidx)"]
     valf = ["octets", "bits", "packets", "bits desc", "packets asc"]
     tables = []
     for _ in range(int(rng.integers(0, 4))):

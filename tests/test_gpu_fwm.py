@@ -133,7 +133,9 @@ def test_table_that_is_too_small_counts_what_it_drops(eng, orc):
 
 def test_unsupported_fields_are_reported(eng):
     eng.add_mo("mo", "", -1)
-    for f in (["div(octets, packets)", "octets"], ["sni", "packets"], ["tfstr(tcp-flags)", "packets"]):
+    for f in (["mfreq(src port, dst port)", "octets"], ["sni", "packets"], ["country(src host)", "packets"],
+              ["portstr(src port)", "packets"],      # no port names on this handle
+              ["min(src mac, dst mac)", "packets"]):
         with pytest.raises(xenoeye_amd.XeError) as e:
             eng.add_fwm(0, f)
         assert e.value.code == -5
@@ -159,7 +161,8 @@ def test_tables_from_mo_conf(tmp_path, eng, orc):
             { "time": 15, "name": "total", "fields": ["packets", "octets"] },
             { "time": 15, "name": "proto", "fields": ["packets desc", "octets desc", "proto"] },
             { "time": 15, "name": "saddr", "fields": ["packets desc", "octets desc", "src host"], "limit": 5 },
-            { "name": "strange", "fields": ["div(octets, packets)", "packets"] }   // stays with the reference
+            { "name": "sizes", "fields": ["div(octets, packets)", "packets"] },
+            { "name": "strange", "fields": ["mfreq(src port, dst port)", "packets"] }   // stays with the reference
         ],
         "mavg": []
     }""")
@@ -170,10 +173,10 @@ def test_tables_from_mo_conf(tmp_path, eng, orc):
     eng.add_iplist("mynet", w["iplists"]["mynet"])
     orc.iplist_add("mynet", w["iplists"]["mynet"])
     added, skipped = eng.load_mos_with_tables(root, 1 << 16)
-    assert (added, skipped) == (4, 1)
+    assert (added, skipped) == (5, 1)
     names = [eng.mo_name(i) for i in range(eng.mo_count())]
     tabs = eng.fwm_tables()
-    assert sorted(n for _, n in tabs) == ["ports", "proto", "saddr", "total"]
+    assert sorted(n for _, n in tabs) == ["ports", "proto", "saddr", "sizes", "total"]
     eng.commit()
     # the same objects and tables for the oracle, in the library's object order
     filters = {"ingress": "dst net mynet", "ingress_tcp": "proto 6", "plain": "proto 17"}
@@ -181,7 +184,8 @@ def test_tables_from_mo_conf(tmp_path, eng, orc):
     for n in names:
         orc.mo_add(filters[n], parents[n])
     fields = {"total": ["packets", "octets"], "proto": ["packets desc", "octets desc", "proto"],
-              "saddr": ["packets desc", "octets desc", "src host"], "ports": ["dst port", "bits desc"]}
+              "saddr": ["packets desc", "octets desc", "src host"], "ports": ["dst port", "bits desc"],
+              "sizes": ["div(octets, packets)", "packets"]}
     for mo, n in tabs:
         orc.fwm_add(mo, fields[n])
     b = eng.prepare(w["batch"])
@@ -304,3 +308,51 @@ def test_the_key_a_one_word_table_cannot_store_among_the_others(eng, orc):
         assert special in got and len(got) > 1400
         for t in ids:
             eng.fwm_clear(t)
+
+
+def test_function_fields_as_keys(eng, orc):
+    """div / div_r / div_l, min, tfstr, portstr, ppstr as key fields
+    (monit_object_key_add_fld(), monit-objects.c:878-921): the rows, with the
+    texts the reference writes into the key, equal the oracle's"""
+    from oracle_binding import port_names
+    names = port_names()
+    eng.set_port_names(names)
+    orc.set_port_names(names)
+    w = synth.workload_c2(30000, prefixes=300)
+    w["mos"] = list(w["mos"]) + [("", -1), ("proto 6", 16)]
+    tables = [(16, ["div(octets, packets)", "packets"]),
+              (16, ["div_r(octets, packets, 100) desc", "proto", "octets"]),
+              (16, ["div_l(bits, packets, 2)", "octets", "packets"]),
+              (16, ["div_l(octets, packets, 10)", "div(packets, octets)", "packets"]),
+              (16, ["min(src port, dst port)", "bits"]),
+              (17, ["tfstr(tcp-flags)", "packets desc"]),
+              (16, ["proto", "portstr(dst port)", "octets"]),
+              (16, ["ppstr(src port, dst port)", "packets"]),
+              (0, ["src host", "min(src as, dst as)", "tfstr(tcp-flags)", "portstr(src port)", "octets"])]
+    ids = setup(eng, orc, w, tables)
+    for seed in (None, 77):
+        wb = w if seed is None else synth.workload_c2(9000, prefixes=300, seed=seed)
+        b = eng.prepare(wb["batch"])
+        b.run()
+        run_oracle(orc, wb["batch"], keep_flows=False)
+        same_tables(eng, orc, ids)
+        b.free()
+    rows, _ = eng.fwm_read(ids[5])
+    assert any(k.rstrip(b"\0") in (b"ACK", b"ACK+SYN", b"SYN", b"ACK+PSH") for k in rows) and all(len(k) == 32 for k in rows)
+    rows, _ = eng.fwm_read(ids[6])
+    assert any(b" (" in k[1:] for k in rows) and all(len(k) == 41 for k in rows)
+    # the export sorts by the texts and sums as the reference does
+    for t in (ids[1], ids[5], ids[7]):
+        assert eng.fwm_export(t, 5) == orc.fwm_export(t, 5), t
+
+
+def test_function_fields_on_sflow_and_absent_fields(eng, orc):
+    w = synth.workload_c3(4000)
+    w["mos"] = [("", -1)]
+    ids = setup(eng, orc, w, [(0, ["div(octets, packets)", "tfstr(tcp-flags)", "packets"]),
+                              (0, ["min(src port, dst port)", "div_r(bits, packets, 64)", "octets"]),
+                              (0, ["min(src as, dst as)", "packets"])])      # sFlow sets no AS: zeros
+    b = eng.prepare(w["batch"])
+    b.run()
+    run_oracle(orc, w["batch"], keep_flows=False)
+    same_tables(eng, orc, ids)

@@ -87,7 +87,11 @@ struct fwm_host
 {
 	struct xe_fwm_dev dev;     /* with the device pointers */
 	size_t slots, max_keys;
-	uint32_t keybytes;
+	uint32_t keybytes;         /* of a row as the reference keeps it */
+	uint32_t devkeybytes;      /* of a row in the device table (function fields in their short forms) */
+	uint8_t kfunc[XE_FWM_MAX_KEY_FIELDS];
+	uint16_t krefsize[XE_FWM_MAX_KEY_FIELDS];
+	int texts;                 /* some key field is a text made at read-out */
 	char name[256];            /* the entry's "name" in mo.conf, when it came from there */
 	int limit, time;           /* "limit" (rows exported, 0 = all) and "time" (window seconds) of the entry */
 	/* the fields in the order of the entry: what the export sorts by */
@@ -298,6 +302,7 @@ xe_gpu_destroy(xe_gpu *h)
 		if (h->fwms[i].dev.slots) (void)hipFree(h->fwms[i].dev.slots);
 		if (h->fwms[i].dev.vals) (void)hipFree(h->fwms[i].dev.vals);
 		if (h->fwms[i].dev.dropped) (void)hipFree(h->fwms[i].dev.dropped);
+		if (h->fwms[i].dev.dl) (void)hipFree((void *)h->fwms[i].dev.dl);
 	}
 	free(h->fwms);
 	if (h->d_fwmdesc) (void)hipFree(h->d_fwmdesc);
@@ -1295,7 +1300,9 @@ extern "C" int
 xe_gpu_add_fwm(xe_gpu *h, int mo, const char *const *fields, int nfields, size_t max_keys)
 {
 	struct fwm_host w, *tmp;
-	uint32_t pos = 0;
+	uint32_t pos = 0, refpos = 0;
+	int32_t dlp[3 * 80 * 2];       /* pieces of the table's div_l() fields */
+	size_t ndl = 0;
 
 	if (!h || !fields || (nfields < 1) || (mo < 0) || ((size_t)mo >= h->hs.nmos)) return XE_EINVAL;
 	if (mo_host_gated(h, mo)) {
@@ -1330,23 +1337,57 @@ xe_gpu_add_fwm(xe_gpu *h, int mo, const char *const *fields, int nfields, size_t
 			w.dev.vscale[w.dev.nval] = f.scale;
 			w.dev.nval++;
 		} else {
-			if ((f.size > 16) || (f.size > xe_fields[f.field].col_width)) {
+			/* bytes of the field in the device table */
+			uint32_t dsize = f.size;
+			if (f.func != XE_FN_NONE) {
+				const int two = (f.func != XE_FN_TFSTR) && (f.func != XE_FN_PORTSTR);
+				dsize = (f.func == XE_FN_TFSTR) ? 1 : (f.func == XE_FN_PORTSTR) ? 2 : (f.func == XE_FN_PPSTR) ? 4 : 8;
+				const uint32_t sa = xe_fields[f.field].size_max, sb = two ? xe_fields[f.fb].size_max : 1;
+				if (((sa != 1) && (sa != 2) && (sa != 4) && (sa != 8)) || ((sb != 1) && (sb != 2) && (sb != 4) && (sb != 8))) {
+					/* (get_nf_val() reads such a field as 0; none of the port, flag or
+					 * counter fields is one) */
+					snprintf(h->err, sizeof(h->err), "field '%.100s': function over a field that is not 1, 2, 4 or 8 bytes long", fields[i]);
+					return XE_EUNSUPPORTED;
+				}
+				if (((f.func == XE_FN_PORTSTR) || (f.func == XE_FN_PPSTR)) && !h->port_names) {
+					snprintf(h->err, sizeof(h->err), "field '%.100s': portstr() / ppstr() need the port names (xe_gpu_set_port_names)", fields[i]);
+					return XE_EUNSUPPORTED;
+				}
+				if (f.func == XE_FN_DIV_L) {
+					int32_t lo[80], hi[80], val[80];
+					const int np = xe_div_l_pieces(f.k, lo, hi, val, 80);
+					if ((np < 0) || (ndl + 3 * (size_t)np > sizeof(dlp) / sizeof(dlp[0]))) {
+						snprintf(h->err, sizeof(h->err), "field '%.100s': div_l() has too many steps", fields[i]);
+						return XE_EUNSUPPORTED;
+					}
+					w.dev.dl_off[w.dev.nkey] = (uint16_t)ndl;
+					w.dev.dl_n[w.dev.nkey] = (uint16_t)np;
+					for (int q = 0; q < np; q++) { dlp[ndl++] = lo[q]; dlp[ndl++] = hi[q]; dlp[ndl++] = val[q]; }
+				}
+				if (f.func >= XE_FN_TFSTR) w.texts = 1;
+			} else if ((f.size > 16) || (f.size > xe_fields[f.field].col_width)) {
 				snprintf(h->err, sizeof(h->err), "field '%.100s': key fields of more than 16 bytes are not aggregated", fields[i]);
 				return XE_EUNSUPPORTED;
 			}
-			if ((w.dev.nkey == XE_FWM_MAX_KEY_FIELDS) || (pos + f.size > 8 * XE_FWM_MAX_KWORDS)) {
+			if ((w.dev.nkey == XE_FWM_MAX_KEY_FIELDS) || (pos + dsize > 8 * XE_FWM_MAX_KWORDS)) {
 				snprintf(h->err, sizeof(h->err), "key of more than %d fields or %d bytes",
 					XE_FWM_MAX_KEY_FIELDS, 8 * XE_FWM_MAX_KWORDS);
 				return XE_EUNSUPPORTED;
 			}
 			if (f.field == XF_dev_ip) h->fwm_devip = 1;
 			w.dev.kfield[w.dev.nkey] = f.field;
-			w.dev.ksize[w.dev.nkey] = (uint8_t)f.size;
+			w.dev.ksize[w.dev.nkey] = (uint8_t)dsize;
+			w.dev.kfunc[w.dev.nkey] = w.kfunc[w.dev.nkey] = f.func;
+			w.dev.kfield2[w.dev.nkey] = f.fb;
+			w.dev.kk[w.dev.nkey] = f.k;
+			w.krefsize[w.dev.nkey] = (uint16_t)f.size;
 			w.dev.nkey++;
-			pos += f.size;
+			pos += dsize;
+			refpos += f.size;
 		}
 	}
-	w.keybytes = pos;
+	w.keybytes = refpos;
+	w.devkeybytes = pos;
 	w.dev.kwords = (pos + 7) / 8;
 	if (!w.dev.kwords) w.dev.kwords = 1;     /* no key field: one row for everything */
 	w.max_keys = max_keys ? max_keys : 65536;
@@ -1367,6 +1408,10 @@ xe_gpu_add_fwm(xe_gpu *h, int mo, const char *const *fields, int nfields, size_t
 		hipError_t e = hipMalloc((void **)&w.dev.slots, (w.slots + 1) * w.dev.swords * 8);
 		if (e == hipSuccess) e = hipMalloc((void **)&w.dev.vals, (w.slots + 1) * (w.dev.nval ? w.dev.nval : 1) * 8);
 		if (e == hipSuccess) e = hipMalloc((void **)&w.dev.dropped, 8);
+		if ((e == hipSuccess) && ndl) {
+			e = hipMalloc((void **)&w.dev.dl, ndl * 4);
+			if (e == hipSuccess) e = hipMemcpy((void *)w.dev.dl, dlp, ndl * 4, hipMemcpyHostToDevice);
+		}
 		if (e == hipSuccess) e = hipMemset(w.dev.slots, 0, (w.slots + 1) * w.dev.swords * 8);
 		if (e == hipSuccess) e = hipMemset(w.dev.vals, 0, (w.slots + 1) * (w.dev.nval ? w.dev.nval : 1) * 8);
 		if (e == hipSuccess) e = hipMemset(w.dev.dropped, 0, 8);
@@ -1374,6 +1419,7 @@ xe_gpu_add_fwm(xe_gpu *h, int mo, const char *const *fields, int nfields, size_t
 			if (w.dev.slots) (void)hipFree(w.dev.slots);
 			if (w.dev.vals) (void)hipFree(w.dev.vals);
 			if (w.dev.dropped) (void)hipFree(w.dev.dropped);
+			if (w.dev.dl) (void)hipFree((void *)w.dev.dl);
 			return hip_fail(h, e, "device memory of a fixed-window table");
 		}
 	}
@@ -1392,43 +1438,30 @@ xe_gpu_fwm_info(const xe_gpu *h, int fwm, size_t *key_bytes, int *nvals, size_t 
 	return XE_OK;
 }
 
+static long fwm_rows(xe_gpu *h, struct fwm_host *w, uint8_t **keys, uint64_t **vals);
+
 extern "C" long
 xe_gpu_fwm_read(xe_gpu *h, int fwm, uint8_t *keys, uint64_t *vals, size_t max_rows, uint64_t *dropped)
 {
 	struct fwm_host *w;
-	uint64_t *sl = NULL, *vl = NULL;
-	size_t n = 0, nv;
-	long rc = XE_ENOMEM;
+	uint8_t *rk = NULL;
+	uint64_t *rv = NULL;
+	long n;
 
 	if (!h || (fwm < 0) || ((size_t)fwm >= h->nfwm)) return XE_EINVAL;
 	w = &h->fwms[fwm];
-	HIPCHK(h, hipSetDevice(h->device));
-	HIPCHK(h, hipDeviceSynchronize());
-	nv = w->dev.nval ? w->dev.nval : 1;
-	sl = (uint64_t *)malloc((w->slots + 1) * w->dev.swords * 8);
-	vl = (uint64_t *)malloc((w->slots + 1) * nv * 8);
-	if (!sl || !vl) goto out;
-	if ((hipMemcpy(sl, w->dev.slots, (w->slots + 1) * w->dev.swords * 8, hipMemcpyDeviceToHost) != hipSuccess)
-		|| (hipMemcpy(vl, w->dev.vals, (w->slots + 1) * nv * 8, hipMemcpyDeviceToHost) != hipSuccess)
-		|| (dropped && (hipMemcpy(dropped, w->dev.dropped, 8, hipMemcpyDeviceToHost) != hipSuccess))) {
-		rc = XE_EHIP;
-		goto out;
+	n = fwm_rows(h, w, &rk, &rv);
+	if ((n >= 0) && dropped && (hipMemcpy(dropped, w->dev.dropped, 8, hipMemcpyDeviceToHost) != hipSuccess)) {
+		n = hip_fail(h, hipGetLastError(), "hipMemcpy(fixed-window table)");
 	}
-	for (size_t i = 0; i < w->slots + 1; i++) {
-		uint64_t *S = sl + i * w->dev.swords;
-		if ((uint32_t)S[0] != 2) continue;
-		if (n < max_rows) {
-			if (w->dev.kwords == 1) S[1] ^= XE_FWM_KEY_XOR;
-			if (keys) memcpy(keys + n * w->keybytes, S + 1, w->keybytes);
-			if (vals) memcpy(vals + n * w->dev.nval, vl + i * nv, (size_t)w->dev.nval * 8);
-		}
-		n++;
+	if (n > 0) {
+		const size_t m = ((size_t)n < max_rows) ? (size_t)n : max_rows;
+		if (keys) memcpy(keys, rk, m * w->keybytes);
+		if (vals) memcpy(vals, rv, m * (size_t)w->dev.nval * 8);
 	}
-	rc = (long)n;
-out:
-	free(sl);
-	free(vl);
-	return rc;
+	free(rk);
+	free(rv);
+	return n;
 }
 
 extern "C" int
@@ -1445,6 +1478,80 @@ xe_gpu_fwm_window(const xe_gpu *h, int fwm, int *limit, int *seconds)
  * big-endian u64, key fields as stored, `desc` fields bitwise inverted;
  * rows ascending by the bytes of that key. */
 struct fwm_sortrow { const uint8_t *sk; uint32_t row; };
+
+/* a row's key as the reference keeps it (monit_object_key_add_fld(),
+ * monit-objects.c:878-921) from the row of the device table: plain fields, div
+ * and min are the same bytes; tfstr, portstr and ppstr are zero-padded texts
+ * of TCP_FLAGS_STR_MAX_SIZE, TCP_UDP_PORT_STR_MAX_SIZE, TCP_UDP_PP_STR_MAX_SIZE
+ * bytes (utils.h:13-15) made of the flags byte / the ports the table keeps */
+static void
+fwm_ref_key(const xe_gpu *h, const struct fwm_host *w, const uint8_t *dk, uint8_t *out)
+{
+	for (uint32_t k = 0; k < w->dev.nkey; k++) {
+		const uint32_t ds = w->dev.ksize[k], rs = w->krefsize[k];
+		char txt[200];
+		txt[0] = '\0';
+		switch (w->kfunc[k]) {
+			case XE_FN_TFSTR:
+				tcp_flags_text(dk[0], txt);
+				break;
+			case XE_FN_PORTSTR:
+				port_text(h, (uint32_t)dk[0] | ((uint32_t)dk[1] << 8), txt);
+				break;
+			case XE_FN_PPSTR:
+				port_pair_text(h, (uint32_t)dk[0] | ((uint32_t)dk[1] << 8), (uint32_t)dk[2] | ((uint32_t)dk[3] << 8), txt);
+				break;
+			default:
+				memcpy(out, dk, rs);
+				dk += ds;
+				out += rs;
+				continue;
+		}
+		memset(out, 0, rs);
+		memcpy(out, txt, (strlen(txt) < rs - 1) ? strlen(txt) : rs - 1);
+		dk += ds;
+		out += rs;
+	}
+}
+
+/* rows whose texts came out equal are one row in the reference (two pairs of
+ * ports can print the same ppstr text): sums added, first row kept */
+struct fwm_mrow { const uint8_t *key; uint32_t row; };
+static int
+fwm_mrow_cmp(const void *a, const void *b, void *len)
+{
+	const struct fwm_mrow *x = (const struct fwm_mrow *)a, *y = (const struct fwm_mrow *)b;
+	const int c = memcmp(x->key, y->key, *(const size_t *)len);
+	return c ? c : (x->row > y->row) - (x->row < y->row);
+}
+
+static size_t
+fwm_merge_rows(const struct fwm_host *w, uint8_t *keys, uint64_t *vals, size_t n)
+{
+	const size_t kb = w->keybytes, nv = w->dev.nval;
+	struct fwm_mrow *idx = (struct fwm_mrow *)malloc(n * sizeof(*idx));
+	uint8_t *dead = (uint8_t *)calloc(n, 1);
+	size_t kblen = kb, out = 0;
+	if (!idx || !dead) { free(idx); free(dead); return n; }
+	for (size_t r = 0; r < n; r++) { idx[r].key = keys + r * kb; idx[r].row = (uint32_t)r; }
+	qsort_r(idx, n, sizeof(*idx), fwm_mrow_cmp, &kblen);
+	for (size_t r = 1, first = 0; r < n; r++) {
+		if (memcmp(idx[r].key, idx[first].key, kb)) { first = r; continue; }
+		for (size_t j = 0; j < nv; j++) vals[(size_t)idx[first].row * nv + j] += vals[(size_t)idx[r].row * nv + j];
+		dead[idx[r].row] = 1;
+	}
+	for (size_t r = 0; r < n; r++) {
+		if (dead[r]) continue;
+		if (out != r) {
+			memmove(keys + out * kb, keys + r * kb, kb);
+			memmove(vals + out * nv, vals + r * nv, nv * 8);
+		}
+		out++;
+	}
+	free(idx);
+	free(dead);
+	return out;
+}
 
 /* all rows of a table in freshly allocated arrays (the caller frees them):
  * keys[row][keybytes], vals[row][nval]; returns the number of rows or a
@@ -1477,10 +1584,11 @@ fwm_rows(xe_gpu *h, struct fwm_host *w, uint8_t **keys, uint64_t **vals)
 		uint64_t *S = sl + i * w->dev.swords;
 		if ((uint32_t)S[0] != 2) continue;
 		if (w->dev.kwords == 1) S[1] ^= XE_FWM_KEY_XOR;
-		memcpy(*keys + k * w->keybytes, S + 1, w->keybytes);
+		fwm_ref_key(h, w, (const uint8_t *)(S + 1), *keys + k * w->keybytes);
 		memcpy(*vals + k * w->dev.nval, vl + i * nv, (size_t)w->dev.nval * 8);
 		k++;
 	}
+	if (w->texts && (n > 1)) n = fwm_merge_rows(w, *keys, *vals, n);
 	rc = (long)n;
 out:
 	free(sl);

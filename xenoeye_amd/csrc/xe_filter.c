@@ -745,9 +745,9 @@ parse_expr(struct pctx *p)
 }
 
 /* One field of a fixed-window table, `[src|dst] name [asc|desc]` or an
- * aggregable name (parse_field(), filter-parser.c:396-484).  The function
- * forms (div, min, mfreq, tfstr, portstr, ppstr, geoip, asn, asd) are
- * recognised and reported as XE_EUNSUPPORTED. */
+ * aggregable name, or a function form (parse_field(), filter-parser.c:396-484).
+ * mfreq, the geo functions, asn and asd are recognised and reported as
+ * XE_EUNSUPPORTED. */
 int
 xe_field_parse(const char *text, struct xe_agfield *out, char *err, size_t errlen)
 {
@@ -762,12 +762,57 @@ xe_field_parse(const char *text, struct xe_agfield *out, char *err, size_t errle
 	if (p.lx.failed) goto bad;
 	if (p.lx.at_end) { fail(&p.lx, "Empty field not allowed"); goto bad; }
 	switch (p.lx.t) {
-		case T_DIV: case T_DIV_R: case T_DIV_L: case T_MIN: case T_TFSTR: case T_PORTSTR: case T_PPSTR:
 		case T_MFREQ: case T_ASN: case T_ASD: case T_GEO:
-			if (err && errlen) snprintf(err, errlen, "function fields are not supported by this library");
+			/* mfreq() keeps state from record to record, the others put database
+			 * payload into the key */
+			if (err && errlen) snprintf(err, errlen, "mfreq, geo and AS function fields are not supported by this library");
 			return XE_EUNSUPPORTED;
 		default:
 			break;
+	}
+	if ((p.lx.t == T_DIV) || (p.lx.t == T_DIV_R) || (p.lx.t == T_DIV_L) || (p.lx.t == T_MIN) || (p.lx.t == T_TFSTR)
+		|| (p.lx.t == T_PORTSTR) || (p.lx.t == T_PPSTR)) {
+		/* the function forms (function_div_parse() ... function_ppstr_parse(),
+		 * filter-parser-funcs.c:83-282, :526-705): the same argument lists as in a
+		 * filter, no values behind them */
+		const enum tok which = p.lx.t;
+		const int two = (which != T_TFSTR) && (which != T_PORTSTR);
+		const int aggr_args = (which == T_DIV) || (which == T_DIV_R) || (which == T_DIV_L);
+		(void)take(&p, which);
+		out->k = aggr_args ? 1 : 0;
+		out->func = (which == T_DIV) ? XE_FN_DIV : (which == T_DIV_R) ? XE_FN_DIV_R : (which == T_DIV_L) ? XE_FN_DIV_L
+			: (which == T_MIN) ? XE_FN_MIN : (which == T_TFSTR) ? XE_FN_TFSTR : (which == T_PORTSTR) ? XE_FN_PORTSTR : XE_FN_PPSTR;
+		out->size = aggr_args || (which == T_MIN) ? 8 : (which == T_TFSTR) ? 32 : (which == T_PORTSTR) ? 40 : 90;
+		if (!take(&p, T_LP)) { fail(&p.lx, "Expected '(' after function name"); goto bad; }
+		if (!(aggr_args ? aggr_arg(&p, &out->field) : field_arg(&p, &out->field))) {
+			fail(&p.lx, aggr_args ? "Expected aggregable field name" : "Incorrect field name");
+			goto bad;
+		}
+		if (two) {
+			if (!take(&p, T_COMMA)) { fail(&p.lx, "Expected ',' after field name"); goto bad; }
+			if (!(aggr_args ? aggr_arg(&p, &out->fb) : field_arg(&p, &out->fb))) {
+				fail(&p.lx, aggr_args ? "Expected aggregable field name after comma" : "Incorrect field name after comma");
+				goto bad;
+			}
+		}
+		if ((which == T_DIV_R) || (which == T_DIV_L)) {
+			int k;
+			if (!take(&p, T_COMMA)) { fail(&p.lx, "Expected ',' after second field name"); goto bad; }
+			k = p.lx.lo;
+			if (!take(&p, T_RANGE)) { fail(&p.lx, "Expected INT"); goto bad; }
+			out->k = k;
+		}
+		if (!take(&p, T_RP)) { fail(&p.lx, "Expected ')'"); goto bad; }
+		if (p.lx.failed) goto bad;
+		if (!p.lx.at_end && take(&p, T_DESC)) out->descending = 1;
+		else if (!p.lx.at_end) (void)take(&p, T_ASC);
+		if (p.lx.failed) goto bad;
+		if (!p.lx.at_end) { fail(&p.lx, "Extra symbols after field name"); goto bad; }
+		if ((xe_fields[out->field].type == XE_T_STR) || (two && (xe_fields[out->fb].type == XE_T_STR))) {
+			if (err && errlen) snprintf(err, errlen, "function fields over string fields are not supported as table keys by this library");
+			return XE_EUNSUPPORTED;
+		}
+		return XE_OK;
 	}
 	if (p.lx.t == T_AGGR) {
 		out->aggr = 1;

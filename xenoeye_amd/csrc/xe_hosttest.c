@@ -114,12 +114,16 @@ void xe_ht_set_prepass_threads(struct xe_host *hs, int n) { hs->prepass_threads 
 
 /* a fixed-window field text: {aggr, offset in struct flow_info, size, scale, descending} */
 int
-xe_ht_field_parse(const char *text, int out[5], char *err, size_t errlen)
+xe_ht_field_parse(const char *text, int out[9], char *err, size_t errlen)
 {
 	struct xe_agfield f;
 	int rc = xe_field_parse(text, &f, err, errlen);
 	if (rc != XE_OK) return rc;
 	out[0] = f.aggr; out[1] = xe_fields[f.field].off; out[2] = (int)f.size; out[3] = f.scale; out[4] = f.descending;
+	/* function forms: which, the second argument, k (the first argument is out[1]) */
+	const int two = f.func && (f.func != XE_FN_TFSTR) && (f.func != XE_FN_PORTSTR);
+	out[5] = f.func; out[6] = two ? (int)xe_fields[f.fb].off : 0; out[7] = f.func ? f.k : 0;
+	out[8] = f.func ? (int)xe_fields[f.field].size_max * 256 + (two ? (int)xe_fields[f.fb].size_max : 0) : 0;
 	return XE_OK;
 }
 

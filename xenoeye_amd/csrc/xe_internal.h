@@ -426,7 +426,9 @@ int xe_filter_compile(const struct xe_iplists *reg, const char *text, struct xe_
 void xe_filter_free(struct xe_filter *f);
 int xe_filter_dump_text(const struct xe_iplists *reg, const struct xe_filter *f, char *out, size_t outlen);
 /* a field of a fixed-window table (struct field, monit-objects.h) */
-struct xe_agfield { uint8_t aggr, field, descending, scale; uint32_t size; };
+/* func != XE_FN_NONE: a function form; field / fb are its arguments, k its third
+ * (div_r, div_l), size the bytes it takes in the reference's key */
+struct xe_agfield { uint8_t aggr, field, descending, scale; uint32_t size; uint8_t func, fb; int32_t k; };
 int xe_field_parse(const char *text, struct xe_agfield *out, char *err, size_t errlen);
 /* row i of the keyword tables (filter.def, filter-ag.def); 0 past the end */
 int xe_filter_keyword(int i, const char **kw, int *type, int *src, int *dst);

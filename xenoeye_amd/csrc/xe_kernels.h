@@ -155,6 +155,17 @@ struct xe_fwm_dev
 	unsigned long long *dropped;      /* records whose key found no free slot */
 	uint8_t kfield[XE_FWM_MAX_KEY_FIELDS], ksize[XE_FWM_MAX_KEY_FIELDS];
 	uint8_t vfield[XE_FWM_MAX_VALS], vscale[XE_FWM_MAX_VALS];
+	/* function forms as key fields (monit_object_key_add_fld(), monit-objects.c:878-921):
+	 * kfunc = XE_FN_* (0: the field's bytes), kfield / kfield2 the arguments, kk the
+	 * third argument of div_r / div_l.  The table keeps div and min as the 8 bytes
+	 * the reference keeps (big-endian), tfstr as the flags byte, portstr as the
+	 * port (2 bytes) and ppstr as both ports (4 bytes): ksize is that size, and
+	 * the texts are made of them when the table is read.  div_l: dl + dl_off[k]
+	 * holds dl_n[k] pieces {lo, hi, value} of the int quotient line. */
+	uint8_t kfunc[XE_FWM_MAX_KEY_FIELDS], kfield2[XE_FWM_MAX_KEY_FIELDS];
+	int32_t kk[XE_FWM_MAX_KEY_FIELDS];
+	uint16_t dl_off[XE_FWM_MAX_KEY_FIELDS], dl_n[XE_FWM_MAX_KEY_FIELDS];
+	const int32_t *dl;
 };
 /* kwmax / nvmax: the longest key (words) and the most sums among the tables */
 int xe_launch_fwm(const struct xe_kparams *kp, const struct xe_fwm_dev *tables, uint32_t ntables, uint32_t kwmax, uint32_t nvmax,

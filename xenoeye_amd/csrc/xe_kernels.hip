@@ -3048,6 +3048,40 @@ fwm_lds_bytes(uint32_t kwmax, uint32_t nvmax)
 		+ XE_FWM_CACHE * (size_t)nvmax * 8;        /* c_sum */
 }
 
+/* a function form as a key field (monit-objects.c:679-717, :827-876), in the
+ * form the table keeps it: div / div_r / div_l and min as the bytes of
+ * htobe64(result), tfstr as the flags byte, portstr as the port, ppstr as
+ * port1 | port2 << 16; a, b = the arguments' values */
+__device__ __forceinline__ uint64_t
+fwm_func_key(const xe_fwm_dev &F, int k, uint64_t a, uint64_t b)
+{
+	const uint32_t fn = F.kfunc[k];
+	if (fn == XE_FN_MIN) return __builtin_bswap64((a < b) ? a : b);
+	if (fn == XE_FN_TFSTR) {
+		/* byte 1 of a 2-byte field, else byte 0 of the storage (monit-objects.c:836-843) */
+		const uint32_t colw = c_colw[F.kfield[k]];
+		return (colw == 2) ? (a & 0xFF) : ((a >> (8 * (colw - 1))) & 0xFF);
+	}
+	if (fn == XE_FN_PORTSTR) return a & 0xFFFF;
+	if (fn == XE_FN_PPSTR) return (a & 0xFFFF) | ((b & 0xFFFF) << 16);
+	/* xdiv(), filter.h:396-418: the quotient is an int from the start */
+	int32_t q = 0;
+	if (b != 0) {
+		q = (int32_t)(a / b);
+		if (fn == XE_FN_DIV_L) {
+			const int32_t *pc = F.dl + F.dl_off[k];
+			int32_t v = 0;
+			for (uint32_t i = 0; i < F.dl_n[k]; i++) {
+				if ((q >= pc[3 * i]) && (q <= pc[3 * i + 1])) v = pc[3 * i + 2];
+			}
+			q = v;
+		} else if (F.kk[k] > 1) {
+			q = (q / F.kk[k]) * F.kk[k];
+		}
+	}
+	return __builtin_bswap64((uint64_t)(int64_t)q);
+}
+
 /* the column elements the key and the sums of one record need, all loads in
  * flight together (a 16-byte field takes two); a field no template of the
  * batch carries reads as zeros */
@@ -3075,6 +3109,24 @@ fwm_load_cols(const xe_kparams &kp, const xe_fwm_dev &F, uint32_t r, bool hit, f
 			else if (colw == 4) C.part0[k] = *(const uint32_t *)p;
 			else if (colw == 8) C.part0[k] = *(const uint64_t *)p;
 			else { C.part0[k] = ((const uint64_t *)p)[0]; C.part1[k] = ((const uint64_t *)p)[1]; }
+		}
+		if (F.kfunc[k] != XE_FN_NONE) {
+			/* a function form: both parts hold the arguments as get_nf_val()
+			 * (filter.h:370-394) reads them, fields of 1, 2, 4 or 8 bytes as
+			 * big-endian numbers (the host refuses longer ones) */
+			const uint32_t f2 = F.kfield2[k], colw2 = c_colw[f2];
+			const uint64_t co2 = kp.col_off[f2];
+			uint64_t b = 0;
+			const bool two = (F.kfunc[k] != XE_FN_TFSTR) && (F.kfunc[k] != XE_FN_PORTSTR);
+			if (two && (co2 != ~0ull)) {
+				const uint8_t *p = kp.out_base + co2 + (size_t)r * colw2;
+				if (colw2 == 1) b = *p;
+				else if (colw2 == 2) b = *(const uint16_t *)p;
+				else if (colw2 == 4) b = *(const uint32_t *)p;
+				else b = *(const uint64_t *)p;
+			}
+			C.part0[k] = __builtin_bswap64(C.part0[k]) >> (64 - 8 * colw);
+			C.part1[k] = two ? __builtin_bswap64(b) >> (64 - 8 * colw2) : 0;
 		}
 	}
 #pragma unroll
@@ -3171,7 +3223,8 @@ xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables, u
 				for (int k = 0; k < XE_FWM_MAX_KEY_FIELDS; k++) {
 					if ((uint32_t)k >= F.nkey) continue;
 					const uint32_t size = F.ksize[k];
-					const uint64_t part[2] = { part0[k], part1[k] };
+					uint64_t part[2] = { part0[k], part1[k] };
+					if (F.kfunc[k] != XE_FN_NONE) part[0] = fwm_func_key(F, k, part0[k], part1[k]);
 					/* its first `size` bytes go behind what the key holds so far */
 #pragma unroll
 					for (int h2 = 0; h2 < 2; h2++) {
