@@ -125,7 +125,10 @@ int xe_gpu_commit(xe_gpu *h);
  * one after the other) the wrapping u64 sums of value * scale * sampling rate
  * of the aggregable fields.  `fields` are the strings of the entry's "fields"
  * array (`[src|dst] name [asc|desc]`, `octets`, `bits`, `packets` ...,
- * filter-parser.c:396-484; the function forms answer XE_EUNSUPPORTED).  The
+ * filter-parser.c:396-484) or the function forms div(), div_r(), div_l(),
+ * min(), tfstr(), portstr(), ppstr() (monit_object_key_add_fld(),
+ * monit-objects.c:878-921; the last two need xe_gpu_set_port_names() first);
+ * mfreq(), the geo / AS functions and string fields answer XE_EUNSUPPORTED.  The
  * table lives on the device as long as the handle; every xe_gpu_batch_run()
  * adds the batch's records to it.  Returns the table's index.  max_keys = the
  * distinct keys to make room for (0: 65536); records whose key finds no room
@@ -133,7 +136,7 @@ int xe_gpu_commit(xe_gpu *h);
 int xe_gpu_add_fwm(xe_gpu *h, int mo, const char *const *fields, int nfields, size_t max_keys);
 /* xe_gpu_load_mos() that also registers the "fwm" entries of every mo.conf
  * (fwm_config(), monit-objects-fwm.c:139-205: "name" and "fields") as tables;
- * entries with fields this library does not aggregate (functions, strings)
+ * entries with fields this library does not aggregate (mfreq, geo / AS, strings)
  * are left to the reference's own consumer and counted in *skipped.  Returns
  * the number of tables added. */
 int xe_gpu_load_mos_with_tables(xe_gpu *h, const char *mo_dir, size_t max_keys, int *skipped);
