@@ -43,7 +43,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--records", type=int, default=1 << 22, help="records per GPU per step")
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5", "c2m"])
     ap.add_argument("--c4-prefixes", type=int, default=1000000, help="prefixes per list of the c4 workload")
     ap.add_argument("--c4-lists", type=int, default=8, help="distinct lists of the c4 workload (objects = 256)")
     ap.add_argument("--cpu-sample", type=int, default=8000000, help="records timed on the CPU oracle (0 = skip)")
@@ -102,6 +102,13 @@ def build_workload(name, nrec, rank, c4_prefixes=1000000, world=1, c4_lists=8):
             "C1 netflow-v9 1 exporter 21B records 1 object (src net mynet)"
     # every rank owns its own 64 exporters (10.255.0.x on rank 0, 10.254.0.x on rank 1 ...)
     w = synth.workload_c2(nrec, seed=synth.SEED_C2 ^ (rank << 32), exporter_net=255 - rank)
+    if name == "c2m":
+        # the same traffic with a devices.conf entry per exporter: a sampling rate, two mark filters
+        # (device_rules_check(), devices.c:286-314), and an object that reads the mark
+        w["devices"] = [dict(ip="10.%d.%d.%d" % ((255 - rank) & 255, (e + 1) >> 8, (e + 1) & 255), sampling_rate=100 + e,
+                             marks=("proto 6", "dst port 0-1023")) for e in range(64)]
+        w["mos"] = list(w["mos"]) + [("dev-mark 2", -1)]
+        return w, "C2 + devices.conf: 64 entries with a sampling rate and two mark filters each, 17 objects (one reads the mark)"
     return w, "C2 ipfix 64 exporters 70% v4(46B)/30% v6(62B) 16 objects x 10k+10k-prefix lists"
 
 
@@ -127,6 +134,8 @@ def make_engine(w, device):
         eng.add_iplist(name, text)
     for filt, parent in w["mos"]:
         eng.add_mo("mo", filt, parent)
+    for d in w.get("devices", ()):
+        eng.add_device(**d)
     eng.commit()
     return eng
 
@@ -327,7 +336,7 @@ def measure_other(torch, name, args, device, stream):
     t0 = time.perf_counter()
     # the sFlow generator builds every sampled header one by one: a smaller set of
     # distinct datagrams, repeated (every copy is decoded and classified like the first)
-    nrec = {"c1": 1 << 22, "c3": 200000, "c4": 1 << 21, "c5": 1 << 22}[name]
+    nrec = {"c1": 1 << 22, "c2": 1 << 22, "c2m": 1 << 22, "c3": 200000, "c4": 1 << 21, "c5": 1 << 22}[name]
     rep = {"c3": 16}.get(name, 1)
     w, wl_name = build_workload(name, nrec, 0, args.c4_prefixes, 1, args.c4_lists)
     replicate(w["batch"], rep)
@@ -344,6 +353,7 @@ def measure_other(torch, name, args, device, stream):
            "ms_per_step": dt / args.other_steps * 1e3, "records_per_s": n * args.other_steps / dt,
            "payload_GBps": batch.payload_bytes * args.other_steps / dt / 1e9,
            "roofline": roofline_of(batch, kms, name, n)}
+    out["per_lane_kernel_records"] = batch.per_lane_records
     out["device_path"] = device_path(out["roofline"], walk_ms, n)
     if name in ("c4", "c2", "c5"):
         out["list_walks"] = list_walks(torch, batch, stream, w, device, out["roofline"]["kernel_ms"])
@@ -841,7 +851,7 @@ def main():
         eng.close()
         if args.others and world == 1:
             others = {}
-            for name in ("c1", "c2", "c3", "c4", "c5"):
+            for name in ("c1", "c2", "c3", "c4", "c5", "c2m"):
                 if name == args.workload:
                     continue
                 try:

@@ -297,6 +297,10 @@ size_t xe_gpu_batch_oversized_datagrams(const xe_batch *b);
 
 /* sizes */
 size_t xe_gpu_batch_records(const xe_batch *b);      /* records reaching classification */
+/* of those, the Netflow records left to the per-lane kernel (cut-short or
+ * variable-length records, templates with repeated or string elements ...):
+ * the others go through the kernel that decodes a tile of one template at a time */
+size_t xe_gpu_batch_per_lane_records(const xe_batch *b);
 size_t xe_gpu_batch_mask_words(const xe_batch *b);   /* 64-bit words per record */
 size_t xe_gpu_batch_payload_bytes(const xe_batch *b);/* datagram bytes in the batch */
 /* bytes the kernels must move at minimum for this batch: datagram bytes +

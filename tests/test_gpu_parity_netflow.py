@@ -273,7 +273,8 @@ def test_tfstr_in_device_marks(eng, orc):
     w2["mos"] = [("proto 6", -1), ("tfstr(tcp-flags) 'SYN'", 0), ("not tfstr(proto) 'RST+SYN'", -1)]
     w2["devices"] = [dict(ip="192.0.2.1", sampling_rate=10, marks=("tfstr(proto) 'RST+SYN'", "tfstr(dst port) 'SYN'"))]
     w2["mos"] = list(w2["mos"]) + [("dev-mark 1", -1), ("dev-mark 2", -1)]
-    both(eng, orc, w2)
+    b = both(eng, orc, w2)
+    assert b.per_lane_records == 0      # mark filters run in the kernel that takes a tile of one template
 
 
 def test_devices_marks_and_sampling(eng, orc):
@@ -283,6 +284,7 @@ def test_devices_marks_and_sampling(eng, orc):
     w["mos"] = [("src net mynet", -1), ("dev-mark 1", -1), ("dev-mark 2-3", -1), ("", -1)]
     b = both(eng, orc, w)
     assert b.dropped().sum() > 0
+    assert b.per_lane_records == 0
 
 
 def test_devices_sampling_rate_only(eng, orc):
@@ -297,13 +299,15 @@ def test_devices_sampling_rate_only(eng, orc):
     fi = b.flow_info()
     rates = np.unique(fi[:, 2304:2308].copy().view("<u4"))
     assert set(rates.tolist()) >= {1, 10, 64, 1000}
+    assert b.per_lane_records == 0      # four kinds of entries share the tiles
 
 
 def test_devices_mark_read_by_an_object(eng, orc):
     w = synth.workload_c2(2000, prefixes=100)
     w["devices"] = [dict(ip="10.255.0.1", sampling_rate=1000), dict(ip="10.255.0.5", sampling_rate=2, marks=("proto 17",))]
     w["mos"] = list(w["mos"]) + [("dev-mark 0", -1), ("dev-mark 1", -1), ("not dev-mark 0", -1)]
-    both(eng, orc, w)
+    b = both(eng, orc, w)
+    assert b.per_lane_records == 0
 
 
 def test_devices_id_only_fallthrough(eng, orc):

@@ -89,6 +89,7 @@ def load_library(path=LIB_PATH):
         "xe_gpu_set_overlap": (i32, [vp, i32]),
         "xe_gpu_batch_input_done": (i32, [vp]),
         "xe_gpu_batch_done": (i32, [vp]),
+        "xe_gpu_batch_per_lane_records": (C.c_size_t, [vp]),
         "xe_gpu_set_walk_timing": (i32, [vp, i32]),
         "xe_gpu_set_list_root_bits": (i32, [vp, i32]),
         "xe_gpu_batch_walk_ms": (i32, [vp, C.POINTER(C.c_float)]),
@@ -480,6 +481,11 @@ class PreparedBatch:
     def input_done(self):
         """overlap mode: blocks until the datagram buffer given to prepare() may be reused"""
         self.eng._chk(self.L.xe_gpu_batch_input_done(self._b))
+
+    @property
+    def per_lane_records(self):
+        """Netflow records left to the per-lane kernel"""
+        return int(self.L.xe_gpu_batch_per_lane_records(self._b))
 
     def done(self):
         """has the last run finished? (never blocks)"""

@@ -23,7 +23,9 @@ struct xe_gpu
 	int device;
 	struct xe_host hs;
 	int committed;
-	void *d_progs, *d_ops, *d_terms, *d_opnds, *d_trie, *d_lists, *d_devrules, *d_lookups, *d_fterms, *d_fprogs, *d_motab, *d_tneed, *d_cjgb, *d_cjtab, *d_cjderived, *d_cjcand, *d_rgroups, *d_rgdata;
+	void *d_progs, *d_ops, *d_terms, *d_opnds, *d_trie, *d_lists, *d_devrules, *d_lookups, *d_fterms, *d_fprogs, *d_motab, *d_tneed, *d_cjgb, *d_cjtab, *d_cjderived, *d_cjcand, *d_rgroups, *d_rgdata, *d_mark_fprogs, *d_tmark;
+	uint32_t nmarkprogs, ntmark;   /* mark filters in their fast-kernel form; terms that read the device mark */
+	uint32_t *dev_canon;       /* per devices.conf entry: the first entry with the same mark filters and skip-unmarked */
 	uint32_t nmo, mask_words, nprogs_total, nlookups;
 	struct xe_list_dev *h_lists;
 	struct xe_probe *h_probes;   /* host copy of the probe table (nlookups entries) */
@@ -279,7 +281,7 @@ free_config_dev(xe_gpu *h)
 {
 	void **p[] = { &h->d_progs, &h->d_ops, &h->d_terms, &h->d_opnds, &h->d_trie, &h->d_lists, &h->d_devrules,
 		&h->d_lookups, &h->d_fterms, &h->d_fprogs, &h->d_motab, &h->d_tneed,
-		&h->d_cjgb, &h->d_cjtab, &h->d_cjderived, &h->d_cjcand, &h->d_rgroups, &h->d_rgdata };
+		&h->d_cjgb, &h->d_cjtab, &h->d_cjderived, &h->d_cjcand, &h->d_rgroups, &h->d_rgdata, &h->d_mark_fprogs, &h->d_tmark };
 	for (size_t i = 0; i < sizeof(p) / sizeof(p[0]); i++) {
 		if (*p[i]) (void)hipFree(*p[i]);
 		*p[i] = NULL;
@@ -288,6 +290,8 @@ free_config_dev(xe_gpu *h)
 	h->h_lists = NULL;
 	free(h->h_probes);
 	h->h_probes = NULL;
+	free(h->dev_canon);
+	h->dev_canon = NULL;
 }
 
 extern "C" void
@@ -1744,9 +1748,21 @@ xe_gpu_commit(xe_gpu *h)
 	for (size_t m = 0; (m < h->hs.nmos) && (rc == XE_OK); m++) {
 		rc = append_prog(&progs, &ops, &cx, &h->hs.mos[m].filter, h->hs.mos[m].parent, h->hs.mos[m].host_only);
 	}
+	/* the mark filters of devices.conf follow the objects' programs; their terms share the term table */
+	for (size_t d = 0; (d < h->hs.ndevs) && (rc == XE_OK); d++) {
+		struct xe_devrule r;
+		memset(&r, 0, sizeof(r));
+		r.first_prog = (uint32_t)progs.n;
+		r.nprogs = (uint32_t)h->hs.devs[d].nmarks;
+		r.skip_unmarked = (uint32_t)h->hs.devs[d].skip_unmarked;
+		for (size_t k = 0; (k < h->hs.devs[d].nmarks) && (rc == XE_OK); k++) {
+			rc = append_prog(&progs, &ops, &cx, &h->hs.devs[d].marks[k], -1, 0);
+		}
+		if ((rc == XE_OK) && !xe_blob_push(&rules, &r, sizeof(r))) rc = XE_ENOMEM;
+	}
 	if (rc == XE_OK) {
-		/* the fast kernel evaluates the object programs' terms [0, nterms);
-		 * terms used only by device mark filters follow them */
+		/* the fast kernel evaluates the terms of the object programs and of the
+		 * mark filters alike */
 		h->nterms = (uint32_t)terms.n;
 		h->fast_ok = 1;
 		{
@@ -1792,17 +1808,6 @@ xe_gpu_commit(xe_gpu *h)
 		h->nlookups = (uint32_t)lookups.n;
 		if (h->nlookups > XE_MAX_PROBES) h->fast_ok = 0;
 		h->lw = (h->nlookups <= 8) ? 1u : (uint32_t)XE_LK_WORDS;
-	}
-	for (size_t d = 0; (d < h->hs.ndevs) && (rc == XE_OK); d++) {
-		struct xe_devrule r;
-		memset(&r, 0, sizeof(r));
-		r.first_prog = (uint32_t)progs.n;
-		r.nprogs = (uint32_t)h->hs.devs[d].nmarks;
-		r.skip_unmarked = (uint32_t)h->hs.devs[d].skip_unmarked;
-		for (size_t k = 0; (k < h->hs.devs[d].nmarks) && (rc == XE_OK); k++) {
-			rc = append_prog(&progs, &ops, &cx, &h->hs.devs[d].marks[k], -1, 0);
-		}
-		if ((rc == XE_OK) && !xe_blob_push(&rules, &r, sizeof(r))) rc = XE_ENOMEM;
 	}
 	if (rc == XE_OK) {
 		h->h_lists = (struct xe_list_dev *)calloc(h->hs.lists.n ? h->hs.lists.n : 1, sizeof(struct xe_list_dev));
@@ -2026,6 +2031,46 @@ xe_gpu_commit(xe_gpu *h)
 				fp[nb++] = q;
 			}
 			h->nfprogs = (uint32_t)nb;
+			/* the mark filters of devices.conf (device_get_mark(), devices.c:276-281) in
+			 * the form the fast kernel interprets; entry i belongs to program nmos + i */
+			h->nmarkprogs = 0;
+			if ((rc == XE_OK) && (progs.n > h->hs.nmos)) {
+				const size_t nm = progs.n - h->hs.nmos;
+				struct xe_fprog *mf = (struct xe_fprog *)calloc(nm, sizeof(*mf));
+				if (!mf) rc = XE_ENOMEM;
+				for (size_t i = 0; (rc == XE_OK) && (i < nm); i++) {
+					const struct xe_prog *g = &pg[h->hs.nmos + i];
+					struct xe_fprog q;
+					memset(&q, 0, sizeof(q));
+					q.op_base = g->op_base;
+					q.nops = g->nops;
+					q.parent = -1;
+					q.cval = g->cval;
+					if (g->flags & XE_PROG_CONST) {
+						q.kind = XE_FPROG_CONST;
+					} else if ((g->nops == 1) && ((op[g->op_base] & 3) == XE_OP_BASIC)) {
+						const uint32_t t = op[g->op_base] >> 2;
+						if ((ft[t].kind & 1) && (h->lw == 1)) {
+							q.kind = XE_FPROG_MASK;
+							q.mask = ft[t].mask[0];
+						} else {
+							q.kind = XE_FPROG_TERM;
+							q.term = t;
+							ft[t].kind |= 2;
+						}
+					} else {
+						q.kind = XE_FPROG_GENERAL;
+						for (uint32_t k = 0; k < g->nops; k++) {
+							const uint32_t w = op[g->op_base + k];
+							if ((w & 3) == XE_OP_BASIC) ft[w >> 2].kind |= 2;
+						}
+					}
+					mf[i] = q;
+				}
+				if (rc == XE_OK) rc = upload(h, &h->d_mark_fprogs, mf, nm * sizeof(*mf));
+				if (rc == XE_OK) h->nmarkprogs = (uint32_t)nm;
+				free(mf);
+			}
 			/* rows in mask-word order (stable: a simple insertion sort, few rows) */
 			for (size_t i = 1; i < nrows; i++) {
 				struct xe_cjrow x = rows[i];
@@ -2215,6 +2260,15 @@ xe_gpu_commit(xe_gpu *h)
 			h->ntneed = n;
 			if (h->dbg) fprintf(stderr, "xe_gpu_commit: %u terms evaluated per record\n", n);
 			if (rc == XE_OK) rc = upload(h, &h->d_tneed, need, (size_t)n * sizeof(uint32_t));
+			/* terms that read the device mark: the fast kernel evaluates them again
+			 * once the mark filters have run (the filters themselves see no mark) */
+			n = 0;
+			for (uint32_t t = 0; (rc == XE_OK) && (t < h->nterms); t++) {
+				if (!(ft[t].kind & 6)) continue;
+				if (reads_device_fields(&tt[t], 1) & 2) need[n++] = t;
+			}
+			h->ntmark = n;
+			if ((rc == XE_OK) && n) rc = upload(h, &h->d_tmark, need, (size_t)n * sizeof(uint32_t));
 			free(need);
 		}
 		free(ft);
@@ -2234,6 +2288,27 @@ xe_gpu_commit(xe_gpu *h)
 	if (rc == XE_OK) rc = upload(h, &h->d_trie, trie.p, trie.n * 4);
 	if (rc == XE_OK) rc = upload(h, &h->d_lists, h->h_lists, h->hs.lists.n * sizeof(struct xe_list_dev));
 	if (rc == XE_OK) rc = upload(h, &h->d_devrules, rules.p, rules.n * sizeof(struct xe_devrule));
+	if (rc == XE_OK) {
+		/* entries whose filters compile to the same programs are one rule set to the
+		 * fast kernel, which makes one pass per distinct set among a tile's lanes */
+		const struct xe_devrule *rl = (const struct xe_devrule *)rules.p;
+		const struct xe_prog *pg = (const struct xe_prog *)progs.p;
+		const uint32_t *op = (const uint32_t *)ops.p;
+		h->dev_canon = (uint32_t *)calloc(h->hs.ndevs ? h->hs.ndevs : 1, sizeof(uint32_t));
+		if (!h->dev_canon) rc = XE_ENOMEM;
+		for (size_t d = 0; (rc == XE_OK) && (d < h->hs.ndevs); d++) {
+			h->dev_canon[d] = (uint32_t)d;
+			for (size_t e = 0; e < d; e++) {
+				int same = (h->dev_canon[e] == e) && (rl[e].nprogs == rl[d].nprogs) && (rl[e].skip_unmarked == rl[d].skip_unmarked);
+				for (uint32_t k = 0; same && (k < rl[d].nprogs); k++) {
+					const struct xe_prog *a = &pg[rl[e].first_prog + k], *b2 = &pg[rl[d].first_prog + k];
+					same = (a->nops == b2->nops) && (a->flags == b2->flags) && (a->cval == b2->cval)
+						&& !memcmp(op + a->op_base, op + b2->op_base, (size_t)a->nops * 4);
+				}
+				if (same) { h->dev_canon[d] = (uint32_t)e; break; }
+			}
+		}
+	}
 	if (rc == XE_OK) rc = upload(h, &h->d_lookups, lookups.p, lookups.n * sizeof(struct xe_probe));
 	if (rc == XE_OK) {
 		h->h_probes = (struct xe_probe *)calloc(lookups.n ? lookups.n : 1, sizeof(struct xe_probe));
@@ -2251,7 +2326,9 @@ xe_gpu_commit(xe_gpu *h)
 			dk[i].ip = d->ip;
 			dk[i].id = d->id;
 			dk[i].rate = (uint32_t)d->sampling_rate;
-			dk[i].plain = ((d->nmarks == 0) && !d->skip_unmarked && !h->reads_mark) ? 1u : 0u;
+			/* (a run names its entry in 15 bits) */
+			dk[i].plain = (i < 0x7FFEu) ? 1u : 0u;
+			dk[i].rules = (d->nmarks || d->skip_unmarked) ? h->dev_canon[i] + 1u : 0u;
 		}
 		if (h->d_devkeys) (void)hipFree(h->d_devkeys);
 		h->d_devkeys = NULL;
@@ -2920,8 +2997,8 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 		/* an exporter with a devices.conf entry that only sets the sampling rate
 		 * (no mark filters, nothing dropped) needs no per-record rule check */
 		const int dev = ex[sets[i].exporter].device;
-		const int plain_dev = (dev < 0) || ((h->hs.devs[dev].nmarks == 0) && !h->hs.devs[dev].skip_unmarked
-			&& !h->reads_mark);
+		/* (a run names its devices.conf entry in 15 bits) */
+		const int plain_dev = (dev < 0) || (dev < 0x7FFE);
 		int ok = !force_general && tfast[sets[i].tmpl] && !(sets[i].flags & (XE_SET_CHECKED | XE_SET_PARTIAL))
 			&& plain_dev;
 		is_fast[i] = (uint8_t)ok;
@@ -2980,7 +3057,12 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 				r->start = sets[i].tmpl;   /* template for now, position below */
 				r->nrec = sets[i].nrec;
 				/* bit 31: the exporter has a devices.conf entry (mark present, value 0) */
+				/* bit 31: the exporter has a devices.conf entry; bits 16-30: that entry + 1
+				 * when it has mark filters to run or drops what they leave unmarked */
 				r->stride = sets[i].stride | ((e->device >= 0) ? 0x80000000u : 0u);
+				if ((e->device >= 0) && (h->hs.devs[e->device].nmarks || h->hs.devs[e->device].skip_unmarked)) {
+					r->stride |= (h->dev_canon[e->device] + 1u) << 16;
+				}
 				r->rate = e->sampling_rate;
 				r->dev_ip = ntohl(ipw);
 				r->dev_id = ntohl(idw);
@@ -3460,6 +3542,12 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 	b->kp.nmo = h->nmo;
 	b->kp.mask_words = h->mask_words;
 	b->kp.ndevrules = (uint32_t)h->hs.ndevs;
+	b->kp.mark_fprogs = (const struct xe_fprog *)h->d_mark_fprogs;
+	b->kp.nmarkprogs = h->nmarkprogs;
+	b->kp.tmark = (const uint32_t *)h->d_tmark;
+	b->kp.ntmark = h->ntmark;
+	b->kp.nruledevs = 0;
+	for (size_t d = 0; d < h->hs.ndevs; d++) b->kp.nruledevs += (h->hs.devs[d].nmarks || h->hs.devs[d].skip_unmarked) ? 1u : 0u;
 	b->kp.tmpls = (const struct xe_tmpl *)h->d_tmpls;
 	b->kp.tents = (const struct xe_tent *)h->d_tents;
 	b->kp.pkt = (const uint8_t *)b->d_pkt;
@@ -3641,6 +3729,7 @@ xe_gpu_batch_kernel_ms(xe_batch *b, float ms[3])
 }
 
 extern "C" size_t xe_gpu_batch_records(const xe_batch *b) { return b ? b->ntot : 0; }
+extern "C" size_t xe_gpu_batch_per_lane_records(const xe_batch *b) { return b ? b->kp.nslowrec : 0; }
 extern "C" size_t xe_gpu_batch_mask_words(const xe_batch *b) { return b ? b->h->mask_words : 0; }
 extern "C" size_t xe_gpu_batch_payload_bytes(const xe_batch *b) { return b ? b->payload_bytes : 0; }
 

@@ -115,6 +115,11 @@ struct xe_kparams
 	const uint32_t *sfbase;
 	const struct xe_sfrd *sfrd;
 	uint32_t *sf_rate;           /* per sFlow record: the sampling rate of its sample */
+	/* the mark filters of devices.conf for the fast kernel: entry i is program nmo + i */
+	const struct xe_fprog *mark_fprogs;
+	const uint32_t *tmark;       /* terms that read the device mark */
+	uint32_t nmarkprogs, ntmark;
+	uint32_t nruledevs, pad5;    /* devices.conf entries with mark filters or skip-unmarked */
 	/* instrumentation (NULL = off): [0] += root-table loads, [1] += node and chain-record loads of the list walks */
 	unsigned long long *gathers;
 };
@@ -197,8 +202,9 @@ struct xe_devkey
 {
 	uint32_t use_ip, use_id, ip, id;   /* ip: bytes as stored; id: htonl(value) */
 	uint32_t rate;
-	uint32_t plain;                    /* no mark filters, nothing dropped */
-	uint32_t pad[2];
+	uint32_t plain;                    /* the device walk may list this exporter's runs */
+	uint32_t rules;                    /* mark filters to run, or unmarked records to drop: 1 + the entry runs name for them (the first with the same filters) */
+	uint32_t pad;
 };
 
 /* template store entry for the device: open addressing over `cap` entries

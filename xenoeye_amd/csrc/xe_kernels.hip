@@ -615,7 +615,8 @@ struct fast_tile
 	const uint32_t *stg;       /* LDS: record dword d of record r of this lane at stg[(d * R + r) * 64] */
 	cu32 fld;                  /* per field of the template: XE_FFLD_* word */
 	uint32_t dev_ip[R], dev_id[R];
-	bool live[R];
+	uint32_t mark[R];          /* the device mark once the mark filters have run (0 before) */
+	bool live[R], markhas[R];
 };
 
 /* `len` wire bytes at record offset `off` (both wave-uniform) of the lane's
@@ -669,6 +670,14 @@ template <int R>
 __device__ __forceinline__ void
 fld_get(const fast_tile<R> &T, uint32_t field, uint32_t r, bool &has, uint32_t &fmax, uint64_t &hi, uint64_t &lo)
 {
+	if (field == XF_dev_mark) {
+		/* device_rules_check(), devices.c:308-311: 4 bytes, present once the rules have run */
+		has = T.markhas[r];
+		fmax = 4;
+		hi = 0;
+		lo = T.mark[r];
+		return;
+	}
 	const uint32_t fe = T.fld[field];
 	has = (fe >> 31) != 0;
 	fmax = (fe >> 21) & 31;
@@ -1207,6 +1216,7 @@ template <int R>
 struct tile_lanes
 {
 	uint32_t voff[R], ridx[R], rate[R], dev_ip[R], dev_id[R];
+	uint32_t dev[R];          /* devices.conf entry + 1 when it has mark filters or drops unmarked records, else 0 */
 	bool live[R], hasdev[R];  /* hasdev: the exporter has a devices.conf entry */
 	uint32_t tmpl, nchunk;    /* wave-uniform */
 };
@@ -1231,7 +1241,7 @@ tile_setup(const xe_kparams &kp, uint32_t tile, uint32_t lane, bool want_dev, ti
 		S.live[r] = false;
 		S.hasdev[r] = false;
 		S.voff[r] = S.ridx[r] = S.rate[r] = 0;
-		S.dev_ip[r] = S.dev_id[r] = 0;
+		S.dev_ip[r] = S.dev_id[r] = S.dev[r] = 0;
 	}
 	for (;;) {
 		const uint32_t start = RN[2], nrec = RN[3];
@@ -1243,8 +1253,9 @@ tile_setup(const xe_kparams &kp, uint32_t tile, uint32_t lane, bool want_dev, ti
 			if ((start + nrec <= sub0) || (start >= sub0 + 64)) continue;
 			const uint32_t g = sub0 + lane, i = g - start;
 			const bool in = (g >= start) && (i < nrec);
-			S.voff[r] = in ? (RN[0] + i * (RN[4] & 0x7FFFFFFFu)) : S.voff[r];
+			S.voff[r] = in ? (RN[0] + i * (RN[4] & 0xFFFFu)) : S.voff[r];
 			S.hasdev[r] = in ? ((RN[4] >> 31) != 0) : S.hasdev[r];
+			S.dev[r] = in ? ((RN[4] >> 16) & 0x7FFFu) : S.dev[r];
 			S.ridx[r] = in ? (RN[1] + i) : S.ridx[r];
 			S.rate[r] = in ? RN[5] : S.rate[r];
 			if (want_dev) {
@@ -1742,6 +1753,8 @@ xe_nf_fast_kernel(const xe_kparams kp)
 			T.live[r] = C.live[r];
 			T.dev_ip[r] = C.dev_ip[r];
 			T.dev_id[r] = C.dev_id[r];
+			T.mark[r] = 0;
+			T.markhas[r] = false;
 			ridx[r] = C.ridx[r];
 			rate[r] = C.rate[r];
 		}
@@ -1789,9 +1802,6 @@ xe_nf_fast_kernel(const xe_kparams kp)
 			uint64_t hi, b, p;
 			if (T.live[r]) {
 				XE_MASK_STORE(&((XE_GLOBAL uint8_t *)kp.nparsed)[ridx[r]], (uint8_t)nparsed);
-				/* device_rules_check() without mark filters (devices.c:286-314):
-				 * the mark is present, its value 0 */
-				if (kp.marks) ((XE_GLOBAL uint32_t *)kp.marks)[ridx[r]] = C.hasdev[r] ? XE_MARK_HAS : 0u;
 				if (kp.rates) ((XE_GLOBAL uint32_t *)kp.rates)[ridx[r]] = rate[r];
 				if (kp.devips) ((XE_GLOBAL uint32_t *)kp.devips)[ridx[r]] = __builtin_bswap32(C.dev_ip[r]);
 			}
@@ -1831,7 +1841,61 @@ xe_nf_fast_kernel(const xe_kparams kp)
 			if (PL[6]) general_ops<R>(kp, stg, j, PL[6], ridx, T.live);
 		}
 		XE_PHASE(4);
-		classify_objects<R, LEAN, LW>(kp, T.live, lk, tb, ridx, bxr, pxr, lcnt, lmt);
+		/* device_rules_check() (devices.c:286-314): the mark filters of the
+		 * record's devices.conf entry are counted, a record that stays unmarked
+		 * where the entry says so is dropped, and the objects then see the mark.
+		 * The filters are wave-uniform programs over the term and lookup bits:
+		 * one pass per distinct entry among the tile's lanes. */
+		bool clive[R];
+#pragma unroll
+		for (int r = 0; r < R; r++) {
+			uint32_t cnt = 0;
+			bool drop = false;
+			unsigned long long pend = LEAN ? 0ull : __ballot(T.live[r] && (C.dev[r] != 0));
+			while (pend) {
+				const uint32_t d1 = (uint32_t)__builtin_amdgcn_readlane((int)C.dev[r], (int)__builtin_ctzll(pend));
+				const bool mine = T.live[r] && (C.dev[r] == d1);
+				cu32 DR = (cu32)(kp.devrules + (d1 - 1));
+				const uint32_t first = DR[0] - kp.nmo, np = DR[1], skip = DR[2];
+				uint32_t c = 0;
+				for (uint32_t i = 0; i < np; i++) {
+					typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+					const XE_CONST u32x4v *fq = (const XE_CONST u32x4v *)(kp.mark_fprogs + first + i);
+					const u32x4v f0 = fq[0], f1 = fq[1], f2 = fq[2];
+					const uint32_t FP[12] = { f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w };
+					c += prog_eval<R>(kp, FP, lk[r][0], tb[r]) ? 1u : 0u;
+				}
+				if (mine) {
+					cnt = c;
+					drop = skip && (c == 0);
+				}
+				pend &= ~__ballot(mine);
+			}
+			T.mark[r] = cnt;
+			T.markhas[r] = C.hasdev[r] && !drop;
+			clive[r] = T.live[r] && !drop;
+			if (T.live[r] && kp.marks) {
+				XE_MASK_STORE(&((XE_GLOBAL uint32_t *)kp.marks)[ridx[r]], drop ? (uint32_t)XE_MARK_DROPPED
+					: C.hasdev[r] ? (uint32_t)(XE_MARK_HAS | (cnt & 0x3FFFFFFFu)) : 0u);
+			}
+		}
+		/* the terms that read the mark, now that it is known */
+		for (uint32_t ti = 0; !LEAN && (ti < kp.ntmark); ti++) {
+			const uint32_t t = ((cu32)kp.tmark)[ti];
+			const term_s tm = ld_term(kp, t);
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				const uint64_t bit = (uint64_t)(clive[r] && fast_term<R, LW, fast_tile<R>>(kp, T, tm, r, lk[r])) << (t & 63);
+				const uint64_t clr = ~(1ull << (t & 63));
+				switch (t >> 6) {
+					case 0: tb[r][0] = (tb[r][0] & clr) | bit; break;
+					case 1: tb[r][1] = (tb[r][1] & clr) | bit; break;
+					case 2: tb[r][2] = (tb[r][2] & clr) | bit; break;
+					default: tb[r][3] = (tb[r][3] & clr) | bit; break;
+				}
+			}
+		}
+		classify_objects<R, LEAN, LW>(kp, clive, lk, tb, ridx, bxr, pxr, lcnt, lmt);
 		XE_PHASE(5);
 		C = N;
 	}
@@ -3537,7 +3601,8 @@ xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events)
 		if (blocks < 8) blocks = 8;
 		if (ev && !fast_started) (void)hipEventRecord(ev[0], st);
 		fast_started = true;
-		const bool lean = !kq->nrgroups && !kq->ncjgroups && !kq->ncjderived && !kq->nfprogs && (kq->lw == 1);
+		const bool lean = !kq->nrgroups && !kq->ncjgroups && !kq->ncjderived && !kq->nfprogs && (kq->lw == 1)
+			&& !kq->nruledevs && !kq->ntmark;
 		if (kq->lw != 1) hipLaunchKernelGGL((xe_nf_fast_kernel<1, false, XE_LK_WORDS>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kq);
 		else if (kq->fast_r == 4) hipLaunchKernelGGL((xe_nf_fast_kernel<4, false, 1>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kq);
 		else if (kq->fast_r == 2) hipLaunchKernelGGL((xe_nf_fast_kernel<2, false, 1>), dim3(blocks), dim3(XE_BLOCK), shmem, st, *kq);

@@ -742,6 +742,12 @@ xw_nf_runs_kernel(const xe_walk_in in, const xe_dgrun *runs, uint32_t nsets, con
 		f.start = g.pos0 + p.x;
 		f.nrec = r.nrec;
 		f.stride = in.twalk[tm].stride | (r.rate & 0x80000000u);
+		if (r.rate & 0x80000000u) {
+			/* an entry with mark filters (or one that drops unmarked records) is named
+			 * in the run: the decode kernel runs its filters */
+			const int d = dev_find(in, in.src[i], __builtin_bswap32(r.dev_id));
+			if (d >= 0) f.stride |= (in.devs[d].rules & 0x7FFFu) << 16;
+		}
 		f.rate = r.rate & 0x7FFFFFFFu;
 		f.dev_ip = __builtin_bswap32(in.src[i]);
 		f.dev_id = r.dev_id;
