@@ -176,13 +176,22 @@ int xe_gpu_fwm_clear(xe_gpu *h, int fwm);
  * answers (an absent field is looked up as zeros, as the reference reads it).
  * Without its database an object with such a function is host-only
  * (xe_gpu_mo_host_only).  XE_EPARSE: the image is not a tree of whole nodes.
- * The reference re-reads the files on a signal (geoip.c:131-178); here a new
- * image needs a new handle.  Parity of these functions is checked against the
- * CPU oracle over synthetic databases only: the reference tree holds no
- * database file. */
+ * The reference re-reads the files on a signal (geoip_reload(),
+ * geoip.c:131-178): once objects exist a loaded database may be REPLACED by a
+ * new image (not added or dropped: which objects the device decides was
+ * settled when they were added; XE_ESTATE otherwise), and the next
+ * xe_gpu_commit() rebuilds the lists made from it.  The lookups are checked
+ * against the reference's own walk (ip-btrie.h:88-115) over synthetic
+ * databases: the reference tree holds no database file. */
 int xe_gpu_set_geodb(xe_gpu *h, int kind, int family, const void *image, size_t bytes);
 /* the four files of `dir` that exist (geoip.c:146-149); returns how many were loaded */
 int xe_gpu_load_geodb(xe_gpu *h, const char *dir);
+/* geoip_reload() (geoip.c:131-178, on SIGHUP xenoeye.c:576): re-reads the files
+ * of `dir` into a configured handle and commits.  Call it between batches, on
+ * the thread that owns the handle; batches prepared before it must have been
+ * freed.  Returns how many files were loaded, or a negative code (the handle
+ * then still needs a successful xe_gpu_commit()). */
+int xe_gpu_reload_geodb(xe_gpu *h, const char *dir);
 
 /* IP lists on the device (iplist_match4/6, iplist.c:160-216, flattened): the
  * table of a group of 8 lists starts with a root indexed by the first 16

@@ -189,3 +189,51 @@ def test_functions_when_every_object_runs_on_its_own(orc):
     run_oracle(orc, w["batch"])
     compare(b, orc)
     eng.close()
+
+
+def test_reload_replaces_the_databases(orc, tmp_path):
+    """geoip_reload() (geoip.c:131-178): new files into a configured handle; the objects stay, the
+    lists made from the databases are rebuilt, the answers follow the new images"""
+    w = synth.workload_c2(8000, prefixes=200)
+    dbs = _databases(w)
+    eng = xenoeye_amd.Engine(device=0)
+    _set(eng, orc, dbs)
+    configure(eng, orc, w["iplists"], w["mos"][:4] + MOS)
+    b = eng.prepare(w["batch"])
+    b.run()
+    run_oracle(orc, w["batch"])
+    compare(b, orc)
+    before = b.counters().copy()
+    b.free()
+    # the same prefixes with other owners and places: AS numbers moved out of the objects' ranges,
+    # countries swapped
+    rng = synth.Rng(77)
+    as4 = [(bytes(4), 8, as_payload(7, "Zero Net"))]
+    geo4 = [(bytes(4), 8, geo_payload("ZZ", "ZZ", "Nowhere", "", "", "", "0", "0"))]
+    for k in range(300):
+        a = bytes(rng.bytes(4))
+        if a[0] == 0:
+            a = b"\x01" + a[1:]
+        m = int(rng.below(1, 12)[0]) + 2
+        as4.append((a, m, as_payload(64100 + k % 7, "ACME" if k % 2 else "x")))
+        geo4.append((a, m, geo_payload("EU", "DE", "Germany", "Berlin", "Berlin", "10115", "52.5", "13.4")))
+    new = dict(dbs)
+    new["as4"] = build_db(as4, 216)
+    new["geo4"] = build_db(geo4, 228)
+    for name in ("as4", "geo4", "as6", "geo6"):
+        (tmp_path / (name + ".db")).write_bytes(new[name])
+    assert eng.reload_geodb(str(tmp_path)) == 4
+    for name in ("as4", "as6", "geo4", "geo6"):
+        orc.geodb_set(1 if name.startswith("as") else 0, 6 if name.endswith("6") else 4, new[name])
+    orc.log_clear()
+    b = eng.prepare(w["batch"])
+    b.run()
+    run_oracle(orc, w["batch"])
+    compare(b, orc)
+    after = b.counters()
+    assert (before[4:, 0] != after[4:, 0]).sum() >= 4
+    b.free()
+    # a database cannot be added or dropped once objects exist
+    with pytest.raises(xenoeye_amd.XeError):
+        eng.set_geodb(0, 4, b"")
+    eng.close()

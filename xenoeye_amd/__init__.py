@@ -89,6 +89,7 @@ def load_library(path=LIB_PATH):
         "xe_gpu_set_overlap": (i32, [vp, i32]),
         "xe_gpu_batch_input_done": (i32, [vp]),
         "xe_gpu_batch_done": (i32, [vp]),
+        "xe_gpu_reload_geodb": (i32, [vp, C.c_char_p]),
         "xe_gpu_batch_per_lane_records": (C.c_size_t, [vp]),
         "xe_gpu_set_walk_timing": (i32, [vp, i32]),
         "xe_gpu_set_list_root_bits": (i32, [vp, i32]),
@@ -357,6 +358,10 @@ class Engine:
 
     def load_geodb(self, d):
         return self._chk(self.L.xe_gpu_load_geodb(self._h, d.encode()))
+
+    def reload_geodb(self, d):
+        """re-read the database files of a directory into the configured handle and commit"""
+        return self._chk(self.L.xe_gpu_reload_geodb(self._h, d.encode()))
 
     def set_device_walk(self, mode):
         """which headers the device walks itself: bit 0 sFlow, bit 1 Netflow datagrams of the usual shape"""

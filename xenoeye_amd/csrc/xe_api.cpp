@@ -502,8 +502,13 @@ xe_gpu_set_geodb(xe_gpu *h, int kind, int family, const void *image, size_t byte
 {
 	int rc;
 	if (!h) return XE_EINVAL;
-	if (h->hs.nmos || h->hs.ndevs) {
-		snprintf(h->err, sizeof(h->err), "the geo / AS databases are set before the objects and devices are added");
+	if ((h->hs.nmos || h->hs.ndevs) && !((kind >= 0) && (kind < 2) && ((family == 4) || (family == 6))
+		&& h->hs.geodb[kind][family == 6].img && image && bytes)) {
+		/* which objects the device decides was settled when they were added: a
+		 * database may be replaced by a newer image afterwards (the reference's
+		 * reload, geoip.c:131-178), not added or dropped */
+		snprintf(h->err, sizeof(h->err), "the geo / AS databases are set before the objects and devices are added "
+			"(afterwards a loaded database can only be replaced by a new image)");
 		return XE_ESTATE;
 	}
 	rc = xe_geodb_set(&h->hs, kind, family, image, bytes, h->err, sizeof(h->err));
@@ -538,6 +543,17 @@ xe_gpu_load_geodb(xe_gpu *h, const char *dir)
 		loaded++;
 	}
 	return loaded;
+}
+
+extern "C" int
+xe_gpu_reload_geodb(xe_gpu *h, const char *dir)
+{
+	int n, rc;
+	if (!h || !dir) return XE_EINVAL;
+	n = xe_gpu_load_geodb(h, dir);
+	if (n < 0) return n;
+	rc = xe_gpu_commit(h);
+	return (rc == XE_OK) ? n : rc;
 }
 
 extern "C" const char *
