@@ -192,10 +192,11 @@ int xe_launch_trie_probe_static(int device, const uint32_t *trie, struct xe_list
  * thread per datagram.  sFlow datagrams keep no state from one to the next, so
  * all of them are walked here.  Of the Netflow datagrams those of the usual
  * shape are (v5; v9 with one data set that ends with the datagram; IPFIX with
- * up to XE_WALK_SETS data sets; templates the handle already knows,
- * fixed-length records, all of them complete); anything else - template sets,
- * several v9 sets, cut-short records, unknown templates, exporters with mark
- * rules - is left to the host walk, which keeps the template store. */
+ * up to XE_WALK_SETS data sets; templates the handle already knows - a
+ * template set that repeats one byte for byte included -, fixed-length
+ * records, all of them complete); anything else - template sets that define or
+ * change a template, several v9 sets, cut-short records, unknown templates -
+ * is left to the host walk, which keeps the template store. */
 
 /* devices.conf entry as device_find() tests it (devices.c:205-232) */
 struct xe_devkey

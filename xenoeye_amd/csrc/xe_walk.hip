@@ -3,15 +3,17 @@
  *
  * One thread per datagram follows the reference's cursor arithmetic over
  * datagram, set and sample headers and leaves what the decode kernels work
- * from: sFlow element descriptors (struct xe_sfrec) and, for Netflow datagrams
- * of the usual shape, runs of complete records grouped by template with their
- * tile list.  Prefix sums give every record the index the walk in arrival
- * order gives it.  Datagrams that touch the template store (or are unusual in
- * any other way) are not decided here: they are flagged and the host walks
- * them.
+ * from: per sFlow datagram its record count and where its first samples start
+ * (struct xe_sfdg), per sFlow record a 16-byte entry (struct xe_sfrd); for
+ * Netflow datagrams of the usual shape, runs of complete records grouped by
+ * template with their tile list.  Prefix sums give every record the index the
+ * walk in arrival order gives it.  Datagrams that change the template store
+ * (or are unusual in any other way) are not decided here: they are flagged and
+ * the host walks them.
  *
- * The prefix sums and the two stable sorts are rocPRIM's device-wide
- * primitives; everything that knows about flow export formats is below.
+ * The Netflow tables need no sort: per template, prefix sums over the
+ * datagrams' runs and tiles (in chunks of XW_CHUNK slots) give every run and
+ * tile its place.  Only the sFlow record counts go through rocPRIM's scan.
  */
 #include <cstring>
 #include <hip/hip_runtime.h>
