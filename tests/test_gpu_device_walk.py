@@ -396,6 +396,34 @@ def test_devices_conf_exporters(orc):
     host.close()
 
 
+def test_many_devices_conf_entries_first_match_wins(orc):
+    """from nine entries on the device walk finds an exporter's entry through a table instead of a
+    scan: the answer must stay the FIRST entry that matches, including the entries with address and
+    id whose id alone matches in the second test (devices.c:224 is `if`, not `else if`)"""
+    w = synth.workload_c5(8000, prefixes=100, n_exporters=8)
+    ids = sorted({int.from_bytes(p[16:20] if p[1] == 9 else p[12:16], "big") for p in w["batch"].pkts})
+    devices = [dict(ip="10.9.9.9", sampling_rate=11),
+               dict(ip="10.9.9.8", dev_id=ids[0], sampling_rate=12),          # wrong address: matches by id alone
+               dict(ip="10.5.0.1", sampling_rate=13),                         # never reached by exporters of id ids[0]
+               dict(ip="10.5.0.2", dev_id=4242, sampling_rate=14),            # neither
+               dict(ip="10.5.0.2", sampling_rate=15, marks=["proto 6"]),
+               dict(dev_id=ids[-1], sampling_rate=16, skip_unmarked=True, marks=["proto 17", "dst port 0-1023"]),
+               dict(ip="10.5.0.3", dev_id=ids[-1], sampling_rate=17),         # shadowed by the entry before
+               dict(ip="10.5.0.4", sampling_rate=18),
+               dict(ip="10.5.0.4", sampling_rate=19),                         # shadowed
+               dict(ip="10.5.0.5", dev_id=ids[len(ids) // 2], sampling_rate=20),
+               dict(dev_id=ids[len(ids) // 2], sampling_rate=21),
+               dict(ip="10.5.0.6", sampling_rate=22, marks=["proto 6"]),
+               dict(ip="10.5.0.7", sampling_rate=23)]
+    w["mos"] = list(w["mos"]) + [("dev-mark 1", -1), ("dev-mark 0", -1)]
+    dev, host = _engines(orc, w, devices=devices)
+    _round(dev, host, orc, w["batch"])
+    got = _round(dev, host, orc, w["batch"])
+    assert got[0] == len(w["batch"].pkts)
+    dev.close()
+    host.close()
+
+
 def test_batch_beyond_the_fast_kernels_reach(orc, monkeypatch):
     """from 2^28 records on a batch goes to the per-lane kernel, and the device walk hands such a
     batch back to the host walk with the template store as it was (here the limit is lowered so

@@ -68,6 +68,8 @@ struct xe_gpu
 	int dbg;                   /* XE_DEBUG: timers of prepare on stderr */
 	int diag_force_general, diag_fast_r, diag_counter_copies;   /* diagnostic builds (-DXE_DIAG) only, else 0 */
 	void *d_devkeys;           /* struct xe_devkey per devices.conf entry */
+	void *d_devhash;           /* struct xe_devhent: the look-up table of the device walk (NULL: few entries) */
+	uint32_t devhash_mask;
 	void *d_thash, *d_twalk;   /* the template store and the device templates as the walk reads them */
 	void *d_traw;              /* the stored templates' bytes, for the walk's "same template again?" test */
 	uint32_t thash_mask;
@@ -318,6 +320,7 @@ xe_gpu_destroy(xe_gpu *h)
 	pinned_free(h->wstage);
 	pinned_free(h->pin);
 	if (h->d_devkeys) (void)hipFree(h->d_devkeys);
+	if (h->d_devhash) (void)hipFree(h->d_devhash);
 	if (h->d_thash) (void)hipFree(h->d_thash);
 	if (h->d_twalk) (void)hipFree(h->d_twalk);
 	if (h->d_traw) (void)hipFree(h->d_traw);
@@ -2349,6 +2352,36 @@ xe_gpu_commit(xe_gpu *h)
 		if (h->d_devkeys) (void)hipFree(h->d_devkeys);
 		h->d_devkeys = NULL;
 		if (rc == XE_OK) rc = upload(h, &h->d_devkeys, dk, h->hs.ndevs * sizeof(*dk));
+		if (h->d_devhash) (void)hipFree(h->d_devhash);
+		h->d_devhash = NULL;
+		h->devhash_mask = 0;
+		if ((rc == XE_OK) && (h->hs.ndevs >= XE_DEVHASH_MIN)) {
+			/* device_find() (devices.c:205-232) as three look-ups: per kind of test
+			 * and key the FIRST entry that passes it */
+			size_t cap = 16;
+			struct xe_devhent *ht;
+			while (cap < 4 * 2 * h->hs.ndevs) cap <<= 1;
+			ht = (struct xe_devhent *)calloc(cap, sizeof(*ht));
+			if (!ht) rc = XE_ENOMEM;
+			for (size_t i = 0; ht && (i < h->hs.ndevs); i++) {
+				for (uint32_t kind = 1; kind <= 3; kind++) {
+					uint32_t kip, kid;
+					size_t j;
+					if ((kind == 1) && !(dk[i].use_ip && !dk[i].use_id)) continue;
+					if ((kind == 2) && !(dk[i].use_ip && dk[i].use_id)) continue;
+					if ((kind == 3) && !dk[i].use_id) continue;
+					kip = (kind == 3) ? 0u : dk[i].ip;
+					kid = (kind == 1) ? 0u : dk[i].id;
+					for (j = xe_devh_hash(kind, kip, kid) & (cap - 1); ht[j].kind; j = (j + 1) & (cap - 1)) {
+						if ((ht[j].kind == kind) && (ht[j].ip == kip) && (ht[j].id == kid)) break;   /* an earlier entry answers */
+					}
+					if (!ht[j].kind) { ht[j].kind = kind; ht[j].ip = kip; ht[j].id = kid; ht[j].dev = (uint32_t)i; }
+				}
+			}
+			if (rc == XE_OK) rc = upload(h, &h->d_devhash, ht, cap * sizeof(*ht));
+			if (rc == XE_OK) h->devhash_mask = (uint32_t)(cap - 1);
+			free(ht);
+		}
 		free(dk);
 		h->walk_epoch = 0;   /* which templates the fast kernel takes depends on the configuration */
 	}
@@ -2530,6 +2563,8 @@ walk_input(const xe_gpu *h, const xe_batch *b, struct xe_walk_in *in)
 	in->n = (uint32_t)w->n;
 	in->ndevs = (uint32_t)h->hs.ndevs;
 	in->devs = (const struct xe_devkey *)h->d_devkeys;
+	in->devhash = (const struct xe_devhent *)h->d_devhash;
+	in->devhash_mask = h->devhash_mask;
 	in->thash = (const struct xe_thent *)h->d_thash;
 	in->thash_mask = h->thash_mask;
 	in->v5_slot_plus1 = h->hs.v5_slot_plus1;

@@ -208,6 +208,26 @@ struct xe_devkey
 	uint32_t pad;
 };
 
+/* one slot of the devices.conf look-up table: open addressing, kind 0 = free */
+struct xe_devhent
+{
+	uint32_t kind, ip, id;
+	uint32_t dev;                      /* first entry of that kind with that key */
+};
+#define XE_DEVHASH_MIN 9               /* devices.conf entries from which the table is built */
+#ifdef __cplusplus
+static inline __host__ __device__
+#else
+static inline
+#endif
+uint32_t
+xe_devh_hash(uint32_t kind, uint32_t ip, uint32_t id)
+{
+	uint32_t h = kind * 0x9E3779B1u ^ ip * 0x85EBCA6Bu ^ id * 0xC2B2AE35u;
+	h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;
+	return h;
+}
+
 /* template store entry for the device: open addressing over `cap` entries
  * (a power of two), ver == 0 marks a free entry */
 struct xe_thent
@@ -309,8 +329,14 @@ struct xe_walk_in
 	uint32_t v5_slot_plus1;        /* device template of the v5 record, 0 = not built yet */
 	const struct xe_twalk *twalk;  /* per device template */
 	uint32_t ntmpl;
-	uint32_t pad;
+	uint32_t devhash_mask;         /* entries of devhash - 1 (a power of two) */
 	const uint8_t *traw;           /* the stored templates' bytes (xe_thent.raw_off) */
+	/* device_find() without the scan over all entries: the first entry that
+	 * matches an exporter is the smallest of three answers - entries that test
+	 * the address alone (kind 1, key = address), address and id (kind 2), the id
+	 * in their second test (kind 3: every entry with use_id, devices.c:224-230) -
+	 * each the first entry of its kind with that key.  NULL: few entries, scanned */
+	const struct xe_devhent *devhash;
 };
 
 #ifdef __cplusplus

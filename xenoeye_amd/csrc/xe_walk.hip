@@ -43,6 +43,21 @@ be16(const uint8_t *p)
 static __device__ int
 dev_find(const xe_walk_in &in, uint32_t ip, uint32_t id)
 {
+	if (in.devhash) {
+		/* the first matching entry = the smallest of the first entries that match
+		 * by address alone, by address and id, and by id in the second test */
+		uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+		for (uint32_t kind = 1; kind <= 3; kind++) {
+			const uint32_t kip = (kind == 3) ? 0u : ip, kid = (kind == 1) ? 0u : id;
+			for (uint32_t j = xe_devh_hash(kind, kip, kid) & in.devhash_mask;; j = (j + 1) & in.devhash_mask) {
+				const xe_devhent e = in.devhash[j];
+				if (!e.kind) break;
+				if ((e.kind == kind) && (e.ip == kip) && (e.id == kid)) { best = (e.dev < best) ? e.dev : best; break; }
+			}
+		}
+		return (best == 0xFFFFFFFFu) ? -1 : (int)best;
+	}
 	for (uint32_t i = 0; i < in.ndevs; i++) {
 		const xe_devkey d = in.devs[i];
 		if (d.use_ip && d.use_id) {
