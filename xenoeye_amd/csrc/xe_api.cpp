@@ -3492,8 +3492,11 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 		 * On the handle's copy stream, which prepare waits for before it
 		 * returns: nothing is left to the ordering rules of the null stream,
 		 * and other handles' streams are not held up */
-		e = hipMemsetAsync(b->d_out, 0, b->out_bytes, h->copy_stream);
-		if (e != hipSuccess) { (void)hipStreamSynchronize(h->copy_stream); xe_gpu_batch_free(b); return hip_fail(h, e, "hipMemsetAsync(outputs)"); }
+		/* (with streaming stores: measured on MI355X, the runtime's fill of a C2 batch's
+		 * 245 MB leaves the decode kernel that follows 0.281 ms, this one 0.249 ms -
+		 * the list tables and the datagrams stay in the caches) */
+		e = (xe_launch_zero_fill(b->d_out, b->out_bytes, h->copy_stream) == XE_OK) ? hipSuccess : hipErrorLaunchFailure;
+		if (e != hipSuccess) { (void)hipStreamSynchronize(h->copy_stream); xe_gpu_batch_free(b); return hip_fail(h, e, "clearing the outputs"); }
 	}
 
 	XE_TICK();

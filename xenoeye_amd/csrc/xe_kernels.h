@@ -133,6 +133,8 @@ struct xe_kparams
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* zeroes `bytes` (a multiple of 16) at p (16-byte aligned) with streaming stores */
+int xe_launch_zero_fill(void *p, size_t bytes, void *stream);
 /* enqueue decode+classify of the whole batch on `stream` (hipStream_t) */
 /* events: NULL, or 6 hipEvent_t = start/stop pairs recorded on `stream` around
  * the fast, general and sFlow kernel launches (only around those that run) */

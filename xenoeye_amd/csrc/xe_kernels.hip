@@ -1896,6 +1896,15 @@ xe_nf_fast_kernel(const xe_kparams kp)
 			}
 		}
 		classify_objects<R, LEAN, LW>(kp, clive, lk, tb, ridx, bxr, pxr, lcnt, lmt);
+		if (!LEAN) {
+			/* a dropped record still owns its mask words */
+#pragma unroll
+			for (int r = 0; r < R; r++) {
+				if (T.live[r] && !clive[r]) {
+					for (uint32_t w = 0; w < kp.mask_words; w++) ((XE_GLOBAL uint64_t *)kp.masks)[(size_t)ridx[r] * kp.mask_words + w] = 0;
+				}
+			}
+		}
 		XE_PHASE(5);
 		C = N;
 	}
@@ -3514,6 +3523,31 @@ upload_tables(void)
 		if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_sf_slot), sl, sizeof(sl))) != hipSuccess) return e;
 	}
 	return hipSuccess;
+}
+
+/* clears a batch's output area with streaming stores: what a kernel writes
+ * once and nothing reads back soon should not push the list tables (or the
+ * datagrams that have just arrived) out of the caches, which the runtime's own
+ * fill does */
+__global__ void __launch_bounds__(256)
+xe_zero_fill_kernel(u32x4 *p, size_t n16)
+{
+	const u32x4 z = {0, 0, 0, 0};
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
+		__builtin_nontemporal_store(z, p + i);
+	}
+}
+
+extern "C" int
+xe_launch_zero_fill(void *p, size_t bytes, void *stream)
+{
+	/* (p is 256-byte aligned, bytes a multiple of 256: the output area's layout) */
+	const size_t n16 = bytes / 16;
+	if (!n16) return XE_OK;
+	size_t blocks = (n16 + 256 * 8 - 1) / (256 * 8);
+	if (blocks > 65536) blocks = 65536;
+	hipLaunchKernelGGL(xe_zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (u32x4 *)p, n16);
+	return (hipGetLastError() == hipSuccess) ? XE_OK : XE_EHIP;
 }
 
 extern "C" int
