@@ -1473,7 +1473,14 @@ xe_prepass(struct xe_host *hs, const uint8_t *data, const uint64_t *offs, const 
 	{
 		const char *e = getenv("XE_PREPASS_MIN_DATAGRAMS");
 		const size_t least = e ? (size_t)atol(e) : 4096;
-		if ((T > 1) && (n >= least)) {
+		/* what the device has walked itself is only passed by: a batch that leaves
+		 * the host a few datagrams does not pay for starting threads either */
+		size_t left = n;
+		if (kinds) {
+			left = 0;
+			for (i = 0; i < n; i++) left += !(kinds[i] & XE_KIND_ON_DEVICE);
+		}
+		if ((T > 1) && (n >= least) && (left >= least)) {
 			int rc = prepass_threads(hs, data, offs, src, kinds, n, plan, T);
 			if (rc != XE_OK) xe_plan_free(plan);   /* also after an early return */
 			return rc;
