@@ -700,6 +700,37 @@ def main():
             assert (c_o == c).all()
             overlapped = {"rounds": rounds, "records": int(done_o), "seconds": dt_o, "records_per_s": done_o / dt_o,
                           "ms_per_batch": dt_o / rounds * 1e3}
+            # one step further: the bytes of batch k + 1 are sent before batch k is prepared, the walk
+            # reads the device copy (three input buffers; nothing but uploads and results on the link)
+            ins.append((eng.pinned(packed[0]),) + tuple(packed[1:]))
+
+            def ahead_pass(rounds):
+                prev = None
+                done = 0
+                t1 = time.perf_counter()
+                up = eng.upload_begin(ins[0][0])
+                for k in range(rounds):
+                    nxt = eng.upload_begin(ins[(k + 1) % 3][0]) if k + 1 < rounds else None
+                    cur = eng.prepare(ins[k % 3], upload=up)
+                    up = nxt
+                    cur.run(stream)
+                    if prev is not None:
+                        prev.masks(out=mb2[(k - 1) & 1])
+                        prev.counters()
+                        done += prev.records
+                        prev.free()
+                    prev = cur
+                prev.masks(out=mb2[(rounds - 1) & 1])
+                cl = prev.counters()
+                done += prev.records
+                prev.free()
+                return time.perf_counter() - t1, done, cl
+
+            ahead_pass(3)
+            dt_a, done_a, c_a = ahead_pass(rounds)
+            assert (c_a == c).all()
+            overlapped["uploads_sent_ahead"] = {"rounds": rounds, "records": int(done_a), "seconds": dt_a,
+                                                "records_per_s": done_a / dt_a, "ms_per_batch": dt_a / rounds * 1e3}
         except Exception as ex:
             overlapped = {"error": repr(ex)}
         finally:

@@ -22,6 +22,7 @@ extern "C" {
 
 typedef struct xe_gpu xe_gpu;        /* configuration + device state */
 typedef struct xe_batch xe_batch;    /* one prepared batch, resident in HBM */
+typedef struct xe_upload xe_upload;  /* datagram bytes sent ahead of their batch */
 
 enum
 {
@@ -245,6 +246,8 @@ void xe_gpu_host_free(xe_gpu *h, void *p);
  * pointer into the caller's arrays. */
 int xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets,
 	const uint32_t *src_ip4, const uint8_t *kinds, size_t n, xe_batch **out);
+int xe_gpu_batch_prepare_uploaded(xe_gpu *h, xe_upload *up, const uint8_t *data, const uint64_t *offsets,
+	const uint32_t *src_ip4, const uint8_t *kinds, size_t n, xe_batch **out);
 void xe_gpu_batch_free(xe_batch *b);
 
 /* Overlap of consecutive batches on ONE handle (off by default).  With it on,
@@ -259,6 +262,19 @@ void xe_gpu_batch_free(xe_batch *b);
  * and for sFlow, prepare still waits for the copy.  No counterpart in the
  * reference, which handles one datagram at a time (scapture.c:25-61). */
 int xe_gpu_set_overlap(xe_gpu *h, int on);
+/* The same one step further: the bytes of a batch are sent to the device before
+ * the batch is prepared.  xe_gpu_upload_begin() only starts the copy (behind
+ * the uploads started before it) and returns; xe_gpu_batch_prepare_uploaded()
+ * is xe_gpu_batch_prepare() for those bytes (`data` and the per-datagram arrays
+ * as there; the upload belongs to the batch afterwards, also when the call
+ * fails).  The header walk then reads the device copy, so nothing but uploads
+ * and results crosses the link: a caller that starts the upload of batch k + 1
+ * before it prepares batch k keeps the link busy with one thread (three input
+ * buffers in rotation; `data` of an upload stays unchanged until
+ * xe_gpu_batch_input_done() of its batch).  xe_gpu_upload_free(): an upload
+ * that will not be prepared.  No counterpart in the reference. */
+int xe_gpu_upload_begin(xe_gpu *h, const uint8_t *data, size_t bytes, xe_upload **out);
+void xe_gpu_upload_free(xe_upload *u);
 int xe_gpu_batch_input_done(xe_batch *b);
 /* 1 when the batch's last run has finished, 0 while it has not (never blocks) */
 int xe_gpu_batch_done(xe_batch *b);

@@ -84,3 +84,43 @@ def test_overlapped_batches_equal_the_oracle(orc):
     compare(b, orc)
     b.free()
     eng.close()
+
+
+def test_uploads_sent_ahead_equal_the_oracle(orc):
+    """xe_gpu_upload_begin / xe_gpu_batch_prepare_uploaded: the bytes of the next batch are on their way
+    while this one is prepared; the walk reads the device copy.  Netflow, sFlow, an upload that is given
+    up, and a batch whose byte count does not match its upload."""
+    w = synth.workload_c2(20000, prefixes=500, seed=41)
+    eng = xenoeye_amd.Engine(device=0)
+    configure(eng, orc, w["iplists"], w["mos"])
+    batches = [w["batch"],
+               synth.workload_c2(9000, prefixes=500, seed=42)["batch"],
+               synth.workload_c3(2500, seed=10)["batch"],
+               synth.workload_c2(14000, prefixes=500, seed=43)["batch"]]
+    packed = []
+    for b in batches:
+        p = b.packed()
+        packed.append((eng.pinned(p[0]),) + tuple(p[1:]))
+    up = eng.upload_begin(packed[0][0])
+    prev = None
+    for i in range(len(batches)):
+        nxt = eng.upload_begin(packed[i + 1][0]) if i + 1 < len(batches) else None
+        cur = eng.prepare(packed[i], upload=up)
+        up = nxt
+        cur.run()
+        if prev is not None:
+            orc.log_clear()
+            run_oracle(orc, prev[1])
+            compare(prev[0], orc)
+            prev[0].free()
+        prev = (cur, batches[i])
+    orc.log_clear()
+    run_oracle(orc, prev[1])
+    compare(prev[0], orc)
+    prev[0].free()
+    # an upload nobody prepares, and one of the wrong size
+    eng.upload_free(eng.upload_begin(packed[1][0]))
+    bad = eng.upload_begin(packed[1][0])
+    with pytest.raises(xenoeye_amd.XeError):
+        eng.prepare(packed[0], upload=bad)      # (the call takes the upload over even when it fails)
+    eng.close()

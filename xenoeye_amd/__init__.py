@@ -89,6 +89,9 @@ def load_library(path=LIB_PATH):
         "xe_gpu_set_overlap": (i32, [vp, i32]),
         "xe_gpu_batch_input_done": (i32, [vp]),
         "xe_gpu_batch_done": (i32, [vp]),
+        "xe_gpu_upload_begin": (i32, [vp, vp, C.c_size_t, C.POINTER(vp)]),
+        "xe_gpu_upload_free": (None, [vp]),
+        "xe_gpu_batch_prepare_uploaded": (i32, [vp, vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(vp)]),
         "xe_gpu_reload_geodb": (i32, [vp, C.c_char_p]),
         "xe_gpu_batch_per_lane_records": (C.c_size_t, [vp]),
         "xe_gpu_set_walk_timing": (i32, [vp, i32]),
@@ -421,8 +424,20 @@ class Engine:
         raw = np.ctypeslib.as_array((C.c_uint8 * n).from_address(p))
         return raw[:int(np.prod(shape)) * dt.itemsize].view(dt).reshape(shape)
 
-    def prepare(self, batch):
-        """batch: synth.Batch or (data, offsets, src, kinds) arrays."""
+    def upload_begin(self, data):
+        """start sending a batch's datagram bytes (uint8 array, page-locked for an asynchronous copy)
+        ahead of prepare(batch, upload=...); returns the upload"""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        up = C.c_void_p()
+        self._chk(self.L.xe_gpu_upload_begin(self._h, data.ctypes.data, data.size, C.byref(up)))
+        return up
+
+    def upload_free(self, up):
+        self.L.xe_gpu_upload_free(up)
+
+    def prepare(self, batch, upload=None):
+        """batch: synth.Batch or (data, offsets, src, kinds) arrays; upload: what upload_begin()
+        returned for the same data (the batch takes it over)."""
         if hasattr(batch, "packed"):
             data, offs, src, kinds = batch.packed()
         else:
@@ -433,8 +448,12 @@ class Engine:
         kinds = None if kinds is None else np.ascontiguousarray(kinds, dtype=np.uint8)
         n = len(offs) - 1
         b = C.c_void_p()
-        self._chk(self.L.xe_gpu_batch_prepare(self._h, data.ctypes.data, offs.ctypes.data, src.ctypes.data,
-                                              kinds.ctypes.data if kinds is not None else None, n, C.byref(b)))
+        if upload is not None:
+            self._chk(self.L.xe_gpu_batch_prepare_uploaded(self._h, upload, data.ctypes.data, offs.ctypes.data, src.ctypes.data,
+                                                           kinds.ctypes.data if kinds is not None else None, n, C.byref(b)))
+        else:
+            self._chk(self.L.xe_gpu_batch_prepare(self._h, data.ctypes.data, offs.ctypes.data, src.ctypes.data,
+                                                  kinds.ctypes.data if kinds is not None else None, n, C.byref(b)))
         pb = PreparedBatch(self, b)
         self._batches.add(pb)
         return pb

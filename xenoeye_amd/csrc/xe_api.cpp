@@ -156,6 +156,7 @@ struct xe_batch
 	int ran;
 	hipEvent_t ev_bulk;        /* overlap mode: the datagram bytes have arrived */
 	hipEvent_t ev_ran;         /* overlap mode: this batch's last run has finished (the stream may carry the next batch already) */
+	int sent_ahead;            /* its datagram bytes were sent with xe_gpu_upload_begin() */
 	int timing;              /* record events around each kernel launch */
 	hipEvent_t ev[6];
 	hipEvent_t ev_fwm[2];      /* around the fixed-window kernel */
@@ -2592,7 +2593,7 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 	w->mode = mode;
 	w->n = n;
 	w->hdr_src = (const uint8_t *)b->d_pkt;
-	if (mode == 2) {
+	if ((mode == 2) && !b->sent_ahead) {
 		/* Netflow only, from page-locked memory the GPU can read in place: the
 		 * walk needs 24 bytes of every datagram, which it fetches over the link
 		 * itself while the copy of the whole buffer is under way */
@@ -3233,9 +3234,18 @@ out:
 	return rc;
 }
 
+/* datagram bytes on their way to the device ahead of the batch they belong to */
+struct xe_upload
+{
+	xe_gpu *h;
+	void *d_pkt;
+	hipEvent_t ev;
+	size_t bytes;
+};
+
 static int
 prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint32_t *src_ip4,
-	const uint8_t *kinds, size_t n, xe_batch **out, int walk_mode);
+	const uint8_t *kinds, size_t n, xe_batch **out, int walk_mode, struct xe_upload *up);
 
 extern "C" int
 xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint32_t *src_ip4,
@@ -3243,9 +3253,68 @@ xe_gpu_batch_prepare(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, co
 {
 	int rc;
 	if (!h) return XE_EINVAL;
-	rc = prepare_impl(h, data, offsets, src_ip4, kinds, n, out, h->device_walk);
+	rc = prepare_impl(h, data, offsets, src_ip4, kinds, n, out, h->device_walk, NULL);
 	/* a batch the device walk cannot take (2^28 records and more) */
-	if (rc == XE_WALK_RETRY_ON_HOST) rc = prepare_impl(h, data, offsets, src_ip4, kinds, n, out, 0);
+	if (rc == XE_WALK_RETRY_ON_HOST) rc = prepare_impl(h, data, offsets, src_ip4, kinds, n, out, 0, NULL);
+	return rc;
+}
+
+extern "C" int
+xe_gpu_upload_begin(xe_gpu *h, const uint8_t *data, size_t bytes, xe_upload **out)
+{
+	struct xe_upload *u;
+	hipError_t e = hipSuccess;
+	int rc;
+
+	if (!h || !out || (bytes && !data)) return XE_EINVAL;
+	*out = NULL;
+	HIPCHK(h, hipSetDevice(h->device));
+	if (!h->bulk_stream) HIPCHK(h, hipStreamCreateWithFlags(&h->bulk_stream, hipStreamNonBlocking));
+	u = (struct xe_upload *)calloc(1, sizeof(*u));
+	if (!u) return XE_ENOMEM;
+	u->h = h;
+	u->bytes = bytes;
+	rc = dev_get(h, &u->d_pkt, bytes + 64);
+	if (rc != XE_OK) { free(u); return rc; }
+	if (bytes) e = hipMemcpyAsync(u->d_pkt, data, bytes, hipMemcpyHostToDevice, h->bulk_stream);
+	if (e == hipSuccess) e = hipMemsetAsync((uint8_t *)u->d_pkt + bytes, 0, 64, h->bulk_stream);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&u->ev, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventRecord(u->ev, h->bulk_stream);
+	if (e != hipSuccess) {
+		(void)hipStreamSynchronize(h->bulk_stream);
+		if (u->ev) (void)hipEventDestroy(u->ev);
+		dev_put(h, u->d_pkt);
+		free(u);
+		return hip_fail(h, e, "hipMemcpyAsync(packets)");
+	}
+	*out = u;
+	return XE_OK;
+}
+
+extern "C" void
+xe_gpu_upload_free(xe_upload *u)
+{
+	if (!u) return;
+	(void)hipSetDevice(u->h->device);
+	if (u->ev) { (void)hipEventSynchronize(u->ev); (void)hipEventDestroy(u->ev); }
+	dev_put(u->h, u->d_pkt);
+	free(u);
+}
+
+extern "C" int
+xe_gpu_batch_prepare_uploaded(xe_gpu *h, xe_upload *up, const uint8_t *data, const uint64_t *offsets, const uint32_t *src_ip4,
+	const uint8_t *kinds, size_t n, xe_batch **out)
+{
+	int rc;
+	if (!h || !up || (up->h != h)) return XE_EINVAL;
+	if (up->bytes != (n ? (size_t)offsets[n] : 0)) {
+		snprintf(h->err, sizeof(h->err), "the upload holds %zu bytes, the batch's datagrams %zu", up->bytes, n ? (size_t)offsets[n] : 0);
+		xe_gpu_upload_free(up);
+		return XE_EINVAL;
+	}
+	/* (the upload belongs to the batch from here on, whatever becomes of it) */
+	rc = prepare_impl(h, data, offsets, src_ip4, kinds, n, out, h->device_walk, up);
+	if (rc == XE_WALK_RETRY_ON_HOST) rc = prepare_impl(h, data, offsets, src_ip4, kinds, n, out, 0, NULL);
 	return rc;
 }
 
@@ -3306,7 +3375,7 @@ xe_gpu_batch_walk_ms(xe_batch *b, float *ms)
 
 static int
 prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint32_t *src_ip4,
-	const uint8_t *kinds, size_t n, xe_batch **out, int walk_mode)
+	const uint8_t *kinds, size_t n, xe_batch **out, int walk_mode, struct xe_upload *up)
 {
 	xe_batch *b;
 	int rc;
@@ -3317,15 +3386,16 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 #define XE_TICK() do { if (dbg && (ntm_ < 8)) { struct timespec ts_; clock_gettime(CLOCK_MONOTONIC, &ts_); \
 	tm_[ntm_++] = ts_.tv_sec * 1e3 + ts_.tv_nsec * 1e-6; } } while (0)
 
-	if (!h || !out || (n && (!data || !offsets || !src_ip4))) return XE_EINVAL;
+	if (!h || !out || (n && (!data || !offsets || !src_ip4))) { xe_gpu_upload_free(up); return XE_EINVAL; }
 	*out = NULL;
 	if (!h->committed) {
 		snprintf(h->err, sizeof(h->err), "xe_gpu_commit() must follow configuration changes");
+		xe_gpu_upload_free(up);
 		return XE_ESTATE;
 	}
-	HIPCHK(h, hipSetDevice(h->device));
+	if (hipSetDevice(h->device) != hipSuccess) { xe_gpu_upload_free(up); return hip_fail(h, hipGetLastError(), "hipSetDevice"); }
 	b = (xe_batch *)calloc(1, sizeof(*b));
-	if (!b) return XE_ENOMEM;
+	if (!b) { xe_gpu_upload_free(up); return XE_ENOMEM; }
 	b->h = h;
 	pin_begin(h, 14 * (n + 8) + (h->hs.dev_tmpls.n + 8) * (sizeof(struct xe_fplan) + XE_NFIELDS * 4 + sizeof(struct xe_wgroup) + 8 + 256)
 		+ (h->hs.dev_tents.n + 16) * sizeof(struct xe_fop) + 16 * 256);
@@ -3336,9 +3406,20 @@ prepare_impl(xe_gpu *h, const uint8_t *data, const uint64_t *offsets, const uint
 	 * stays inside the allocation. */
 	total = n ? (size_t)offsets[n] : 0;
 	b->payload_bytes = total;
-	rc = upload_pooled(h, &b->d_pkt, NULL, total + 64);
-	if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
-	{
+	if (up) {
+		/* the bytes were sent ahead (xe_gpu_upload_begin): the batch takes the
+		 * buffer and the event over; the walk reads the device copy, behind the
+		 * event, and the link carries nothing but the next upload meanwhile */
+		b->d_pkt = up->d_pkt;
+		b->ev_bulk = up->ev;
+		b->sent_ahead = 1;
+		free(up);
+		up = NULL;
+	} else {
+		rc = upload_pooled(h, &b->d_pkt, NULL, total + 64);
+		if (rc != XE_OK) { xe_gpu_batch_free(b); return rc; }
+	}
+	if (!b->sent_ahead) {
 		hipError_t e = hipSuccess;
 		const hipStream_t bulk = h->overlap ? h->bulk_stream : h->copy_stream;
 		if (total) e = hipMemcpyAsync(b->d_pkt, data, total, hipMemcpyHostToDevice, bulk);
