@@ -6,7 +6,8 @@ sys.path.insert(0, ".")
 import xenoeye_amd
 from xenoeye_amd import synth
 
-w = synth.workload_c2(1 << 21)
+NREC = int(sys.argv[1]) if len(sys.argv) > 1 else (1 << 21)
+w = synth.workload_c2(NREC)
 packed = w["batch"].packed()
 cases = [("all: proto,dst port", "", ["proto", "dst port", "octets", "packets"]),
          ("all: proto", "", ["proto", "octets"]),
@@ -20,7 +21,7 @@ for name, filt, fields in cases:
     for f, p in w["mos"]:
         e.add_mo("mo", f, p)
     mo = e.add_mo("mo", filt, -1) if filt is not None else 0
-    t = e.add_fwm(mo, fields, 1 << 21)
+    t = e.add_fwm(mo, fields, 1 << 21 if "src host" in fields else 1 << 19)
     e.commit()
     b = e.prepare(packed)
     b.timing(True)
