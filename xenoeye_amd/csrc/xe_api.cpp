@@ -3739,12 +3739,13 @@ xe_gpu_batch_run(xe_batch *b, void *stream)
 	if (b->ev_bulk) HIPCHK(b->h, hipStreamWaitEvent((hipStream_t)stream, b->ev_bulk, 0));
 	rc = xe_launch_batch(&b->kp, stream, b->timing ? (void **)b->ev : NULL);
 	if ((rc == XE_OK) && b->h->nfwm) {
-		uint32_t kwmax = 1, nvmax = 1;
+		uint32_t kwmax = 1, nvmax = 1, nkmax = 0;
 		for (size_t i = 0; i < b->h->nfwm; i++) {
 			if (b->h->fwms[i].dev.kwords > kwmax) kwmax = b->h->fwms[i].dev.kwords;
+			if (b->h->fwms[i].dev.nkey > nkmax) nkmax = b->h->fwms[i].dev.nkey;
 			if (b->h->fwms[i].dev.nval > nvmax) nvmax = b->h->fwms[i].dev.nval;
 		}
-		rc = xe_launch_fwm(&b->kp, (const struct xe_fwm_dev *)b->h->d_fwmdesc, (uint32_t)b->h->nfwm, kwmax, nvmax, stream,
+		rc = xe_launch_fwm(&b->kp, (const struct xe_fwm_dev *)b->h->d_fwmdesc, (uint32_t)b->h->nfwm, kwmax, nkmax, nvmax, stream,
 			b->timing ? (void **)b->ev_fwm : NULL);
 	}
 	if (rc != XE_OK) {

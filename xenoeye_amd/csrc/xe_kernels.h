@@ -174,8 +174,8 @@ struct xe_fwm_dev
 	uint16_t dl_off[XE_FWM_MAX_KEY_FIELDS], dl_n[XE_FWM_MAX_KEY_FIELDS];
 	const int32_t *dl;
 };
-/* kwmax / nvmax: the longest key (words) and the most sums among the tables */
-int xe_launch_fwm(const struct xe_kparams *kp, const struct xe_fwm_dev *tables, uint32_t ntables, uint32_t kwmax, uint32_t nvmax,
+/* kwmax / nkmax / nvmax: the longest key (words), the most key fields and the most sums among the tables */
+int xe_launch_fwm(const struct xe_kparams *kp, const struct xe_fwm_dev *tables, uint32_t ntables, uint32_t kwmax, uint32_t nkmax, uint32_t nvmax,
 	void *stream, void **events);
 /* n addresses (4 or 16 bytes each) against one flattened list */
 int xe_launch_trie_probe(const uint32_t *trie, struct xe_list_dev list, int family,

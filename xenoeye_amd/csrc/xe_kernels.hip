@@ -3007,8 +3007,9 @@ xe_sf_kernel(const xe_kparams kp)
  * slot (one line per record instead of two) the adds to a line hold up the
  * probes of the same line - 0.820 and 0.542 ms for the two cases above. */
 #define XE_FWM_NOROW 0xFFFFFFFFu
+template <int MKW>
 __device__ __forceinline__ uint32_t
-fwm_global_find(const xe_fwm_dev &F, bool want, const uint64_t (&kw)[XE_FWM_MAX_KWORDS], uint64_t h, uint32_t nrecords)
+fwm_global_find(const xe_fwm_dev &F, bool want, const uint64_t (&kw)[MKW], uint64_t h, uint32_t nrecords)
 {
 	uint32_t slot = (uint32_t)h & F.cap_mask, tried = 0;
 	bool done = !want;
@@ -3060,7 +3061,7 @@ fwm_global_find(const xe_fwm_dev &F, bool want, const uint64_t (&kw)[XE_FWM_MAX_
 			if (st == 0) mine = atomicCAS((uint32_t *)S, 0u, 1u) == 0u;
 			if (mine) {
 #pragma unroll
-				for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
+				for (int i = 0; i < MKW; i++) {
 					if ((uint32_t)i < F.kwords) __hip_atomic_store(&S[1 + i], (unsigned long long)kw[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				}
 				__hip_atomic_store((uint32_t *)S, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -3077,7 +3078,7 @@ fwm_global_find(const xe_fwm_dev &F, bool want, const uint64_t (&kw)[XE_FWM_MAX_
 				 * state load, which the memory model alone would let it do */
 				__atomic_signal_fence(__ATOMIC_ACQUIRE);
 #pragma unroll
-				for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
+				for (int i = 0; i < MKW; i++) {
 					if ((uint32_t)i < F.kwords) {
 						eq = eq && (__hip_atomic_load(&S[1 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kw[i]);
 					}
@@ -3112,10 +3113,11 @@ fwm_global_find(const xe_fwm_dev &F, bool want, const uint64_t (&kw)[XE_FWM_MAX_
  * instruction g of 2 covers the rows of lanes 32 g ... 32 g + 31, lane l adding
  * sum l & 1 of the row of lane 32 g + (l >> 1); with three or four sums four
  * instructions cover 16 rows each. */
+template <int MNV>
 __device__ __forceinline__ void
-fwm_wave_add(const xe_fwm_dev &F, uint32_t row, const unsigned long long (&val)[XE_FWM_MAX_VALS])
+fwm_wave_add(const xe_fwm_dev &F, uint32_t row, const unsigned long long (&val)[MNV])
 {
-	static_assert(XE_FWM_MAX_VALS <= 4, "the lanes share out at most four sums");
+	static_assert(MNV <= 4, "the lanes share out at most four sums");
 	const uint32_t lane = threadIdx.x & 63;
 	if (F.nval == 1) {
 		if (row != XE_FWM_NOROW) atomicAdd(&F.vals[row], val[0]);
@@ -3132,7 +3134,7 @@ fwm_wave_add(const xe_fwm_dev &F, uint32_t row, const unsigned long long (&val)[
 		const uint32_t r = __shfl(row, src, 64);
 		unsigned long long v = 0;
 #pragma unroll
-		for (int q = 0; q < XE_FWM_MAX_VALS; q++) {
+		for (int q = 0; q < MNV; q++) {
 			const unsigned long long x = __shfl(val[q], src, 64);
 			if ((uint32_t)q == j) v = x;
 		}
@@ -3194,17 +3196,19 @@ fwm_func_key(const xe_fwm_dev &F, int k, uint64_t a, uint64_t b)
 /* the column elements the key and the sums of one record need, all loads in
  * flight together (a 16-byte field takes two); a field no template of the
  * batch carries reads as zeros */
+template <int MKF, int MNV>
 struct fwm_cols
 {
-	uint64_t part0[XE_FWM_MAX_KEY_FIELDS], part1[XE_FWM_MAX_KEY_FIELDS], vraw[XE_FWM_MAX_VALS];
+	uint64_t part0[MKF], part1[MKF], vraw[MNV];
 	uint32_t rate;
 };
 
+template <int MKF, int MNV>
 __device__ __forceinline__ void
-fwm_load_cols(const xe_kparams &kp, const xe_fwm_dev &F, uint32_t r, bool hit, fwm_cols &C)
+fwm_load_cols(const xe_kparams &kp, const xe_fwm_dev &F, uint32_t r, bool hit, fwm_cols<MKF, MNV> &C)
 {
 #pragma unroll
-	for (int k = 0; k < XE_FWM_MAX_KEY_FIELDS; k++) {
+	for (int k = 0; k < MKF; k++) {
 		C.part0[k] = C.part1[k] = 0;
 		if (!hit || ((uint32_t)k >= F.nkey)) continue;
 		const uint32_t fld = F.kfield[k], colw = c_colw[fld];
@@ -3239,7 +3243,7 @@ fwm_load_cols(const xe_kparams &kp, const xe_fwm_dev &F, uint32_t r, bool hit, f
 		}
 	}
 #pragma unroll
-	for (int j = 0; j < XE_FWM_MAX_VALS; j++) {
+	for (int j = 0; j < MNV; j++) {
 		C.vraw[j] = 0;
 		if (!hit || ((uint32_t)j >= F.nval)) continue;
 		const uint64_t co = kp.col_off[F.vfield[j]];
@@ -3248,8 +3252,13 @@ fwm_load_cols(const xe_kparams &kp, const xe_fwm_dev &F, uint32_t r, bool hit, f
 	C.rate = hit ? kp.rates[r] : 0u;
 }
 
+/* MKW, MKF, MNV: the most key words, key fields and sums the kernel is built
+ * for (registers are what limits the waves in flight, and the arrays of a
+ * record's key and sums are most of them: 189 registers and two waves per SIMD
+ * for the limits of the interface, four and more for the usual short keys) */
+template <int MKW, int MKF, int MNV>
 __global__ void __launch_bounds__(XE_BLOCK)
-xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables, uint32_t kwmax, uint32_t nvmax)
+xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables, uint32_t kwmax, uint32_t nvmax, uint32_t nchunks)
 {
 	extern __shared__ uint64_t fwm_lds[];
 	constexpr uint32_t WAVES = XE_BLOCK / 64;
@@ -3274,7 +3283,7 @@ xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables, u
 #define s_lane(W, H) s_lane_[(W) * 128 + (H)]
 	const uint32_t ntot = kp.nrec + kp.nsf;
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const uint32_t r0 = blockIdx.x * (XE_BLOCK * XE_FWM_CHUNKS);
+	const uint32_t r0 = blockIdx.x * (XE_BLOCK * nchunks);
 	XE_PHASE_DECL;
 
 	for (uint32_t f = 0; f < ntables; f++) {
@@ -3284,14 +3293,14 @@ xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables, u
 			c_state[i] = 0;
 			c_cnt[i] = 0;
 #pragma unroll
-			for (int j = 0; j < XE_FWM_MAX_VALS; j++) if ((uint32_t)j < nvmax) c_sum(i, j) = 0;
+			for (int j = 0; j < MNV; j++) if ((uint32_t)j < nvmax) c_sum(i, j) = 0;
 		}
 		__syncthreads();
 
 		/* Two chunks ahead the mask word of a record is fetched, one chunk ahead the
 		 * column elements its key and sums need: what a chunk waits for was asked
 		 * for while the chunk before it went through the tables */
-		fwm_cols cnext;
+		fwm_cols<MKF, MNV> cnext;
 		uint64_t m1, m2;
 		bool hit_next;
 		{
@@ -3301,35 +3310,35 @@ xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables, u
 			hit_next = ((m0 >> (F.mo & 63)) & 1) != 0;
 			fwm_load_cols(kp, F, ra, hit_next, cnext);
 		}
-		for (uint32_t chunk = 0; chunk < XE_FWM_CHUNKS; chunk++) {
+		for (uint32_t chunk = 0; chunk < nchunks; chunk++) {
 			const uint32_t r = r0 + chunk * XE_BLOCK + threadIdx.x;
 			const bool hit = hit_next;
-			const fwm_cols C = cnext;
-			m2 = ((chunk + 2 < XE_FWM_CHUNKS) && (r + 2 * XE_BLOCK < ntot))
+			const fwm_cols<MKF, MNV> C = cnext;
+			m2 = ((chunk + 2 < nchunks) && (r + 2 * XE_BLOCK < ntot))
 				? kp.masks[(size_t)(r + 2 * XE_BLOCK) * kp.mask_words + (F.mo >> 6)] : 0;
-			hit_next = (chunk + 1 < XE_FWM_CHUNKS) && (((m1 >> (F.mo & 63)) & 1) != 0);
+			hit_next = (chunk + 1 < nchunks) && (((m1 >> (F.mo & 63)) & 1) != 0);
 			fwm_load_cols(kp, F, r + XE_BLOCK, hit_next, cnext);
 			m1 = m2;
 			XE_PHASE(0);
 			if (!__ballot(hit)) continue;
 
 			/* the key: field bytes one after the other, packed into words */
-			uint64_t kw[XE_FWM_MAX_KWORDS];
-			unsigned long long val[XE_FWM_MAX_VALS];
+			uint64_t kw[MKW];
+			unsigned long long val[MNV];
 #pragma unroll
-			for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) kw[i] = 0;
+			for (int i = 0; i < MKW; i++) kw[i] = 0;
 #pragma unroll
-			for (int j = 0; j < XE_FWM_MAX_VALS; j++) val[j] = 0;
+			for (int j = 0; j < MNV; j++) val[j] = 0;
 			uint64_t h = 0xcbf29ce484222325ull;
 			if (hit) {
 				uint32_t pos = 0;
-				const uint64_t (&part0)[XE_FWM_MAX_KEY_FIELDS] = C.part0;
-				const uint64_t (&part1)[XE_FWM_MAX_KEY_FIELDS] = C.part1;
-				const uint64_t (&vraw)[XE_FWM_MAX_VALS] = C.vraw;
+				const uint64_t (&part0)[MKF] = C.part0;
+				const uint64_t (&part1)[MKF] = C.part1;
+				const uint64_t (&vraw)[MNV] = C.vraw;
 				const uint64_t rate = C.rate;
 				for (uint32_t i = 0; i < F.kwords; i++) s_key(wave, i, lane) = 0;
 #pragma unroll
-				for (int k = 0; k < XE_FWM_MAX_KEY_FIELDS; k++) {
+				for (int k = 0; k < MKF; k++) {
 					if ((uint32_t)k >= F.nkey) continue;
 					const uint32_t size = F.ksize[k];
 					uint64_t part[2] = { part0[k], part1[k] };
@@ -3347,7 +3356,7 @@ xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables, u
 					}
 				}
 #pragma unroll
-				for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
+				for (int i = 0; i < MKW; i++) {
 					if ((uint32_t)i < F.kwords) {
 						kw[i] = s_key(wave, i, lane);
 						h = (h ^ kw[i]) * 0x100000001b3ull;
@@ -3359,7 +3368,7 @@ xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables, u
 				h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull;
 				h ^= h >> 33;
 #pragma unroll
-				for (int j = 0; j < XE_FWM_MAX_VALS; j++) {
+				for (int j = 0; j < MNV; j++) {
 					if ((uint32_t)j >= F.nval) continue;
 					val[j] = __builtin_bswap64(vraw[j]) * F.vscale[j] * rate;
 				}
@@ -3372,21 +3381,21 @@ xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables, u
 			if (hit) {
 				s_lane(wave, hs) = lane;
 #pragma unroll
-				for (int j = 0; j < XE_FWM_MAX_VALS; j++) if ((uint32_t)j < nvmax) s_sum(wave, lane, j) = 0;
+				for (int j = 0; j < MNV; j++) if ((uint32_t)j < nvmax) s_sum(wave, lane, j) = 0;
 				s_cnt(wave, lane) = 0;
 			}
 			__builtin_amdgcn_wave_barrier();
 			const uint32_t spk = hit ? s_lane(wave, hs) : lane;
 			bool same = hit;
 #pragma unroll
-			for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
+			for (int i = 0; i < MKW; i++) {
 				if ((uint32_t)i >= F.kwords) break;
 				const uint64_t other = __shfl(kw[i], (int)spk, 64);
 				same = same && (other == kw[i]);
 			}
 			if (same) {
 #pragma unroll
-				for (int j = 0; j < XE_FWM_MAX_VALS; j++) {
+				for (int j = 0; j < MNV; j++) {
 					if ((uint32_t)j < F.nval) atomicAdd(&s_sum(wave, spk, j), val[j]);
 				}
 				atomicAdd(&s_cnt(wave, spk), 1u);
@@ -3397,7 +3406,7 @@ xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables, u
 			if (hit && same && (spk == lane)) {
 				nspoken = s_cnt(wave, lane);
 #pragma unroll
-				for (int j = 0; j < XE_FWM_MAX_VALS; j++) if ((uint32_t)j < nvmax) val[j] = s_sum(wave, lane, j);
+				for (int j = 0; j < MNV; j++) if ((uint32_t)j < nvmax) val[j] = s_sum(wave, lane, j);
 			}
 			__builtin_amdgcn_wave_barrier();
 			XE_PHASE(2);
@@ -3412,7 +3421,7 @@ xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables, u
 				if (old == 0) {
 					c_hash[ci] = h;
 #pragma unroll
-					for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
+					for (int i = 0; i < MKW; i++) {
 						if ((uint32_t)i < F.kwords) c_key(ci, i) = kw[i];
 					}
 					__hip_atomic_store(&c_state[ci], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -3425,12 +3434,12 @@ xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables, u
 			if (cs == 2) {
 				bool eq = true;
 #pragma unroll
-				for (int i = 0; i < XE_FWM_MAX_KWORDS; i++) {
+				for (int i = 0; i < MKW; i++) {
 					if ((uint32_t)i < F.kwords) eq = eq && (c_key(ci, i) == kw[i]);
 				}
 				if (eq) {
 #pragma unroll
-					for (int j = 0; j < XE_FWM_MAX_VALS; j++) {
+					for (int j = 0; j < MNV; j++) {
 						if ((uint32_t)j < F.nval) atomicAdd(&c_sum(ci, j), val[j]);
 					}
 					atomicAdd(&c_cnt[ci], nspoken);
@@ -3447,12 +3456,12 @@ xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables, u
 		static_assert(XE_FWM_CACHE % XE_BLOCK == 0, "whole waves go through the block's table");
 		for (uint32_t i = threadIdx.x; i < XE_FWM_CACHE; i += XE_BLOCK) {
 			const bool full = c_state[i] == 2;
-			uint64_t kw[XE_FWM_MAX_KWORDS];
-			unsigned long long val[XE_FWM_MAX_VALS];
+			uint64_t kw[MKW];
+			unsigned long long val[MNV];
 #pragma unroll
-			for (int k = 0; k < XE_FWM_MAX_KWORDS; k++) kw[k] = (full && ((uint32_t)k < F.kwords)) ? c_key(i, k) : 0;
+			for (int k = 0; k < MKW; k++) kw[k] = (full && ((uint32_t)k < F.kwords)) ? c_key(i, k) : 0;
 #pragma unroll
-			for (int j = 0; j < XE_FWM_MAX_VALS; j++) val[j] = (full && ((uint32_t)j < nvmax)) ? c_sum(i, j) : 0ull;
+			for (int j = 0; j < MNV; j++) val[j] = (full && ((uint32_t)j < nvmax)) ? c_sum(i, j) : 0ull;
 			fwm_wave_add(F, fwm_global_find(F, full, kw, full ? c_hash[i] : 0, c_cnt[i]), val);
 		}
 		__syncthreads();
@@ -3467,16 +3476,19 @@ xe_fwm_kernel(const xe_kparams kp, const xe_fwm_dev *tables, uint32_t ntables, u
 #undef s_lane
 
 int
-xe_launch_fwm(const struct xe_kparams *kp, const struct xe_fwm_dev *tables, uint32_t ntables, uint32_t kwmax, uint32_t nvmax,
+xe_launch_fwm(const struct xe_kparams *kp, const struct xe_fwm_dev *tables, uint32_t ntables, uint32_t kwmax, uint32_t nkmax, uint32_t nvmax,
 	void *stream, void **events)
 {
 	hipStream_t st = (hipStream_t)stream;
 	hipEvent_t *ev = (hipEvent_t *)events;
 	const uint32_t ntot = kp->nrec + kp->nsf;
-	const uint32_t per_block = XE_BLOCK * XE_FWM_CHUNKS;
+	/* chunks per block: long runs keep the block's table useful, but the launch
+	 * should hold a few blocks for every CU */
+	uint32_t nchunks = XE_FWM_CHUNKS;
+	while ((nchunks > 4) && ((ntot + XE_BLOCK * nchunks - 1) / (XE_BLOCK * nchunks) < 2048)) nchunks >>= 1;
 
 	if (!ntables || !ntot) return XE_OK;
-	if (!kwmax || (kwmax > XE_FWM_MAX_KWORDS) || !nvmax || (nvmax > XE_FWM_MAX_VALS)) return XE_EINVAL;
+	if (!kwmax || (kwmax > XE_FWM_MAX_KWORDS) || !nvmax || (nvmax > XE_FWM_MAX_VALS) || (nkmax > XE_FWM_MAX_KEY_FIELDS)) return XE_EINVAL;
 #ifdef XE_DIAG
 	struct xe_kparams kcopy;
 	if (getenv("XE_ABLATE")) {      /* diagnostic switches, as in xe_launch_batch() */
@@ -3484,16 +3496,27 @@ xe_launch_fwm(const struct xe_kparams *kp, const struct xe_fwm_dev *tables, uint
 		kcopy.pad2 = (uint32_t)atoi(getenv("XE_ABLATE"));
 		kp = &kcopy;
 	}
+	if (getenv("XE_FWM_CHUNKS_RT")) nchunks = (uint32_t)atoi(getenv("XE_FWM_CHUNKS_RT"));
 #endif
 	if (ev) (void)hipEventRecord(ev[0], st);
-	hipLaunchKernelGGL(xe_fwm_kernel, dim3((ntot + per_block - 1) / per_block), dim3(XE_BLOCK), fwm_lds_bytes(kwmax, nvmax), st,
-		*kp, tables, ntables, kwmax, nvmax);
+	{
+		const uint32_t per_block = XE_BLOCK * nchunks;
+		const dim3 grid((ntot + per_block - 1) / per_block), block(XE_BLOCK);
+		const size_t lds = fwm_lds_bytes(kwmax, nvmax);
+		if ((kwmax <= 1) && (nkmax <= 4) && (nvmax <= 2))
+			hipLaunchKernelGGL((xe_fwm_kernel<1, 4, 2>), grid, block, lds, st, *kp, tables, ntables, kwmax, nvmax, nchunks);
+		else if ((kwmax <= 2) && (nkmax <= 4) && (nvmax <= 2))
+			hipLaunchKernelGGL((xe_fwm_kernel<2, 4, 2>), grid, block, lds, st, *kp, tables, ntables, kwmax, nvmax, nchunks);
+		else
+			hipLaunchKernelGGL((xe_fwm_kernel<XE_FWM_MAX_KWORDS, XE_FWM_MAX_KEY_FIELDS, XE_FWM_MAX_VALS>), grid, block, lds, st,
+				*kp, tables, ntables, kwmax, nvmax, nchunks);
+	}
 	if (ev) (void)hipEventRecord(ev[1], st);
 #ifdef XE_DIAG
 	if (kp->pad2 & 64) {
 		/* diagnostic: print and reset the per-phase wave cycles */
 		unsigned long long pc[8], z[8] = {0};
-		const double nw = (double)((ntot + per_block - 1) / per_block) * (XE_BLOCK / 64);
+		const double nw = (double)((ntot + XE_BLOCK * nchunks - 1) / (XE_BLOCK * nchunks)) * (XE_BLOCK / 64);
 		(void)hipStreamSynchronize(st);
 		(void)hipMemcpyFromSymbol(pc, HIP_SYMBOL(xe_fast_phase_cycles), sizeof(pc));
 		(void)hipMemcpyToSymbol(HIP_SYMBOL(xe_fast_phase_cycles), z, sizeof(z));
