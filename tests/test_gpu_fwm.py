@@ -279,6 +279,50 @@ def test_many_blocks_insert_the_same_new_keys(eng, orc):
             eng.fwm_clear(t)
 
 
+def test_long_keys_that_share_their_first_words(eng, orc):
+    """keys of several words are claimed word by word (seven key bytes to a word): keys that agree
+    in their first words and differ in a later one, keys full of zero bytes and the all-zero key,
+    met by every block at once in the first batch of a window, in a table with long probe chains -
+    every key in exactly one row, with the oracle's sums"""
+    rng = synth.Rng(0x7A)
+    n = 300000
+    fields = [(8, 4), (12, 4), (7, 2), (11, 2), (4, 1), (1, 8), (2, 8), (27, 16), (28, 16)]
+    recs = synth.flow_columns(rng, n, fields)
+    recs[:, 0:4] = np.frombuffer(bytes([10, 0, 0, 0]), dtype=np.uint8)      # one source ...
+    recs[:, 3] = rng.below(n, 2).astype(np.uint8)                            # ... or its neighbour
+    recs[:, 4:7] = 0                                                         # dst host 0.0.0.x: word 0 of few values
+    recs[:, 7] = rng.below(n, 40).astype(np.uint8)
+    recs[:, 8:10] = synth._be(rng.below(n, 30), 2)                           # ports from 0 on: zero bytes
+    recs[:, 10:12] = synth._be(rng.below(n, 3), 2)
+    recs[:, 12] = 6
+    recs[:, 29:45] = 0                                                       # IPv6 addresses: mostly zero bytes
+    recs[:, 44] = rng.below(n, 5).astype(np.uint8)
+    recs[:, 45:61] = 0
+    recs[:, 52] = rng.below(n, 7).astype(np.uint8)
+    for i in range(0, n, 11):                                                # the all-zero keys
+        recs[i, 0:13] = 0
+        recs[i, 29:61] = 0
+    b = synth.Batch()
+    exp = bytes([192, 0, 2, 1])
+    b.add(synth.v9_template_packet(256, fields, 77), exp)
+    b.extend(synth.v9_data_packets(256, recs, 20, 77), exp)
+    w = dict(batch=b, mos=[("", -1)])
+    ids = setup(eng, orc, w, [(0, ["src host", "dst host", "src port", "dst port", "packets"]),
+                              (0, ["src host6", "dst host6", "src port", "proto", "octets", "packets", "bits"]),
+                              (0, ["dst host", "src host6", "packets"])], max_keys=4000)
+    out = eng.prepare(b)
+    for window in range(3):
+        out.run()
+        if window == 0:
+            run_oracle(orc, b, keep_flows=False)
+        same_tables(eng, orc, ids)
+        got, _ = eng.fwm_read(ids[0])
+        assert bytes(12) in got and len(got) > 5000
+        assert bytes(35) in eng.fwm_read(ids[1])[0]
+        for t in ids:
+            eng.fwm_clear(t)
+
+
 def test_the_key_a_one_word_table_cannot_store_among_the_others(eng, orc):
     """tables whose key is one word keep it xor-ed with a constant, 0 meaning a free slot: the
     one key that would be stored as 0 gets a row of its own, with the oracle's sums like any other"""

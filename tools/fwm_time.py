@@ -13,7 +13,9 @@ cases = [("all: proto,dst port", "", ["proto", "dst port", "octets", "packets"])
          ("all: proto", "", ["proto", "octets"]),
          ("all: no key", "", ["octets"]),
          ("all: src host,dst host", "", ["src host", "dst host", "octets"]),
-         ("obj0: src host,dst host", None, ["src host", "dst host", "bits"])]
+         ("obj0: src host,dst host", None, ["src host", "dst host", "bits"]),
+         ("all: hosts + ports (12 bytes)", "", ["src host", "dst host", "src port", "dst port", "octets"]),
+         ("all: src host6,dst host6,proto", "", ["src host6", "dst host6", "proto", "octets", "packets"])]
 for name, filt, fields in cases:
     e = xenoeye_amd.Engine(device=0)
     for n, t in w["iplists"].items():
@@ -37,5 +39,5 @@ for name, filt, fields in cases:
         b.run()            # keys already in the table
         warm.append(b.fwm_ms())
     rows, dr = e.fwm_read(t)
-    print("%-28s rows %7d  empty table %.3f ms  filled table %.3f ms" % (name, len(rows), np.mean(ms), np.mean(warm)))
+    print("%-32s rows %7d  empty table %.3f ms  filled table %.3f ms" % (name, len(rows), np.mean(ms), np.mean(warm)))
     e.close()

@@ -1421,8 +1421,10 @@ xe_gpu_add_fwm(xe_gpu *h, int mo, const char *const *fields, int nfields, size_t
 	w.dev.cap_mask = (uint32_t)(w.slots - 1);
 
 	HIPCHK(h, hipSetDevice(h->device));
-	/* state + key, rounded up to a whole number of 16 bytes */
-	w.dev.swords = (1 + w.dev.kwords + 1) & ~1u;
+	/* a one-word key: state + key; longer ones: seven bytes to a word, no state
+	 * (see struct xe_fwm_dev); rounded up to a whole number of 16 bytes */
+	w.dev.kw7 = (w.dev.kwords > 1) ? (uint32_t)((pos + 6) / 7) : 0;
+	w.dev.swords = (w.dev.kwords > 1) ? ((w.dev.kw7 + 1) & ~1u) : 2;
 	tmp = (struct fwm_host *)realloc(h->fwms, (h->nfwm + 1) * sizeof(*tmp));
 	if (!tmp) return XE_ENOMEM;
 	h->fwms = tmp;
@@ -1600,15 +1602,26 @@ fwm_rows(xe_gpu *h, struct fwm_host *w, uint8_t **keys, uint64_t **vals)
 		rc = hip_fail(h, hipGetLastError(), "hipMemcpy(fixed-window table)");
 		goto out;
 	}
-	for (size_t i = 0; i < w->slots + 1; i++) if ((uint32_t)sl[i * w->dev.swords] == 2) n++;
+	for (size_t i = 0; i < w->slots + 1; i++) {
+		const uint64_t s0 = sl[i * w->dev.swords];
+		if (w->dev.kw7 ? (s0 != 0) : ((uint32_t)s0 == 2)) n++;
+	}
 	*keys = (uint8_t *)malloc((n ? n : 1) * (size_t)(w->keybytes ? w->keybytes : 1));
 	*vals = (uint64_t *)malloc((n ? n : 1) * nv * 8);
 	if (!*keys || !*vals) goto out;
 	for (size_t i = 0; i < w->slots + 1; i++) {
 		uint64_t *S = sl + i * w->dev.swords;
-		if ((uint32_t)S[0] != 2) continue;
-		if (w->dev.kwords == 1) S[1] ^= XE_FWM_KEY_XOR;
-		fwm_ref_key(h, w, (const uint8_t *)(S + 1), *keys + k * w->keybytes);
+		if (w->dev.kw7) {
+			/* seven key bytes in every word, lowest first */
+			uint8_t kb[XE_FWM_MAX_KWORDS * 8 + 8];
+			if (S[0] == 0) continue;
+			for (uint32_t j = 0; j < w->dev.kw7; j++) memcpy(kb + 7 * j, &S[j], 7);
+			fwm_ref_key(h, w, kb, *keys + k * w->keybytes);
+		} else {
+			if ((uint32_t)S[0] != 2) continue;
+			S[1] ^= XE_FWM_KEY_XOR;
+			fwm_ref_key(h, w, (const uint8_t *)(S + 1), *keys + k * w->keybytes);
+		}
 		memcpy(*vals + k * w->dev.nval, vl + i * nv, (size_t)w->dev.nval * 8);
 		k++;
 	}

@@ -142,21 +142,27 @@ int xe_launch_batch(const struct xe_kparams *kp, void *stream, void **events);
 
 /* Fixed-window table of one object on the device (the per-record part of
  * monit_object_process_nf(), monit-objects.c:927-1023): an open-addressing
- * hash table of `cap_mask + 1` slots.  slots[i] = `swords` 64-bit words: state
- * (0 free, 1 being written, 2 ready) and kwords words of key (the key fields'
- * bytes as struct flow_info holds them, one after the other, zero padded to
- * whole words) - written once, then only read; vals[i][nval] = the sums
- * (wrapping: value * scale * sampling rate), kept apart so that the atomic
- * adds to a popular row do not fight with the readers of its key. */
+ * hash table of `cap_mask + 1` slots of `swords` 64-bit words.  A key is the
+ * key fields' bytes as struct flow_info holds them, one after the other, zero
+ * padded to `kwords` whole words.  A key of one word: slots[i] = a state word
+ * (2 = taken; for the host) and the key ^ XE_FWM_KEY_XOR.  Longer keys:
+ * slots[i] = `kw7` words of seven key bytes each under XE_FWM_WORD_MARK, 0 =
+ * not claimed yet.  Either way a word is written once in a window and then
+ * only read.  vals[i][nval] = the sums (wrapping: value * scale * sampling
+ * rate), kept apart so that the atomic adds to a popular row do not fight with
+ * the readers of its key. */
 #define XE_FWM_MAX_KEY_FIELDS 8
 #define XE_FWM_MAX_VALS 4
 #define XE_FWM_MAX_KWORDS 8
 /* tables whose key is one word keep it as key ^ XE_FWM_KEY_XOR, 0 = free slot */
 #define XE_FWM_KEY_XOR 0x9E3779B97F4A7C15ull
+/* longer keys: seven key bytes to a word, this byte on top (so no word of a key is 0) */
+#define XE_FWM_WORD_MARK 0x8000000000000000ull
 struct xe_fwm_dev
 {
 	uint32_t mo, nkey, nval, kwords;
 	uint32_t cap_mask, swords;
+	uint32_t kw7, pad;                /* keys of several words: words of the seven-bytes-a-word form */
 	unsigned long long *slots;
 	unsigned long long *vals;
 	unsigned long long *dropped;      /* records whose key found no free slot */

@@ -2988,24 +2988,17 @@ xe_sf_kernel(const xe_kparams kp)
 /* the row of one key in the table in HBM, claimed when the key is new;
  * XE_FWM_NOROW when the table is full.
  *
- * A slot's state goes 0 (free) -> 1 (its key is being written) -> 2 (key
- * valid) once per window, and its key words are written once, between the two
- * steps, by the thread that won the slot; that thread publishes them with a
- * release store of the state.  Readers load the state and then the key words
- * with agent-scope atomic loads.  Such loads are answered at the point where
- * all CUs of the device agree, never by a cache on the way that may hold the
- * line as it was before the key was written (a plain load may be: the L1 of a
- * CU is not kept coherent), and the key loads are issued only after the state
- * load has returned 2: after the state store had arrived there, and with it
- * the key stores the release put in front of it.  An acquire load of the state
- * gives the same order but invalidates the CU's whole L1 at every probe step of
- * every wave: measured on MI355X, 2.1 M records into a filled table of 177 000
- * keys 0.449 ms with acquire loads, 0.279 ms this way; 1.47 M two-address keys
- * 0.932 against 0.257 ms.
+ * Key words are claimed with compare-and-swap and read with agent-scope
+ * atomic loads.  Such loads are answered at the point where all CUs of the
+ * device agree, never by a cache on the way that may hold the line as it was
+ * before the word was written (a plain load may be: the L1 of a CU is not kept
+ * coherent).  No word ever changes once it is set, so a probe needs no order
+ * between its loads and waits for nobody.
  *
- * State and key in one array, the sums in another: with the sums inside the
- * slot (one line per record instead of two) the adds to a line hold up the
- * probes of the same line - 0.820 and 0.542 ms for the two cases above. */
+ * Keys in one array, the sums in another: with the sums inside the slot (one
+ * line per record instead of two) the adds to a line hold up the probes of
+ * the same line (measured on MI355X, 2.1 M records into a filled table of
+ * 177 000 keys: 0.542 ms against 0.279 ms). */
 #define XE_FWM_NOROW 0xFFFFFFFFu
 template <int MKW>
 __device__ __forceinline__ uint32_t
@@ -3047,57 +3040,58 @@ fwm_global_find(const xe_fwm_dev &F, bool want, const uint64_t (&kw)[MKW], uint6
 		}
 		return slot;
 	}
+	/* A key of several words lies in its slot seven bytes to a word under a
+	 * marker byte, so that no word of a key is 0, and every word is claimed by
+	 * itself, first come first served: a word that reads 0 is set with a
+	 * compare-and-swap, and whatever it holds from then on it holds for the rest
+	 * of the window.  A slot whose words all equal the key's is the key's row; a
+	 * word that differs sends the key to the next slot - for good, so all
+	 * threads with this key pass the slot the same way, and the key gets one row.
+	 * (Two keys that share their first words may both write words of one slot;
+	 * the slot ends up as the key of whoever set the first word they differ in.)
+	 * Nobody waits for anybody, nothing is ordered: one round of loads per probe
+	 * step where a state word ahead of the key cost two and a release per insert. */
 	uint32_t row = XE_FWM_NOROW;
-	/* One probe step per lane and turn, and the lanes of the wave take their turns
-	 * together (the ballot is where they meet): a lane that finds a slot in state 1
-	 * just looks again next turn.  The thread that is writing that key may be a
-	 * lane of the same wave, which gets to finish only if the waiting lane does not
-	 * spin in a loop of its own. */
-	for (;;) {
-		if (!done) {
+	if constexpr (MKW > 1) {
+		constexpr int MK7 = (MKW * 8 + 6) / 7;
+		uint64_t e[MK7];
+#pragma unroll
+		for (int j = 0; j < MK7; j++) {
+			const int bit = 56 * j, w = bit >> 6, sh = bit & 63;
+			uint64_t x = (w < MKW) ? kw[w] >> sh : 0;
+			if ((sh > 8) && (w + 1 < MKW)) x |= kw[w + 1] << (64 - sh);
+			e[j] = (x & 0x00FFFFFFFFFFFFFFull) | XE_FWM_WORD_MARK;
+		}
+		while (!done) {
 			unsigned long long *S = F.slots + (size_t)slot * F.swords;
-			const uint32_t st = __hip_atomic_load((uint32_t *)S, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			bool mine = false;
-			if (st == 0) mine = atomicCAS((uint32_t *)S, 0u, 1u) == 0u;
-			if (mine) {
+			unsigned long long cur[MK7];
 #pragma unroll
-				for (int i = 0; i < MKW; i++) {
-					if ((uint32_t)i < F.kwords) __hip_atomic_store(&S[1 + i], (unsigned long long)kw[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				}
-				__hip_atomic_store((uint32_t *)S, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+			for (int j = 0; j < MK7; j++) {
+				cur[j] = ((uint32_t)j < F.kw7) ? __hip_atomic_load(&S[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : e[j];
 			}
-			/* (a slot lost to another thread, or one in state 1: whatever state it
-			 * is in next turn, it is looked at again) */
-			bool eq = mine;
-			if (st == 2) {
-				eq = true;
-				/* the key words are read after the state said "ready": the loads are
-				 * relaxed (an acquire load would invalidate the CU's whole L1 at every
-				 * probe step) and return in issue order on this part; this fence costs
-				 * no instruction and keeps the compiler from moving them above the
-				 * state load, which the memory model alone would let it do */
-				__atomic_signal_fence(__ATOMIC_ACQUIRE);
+			bool eq = true;
 #pragma unroll
-				for (int i = 0; i < MKW; i++) {
-					if ((uint32_t)i < F.kwords) {
-						eq = eq && (__hip_atomic_load(&S[1 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kw[i]);
-					}
+			for (int j = 0; j < MK7; j++) {
+				if (!eq || ((uint32_t)j >= F.kw7)) continue;
+				unsigned long long c = cur[j];
+				if (c == 0) {
+					c = atomicCAS(&S[j], 0ull, (unsigned long long)e[j]);
+					if (c == 0) c = e[j];
 				}
-				if (!eq) {
-					slot = (slot + 1) & F.cap_mask;
-					if (++tried > F.cap_mask) {
-						/* full: the records behind this key are lost, and counted */
-						atomicAdd(F.dropped, (unsigned long long)nrecords);
-						done = true;
-					}
-				}
+				eq = c == e[j];
 			}
 			if (eq) {
 				row = slot;
 				done = true;
+			} else {
+				slot = (slot + 1) & F.cap_mask;
+				if (++tried > F.cap_mask) {
+					/* full: the records behind this key are lost, and counted */
+					atomicAdd(F.dropped, (unsigned long long)nrecords);
+					done = true;
+				}
 			}
 		}
-		if (!__ballot(!done)) break;
 	}
 	return row;
 }
