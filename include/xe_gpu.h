@@ -353,6 +353,24 @@ int xe_gpu_batch_record_datagram(xe_batch *b, uint32_t *dgram, size_t n);
  * records [first, first+count) from the structure-of-arrays output:
  * out[count][XE_FLOW_INFO_SIZE]; payload_ptr is NULL */
 int xe_gpu_batch_flow_info(xe_batch *b, size_t first, size_t count, void *out);
+/* The same, record after record into ONE buffer of XE_FLOW_INFO_SIZE bytes: for
+ * a consumer that looks at a record and is done with it, as the reference's
+ * exit call is (monit_object_process_nf(), monit-objects.c:923-1033, gets a
+ * pointer to the one struct flow_info netflow.c:273-275 keeps on its stack).
+ * xe_gpu_batch_flow_cursor() waits for the batch, brings ALL its outputs to the
+ * host in one copy (page-locked memory the handle keeps and reuses) and clears
+ * `flow`; xe_gpu_flow_cursor_seek() makes `flow` record r - r must not be below
+ * the record of the call before - by taking back the fields the last record
+ * set and setting r's, so records nobody wants cost nothing and no record costs
+ * a 2312-byte clear.  The caller must not write to `flow` in between.  While a
+ * cursor is open the batch's other read-outs (masks, dropped, columns ...) are
+ * served from the same host copy.  One open cursor per handle:
+ * XE_ESTATE otherwise. */
+typedef struct xe_flowcur xe_flowcur;
+int xe_gpu_batch_flow_cursor(xe_batch *b, void *flow, xe_flowcur **out);
+int xe_gpu_flow_cursor_seek(xe_flowcur *cur, size_t r);
+void xe_gpu_flow_cursor_free(xe_flowcur *cur);
+
 /* one decoded column as the device wrote it: width bytes per record (the
  * field's maximum size; 6-byte MACs are stored in 8).  field = index in the
  * field table (xe_field_*).  Returns XE_EINVAL when no template of the batch

@@ -28,7 +28,6 @@ extern int monit_object_process_nf(struct xe_data *globl, struct monit_object *m
 	uint64_t time_ns, struct flow_info *flow) __attribute__((weak));
 extern int filter_match(struct filter_expr *expr, struct flow_info *flow) __attribute__((weak));
 
-#define SHIM_CHUNK 2048      /* records whose flow_info is re-created at a time */
 
 struct shim_thread
 {
@@ -58,7 +57,7 @@ struct shim_thread
 	uint8_t *status;
 	uint32_t *dgram;
 	size_t rec_cap, mask_cap;
-	uint8_t *flows;              /* SHIM_CHUNK x XE_FLOW_INFO_SIZE */
+	uint8_t *flows;              /* the one struct flow_info the exit calls are handed: XE_FLOW_INFO_SIZE bytes */
 	uint64_t stats[5];
 	char err[320];
 };
@@ -268,7 +267,7 @@ xenoeye_gpu_shim_init(const struct xe_shim_config *cfg)
 		T->src = calloc(nd, sizeof(uint32_t));
 		T->kind = calloc(nd, 1);
 		T->time_ns = calloc(nd, sizeof(uint64_t));
-		T->flows = malloc((size_t)SHIM_CHUNK * XE_FLOW_INFO_SIZE);
+		T->flows = aligned_alloc(64, (XE_FLOW_INFO_SIZE + 63) & ~(size_t)63);
 		if (!T->data || !T->off || !T->src || !T->kind || !T->time_ns || !T->flows) goto fail;
 		if (S.cfg.overlap) {
 			T->pend_data = xe_gpu_host_alloc(T->h, T->cap + 64);
@@ -314,7 +313,8 @@ static int
 deliver(struct xe_data *globl, size_t thread_id, struct shim_thread *T, xe_batch *b, size_t nrec, const uint64_t *time_ns)
 {
 	const size_t w = S.mask_words;
-	size_t c0;
+	xe_flowcur *cur = NULL;
+	size_t r;
 	int rc;
 
 	if (nrec > T->rec_cap) {
@@ -326,50 +326,42 @@ deliver(struct xe_data *globl, size_t thread_id, struct shim_thread *T, xe_batch
 		T->rec_cap = (T->masks && T->status && T->dgram) ? cap : 0;
 		if (!T->rec_cap) return XE_ENOMEM;
 	}
-	if ((rc = xe_gpu_batch_masks(b, T->masks, nrec * w)) != XE_OK) return rc;   /* waits for the kernels */
-	if ((rc = xe_gpu_batch_dropped(b, T->status, nrec)) != XE_OK) return rc;
-	if ((rc = xe_gpu_batch_record_datagram(b, T->dgram, nrec)) != XE_OK) return rc;
+	/* all outputs of the batch in one copy; the reads below come out of it */
+	if ((rc = xe_gpu_batch_flow_cursor(b, T->flows, &cur)) != XE_OK) return rc;   /* waits for the kernels */
+	if ((rc = xe_gpu_batch_masks(b, T->masks, nrec * w)) != XE_OK) goto out;
+	if ((rc = xe_gpu_batch_dropped(b, T->status, nrec)) != XE_OK) goto out;
+	if ((rc = xe_gpu_batch_record_datagram(b, T->dgram, nrec)) != XE_OK) goto out;
 
-	for (c0 = 0; c0 < nrec; c0 += SHIM_CHUNK) {
-		const size_t c1 = (c0 + SHIM_CHUNK < nrec) ? c0 + SHIM_CHUNK : nrec;
-		size_t first = c1, last = c0, r, k;
+	for (r = 0; r < nrec; r++) {
+		struct flow_info *flow = (struct flow_info *)T->flows;
+		const uint64_t *mk = &T->masks[r * w];
+		uint64_t any = 0;
+		size_t k, m;
 
-		/* the records of this chunk that some object receives */
-		for (r = c0; r < c1; r++) {
-			uint64_t any = 0;
-			if (T->status[r]) continue;    /* dropped by device rules / sample never classified */
-			for (k = 0; k < w; k++) any |= T->masks[r * w + k];
-			if (!any) continue;
-			if (first == c1) first = r;
-			last = r;
-		}
-		if (first == c1) continue;
-		if ((rc = xe_gpu_batch_flow_info(b, first, last - first + 1, T->flows)) != XE_OK) return rc;
-		for (r = first; r <= last; r++) {
-			struct flow_info *flow = (struct flow_info *)(T->flows + (r - first) * XE_FLOW_INFO_SIZE);
-			const uint64_t *mk = &T->masks[r * w];
-			const uint64_t tns = time_ns[T->dgram[r]];
-			size_t m;
-
-			if (T->status[r]) continue;
-			for (m = 0; m < S.nmo; m++) {
-				if (!((mk[m >> 6] >> (m & 63)) & 1)) {
-					/* whole words without a bit are common: skip them */
-					if (!(m & 63) && !mk[m >> 6]) m += 63;
-					continue;
-				}
-				if (S.host_only[m] && !S.filter_match(S.expr[m], flow)) {
-					/* the object does not receive the record, and the objects
-					 * below it are not even looked at (netflow.c:223-243) */
-					m = S.subtree_end[m] - 1;
-					continue;
-				}
-				S.process_nf(globl, S.mo[m], thread_id, tns, flow);
-				T->stats[3]++;
+		if (T->status[r]) continue;    /* dropped by device rules / sample never classified */
+		for (k = 0; k < w; k++) any |= mk[k];
+		if (!any) continue;            /* no object receives it */
+		/* the one struct flow_info becomes record r, as netflow.c:273-275 keeps one per record */
+		if ((rc = xe_gpu_flow_cursor_seek(cur, r)) != XE_OK) goto out;
+		for (m = 0; m < S.nmo; m++) {
+			if (!((mk[m >> 6] >> (m & 63)) & 1)) {
+				/* whole words without a bit are common: skip them */
+				if (!(m & 63) && !mk[m >> 6]) m += 63;
+				continue;
 			}
+			if (S.host_only[m] && !S.filter_match(S.expr[m], flow)) {
+				/* the object does not receive the record, and the objects
+				 * below it are not even looked at (netflow.c:223-243) */
+				m = S.subtree_end[m] - 1;
+				continue;
+			}
+			S.process_nf(globl, S.mo[m], thread_id, time_ns[T->dgram[r]], flow);
+			T->stats[3]++;
 		}
 	}
-	return XE_OK;
+out:
+	xe_gpu_flow_cursor_free(cur);
+	return rc;
 }
 
 static void

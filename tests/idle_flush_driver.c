@@ -70,13 +70,20 @@ xe_gpu_batch_record_datagram(xe_batch *b, uint32_t *dgram, size_t n)
 	return XE_OK;
 }
 
+struct xe_flowcur { int unused; };
+static struct xe_flowcur the_cursor;
+
 int
-xe_gpu_batch_flow_info(xe_batch *b, size_t first, size_t count, void *out)
+xe_gpu_batch_flow_cursor(xe_batch *b, void *flow, xe_flowcur **out)
 {
-	(void)b; (void)first;
-	memset(out, 0, count * XE_FLOW_INFO_SIZE);
+	(void)b;
+	memset(flow, 0, XE_FLOW_INFO_SIZE);
+	*out = &the_cursor;
 	return XE_OK;
 }
+
+int xe_gpu_flow_cursor_seek(xe_flowcur *cur, size_t r) { (void)cur; (void)r; return XE_OK; }
+void xe_gpu_flow_cursor_free(xe_flowcur *cur) { (void)cur; }
 
 /* ---- the consumer and the capture loop */
 static pthread_t capture_tid;

@@ -105,6 +105,9 @@ def load_library(path=LIB_PATH):
         "xe_gpu_batch_counters": (i32, [vp, vp, sz]),
         "xe_gpu_batch_dropped": (i32, [vp, vp, sz]),
         "xe_gpu_batch_flow_info": (i32, [vp, sz, sz, vp]),
+        "xe_gpu_batch_flow_cursor": (i32, [vp, vp, C.POINTER(vp)]),
+        "xe_gpu_flow_cursor_seek": (i32, [vp, sz]),
+        "xe_gpu_flow_cursor_free": (None, [vp]),
         "xe_gpu_batch_column": (i32, [vp, i32, vp, sz, C.POINTER(sz)]),
         "xe_gpu_batch_device_ptrs": (i32, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "xe_field_count": (i32, []),
@@ -555,6 +558,22 @@ class PreparedBatch:
         out = np.zeros((count, FLOW_INFO_SIZE), dtype=np.uint8)
         if count:
             self.eng._chk(self.L.xe_gpu_batch_flow_info(self._b, first, count, out.ctypes.data))
+        return out
+
+    def flow_records(self, records):
+        """struct flow_info of the records named (rising indices), made one after the other in one
+        buffer through xe_gpu_batch_flow_cursor / xe_gpu_flow_cursor_seek; returns (len(records), FLOW_INFO_SIZE) bytes"""
+        buf = np.zeros(FLOW_INFO_SIZE, dtype=np.uint8)
+        buf[:] = 0xA5                              # the cursor clears it
+        out = np.zeros((len(records), FLOW_INFO_SIZE), dtype=np.uint8)
+        cur = C.c_void_p()
+        self.eng._chk(self.L.xe_gpu_batch_flow_cursor(self._b, buf.ctypes.data, C.byref(cur)))
+        try:
+            for i, r in enumerate(records):
+                self.eng._chk(self.L.xe_gpu_flow_cursor_seek(cur, int(r)))
+                out[i] = buf
+        finally:
+            self.L.xe_gpu_flow_cursor_free(cur)
         return out
 
     def device_walked(self):

@@ -47,6 +47,9 @@ struct xe_gpu
 	 * waits for the whole device, which serialises handles that share a GPU */
 	struct { void *p; size_t cap; int busy; } dpool[XE_DPOOL];
 	void *stage;               /* page-locked scratch the run list is built in (copies at link speed) */
+	uint8_t *mirror;           /* page-locked copy of all outputs of the batch a flow cursor reads ... */
+	size_t mirror_bytes;
+	struct xe_batch *mirror_owner;   /* ... that batch, NULL while no cursor is open */
 	size_t stage_cap;
 	struct fwm_host *fwms; size_t nfwm;
 	void *d_fwmdesc;
@@ -318,6 +321,7 @@ xe_gpu_destroy(xe_gpu *h)
 	if (h->walk_stream) (void)hipStreamDestroy(h->walk_stream);
 	for (int i = 0; i < XE_DPOOL; i++) if (h->dpool[i].p) (void)hipFree(h->dpool[i].p);
 	if (h->stage) (void)hipHostFree(h->stage);
+	if (h->mirror) (void)hipHostFree(h->mirror);
 	pinned_free(h->wstage);
 	pinned_free(h->pin);
 	if (h->d_devkeys) (void)hipFree(h->d_devkeys);
@@ -2952,6 +2956,7 @@ xe_gpu_batch_free(xe_batch *b)
 {
 	if (!b) return;
 	(void)hipSetDevice(b->h->device);
+	if (b->h->mirror_owner == b) b->h->mirror_owner = NULL;   /* (a cursor left open: its copy is no longer read) */
 	if (b->ran && b->ev_ran) (void)hipEventSynchronize(b->ev_ran);
 	else if (b->ran) (void)hipStreamSynchronize(b->last_stream);
 	if (b->ev_ran) (void)hipEventDestroy(b->ev_ran);
@@ -3895,6 +3900,11 @@ fetch(xe_batch *b, void *dst, size_t off, size_t bytes)
 	int rc = xe_gpu_batch_sync(b);
 	if (rc != XE_OK) return rc;
 	if (!bytes) return XE_OK;
+	if (b->h->mirror_owner == b) {
+		/* a cursor holds a copy of all the batch's outputs on the host */
+		memcpy(dst, b->h->mirror + off, bytes);
+		return XE_OK;
+	}
 	/* on the handle's own stream: the default stream would order this copy
 	 * against every other handle's work on the device */
 	HIPCHK(b->h, hipMemcpyAsync(dst, (uint8_t *)b->d_out + off, bytes, hipMemcpyDeviceToHost, b->h->copy_stream));
@@ -4039,6 +4049,14 @@ slice_free(struct slice *s)
 	for (int f = 0; f < XE_NFIELDS; f++) { free(s->col[f]); free(s->vsize[f]); }
 }
 
+/* fields a record set, for a caller that wants to take them back (NULL: nobody does) */
+struct flow_dirty
+{
+	uint16_t n;
+	uint8_t f[XE_NFIELDS + 8];
+};
+static thread_local struct flow_dirty *g_dirty;
+
 static void
 put_field(uint8_t *fi, int f, const uint8_t *bytes, int size)
 {
@@ -4046,6 +4064,7 @@ put_field(uint8_t *fi, int f, const uint8_t *bytes, int size)
 	memcpy(fi + xe_fields[f].off, bytes, xe_fields[f].size_max);
 	memcpy(fi + xe_fields[f].off_size, &size, 4);
 	memcpy(fi + xe_fields[f].off_has, &one, 4);
+	if (g_dirty && (g_dirty->n < sizeof(g_dirty->f))) g_dirty->f[g_dirty->n++] = (uint8_t)f;
 }
 
 /* sizes the sFlow decoder reports for its fields (sflow.c:35-77, sflow-impl.h) */
@@ -4125,16 +4144,115 @@ out:
 	return rc;
 }
 
+/* what the re-creation of records needs of a batch: the output columns of the
+ * records [base, ...) (copies of a range, or pointers into a copy of all the
+ * outputs), and where the walk over sets and datagrams stands */
+struct flow_ctx
+{
+	struct slice s;
+	size_t base;             /* record of element 0 of nparsed / marks / col / vsize */
+	size_t sfhas_origin;     /* record of element 0 of sfhas */
+	struct xe_sfrec *sf_slice;   /* element descriptors that exist on the device only */
+	size_t sf_slice_first;
+	size_t si, di;           /* set and datagram of the last record built (records are asked for in rising order) */
+};
+
+/* struct flow_info of record r into fi (zeroed, or holding nothing but zeros where this record sets nothing) */
+static void
+flow_build(xe_batch *b, struct flow_ctx *c, size_t r, uint8_t *fi)
+{
+	xe_gpu *h = b->h;
+	const struct xe_set *sets = (const struct xe_set *)b->plan.sets.p;
+	const struct xe_tmpl *tm = (const struct xe_tmpl *)h->hs.dev_tmpls.p;
+	const struct xe_tent *te = (const struct xe_tent *)h->hs.dev_tents.p;
+	const struct xe_exporter *ex = (const struct xe_exporter *)b->plan.exporters.p;
+	const struct xe_sfrec *sf = (const struct xe_sfrec *)b->plan.sfrecs.p;
+	const size_t k = r - c->base;
+	const struct xe_exporter *e;
+	uint32_t rate;
+
+	if (r < b->plan.nrec) {
+		const struct xe_tmpl *t;
+		const struct xe_tent *en;
+		uint32_t np = c->s.nparsed[k];
+		struct xe_exporter from_dev;
+		int on_dev = 0;
+
+		if (b->w.mode & 2) {
+			while (r >= b->w.h_recbase[c->di + 1]) c->di++;
+			on_dev = b->w.h_walked[c->di];
+		}
+		if (on_dev) {
+			/* a datagram the device listed: template, source id and sampling
+			 * rate are in its run, the exporter address came with the datagram */
+			const struct xe_dgrun *g = &b->w.h_dgruns[c->di];
+			size_t within = r - b->w.h_recbase[c->di];
+			for (uint32_t q = 0; (q + 1 < b->w.nsets) && (within >= g->nrec); q++) {
+				within -= g->nrec;
+				g += b->w.n;
+			}
+			const uint32_t idb = htonl(g->dev_id);
+			t = &tm[g->tmpl & 0xFFFFu];
+			memcpy(from_dev.dev_ip, &b->w.h_src[c->di], 4);
+			memcpy(from_dev.dev_id, &idb, 4);
+			from_dev.sampling_rate = g->rate & 0x7FFFFFFFu;
+			from_dev.device = -1;
+			e = &from_dev;
+		} else {
+			while (r >= (size_t)sets[c->si].first_rec + sets[c->si].nrec) c->si++;
+			t = &tm[sets[c->si].tmpl];
+			e = &ex[sets[c->si].exporter];
+		}
+		en = &te[t->ent_base];
+		if (np > t->nfields) np = t->nfields;   /* never trust a count beyond the template */
+		for (uint32_t j = 0; j < np; j++) {
+			int f = en[j].field;
+			if ((f == XE_F_NONE) || !c->s.col[f]) continue;
+			if (c->s.vsize[f]) {
+				uint16_t vs = c->s.vsize[f][k];
+				if (vs == 0xFFFF) continue;
+				put_field(fi, f, c->s.col[f] + k * xe_fields[f].col_width, vs);
+			} else {
+				if (!(en[j].flags & XE_TE_VALID)) continue;
+				put_field(fi, f, c->s.col[f] + k * xe_fields[f].col_width, en[j].len);
+			}
+		}
+		/* virtual_fields_init(), netflow.c:112-124 */
+		put_field(fi, XF_dev_ip, e->dev_ip, 4);
+		put_field(fi, XF_dev_id, e->dev_id, 4);
+		rate = e->sampling_rate;
+	} else {
+		const struct xe_sfrec *q = c->sf_slice ? &c->sf_slice[r - b->plan.nrec - c->sf_slice_first] : &sf[r - b->plan.nrec];
+		uint32_t hb = c->s.sfhas[r - c->sfhas_origin];
+		static const int order[] = { XF_in_bytes, XF_in_pkts, XF_protocol, XF_src_tos, XF_dst_tos,
+			XF_tcp_flags, XF_l4_src_port, XF_ip4_src_addr, XF_input_snmp, XF_l4_dst_port,
+			XF_ip4_dst_addr, XF_output_snmp, XF_ip6_src_addr, XF_ip6_dst_addr, XF_icmp_type,
+			XF_min_ttl, XF_max_ttl, XF_src_mac, XF_dst_mac, XF_src_vlan, XF_dst_vlan,
+			XF_src_dot1q_cvlan, XF_dst_dot1q_cvlan };
+		for (size_t i = 0; i < sizeof(order) / sizeof(order[0]); i++) {
+			int f = order[i];
+			if (!((hb >> i) & 1)) continue;
+			put_field(fi, f, c->s.col[f] + k * xe_fields[f].col_width, sf_field_size(f));
+		}
+		/* sflow_reset(), sflow-impl.h:274-291 */
+		put_field(fi, XF_dev_id, q->dev_id, 4);
+		if (q->agent_ver == 4) put_field(fi, XF_dev_ip, q->agent, 4);
+		else put_field(fi, XF_dev_ip6, q->agent, 16);
+		rate = q->sampling_rate;
+	}
+	if (c->s.marks && (c->s.marks[k] & XE_MARK_HAS)) {
+		uint32_t mk = htonl(c->s.marks[k] & 0x3FFFFFFFu);
+		put_field(fi, XF_dev_mark, (const uint8_t *)&mk, 4);
+	}
+	memcpy(fi + XE_OFF_SAMPLING_RATE, &rate, 4);
+}
+
 extern "C" int
 xe_gpu_batch_flow_info(xe_batch *b, size_t first, size_t count, void *out)
 {
 	struct slice s;
-	xe_gpu *h;
+	struct flow_ctx c;
 	const struct xe_set *sets;
-	const struct xe_tmpl *tm;
-	const struct xe_tent *te;
-	const struct xe_exporter *ex;
-	const struct xe_sfrec *sf;
 	struct xe_sfrec *sf_slice = NULL;   /* element descriptors that exist on the device only */
 	size_t sf_slice_first = 0;
 	int rc = XE_OK;
@@ -4142,7 +4260,6 @@ xe_gpu_batch_flow_info(xe_batch *b, size_t first, size_t count, void *out)
 
 	if (!b || !out || (first + count > b->ntot)) return XE_EINVAL;
 	if (!count) return XE_OK;
-	h = b->h;
 	memset(&s, 0, sizeof(s));
 	memset(out, 0, count * XE_FLOW_INFO_SIZE);
 
@@ -4189,11 +4306,6 @@ xe_gpu_batch_flow_info(xe_batch *b, size_t first, size_t count, void *out)
 	}
 
 	sets = (const struct xe_set *)b->plan.sets.p;
-	tm = (const struct xe_tmpl *)h->hs.dev_tmpls.p;
-	te = (const struct xe_tent *)h->hs.dev_tents.p;
-	ex = (const struct xe_exporter *)b->plan.exporters.p;
-	sf = (const struct xe_sfrec *)b->plan.sfrecs.p;
-
 	if ((first < b->plan.nrec) && b->plan.sets.n) {
 		size_t lo = 0, hi = b->plan.sets.n - 1;
 		while (lo < hi) {
@@ -4202,92 +4314,125 @@ xe_gpu_batch_flow_info(xe_batch *b, size_t first, size_t count, void *out)
 		}
 		si = lo;
 	}
-	for (size_t k = 0; k < count; k++) {
-		size_t r = first + k;
-		uint8_t *fi = (uint8_t *)out + k * XE_FLOW_INFO_SIZE;
-		const struct xe_exporter *e;
-		uint32_t rate;
-
-		if (r < b->plan.nrec) {
-			const struct xe_tmpl *t;
-			const struct xe_tent *en;
-			uint32_t np = s.nparsed[k];
-			struct xe_exporter from_dev;
-			int on_dev = 0;
-
-			if (b->w.mode & 2) {
-				while (r >= b->w.h_recbase[di + 1]) di++;
-				on_dev = b->w.h_walked[di];
-			}
-			if (on_dev) {
-				/* a datagram the device listed: template, source id and sampling
-				 * rate are in its run, the exporter address came with the datagram */
-				const struct xe_dgrun *g = &b->w.h_dgruns[di];
-				size_t within = r - b->w.h_recbase[di];
-				for (uint32_t q = 0; (q + 1 < b->w.nsets) && (within >= g->nrec); q++) {
-					within -= g->nrec;
-					g += b->w.n;
-				}
-				const uint32_t idb = htonl(g->dev_id);
-				t = &tm[g->tmpl & 0xFFFFu];
-				memcpy(from_dev.dev_ip, &b->w.h_src[di], 4);
-				memcpy(from_dev.dev_id, &idb, 4);
-				from_dev.sampling_rate = g->rate & 0x7FFFFFFFu;
-				from_dev.device = -1;
-				e = &from_dev;
-			} else {
-				while (r >= (size_t)sets[si].first_rec + sets[si].nrec) si++;
-				t = &tm[sets[si].tmpl];
-				e = &ex[sets[si].exporter];
-			}
-			en = &te[t->ent_base];
-			if (np > t->nfields) np = t->nfields;   /* never trust a count beyond the template */
-			for (uint32_t j = 0; j < np; j++) {
-				int f = en[j].field;
-				if ((f == XE_F_NONE) || !s.col[f]) continue;
-				if (s.vsize[f]) {
-					uint16_t vs = s.vsize[f][k];
-					if (vs == 0xFFFF) continue;
-					put_field(fi, f, s.col[f] + k * xe_fields[f].col_width, vs);
-				} else {
-					if (!(en[j].flags & XE_TE_VALID)) continue;
-					put_field(fi, f, s.col[f] + k * xe_fields[f].col_width, en[j].len);
-				}
-			}
-			/* virtual_fields_init(), netflow.c:112-124 */
-			put_field(fi, XF_dev_ip, e->dev_ip, 4);
-			put_field(fi, XF_dev_id, e->dev_id, 4);
-			rate = e->sampling_rate;
-		} else {
-			const struct xe_sfrec *q = sf_slice ? &sf_slice[r - b->plan.nrec - sf_slice_first] : &sf[r - b->plan.nrec];
-			uint32_t hb = s.sfhas[k];
-			static const int order[] = { XF_in_bytes, XF_in_pkts, XF_protocol, XF_src_tos, XF_dst_tos,
-				XF_tcp_flags, XF_l4_src_port, XF_ip4_src_addr, XF_input_snmp, XF_l4_dst_port,
-				XF_ip4_dst_addr, XF_output_snmp, XF_ip6_src_addr, XF_ip6_dst_addr, XF_icmp_type,
-				XF_min_ttl, XF_max_ttl, XF_src_mac, XF_dst_mac, XF_src_vlan, XF_dst_vlan,
-				XF_src_dot1q_cvlan, XF_dst_dot1q_cvlan };
-			for (size_t i = 0; i < sizeof(order) / sizeof(order[0]); i++) {
-				int f = order[i];
-				if (!((hb >> i) & 1)) continue;
-				put_field(fi, f, s.col[f] + k * xe_fields[f].col_width, sf_field_size(f));
-			}
-			/* sflow_reset(), sflow-impl.h:274-291 */
-			put_field(fi, XF_dev_id, q->dev_id, 4);
-			if (q->agent_ver == 4) put_field(fi, XF_dev_ip, q->agent, 4);
-			else put_field(fi, XF_dev_ip6, q->agent, 16);
-			rate = q->sampling_rate;
-		}
-		if (s.marks && (s.marks[k] & XE_MARK_HAS)) {
-			uint32_t mk = htonl(s.marks[k] & 0x3FFFFFFFu);
-			put_field(fi, XF_dev_mark, (const uint8_t *)&mk, 4);
-		}
-		memcpy(fi + XE_OFF_SAMPLING_RATE, &rate, 4);
-	}
+	c.s = s;
+	c.base = first;
+	c.sfhas_origin = first;
+	c.sf_slice = sf_slice;
+	c.sf_slice_first = sf_slice_first;
+	c.si = si;
+	c.di = di;
+	for (size_t k = 0; k < count; k++) flow_build(b, &c, first + k, (uint8_t *)out + k * XE_FLOW_INFO_SIZE);
 done:
 	slice_free(&s);
 	free(sf_slice);
 	return rc;
 #undef GRAB
+}
+
+/* The records of a batch one after the other into one caller buffer: all
+ * outputs of the batch come to the host in one copy (into page-locked memory
+ * the handle keeps), and a record takes back what the record before it set
+ * instead of clearing the 2312 bytes again. */
+struct xe_flowcur
+{
+	xe_batch *b;
+	uint8_t *flow;
+	struct flow_ctx c;
+	struct flow_dirty dirty;
+	size_t last;
+	int started;
+};
+
+extern "C" int
+xe_gpu_batch_flow_cursor(xe_batch *b, void *flow, xe_flowcur **out)
+{
+	xe_gpu *h;
+	struct xe_flowcur *cur;
+	int rc;
+
+	if (!b || !flow || !out) return XE_EINVAL;
+	*out = NULL;
+	h = b->h;
+	if (h->mirror_owner) {
+		snprintf(h->err, sizeof(h->err), "xe_gpu_batch_flow_cursor: the handle's other cursor is still open");
+		return XE_ESTATE;
+	}
+	if ((rc = xe_gpu_batch_sync(b)) != XE_OK) return rc;
+	HIPCHK(h, hipSetDevice(h->device));
+	if (h->mirror_bytes < b->out_bytes) {
+		if (h->mirror) (void)hipHostFree(h->mirror);
+		h->mirror = NULL;
+		h->mirror_bytes = 0;
+		const size_t want = b->out_bytes + b->out_bytes / 4 + 4096;
+		if (hipHostMalloc((void **)&h->mirror, want, hipHostMallocDefault) != hipSuccess) {
+			(void)hipGetLastError();
+			snprintf(h->err, sizeof(h->err), "hipHostMalloc(%zu) failed", want);
+			return XE_ENOMEM;
+		}
+		h->mirror_bytes = want;
+	}
+	if (b->out_bytes) {
+		HIPCHK(h, hipMemcpyAsync(h->mirror, b->d_out, b->out_bytes, hipMemcpyDeviceToHost, h->copy_stream));
+		HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+	}
+	cur = (struct xe_flowcur *)calloc(1, sizeof(*cur));
+	if (!cur) return XE_ENOMEM;
+	cur->b = b;
+	cur->flow = (uint8_t *)flow;
+	cur->c.s.nparsed = h->mirror + b->nparsed_off;
+	if (b->kp.marks) cur->c.s.marks = (uint32_t *)(h->mirror + b->marks_off);
+	for (int f = 0; f < XE_NTABLE_FIELDS; f++) {
+		if (b->kp.col_off[f] != ~0ull) cur->c.s.col[f] = h->mirror + b->kp.col_off[f];
+		if (b->kp.vsize_off[f] != ~0ull) cur->c.s.vsize[f] = (uint16_t *)(h->mirror + b->kp.vsize_off[f]);
+	}
+	h->mirror_owner = b;      /* from here on the batch's results are read from the copy */
+	if (b->plan.nsf) {
+		cur->c.s.sfhas = (uint32_t *)(h->mirror + b->sfhas_off);
+		cur->c.sfhas_origin = b->plan.nrec;
+		if (b->w.mode & 1) {
+			rc = sf_meta_fetch(b, 0, b->plan.nsf, &cur->c.sf_slice);
+			if (rc != XE_OK) { xe_gpu_flow_cursor_free(cur); return rc; }
+		}
+	}
+	if ((b->w.mode & 2) && b->plan.nrec) {
+		rc = walk_fetch(b, 5);
+		if (rc != XE_OK) { xe_gpu_flow_cursor_free(cur); return rc; }
+	}
+	memset(flow, 0, XE_FLOW_INFO_SIZE);
+	*out = cur;
+	return XE_OK;
+}
+
+extern "C" int
+xe_gpu_flow_cursor_seek(xe_flowcur *cur, size_t r)
+{
+	if (!cur || (r >= cur->b->ntot) || (cur->started && (r < cur->last))) return XE_EINVAL;
+	if (cur->dirty.n >= sizeof(cur->dirty.f)) {
+		memset(cur->flow, 0, XE_FLOW_INFO_SIZE);      /* more fields than the list holds */
+	} else {
+		for (uint32_t i = 0; i < cur->dirty.n; i++) {
+			const struct xe_field *fd = &xe_fields[cur->dirty.f[i]];
+			memset(cur->flow + fd->off, 0, fd->size_max);
+			memset(cur->flow + fd->off_size, 0, 4);
+			memset(cur->flow + fd->off_has, 0, 4);
+		}
+	}
+	cur->dirty.n = 0;
+	g_dirty = &cur->dirty;
+	flow_build(cur->b, &cur->c, r, cur->flow);
+	g_dirty = NULL;
+	cur->last = r;
+	cur->started = 1;
+	return XE_OK;
+}
+
+extern "C" void
+xe_gpu_flow_cursor_free(xe_flowcur *cur)
+{
+	if (!cur) return;
+	if (cur->b->h->mirror_owner == cur->b) cur->b->h->mirror_owner = NULL;
+	free(cur->c.sf_slice);
+	free(cur);
 }
 
 /* ------------------------------------------------------------------ list probe */
