@@ -58,6 +58,8 @@ def parse_args():
     ap.add_argument("--pipeline-rounds", type=int, default=20)
     ap.add_argument("--pipeline-walkers", type=int, default=0,
                     help="header-walking threads per capture thread of the pipelined measurement (0: 16 / threads)")
+    ap.add_argument("--shim-records", type=int, default=1 << 20,
+                    help="records of the workload sent through the drop-in library's entry points (0 = skip)")
     ap.add_argument("--fwm", type=int, default=1, help="also time the fixed-window table kernel (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus > 1 (gloo: rehearsal of the multi-rank path on one GPU)")
@@ -82,6 +84,7 @@ def parse_args():
         a.sustain_seconds = 0.0
         a.pipeline = 0
         a.fwm = 0
+        a.shim_records = 0
         a.overlap_leg = 0
     return a
 
@@ -539,6 +542,36 @@ def c5_sharded(torch, dist, args, rank, world, device, stream, dev):
     return out
 
 
+def shim_leg(w, records, passes=3):
+    """datagrams through the reference's entry points of the drop-in library (netflow_process /
+    sflow_process -> monit_object_process_nf) on one capture thread: tools/shimbench/shim_bench,
+    a program of its own, run while this process has not touched the GPU.  A bounded sample of
+    the workload: the first datagrams, about `records` records of them, `passes` times."""
+    import shutil
+    import subprocess
+    import tempfile
+    from xenoeye_amd import synth
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "shimbench", "shim_bench")
+    if not os.path.exists(exe):
+        return {"error": "tools/shimbench/shim_bench is not built (__graft_entry__.build())"}
+    if w.get("devices"):
+        return {"error": "the program loads no devices.conf"}
+    nd = len(w["batch"].pkts)
+    nd = max(1, min(nd, int(nd * min(1.0, records / max(1, w["nrec"])))))
+    d = tempfile.mkdtemp(prefix="xe_shimbench_")
+    try:
+        nd = synth.write_workload_dir(w, d, nd)
+        r = subprocess.run([exe, d, str(passes), "1"], capture_output=True, text=True, timeout=600)
+        if r.returncode != 0 or not r.stdout.strip():
+            return {"error": (r.stderr or "no output").strip()[-400:]}
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        out["unit"] = "records/s through netflow_process()/sflow_process() and the exit calls, one capture thread"
+        out["sample"] = "%d datagrams of the workload, %d passes after one warm-up pass" % (nd, passes)
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -576,6 +609,11 @@ def main():
                               "hash (%d had exporters), each its own oracle" % (n_all, wall, procs, busy)}
             except Exception as ex:
                 cpu["cpu_baseline_nproc"] = {"error": repr(ex)}
+    if rank == 0 and world == 1 and args.shim_records > 0:
+        try:
+            cpu["drop_in"] = shim_leg(w, args.shim_records)
+        except Exception as ex:
+            cpu["drop_in"] = {"error": repr(ex)}
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the flow path has no CPU fallback")

@@ -141,6 +141,11 @@ void xenoeye_gpu_shim_shutdown(void);
  * failed (their datagrams are lost, the reason is in xenoeye_gpu_shim_error) */
 void xenoeye_gpu_shim_stats(size_t thread_id, uint64_t out[5]);
 const char *xenoeye_gpu_shim_error(size_t thread_id);
+/* nanoseconds the thread has spent so far: preparing and starting batches
+ * (header walk, copy to the device), waiting for a batch and copying its
+ * results back, reading masks / status / datagram numbers out of that copy,
+ * and in the loop over the records (struct flow_info + the exit calls) */
+void xenoeye_gpu_shim_times(size_t thread_id, uint64_t out[4]);
 
 /* the reference's entry points */
 void netflow_process_init(void);

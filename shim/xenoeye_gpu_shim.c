@@ -57,6 +57,7 @@ struct shim_thread
 	uint8_t *status;
 	uint32_t *dgram;
 	size_t rec_cap, mask_cap;
+	uint64_t ns[4];              /* time spent: see xenoeye_gpu_shim_times() */
 	uint8_t *flows;              /* the one struct flow_info the exit calls are handed: XE_FLOW_INFO_SIZE bytes */
 	uint64_t stats[5];
 	char err[320];
@@ -97,6 +98,15 @@ mono_ns(void)
 {
 	struct timespec ts;
 	clock_gettime(CLOCK_MONOTONIC_COARSE, &ts);
+	return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+
+/* for the time accounting per batch (the coarse clock above is read per datagram) */
+static uint64_t
+fine_ns(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
 	return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
 }
 
@@ -314,6 +324,7 @@ deliver(struct xe_data *globl, size_t thread_id, struct shim_thread *T, xe_batch
 {
 	const size_t w = S.mask_words;
 	xe_flowcur *cur = NULL;
+	uint64_t t0, t1;
 	size_t r;
 	int rc;
 
@@ -327,39 +338,47 @@ deliver(struct xe_data *globl, size_t thread_id, struct shim_thread *T, xe_batch
 		if (!T->rec_cap) return XE_ENOMEM;
 	}
 	/* all outputs of the batch in one copy; the reads below come out of it */
+	t0 = fine_ns();
 	if ((rc = xe_gpu_batch_flow_cursor(b, T->flows, &cur)) != XE_OK) return rc;   /* waits for the kernels */
+	t1 = fine_ns();
+	T->ns[1] += t1 - t0;
 	if ((rc = xe_gpu_batch_masks(b, T->masks, nrec * w)) != XE_OK) goto out;
 	if ((rc = xe_gpu_batch_dropped(b, T->status, nrec)) != XE_OK) goto out;
 	if ((rc = xe_gpu_batch_record_datagram(b, T->dgram, nrec)) != XE_OK) goto out;
+	t0 = fine_ns();
+	T->ns[2] += t0 - t1;
 
 	for (r = 0; r < nrec; r++) {
 		struct flow_info *flow = (struct flow_info *)T->flows;
 		const uint64_t *mk = &T->masks[r * w];
 		uint64_t any = 0;
-		size_t k, m;
+		size_t k, m, skip_to;
 
 		if (T->status[r]) continue;    /* dropped by device rules / sample never classified */
 		for (k = 0; k < w; k++) any |= mk[k];
 		if (!any) continue;            /* no object receives it */
 		/* the one struct flow_info becomes record r, as netflow.c:273-275 keeps one per record */
 		if ((rc = xe_gpu_flow_cursor_seek(cur, r)) != XE_OK) goto out;
-		for (m = 0; m < S.nmo; m++) {
-			if (!((mk[m >> 6] >> (m & 63)) & 1)) {
-				/* whole words without a bit are common: skip them */
-				if (!(m & 63) && !mk[m >> 6]) m += 63;
-				continue;
+		skip_to = 0;
+		for (k = 0; k < w; k++) {
+			uint64_t x = mk[k];
+			while (x) {
+				m = 64 * k + (size_t)__builtin_ctzll(x);
+				x &= x - 1;
+				if ((m < skip_to) || (m >= S.nmo)) continue;
+				if (S.host_only[m] && !S.filter_match(S.expr[m], flow)) {
+					/* the object does not receive the record, and the objects
+					 * below it are not even looked at (netflow.c:223-243) */
+					skip_to = S.subtree_end[m];
+					continue;
+				}
+				S.process_nf(globl, S.mo[m], thread_id, time_ns[T->dgram[r]], flow);
+				T->stats[3]++;
 			}
-			if (S.host_only[m] && !S.filter_match(S.expr[m], flow)) {
-				/* the object does not receive the record, and the objects
-				 * below it are not even looked at (netflow.c:223-243) */
-				m = S.subtree_end[m] - 1;
-				continue;
-			}
-			S.process_nf(globl, S.mo[m], thread_id, time_ns[T->dgram[r]], flow);
-			T->stats[3]++;
 		}
 	}
 out:
+	T->ns[3] += fine_ns() - t0;
 	xe_gpu_flow_cursor_free(cur);
 	return rc;
 }
@@ -414,8 +433,12 @@ run_batch(struct xe_data *globl, size_t thread_id, struct shim_thread *T, int pa
 		set_due(T, mono_ns());
 		return rc;
 	}
-	rc = xe_gpu_batch_prepare(T->h, T->data, T->off, T->src, T->kind, T->n, &b);
-	if (rc == XE_OK) rc = xe_gpu_batch_run(b, NULL);
+	{
+		const uint64_t t0 = fine_ns();
+		rc = xe_gpu_batch_prepare(T->h, T->data, T->off, T->src, T->kind, T->n, &b);
+		if (rc == XE_OK) rc = xe_gpu_batch_run(b, NULL);
+		T->ns[0] += fine_ns() - t0;
+	}
 	/* (the batch before this one: its exit calls while this one's bytes travel) */
 	(void)deliver_pending(globl, thread_id, T);
 	if (rc == XE_OK) {
@@ -441,6 +464,13 @@ run_batch(struct xe_data *globl, size_t thread_id, struct shim_thread *T, int pa
 	T->used = 0;
 	set_due(T, mono_ns());
 	return rc;
+}
+
+void
+xenoeye_gpu_shim_times(size_t thread_id, uint64_t out[4])
+{
+	memset(out, 0, 4 * sizeof(out[0]));
+	if (S.ready && (thread_id < S.cfg.nthreads)) memcpy(out, S.th[thread_id].ns, sizeof(S.th[thread_id].ns));
 }
 
 int

@@ -130,12 +130,17 @@ main(int argc, char **argv)
 	xenoeye_gpu_shim_flush(NULL, 0);
 	const double s = now() - t0;
 	xenoeye_gpu_shim_stats(0, st1);
+	uint64_t ns[4];
+	xenoeye_gpu_shim_times(0, ns);
 	printf("{\"datagrams\": %llu, \"records\": %llu, \"exit_calls\": %llu, \"batches\": %llu, \"failed_batches\": %llu, "
 		"\"seconds\": %.4f, \"datagrams_per_s\": %.0f, \"records_per_s\": %.0f, \"exit_calls_per_s\": %.0f, "
-		"\"fill_only_seconds_per_pass\": %.4f, \"overlap\": %d, \"checksum\": %llu}\n",
+		"\"fill_only_seconds_per_pass\": %.4f, \"overlap\": %d, \"checksum\": %llu, "
+		"\"seconds_by_part_with_warmup_pass\": {\"prepare_and_start\": %.4f, \"wait_and_copy_back\": %.4f, \"read_outs\": %.4f, "
+		"\"records_and_exit_calls\": %.4f}}\n",
 		(unsigned long long)(st1[0] - st0[0]), (unsigned long long)(st1[2] - st0[2]), (unsigned long long)g_calls,
 		(unsigned long long)(st1[1] - st0[1]), (unsigned long long)(st1[4] - st0[4]), s,
-		(st1[0] - st0[0]) / s, (st1[2] - st0[2]) / s, g_calls / s, fill_s, overlap, (unsigned long long)g_sum);
+		(st1[0] - st0[0]) / s, (st1[2] - st0[2]) / s, g_calls / s, fill_s, overlap, (unsigned long long)g_sum,
+		ns[0] * 1e-9, ns[1] * 1e-9, ns[2] * 1e-9, ns[3] * 1e-9);
 	if (st1[4]) fprintf(stderr, "error: %s\n", xenoeye_gpu_shim_error(0));
 	xenoeye_gpu_shim_shutdown();
 	xe_gpu_destroy(h);

@@ -4057,13 +4057,41 @@ struct flow_dirty
 };
 static thread_local struct flow_dirty *g_dirty;
 
-static void
+/* n bytes, n mostly one of a few small sizes: copies the compiler can inline */
+static inline void
+small_copy(uint8_t *dst, const uint8_t *src, size_t n)
+{
+	switch (n) {
+		case 1: dst[0] = src[0]; break;
+		case 2: memcpy(dst, src, 2); break;
+		case 4: memcpy(dst, src, 4); break;
+		case 8: memcpy(dst, src, 8); break;
+		case 16: memcpy(dst, src, 16); break;
+		default: memcpy(dst, src, n);
+	}
+}
+
+static inline void
+small_clear(uint8_t *dst, size_t n)
+{
+	switch (n) {
+		case 1: dst[0] = 0; break;
+		case 2: memset(dst, 0, 2); break;
+		case 4: memset(dst, 0, 4); break;
+		case 8: memset(dst, 0, 8); break;
+		case 16: memset(dst, 0, 16); break;
+		default: memset(dst, 0, n);
+	}
+}
+
+static inline void
 put_field(uint8_t *fi, int f, const uint8_t *bytes, int size)
 {
+	const struct xe_field *fd = &xe_fields[f];
 	int one = 1;
-	memcpy(fi + xe_fields[f].off, bytes, xe_fields[f].size_max);
-	memcpy(fi + xe_fields[f].off_size, &size, 4);
-	memcpy(fi + xe_fields[f].off_has, &one, 4);
+	small_copy(fi + fd->off, bytes, fd->size_max);
+	memcpy(fi + fd->off_size, &size, 4);
+	memcpy(fi + fd->off_has, &one, 4);
 	if (g_dirty && (g_dirty->n < sizeof(g_dirty->f))) g_dirty->f[g_dirty->n++] = (uint8_t)f;
 }
 
@@ -4412,7 +4440,7 @@ xe_gpu_flow_cursor_seek(xe_flowcur *cur, size_t r)
 	} else {
 		for (uint32_t i = 0; i < cur->dirty.n; i++) {
 			const struct xe_field *fd = &xe_fields[cur->dirty.f[i]];
-			memset(cur->flow + fd->off, 0, fd->size_max);
+			small_clear(cur->flow + fd->off, fd->size_max);
 			memset(cur->flow + fd->off_size, 0, 4);
 			memset(cur->flow + fd->off_has, 0, 4);
 		}

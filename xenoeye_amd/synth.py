@@ -673,3 +673,27 @@ def write_pcap(path, frames, byte_order="<", nanosecond=False, linktype=1, snapl
 
 def batch_to_pcap(path, batch, dport=2055, **kw):
     write_pcap(path, [udp_frame(p, s, dport=dport) for p, s in zip(batch.pkts, batch.src)], **kw)
+
+
+def write_workload_dir(w, path, max_datagrams=None):
+    """A workload as files, for programs that are not Python (tools/shimbench/shim_bench.c):
+    batch.bin = u64 n, u64 offsets[n + 1], u32 src[n], u8 kind[n], the datagram bytes;
+    mos.txt = one object per line (parent index, tab, filter); iplists/<name>.  Returns the
+    number of datagrams written (the first max_datagrams of the batch: templates come first)."""
+    import os
+    os.makedirs(os.path.join(path, "iplists"), exist_ok=True)
+    for n, t in (w.get("iplists") or {}).items():
+        with open(os.path.join(path, "iplists", n), "w") as f:
+            f.write(t)
+    with open(os.path.join(path, "mos.txt"), "w") as f:
+        for filt, parent in w["mos"]:
+            f.write("%d\t%s\n" % (parent, filt))
+    data, offs, src, kinds = w["batch"].packed()[:4]
+    n = len(src) if max_datagrams is None else min(len(src), int(max_datagrams))
+    with open(os.path.join(path, "batch.bin"), "wb") as f:
+        f.write(np.uint64(n).tobytes())
+        f.write(np.asarray(offs[:n + 1], dtype=np.uint64).tobytes())
+        f.write(np.asarray(src[:n], dtype=np.uint32).tobytes())
+        f.write(np.asarray(kinds[:n], dtype=np.uint8).tobytes())
+        f.write(np.asarray(data[:int(offs[n])], dtype=np.uint8).tobytes())
+    return n
