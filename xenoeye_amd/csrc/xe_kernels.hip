@@ -2540,34 +2540,53 @@ sf_elem_of(const sf_desc &x)
 
 /* apply one element to the flow image; returns the parser state (4 for the
  * IPv4 structure element, which is always delivered) */
+/* wide loads of an element's first SF_STAGE_BYTES bytes, all issued before the
+ * first one is used; a piece that starts inside the datagram may run past its
+ * end (the batch buffer is padded), those bytes are never used; a piece that
+ * starts beyond it is not read (the load goes to the element's first bytes
+ * instead and its result is dropped) */
+struct sf_staged { u32x4 v[SF_STAGE_DWORDS / 4]; };
+
+__device__ __forceinline__ void
+sf_stage_load(sf_staged &S, const uint8_t *p, int32_t left)
+{
+#pragma unroll
+	for (int i = 0; i < SF_STAGE_DWORDS / 4; i++) {
+		const bool in = 16 * i < left;
+		S.v[i] = *(const XE_GLOBAL u32x4 *)(p + (in ? 16 * i : 0));
+	}
+}
+
+/* ... into this thread's LDS column */
+__device__ __forceinline__ void
+sf_stage_put(sf_rec &r, const sf_staged &S)
+{
+	uint32_t *d = const_cast<uint32_t *>(r.stg);
+#pragma unroll
+	for (int i = 0; i < SF_STAGE_DWORDS / 4; i++) {
+		const bool in = 16 * i < r.left;
+		d[(4 * i + 0) * XE_BLOCK] = in ? S.v[i].x : 0u;
+		d[(4 * i + 1) * XE_BLOCK] = in ? S.v[i].y : 0u;
+		d[(4 * i + 2) * XE_BLOCK] = in ? S.v[i].z : 0u;
+		d[(4 * i + 3) * XE_BLOCK] = in ? S.v[i].w : 0u;
+	}
+}
+
+/* PRE: the element's bytes were asked for ahead (pre) */
+template <bool PRE>
 __device__ __forceinline__ int
-sf_apply(const xe_kparams &kp, sf_rec &r, const sf_elem &q)
+sf_apply(const xe_kparams &kp, sf_rec &r, const sf_elem &q, const sf_staged *pre)
 {
 	r.p = kp.pkt + q.hdr_off;
 	r.left = q.left;
 	/* a word read looks one dword ahead of the one it starts in */
 	r.lim = ((r.left < SF_STAGE_BYTES) ? r.left : SF_STAGE_BYTES) - 4;
-	{
-		/* wide loads of the element into this thread's LDS column, all issued
-		 * before the first one is used; a piece that starts inside the datagram
-		 * may run past its end (the batch buffer is padded), those bytes are
-		 * never used; a piece that starts beyond it is not read (the load goes
-		 * to the element's first bytes instead and its result is dropped) */
-		uint32_t *d = const_cast<uint32_t *>(r.stg);
-		u32x4 v[SF_STAGE_DWORDS / 4];
-#pragma unroll
-		for (int i = 0; i < SF_STAGE_DWORDS / 4; i++) {
-			const bool in = 16 * i < r.left;
-			v[i] = *(const XE_GLOBAL u32x4 *)(r.p + (in ? 16 * i : 0));
-		}
-#pragma unroll
-		for (int i = 0; i < SF_STAGE_DWORDS / 4; i++) {
-			const bool in = 16 * i < r.left;
-			d[(4 * i + 0) * XE_BLOCK] = in ? v[i].x : 0u;
-			d[(4 * i + 1) * XE_BLOCK] = in ? v[i].y : 0u;
-			d[(4 * i + 2) * XE_BLOCK] = in ? v[i].z : 0u;
-			d[(4 * i + 3) * XE_BLOCK] = in ? v[i].w : 0u;
-		}
+	if (PRE) {
+		sf_stage_put(r, *pre);
+	} else {
+		sf_staged S;
+		sf_stage_load(S, r.p, r.left);
+		sf_stage_put(r, S);
 	}
 	/* sflow-impl.h:164-171 / :224-234: in_bytes[4..8] = frame length as on
 	 * the wire, in_pkts[7] = 1 */
@@ -2851,8 +2870,12 @@ xe_sf_kernel(const xe_kparams kp)
 				const bool expanded = (rd.y & XE_SFRD_EXPANDED) != 0;
 				const uint8_t *hp = kp.pkt + hoff;
 				u32x4 u[4];
+				sf_staged pre;
 #pragma unroll
 				for (int i = 0; i < 4; i++) u[i] = *(const XE_GLOBAL u32x4 *)(hp - 64 + 16 * i);
+				/* the sampled header's bytes are asked for in the same breath: where it
+				 * lies does not depend on what the window holds */
+				sf_stage_load(pre, hp, (int32_t)rd.z);
 				/* the element is described relative to the sampled header itself */
 				dgoff = hoff;
 				dglen = (uint32_t)rd.z;
@@ -2868,6 +2891,11 @@ xe_sf_kernel(const xe_kparams kp)
 				el.rp_type = (hproto == 11) ? 1 : (hproto == 12) ? 2 : 0;
 				el.frame_len_be = u[3].y;
 				el.header_len = __builtin_bswap32(u[3].w);
+				rate = el.rate;
+				in_if_be = el.in_if_be;
+				out_if_be = el.out_if_be;
+				state = sf_apply<true>(kp, rec, sf_elem_of(el, dgoff, dglen), &pre);
+				found = false;      /* (done: nothing left for the walk below) */
 			} else {
 				/* any other shape: walk the datagram to the record; when earlier
 				 * elements of its sample yielded records too, the flow carries over
@@ -2897,10 +2925,10 @@ xe_sf_kernel(const xe_kparams kp)
 						if (!sf_next_slow(it, e)) break;
 						last = e.hdr_pos >= el.hdr_pos;
 					}
-					state = sf_apply(kp, rec, sf_elem_of(e, dgoff, dglen));
+					state = sf_apply<false>(kp, rec, sf_elem_of(e, dgoff, dglen), nullptr);
 					if (last) break;
 				}
-			} else {
+			} else if (rd.y & XE_SFRD_WALK) {
 				state = 0;   /* (the count pass and this walk disagree: cannot happen; the record stays empty) */
 			}
 		} else {
@@ -2922,7 +2950,7 @@ xe_sf_kernel(const xe_kparams kp)
 			for (uint32_t k = first; k <= g; k++) {
 				sf_desc x = own;
 				if (k != g) x = sf_desc_load(kp.sfrecs + k);
-				state = sf_apply(kp, rec, sf_elem_of(x));
+				state = sf_apply<false>(kp, rec, sf_elem_of(x), nullptr);
 			}
 		}
 		/* sf5_flow(), sflow-impl.h:106-143: interface indices, bytes as stored */
