@@ -120,6 +120,7 @@ struct walk_dev
 	uint8_t *d_kinds;
 	uint32_t *d_sfcnt, *d_sfbase;
 	struct xe_sfdg *d_sfdg;    /* per datagram: what the sFlow decode kernel needs of it */
+	struct xe_sfagent *d_sfag; /* per datagram: agent address and sub-agent id, for the host */
 	void *d_rec2dg;            /* struct xe_sfrd per sFlow record (an allocation of its own: sized after the count) */
 	unsigned long long *d_total;   /* [0] sFlow records, [1] Netflow records */
 	void *d_temp; size_t temp_bytes;
@@ -2639,7 +2640,8 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 #define CARVE(BYTES) (off = ALIGN_UP(off, 256), off += (BYTES), off - (BYTES))
 	const size_t o_offs = CARVE(8 * (n + 1)), o_src = CARVE(4 * n), o_kinds = CARVE(n), o_sfcnt = CARVE(4 * (n + 2)),
 		o_sfbase = CARVE(4 * (n + 2)), o_total = CARVE(XE_WZERO_BYTES(nt)), o_temp = CARVE((mode & 1) ? w->temp_bytes : 0),
-		o_sfdg = CARVE((mode & 1) ? sizeof(struct xe_sfdg) * (n + 1) : 0);
+		o_sfdg = CARVE((mode & 1) ? sizeof(struct xe_sfdg) * (n + 1) : 0),
+		o_sfag = CARVE((mode & 1) ? sizeof(struct xe_sfagent) * (n + 1) : 0);
 	size_t o_dgruns = 0, o_walked = 0, o_hostfirst = 0, o_recbase = 0;
 	if (mode & 2) {
 		o_dgruns = CARVE(sizeof(struct xe_dgrun) * nr); o_walked = CARVE(n); o_hostfirst = CARVE(4 * (n + 2));
@@ -2655,6 +2657,7 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 	w->d_sfcnt = (uint32_t *)(base + o_sfcnt);
 	w->d_sfbase = (uint32_t *)(base + o_sfbase);
 	w->d_sfdg = (struct xe_sfdg *)(base + o_sfdg);
+	w->d_sfag = (struct xe_sfagent *)(base + o_sfag);
 	w->d_total = (unsigned long long *)(base + o_total);
 	w->d_temp = base + o_temp;
 	if (mode & 2) {
@@ -2699,7 +2702,7 @@ walk_begin(xe_gpu *h, xe_batch *b, const uint8_t *data, const uint64_t *offsets,
 	}
 	if (mode & 1) {
 		in.pkt = (const uint8_t *)b->d_pkt;
-		rc = xe_walk_sf_count(&in, w->d_sfcnt, w->d_sfdg, w->d_total, st);
+		rc = xe_walk_sf_count(&in, w->d_sfcnt, w->d_sfdg, w->d_sfag, w->d_total, st);
 		if (rc == XE_OK) rc = xe_walk_scan(w->d_temp, w->temp_bytes, w->d_sfcnt, w->d_sfbase, n, st);
 		if (rc != XE_OK) return hip_fail(h, hipGetLastError(), "header walk (sFlow)");
 		HIPCHK(h, hipMemcpyAsync(h->wstage, w->d_total, 8, hipMemcpyDeviceToHost, st));
@@ -4116,13 +4119,11 @@ sf_field_size(int f)
 static int
 sf_meta_fetch(xe_batch *b, size_t first, size_t count, struct xe_sfrec **out)
 {
-	if (b && b->ev_bulk) (void)hipEventSynchronize(b->ev_bulk);   /* reads the device copy of the datagrams */
 	xe_gpu *h = b->h;
 	struct xe_sfrec *sl = (struct xe_sfrec *)calloc(count + 1, sizeof(*sl));
 	struct xe_sfrd *r2d = (struct xe_sfrd *)malloc((count + 1) * sizeof(*r2d));
 	uint32_t *rate = (uint32_t *)malloc((count + 1) * 4);
-	struct xe_sfdg *dg = NULL;
-	uint8_t *hdr = NULL;
+	struct xe_sfagent *ag = NULL;
 	int rc = XE_ENOMEM;
 
 	*out = NULL;
@@ -4135,29 +4136,18 @@ sf_meta_fetch(xe_batch *b, size_t first, size_t count, struct xe_sfrec **out)
 	{
 		const uint32_t d0 = r2d[0].dgram, d1 = r2d[count - 1].dgram;
 		const size_t nd = (size_t)d1 - d0 + 1;
-		uint64_t lo, hi;
+		/* the datagrams in between: what the count pass noted of their headers */
 		rc = XE_ENOMEM;
-		dg = (struct xe_sfdg *)malloc(nd * sizeof(*dg));
-		if (!dg) goto out;
+		ag = (struct xe_sfagent *)malloc(nd * sizeof(*ag));
+		if (!ag) goto out;
 		rc = XE_EHIP;
-		if (hipMemcpy(dg, b->w.d_sfdg + d0, nd * sizeof(*dg), hipMemcpyDeviceToHost) != hipSuccess) goto hipfail;
-		/* header bytes of the datagrams in between: one copy of the stretch of the
-		 * batch buffer from the first to the header of the last */
-		lo = dg[0].off;
-		hi = dg[nd - 1].off + 48;
-		if (hi > b->payload_bytes + 64) hi = b->payload_bytes + 64;
-		rc = XE_ENOMEM;
-		hdr = (uint8_t *)malloc((size_t)(hi - lo) + 64);
-		if (!hdr) goto out;
-		rc = XE_EHIP;
-		if (hipMemcpy(hdr, (const uint8_t *)b->d_pkt + lo, (size_t)(hi - lo), hipMemcpyDeviceToHost) != hipSuccess) goto hipfail;
+		if (hipMemcpy(ag, b->w.d_sfag + d0, nd * sizeof(*ag), hipMemcpyDeviceToHost) != hipSuccess) goto hipfail;
 		for (size_t k = 0; k < count; k++) {
-			const struct xe_sfdg *g = &dg[r2d[k].dgram - d0];
-			const uint8_t *p = hdr + (g->off - lo);
-			const int v6 = (g->len & XE_SFDG_AGENT6) != 0;
+			const struct xe_sfagent *g = &ag[r2d[k].dgram - d0];
+			const int v6 = g->ver == 6;
 			sl[k].agent_ver = v6 ? 6 : 4;
-			memcpy(sl[k].agent, p + 8, v6 ? 16 : 4);
-			memcpy(sl[k].dev_id, p + 8 + (v6 ? 16 : 4), 4);
+			memcpy(sl[k].agent, g->agent, v6 ? 16 : 4);
+			memcpy(sl[k].dev_id, g->dev_id, 4);
 			sl[k].sampling_rate = rate[k];
 		}
 	}
@@ -4168,7 +4158,7 @@ sf_meta_fetch(xe_batch *b, size_t first, size_t count, struct xe_sfrec **out)
 hipfail:
 	rc = hip_fail(h, hipGetLastError(), "hipMemcpy(sFlow datagram headers)");
 out:
-	free(sl); free(r2d); free(rate); free(dg); free(hdr);
+	free(sl); free(r2d); free(rate); free(ag);
 	return rc;
 }
 

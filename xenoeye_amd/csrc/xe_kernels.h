@@ -357,7 +357,16 @@ int xe_walk_scan(void *temp, size_t temp_bytes, uint32_t *in, uint32_t *out, siz
 
 /* sFlow: cnt[i] = records datagram i yields (0 for other kinds), dgs[i] = what the decode kernel
  * needs of the datagram; *total += the counts */
-int xe_walk_sf_count(const struct xe_walk_in *in, uint32_t *cnt, struct xe_sfdg *dgs, unsigned long long *total, void *stream);
+/* what sflow_reset() sets per datagram (sflow-impl.h:274-291), bytes as on the wire: for the
+ * host, which re-creates struct flow_info without reading the datagrams again */
+struct xe_sfagent
+{
+	uint8_t agent[16];            /* 4 or 16 bytes of it */
+	uint8_t dev_id[4];            /* the sub-agent id */
+	uint32_t ver;                 /* 4 or 6; 0 = the datagram yields nothing */
+};
+int xe_walk_sf_count(const struct xe_walk_in *in, uint32_t *cnt, struct xe_sfdg *dgs, struct xe_sfagent *agents,
+	unsigned long long *total, void *stream);
 /* sFlow: recs[r] for the records r in [base[i], base[i + 1]) of datagram i < n */
 int xe_walk_sf_place(uint32_t n, const uint32_t *base, const struct xe_sfdg *dgs, struct xe_sfrd *recs, void *stream);
 

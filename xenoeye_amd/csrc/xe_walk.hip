@@ -83,7 +83,7 @@ dev_find(const xe_walk_in &in, uint32_t ip, uint32_t id)
  * record's sample header itself (one window load); only for datagrams of any
  * other shape it walks the datagram again up to its record. */
 __global__ void __launch_bounds__(XW_BLOCK)
-xw_sf_count_kernel(const xe_walk_in in, uint32_t *cnt, xe_sfdg *dgs, unsigned long long *total)
+xw_sf_count_kernel(const xe_walk_in in, uint32_t *cnt, xe_sfdg *dgs, xe_sfagent *agents, unsigned long long *total)
 {
 	const uint32_t i = blockIdx.x * XW_BLOCK + threadIdx.x;
 	uint32_t n = 0;
@@ -121,6 +121,20 @@ xw_sf_count_kernel(const xe_walk_in in, uint32_t *cnt, xe_sfdg *dgs, unsigned lo
 				 * sflow_process() never sets: 0 */
 				g.dev |= (uint32_t)(dev_find(in, in.src[i], 0) + 1) & 0xFFFFu;
 			}
+		}
+		{
+			/* agent address and sub-agent id (the five words behind version and address type) */
+			u32x4 a = { 0u, 0u, 0u, 0u };
+			uint32_t id = 0, ver = 0;
+			if (g.len) {
+				const uint8_t *p = in.pkt + g.off + XE_SF_AGENT_POS;
+				ver = (g.len & XE_SFDG_AGENT6) ? 6u : 4u;
+				a.x = ld32(p);
+				if (ver == 6) { a.y = ld32(p + 4); a.z = ld32(p + 8); a.w = ld32(p + 12); }
+				id = ld32(p + ((ver == 6) ? 16 : 4));
+			}
+			uint32_t *qw = (uint32_t *)(agents + i);
+			qw[0] = a.x; qw[1] = a.y; qw[2] = a.z; qw[3] = a.w; qw[4] = id; qw[5] = ver;
 		}
 		cnt[i] = n;
 		dgs[i] = g;
@@ -818,10 +832,11 @@ xe_walk_scan(void *temp, size_t temp_bytes, uint32_t *in, uint32_t *out, size_t 
 }
 
 extern "C" int
-xe_walk_sf_count(const struct xe_walk_in *in, uint32_t *cnt, struct xe_sfdg *dgs, unsigned long long *total, void *stream)
+xe_walk_sf_count(const struct xe_walk_in *in, uint32_t *cnt, struct xe_sfdg *dgs, struct xe_sfagent *agents,
+	unsigned long long *total, void *stream)
 {
 	if (!in->n) return XE_OK;
-	hipLaunchKernelGGL(xw_sf_count_kernel, dim3(xw_blocks(in->n)), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, cnt, dgs, total);
+	hipLaunchKernelGGL(xw_sf_count_kernel, dim3(xw_blocks(in->n)), dim3(XW_BLOCK), 0, (hipStream_t)stream, *in, cnt, dgs, agents, total);
 	return xw_done();
 }
 
