@@ -4058,7 +4058,6 @@ struct flow_dirty
 	uint16_t n;
 	uint8_t f[XE_NFIELDS + 8];
 };
-static thread_local struct flow_dirty *g_dirty;
 
 /* n bytes, n mostly one of a few small sizes: copies the compiler can inline */
 static inline void
@@ -4088,14 +4087,14 @@ small_clear(uint8_t *dst, size_t n)
 }
 
 static inline void
-put_field(uint8_t *fi, int f, const uint8_t *bytes, int size)
+put_field(struct flow_dirty *dirty, uint8_t *fi, int f, const uint8_t *bytes, int size)
 {
 	const struct xe_field *fd = &xe_fields[f];
 	int one = 1;
 	small_copy(fi + fd->off, bytes, fd->size_max);
 	memcpy(fi + fd->off_size, &size, 4);
 	memcpy(fi + fd->off_has, &one, 4);
-	if (g_dirty && (g_dirty->n < sizeof(g_dirty->f))) g_dirty->f[g_dirty->n++] = (uint8_t)f;
+	if (dirty && (dirty->n < sizeof(dirty->f))) dirty->f[dirty->n++] = (uint8_t)f;
 }
 
 /* sizes the sFlow decoder reports for its fields (sflow.c:35-77, sflow-impl.h) */
@@ -4173,6 +4172,7 @@ struct flow_ctx
 	struct xe_sfrec *sf_slice;   /* element descriptors that exist on the device only */
 	size_t sf_slice_first;
 	size_t si, di;           /* set and datagram of the last record built (records are asked for in rising order) */
+	struct flow_dirty *dirty;    /* NULL, or where the fields a record sets are noted */
 };
 
 /* struct flow_info of record r into fi (zeroed, or holding nothing but zeros where this record sets nothing) */
@@ -4229,15 +4229,15 @@ flow_build(xe_batch *b, struct flow_ctx *c, size_t r, uint8_t *fi)
 			if (c->s.vsize[f]) {
 				uint16_t vs = c->s.vsize[f][k];
 				if (vs == 0xFFFF) continue;
-				put_field(fi, f, c->s.col[f] + k * xe_fields[f].col_width, vs);
+				put_field(c->dirty, fi, f, c->s.col[f] + k * xe_fields[f].col_width, vs);
 			} else {
 				if (!(en[j].flags & XE_TE_VALID)) continue;
-				put_field(fi, f, c->s.col[f] + k * xe_fields[f].col_width, en[j].len);
+				put_field(c->dirty, fi, f, c->s.col[f] + k * xe_fields[f].col_width, en[j].len);
 			}
 		}
 		/* virtual_fields_init(), netflow.c:112-124 */
-		put_field(fi, XF_dev_ip, e->dev_ip, 4);
-		put_field(fi, XF_dev_id, e->dev_id, 4);
+		put_field(c->dirty, fi, XF_dev_ip, e->dev_ip, 4);
+		put_field(c->dirty, fi, XF_dev_id, e->dev_id, 4);
 		rate = e->sampling_rate;
 	} else {
 		const struct xe_sfrec *q = c->sf_slice ? &c->sf_slice[r - b->plan.nrec - c->sf_slice_first] : &sf[r - b->plan.nrec];
@@ -4250,17 +4250,17 @@ flow_build(xe_batch *b, struct flow_ctx *c, size_t r, uint8_t *fi)
 		for (size_t i = 0; i < sizeof(order) / sizeof(order[0]); i++) {
 			int f = order[i];
 			if (!((hb >> i) & 1)) continue;
-			put_field(fi, f, c->s.col[f] + k * xe_fields[f].col_width, sf_field_size(f));
+			put_field(c->dirty, fi, f, c->s.col[f] + k * xe_fields[f].col_width, sf_field_size(f));
 		}
 		/* sflow_reset(), sflow-impl.h:274-291 */
-		put_field(fi, XF_dev_id, q->dev_id, 4);
-		if (q->agent_ver == 4) put_field(fi, XF_dev_ip, q->agent, 4);
-		else put_field(fi, XF_dev_ip6, q->agent, 16);
+		put_field(c->dirty, fi, XF_dev_id, q->dev_id, 4);
+		if (q->agent_ver == 4) put_field(c->dirty, fi, XF_dev_ip, q->agent, 4);
+		else put_field(c->dirty, fi, XF_dev_ip6, q->agent, 16);
 		rate = q->sampling_rate;
 	}
 	if (c->s.marks && (c->s.marks[k] & XE_MARK_HAS)) {
 		uint32_t mk = htonl(c->s.marks[k] & 0x3FFFFFFFu);
-		put_field(fi, XF_dev_mark, (const uint8_t *)&mk, 4);
+		put_field(c->dirty, fi, XF_dev_mark, (const uint8_t *)&mk, 4);
 	}
 	memcpy(fi + XE_OFF_SAMPLING_RATE, &rate, 4);
 }
@@ -4339,6 +4339,7 @@ xe_gpu_batch_flow_info(xe_batch *b, size_t first, size_t count, void *out)
 	c.sf_slice_first = sf_slice_first;
 	c.si = si;
 	c.di = di;
+	c.dirty = NULL;
 	for (size_t k = 0; k < count; k++) flow_build(b, &c, first + k, (uint8_t *)out + k * XE_FLOW_INFO_SIZE);
 done:
 	slice_free(&s);
@@ -4436,9 +4437,8 @@ xe_gpu_flow_cursor_seek(xe_flowcur *cur, size_t r)
 		}
 	}
 	cur->dirty.n = 0;
-	g_dirty = &cur->dirty;
+	cur->c.dirty = &cur->dirty;
 	flow_build(cur->b, &cur->c, r, cur->flow);
-	g_dirty = NULL;
 	cur->last = r;
 	cur->started = 1;
 	return XE_OK;
