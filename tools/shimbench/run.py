@@ -1,5 +1,5 @@
 """Writes a workload for tools/shimbench/shim_bench.c and runs it (this process never touches the GPU).
-Usage: python tools/shimbench/run.py <workload c1|c2|c3> <records> <passes> [overlap] [max_datagrams per batch]"""
+Usage: python tools/shimbench/run.py <workload c1|c2|c3> <records> <passes> [overlap [capture threads [max_datagrams per batch]]]"""
 import os, subprocess, sys
 sys.path.insert(0, ".")
 from xenoeye_amd import synth
