@@ -56,7 +56,9 @@ struct xe_gpu
 	int fwm_devip;             /* some table is keyed by dev-ip: the kernels note it per record */
 	uint32_t lw;               /* 64-bit words of lookup bits per record: 1 or XE_LK_WORDS */
 	uint32_t nplain_terms;     /* object terms [0, nplain_terms) have operands other than IP lists */
-	size_t motab_words;        /* u64 words of the atom table and its non-empty-row masks */
+	size_t motab_words;        /* u64 words of the atom table and its non-empty-row masks (and the range tables behind them, from rg_lds on) */
+	uint64_t *h_motab;         /* host copy while commit runs */
+	uint32_t rg_lds;
 	int fast_ok, want_dev;     /* want_dev: some object program reads dev_ip / dev_id */
 	int reads_mark;            /* some object program reads dev_mark */
 	/* service names of the 65536 ports (NULL = none given; an entry is NULL or
@@ -323,6 +325,7 @@ xe_gpu_destroy(xe_gpu *h)
 	for (int i = 0; i < XE_DPOOL; i++) if (h->dpool[i].p) (void)hipFree(h->dpool[i].p);
 	if (h->stage) (void)hipHostFree(h->stage);
 	if (h->mirror) (void)hipHostFree(h->mirror);
+	free(h->h_motab);
 	pinned_free(h->wstage);
 	pinned_free(h->pin);
 	if (h->d_devkeys) (void)hipFree(h->d_devkeys);
@@ -2169,11 +2172,13 @@ xe_gpu_commit(xe_gpu *h)
 				}
 			}
 			h->motab_words = words * (mrows + h->lw + 1);
+			h->rg_lds = 0;
 			if (rc == XE_OK) rc = upload(h, &h->d_motab, mt, h->motab_words * sizeof(uint64_t));
 			if (rc == XE_OK) rc = upload(h, &h->d_fprogs, fp, nb * sizeof(*fp));
 			if (rc == XE_OK) rc = upload(h, &h->d_cjderived, der, nder * sizeof(*der));
 			if (rc == XE_OK) rc = upload(h, &h->d_cjcand, cand, words * sizeof(uint64_t));
-			free(mt);
+			free(h->h_motab);
+			h->h_motab = mt;      /* (the range groups' tables may join it below) */
 			free(cand);
 			free(der);
 			free(rows);
@@ -2280,6 +2285,27 @@ xe_gpu_commit(xe_gpu *h)
 			if ((rc == XE_OK) && h->nrgroups) {
 				rc = upload(h, &h->d_rgroups, rg, (size_t)nrg * sizeof(rg[0]));
 				if (rc == XE_OK) rc = upload(h, &h->d_rgdata, rgd.p, rgd.n * 4);
+				/* small tables also go behind the atom table, which the kernels copy
+				 * to LDS while all of it stays below the size tested everywhere
+				 * (motab_words): an entry then comes from LDS instead of a gather */
+				const size_t rgw = (rgd.n + 1) / 2;
+				if ((rc == XE_OK) && h->h_motab && h->motab_words && !h->rg_lds
+					&& ((h->motab_words + rgw) * 8 <= 8192 + 64)) {
+					uint64_t *both = (uint64_t *)calloc(h->motab_words + rgw, 8);
+					if (!both) {
+						rc = XE_ENOMEM;
+					} else {
+						memcpy(both, h->h_motab, h->motab_words * 8);
+						memcpy(both + h->motab_words, rgd.p, rgd.n * 4);
+						if (h->d_motab) (void)hipFree(h->d_motab);
+						rc = upload(h, &h->d_motab, both, (h->motab_words + rgw) * 8);
+						if (rc == XE_OK) {
+							h->rg_lds = (uint32_t)h->motab_words;
+							h->motab_words += rgw;
+						}
+						free(both);
+					}
+				}
 			}
 			if (h->dbg) fprintf(stderr, "xe_gpu_commit: %u range groups, %zu table bytes\n", h->nrgroups, rgd.n * 4);
 			free(rgd.p);
@@ -3244,6 +3270,7 @@ build_work_lists(xe_gpu *h, xe_batch *b, size_t total_bytes)
 		}
 		b->kp.motab = (const uint64_t *)h->d_motab;
 		b->kp.motab_words = (uint32_t)h->motab_words;
+		b->kp.rg_lds = h->rg_lds;
 		b->kp.motab_lds = (h->motab_words * 8 <= 8192 + 64) ? 1u : 0u;
 		b->kp.probes = (const struct xe_probe *)h->d_lookups;
 		b->kp.nprobes = h->nlookups;

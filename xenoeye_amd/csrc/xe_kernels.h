@@ -78,6 +78,7 @@ struct xe_kparams
 	const struct xe_cjderived *cjderived;
 	const struct xe_rgroup *rgroups;     /* range-term groups (count padded to a multiple of 4) */
 	const uint32_t *rgdata;      /* their breakpoints and tables */
+	uint32_t rg_lds, pad_rg;     /* not 0: rgdata also lies behind the atom table (motab), from this 64-bit word on, and goes to LDS with it */
 	uint32_t nrgroups, ncjgroups;
 	const uint64_t *cjcand;      /* per mask word: the objects matched through cjrows */
 	uint32_t pad_cj, ncjderived;

@@ -1311,7 +1311,7 @@ tile_issue(const xe_kparams &kp, const tile_lanes<R> &S, u32x4 (&q)[4][R])
  * dependent loads overlap. */
 template <int R, typename TT, int GC>
 __device__ __forceinline__ void
-range_groups(const xe_kparams &kp, const TT &T, uint64_t (&tb)[R][4])
+range_groups(const xe_kparams &kp, const TT &T, uint64_t (&tb)[R][4], const lds_u64 *lmt)
 {
 	typedef uint32_t u32x4r __attribute__((ext_vector_type(4)));
 
@@ -1379,15 +1379,26 @@ range_groups(const xe_kparams &kp, const TT &T, uint64_t (&tb)[R][4])
 			}
 		}
 		u32x4r ea[GC][R], eb[GC][R];
+		/* small tables ride behind the block's copy of the atom table in LDS:
+		 * the entry is there in a hundred cycles, without a gather that waits
+		 * its turn behind every vector memory operation before it */
+		const bool in_lds = (kp.rg_lds != 0) && (kp.motab_lds != 0);
 #pragma unroll
 		for (int c = 0; c < GC; c++) {
 #pragma unroll
 			for (int r = 0; r < R; r++) {
-				const XE_CONST u32x4r *e = (const XE_CONST u32x4r *)(kp.rgdata + tbo[c] + (size_t)pos[c][r] * 8);
 				ea[c][r] = eb[c][r] = (u32x4r){0, 0, 0, 0};
 				if (g0 + c >= kp.nrgroups_used) continue;
-				ea[c][r] = e[0];
-				eb[c][r] = e[1];
+				if (in_lds) {
+					const lds_u64 *e = lmt + kp.rg_lds + ((tbo[c] + (size_t)pos[c][r] * 8) >> 1);
+					const uint64_t e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
+					ea[c][r] = (u32x4r){ (uint32_t)e0, (uint32_t)(e0 >> 32), (uint32_t)e1, (uint32_t)(e1 >> 32) };
+					eb[c][r] = (u32x4r){ (uint32_t)e2, (uint32_t)(e2 >> 32), (uint32_t)e3, (uint32_t)(e3 >> 32) };
+				} else {
+					const XE_CONST u32x4r *e = (const XE_CONST u32x4r *)(kp.rgdata + tbo[c] + (size_t)pos[c][r] * 8);
+					ea[c][r] = e[0];
+					eb[c][r] = e[1];
+				}
 			}
 		}
 #pragma unroll
@@ -1409,7 +1420,8 @@ range_groups(const xe_kparams &kp, const TT &T, uint64_t (&tb)[R][4])
  * compiled out, which keeps the common simple case small */
 template <int R, bool LEAN, int LW, typename TT, int RGC = XE_RG_STEP, int PC = 2>
 __device__ __forceinline__ void
-classify_atoms(const xe_kparams &kp, const TT &T, const uint64_t (&plist)[LW], uint64_t (&lk)[R][LW], uint64_t (&tb)[R][4])
+classify_atoms(const xe_kparams &kp, const TT &T, const uint64_t (&plist)[LW], uint64_t (&lk)[R][LW], uint64_t (&tb)[R][4],
+	const lds_u64 *lmt)
 {
 		if XE_ABL(1) {
 #pragma unroll
@@ -1428,7 +1440,7 @@ classify_atoms(const xe_kparams &kp, const TT &T, const uint64_t (&plist)[LW], u
 		if (!LEAN && !XE_ABL(2)) {
 			XE_PHASE_DECL;
 			const uint32_t lane = threadIdx.x & 63;
-			range_groups<R, TT, RGC>(kp, T, tb);
+			range_groups<R, TT, RGC>(kp, T, tb, lmt);
 			XE_PHASE(7);
 		}
 		for (uint32_t ti = 0; (ti < kp.ntneed) && !XE_ABL(2); ti++) {
@@ -1814,7 +1826,7 @@ xe_nf_fast_kernel(const xe_kparams kp)
 
 		/* every IP-list membership, then every term some program needs, once */
 		uint64_t lk[R][LW], tb[R][4];
-		classify_atoms<R, LEAN, LW>(kp, T, plist, lk, tb);
+		classify_atoms<R, LEAN, LW>(kp, T, plist, lk, tb, lmt);
 		XE_PHASE(2);
 #if XE_PREFETCH_LATE
 		/* the next tile's packet loads go out behind the list walks: vector
@@ -2011,7 +2023,7 @@ classify(const xe_kparams &kp, REC &rec, int32_t device, uint32_t ridx, bool act
 		XE_PHASE_DECL;
 		const uint32_t lane = threadIdx.x & 63;
 		/* per-lane kernels have registers to spare: four range groups at a time */
-		classify_atoms<1, false, 1, lane_tile<REC, GET>, 4, XE_LANE_PC>(kp, T, pl, lk, tb);
+		classify_atoms<1, false, 1, lane_tile<REC, GET>, 4, XE_LANE_PC>(kp, T, pl, lk, tb, lmt);
 		XE_PHASE(2);
 		classify_objects<1, false, 1>(kp, T.live, lk, tb, ri, bx, px, lcnt, lmt);
 		XE_PHASE(3);
@@ -2019,7 +2031,7 @@ classify(const xe_kparams &kp, REC &rec, int32_t device, uint32_t ridx, bool act
 		uint64_t lk[1][XE_LK_WORDS];
 		uint64_t pl[XE_LK_WORDS];
 		for (int k = 0; k < XE_LK_WORDS; k++) pl[k] = kp.all_probes[k];
-		classify_atoms<1, false, XE_LK_WORDS>(kp, T, pl, lk, tb);
+		classify_atoms<1, false, XE_LK_WORDS>(kp, T, pl, lk, tb, lmt);
 		classify_objects<1, false, XE_LK_WORDS>(kp, T.live, lk, tb, ri, bx, px, lcnt, lmt);
 	}
 	/* a dropped record still owns its mask words */
