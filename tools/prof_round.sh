@@ -32,3 +32,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 PY
   cat "$out/${w}_pmc.txt"
 done
+# the fixed-window table kernel on the C2 batch (bench's table leg only)
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_fwm" -- python3 bench.py --steps 5 --warmup 2 --cpu-sample 0 --cpu-procs 0 --others 0 --sustain-seconds 0 --pipeline 0 --shim-records 0 --overlap-leg 0 > "$out/bench_fwm.json" 2> "$out/trace_fwm.log" || { tail -20 "$out/trace_fwm.log"; exit 1; }
+find "$out/trace_fwm" -name "*kernel_stats.csv" -exec cp {} "$out/fwm_kernel_stats.csv" \;
+grep -E "xe_fwm|Name" "$out/fwm_kernel_stats.csv" | cut -c1-200
