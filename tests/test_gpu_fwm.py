@@ -115,9 +115,11 @@ def test_sflow_and_general_path_records(eng, orc):
     same_tables(eng, orc, ids)
 
 
-def test_table_that_is_too_small_counts_what_it_drops(eng, orc):
+@pytest.mark.parametrize("fields", [["src host", "src port", "packets"],                  # a key of one word
+                                    ["src host", "dst host", "src port", "packets"]])     # ten bytes: two words
+def test_table_that_is_too_small_counts_what_it_drops(eng, orc, fields):
     w = synth.workload_c1(20000)
-    ids = setup(eng, orc, w, [(0, ["src host", "src port", "packets"])], max_keys=256)
+    ids = setup(eng, orc, w, [(0, fields)], max_keys=256)
     b = eng.prepare(w["batch"])
     b.run()
     run_oracle(orc, w["batch"], keep_flows=False)
