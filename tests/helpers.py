@@ -53,7 +53,11 @@ def compare(batch_out, orc, flows=True, sflow_states=None):
     assert np.array_equal(dd, od), "dropped flags differ"
     assert np.array_equal(batch_out.counters(), orc.counters()), "counters differ"
     if flows and n:
-        df, of = batch_out.flow_info()[sel], orc.flows()
+        dall = batch_out.flow_info()
+        # the record-after-record read-out hands out the same bytes, whatever it skips
+        picks = np.unique(np.linspace(0, dall.shape[0] - 1, num=min(dall.shape[0], 1500)).astype(np.int64))
+        assert np.array_equal(batch_out.flow_records(picks), dall[picks]), "cursor read-out differs from the block read-out"
+        df, of = dall[sel], orc.flows()
         # a dropped record never reaches consumers; the reference leaves its
         # dev_mark unset, compare only delivered records byte for byte
         keep = od == 0
