@@ -1856,7 +1856,7 @@ xe_gpu_commit(xe_gpu *h)
 		else rc = xe_iplists_flatten(&h->hs.lists, &trie, h->h_lists, h->list_root_bits);
 	}
 	h->port_named_off = 0;
-	if ((rc == XE_OK) && h->port_names && (strs.offs.n || 1)) {
+	if ((rc == XE_OK) && h->port_names) {
 		/* behind the list tables: which ports have a service name (65536 bits),
 		 * then per portstr() text the set of ports whose text equals it
 		 * (port_to_str + strcasecmp, filter.c:861-880) */
