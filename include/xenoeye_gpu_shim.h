@@ -46,7 +46,7 @@ struct monit_object;    /* monit-objects.h:244-279 */
 struct filter_expr;     /* filter.h:256-275 */
 
 /* flow-info.h:10-33: 2312 bytes on x86-64; the shim fills them with
- * xe_gpu_batch_flow_info() and hands them over untyped */
+ * xe_gpu_flow_cursor_seek() (the bytes xe_gpu_batch_flow_info() makes) and hands them over untyped */
 struct flow_info;
 
 #ifndef flow_info_h_included
