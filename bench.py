@@ -428,6 +428,9 @@ def measure_walk(eng, packed, reps):
     eng.set_walk_timing(True)
     ms = []
     try:
+        # (the first prepare with the events on creates them and measures that too: 0.53 against
+        # 0.25 ms on C3 - not part of the mean)
+        eng.prepare(packed).free()
         for _ in range(reps):
             b = eng.prepare(packed)
             t = b.walk_ms()
